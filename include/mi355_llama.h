@@ -1,0 +1,326 @@
+/*
+ * mi355_llama.h — C ABI of libmi355llama.so, the MI355X (gfx950) native hot path for
+ * lit-llama's quantized single-batch decode.
+ *
+ * The reference (Lightning-AI/lit-llama) has no FFI: its operator boundary is the Python
+ * module API (lit_llama/quantization.py, lit_llama/model.py).  This header is the boundary
+ * a maintainer would bind with ctypes from those modules; every entry
+ * point names the reference code it replaces.  Conventions:
+ *
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless the
+ *     name ends in _host; the caller owns every buffer and keeps it alive until the stream
+ *     has drained;
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), performs
+ *     no allocation and no synchronisation (graph instantiate/destroy excepted, see below);
+ *   - return 0 on success, a positive hipError_t for runtime errors, a negative MI355_E_*
+ *     for argument errors; mi355_last_error() returns a thread-local message;
+ *   - dtype codes: MI355_F32 / MI355_BF16 / MI355_F16.
+ */
+#ifndef MI355_LLAMA_H
+#define MI355_LLAMA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ABI_VERSION 1
+
+enum { MI355_F32 = 0, MI355_BF16 = 1, MI355_F16 = 2 };
+enum { MI355_E_ARG = -1, MI355_E_SHAPE = -2, MI355_E_DTYPE = -3, MI355_E_STATE = -4 };
+
+/* weight stream formats of the fast (MFMA, M<=16) linear */
+enum { MI355_W_Q4 = 0, MI355_W_BF16 = 1, MI355_W_I8 = 2 };
+/* epilogues of the fast linear */
+enum { MI355_EPI_STORE = 0, MI355_EPI_ACCUM = 1, MI355_EPI_SWIGLU = 2 };
+
+typedef void* mi355_stream_t; /* hipStream_t */
+
+int mi355_version(void);
+const char* mi355_last_error(void);
+/* number of compute units of the current device (grid sizing on the host side) */
+int mi355_num_cus(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Load-time weight repack into the wave-linear stream layout consumed by mi355_linear_fast.
+ *
+ * Stream layout (all formats): [tile][unit][r][lane 0..63][16 B]; a tile is R row-groups of
+ * 16 output rows, a unit is 128 input columns.  Lane l = (g = l >> 4, row = l & 15).
+ *   Q4  : one 16-B piece per (unit, r): dword d holds k = 128u + 32g + 8d + j, j = 0..7, with
+ *         slot j stored in nibble p = (j >> 1) + 4 (j & 1) (so that `(w >> 4i) & 0x000F000F`
+ *         yields the bf16 pair (j = 2i, j = 2i + 1) of an MFMA A fragment directly).
+ *   BF16: four 16-B pieces per (unit, r), piece d holds bf16 k = 128u + 32g + 8d + j.
+ *   I8  : two 16-B pieces per (unit, r), piece e holds int8 k = 128u + 64e + 16g + j, j < 16.
+ * ---------------------------------------------------------------------------------------- */
+
+/* bytes of the repacked stream for an [N, K] matrix (rows padded to whole tiles, K to whole units);
+ * pair != 0: two [N, K] matrices interleaved per tile (R must be 2) */
+size_t mi355_packed_bytes(int fmt, int N, int K, int R, int pair);
+
+/* Repack ColBlockQuantizedLinear.quant_weight (reference layout: lit_llama/quantization.py:350-359,
+ * byte (n, kb) = q[n, 2kb] | q[n, 2kb+1] << 4 at q + n*stride_n + kb*stride_kb, :387-390).
+ * If q1 != NULL the stream interleaves two matrices per tile (r = 0 -> q0, r = 1 -> q1; R must be 2):
+ * the SwiGLU pair c_fc1 / c_fc2 of lit_llama/model.py:251-253. */
+int mi355_q4_repack(const uint8_t* q0, const uint8_t* q1, int64_t stride_n, int64_t stride_kb,
+                    int N, int K, int R, uint8_t* out, mi355_stream_t stream);
+
+/* Repack a dense row-major [N, K] weight (nn.Linear.weight) of dtype `dtype` (bf16 or f32; f32 is
+ * rounded to bf16 RNE) into the BF16 stream; w1 as above. */
+int mi355_bf16_repack(const void* w0, const void* w1, int dtype, int N, int K, int R, void* out,
+                      mi355_stream_t stream);
+
+/* Repack a row-major int8 [N, K] matrix (Linear8bitLt weight.CB, lit_llama/quantization.py:75-77). */
+int mi355_i8_repack(const int8_t* cb0, const int8_t* cb1, int N, int K, int R, int8_t* out,
+                    mi355_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fast linear, M <= 16 rows of activations:  y[m, n] = epi( sum_k x'[m, k] * W[n, k] )
+ *   x' = x, or RMSNorm(x) * norm_scale when norm_scale != NULL (lit_llama/model.py:270-277),
+ *   rounded once to bf16 (the MFMA operand type).
+ * Replaces, for the decode shapes: ColBlockQuantizedLinear.forward -> qlinear_4bit_weight ->
+ * Triton linear_kernel_4bit_weight (lit_llama/quantization.py:413-423, 284-333, 187-282) for
+ * MI355_W_Q4 (per-row scale/zero, i.e. tile_cols = -1), torch.nn.Linear.forward / F.linear
+ * (lit_llama/model.py:197,235,252-253,120) for MI355_W_BF16.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mi355_linear_args {
+    int32_t fmt;        /* MI355_W_* */
+    int32_t R;          /* row-groups per tile of the stream (1 or 2) */
+    const void* w;      /* repacked stream */
+    int32_t N;          /* output features (per matrix when interleaved) */
+    int32_t K;          /* input features */
+    const void* x;      /* [M, ldx] activations */
+    int32_t x_dtype;
+    int32_t M;          /* 1..16 */
+    int64_t ldx;        /* elements */
+    const void* norm_scale; /* [K] or NULL */
+    int32_t norm_dtype;
+    float eps;
+    /* Q4: per-output-row scale and zero ([N], dtype sz_dtype); *2 for the second interleaved matrix */
+    const void* scales;
+    const void* zeros;
+    const void* scales2;
+    const void* zeros2;
+    int32_t sz_dtype;
+    int32_t epi;        /* MI355_EPI_* */
+    const void* bias;   /* [N] of sz_dtype or NULL (STORE/ACCUM only) */
+    void* y;            /* [M, ldy] */
+    int32_t y_dtype;
+    int32_t reserved0;
+    int64_t ldy;
+    /* launch tuning; 0 = library default */
+    int32_t waves;      /* waves per workgroup (split of K) */
+    int32_t grid;       /* workgroups (persistent loop over tiles) */
+    int32_t prefetch;   /* ring depth variant (4 or 8) */
+    int32_t flags;      /* bit0: non-temporal weight loads off */
+} mi355_linear_args;
+
+int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Generic (any shape, any M, f32 / bf16 / f16 activations) operators.  They follow the
+ * reference arithmetic step by step in f32 and are used for the f32 "plumbing" configuration,
+ * odd shapes (K % 128 != 0), gptq.int8 and grouped scales.
+ * ---------------------------------------------------------------------------------------- */
+
+/* y[M,N] = x[M,K] . W[N,K]^T + bias  — torch.nn.Linear (lit_llama/model.py:57,177,179,247-249) */
+int mi355_linear_dense(const void* x, int64_t ldx, const void* w, const void* bias, void* y, int64_t ldy,
+                       int M, int N, int K, int dtype, mi355_stream_t stream);
+
+/* ColBlockQuantizedLinear.forward via get_weight + F.linear (lit_llama/quantization.py:392-423):
+ * W[n,k] = (q[n,k] - zeros[n, k / tile_cols]) * scales[n, k / tile_cols]; bits in {4, 8}. */
+int mi355_linear_colblock(const void* x, int64_t ldx, const uint8_t* qweight, int64_t stride_n, int64_t stride_kb,
+                          const void* scales, const void* zeros, int sz_dtype, int n_groups, int tile_cols, int bits,
+                          const void* bias, void* y, int64_t ldy, int M, int N, int K, int dtype,
+                          mi355_stream_t stream);
+
+/* ColBlockQuantizedLinear.get_weight (lit_llama/quantization.py:392-411): out[N,K] row-major */
+int mi355_colblock_dequant(const uint8_t* qweight, int64_t stride_n, int64_t stride_kb, const void* scales,
+                           const void* zeros, int sz_dtype, int n_groups, int tile_cols, int bits, void* out,
+                           int out_dtype, int N, int K, mi355_stream_t stream);
+
+/* RMSNorm.forward (lit_llama/model.py:270-277): y = scale * (x * rsqrt(mean(x^2) + eps)) */
+int mi355_rmsnorm(const void* x, int64_t ldx, const void* scale, int scale_dtype, float eps, void* y, int64_t ldy,
+                  int M, int C, int x_dtype, int y_dtype, mi355_stream_t stream);
+
+/* apply_rope (lit_llama/model.py:306-323): x [B, T, n_head, hs] (contiguous), rope [T, hs/2, 2] f32 */
+int mi355_apply_rope(const void* x, const float* rope, void* y, int B, int T, int n_head, int hs, int dtype,
+                     mi355_stream_t stream);
+
+/* MLP gate: y = silu(a) * b  (lit_llama/model.py:252) */
+int mi355_swiglu(const void* a, const void* b, void* y, int64_t n, int dtype, mi355_stream_t stream);
+
+/* residual add: y = a + b (lit_llama/model.py:166-167) */
+int mi355_add(const void* a, const void* b, void* y, int64_t n, int dtype, mi355_stream_t stream);
+
+/* nn.Embedding gather (lit_llama/model.py:102): y[m, :] = wte[idx[m], :]; idx is int32 or int64 */
+int mi355_embedding(const void* idx, int idx_is_i64, const void* wte, int w_dtype, void* y, int y_dtype, int M, int C,
+                    int vocab, mi355_stream_t stream);
+
+/* greedy sampling (generate.py:68-76 with top_k = 1): out[0] = argmax(logits[0..V)) (first maximal index);
+ * optionally also stored at out2[out2_pos ? out2_pos[0] + 1 : 0] (the `idx.index_copy(0, input_pos, idx_next)`
+ * of generate.py:85 with the position read from device memory); pass NULL to skip */
+int mi355_argmax(const float* logits, int V, int32_t* out, int32_t* out2, const int32_t* out2_pos,
+                 mi355_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention with KV cache — CausalSelfAttention.forward without the two linears
+ * (lit_llama/model.py:199-232): split q,k,v ([Q;K;V] along the feature dim, :197), RoPE on q,k in f32
+ * (:204-205), cache write at slot min(pos, S-1) (:217-220; the roll of :214-218 is mi355_kv_roll),
+ * softmax(q k^T / sqrt(hs)) v over slots [0, slot] (:230 with the causal mask of :93-99).
+ *   qkv    [B*T, ld_qkv]: q at column h*hs, k at C + h*hs, v at 2C + h*hs (C = n_head*hs)
+ *   pos    device int32 [T]: absolute positions (RoPE row, cache slot)
+ *   cache  [B, n_head, S, hs] each, dtype cache_dtype; may be NULL (no cache: keys are the T new tokens)
+ *   y      [B*T, ldy] of y_dtype, head h at column h*hs
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mi355_attn_args {
+    const void* qkv;
+    int32_t qkv_dtype;
+    int32_t B;
+    int64_t ld_qkv;
+    const float* rope;  /* [block_size, hs/2, 2] */
+    const int32_t* pos; /* device [T] */
+    void* kcache;
+    void* vcache;
+    int32_t cache_dtype;
+    int32_t T;
+    int32_t n_head;
+    int32_t hs;
+    int32_t S;          /* cache length (max_seq_length) */
+    int32_t y_dtype;
+    void* y;
+    int64_t ldy;
+    void* kv_tmp;       /* when cache == NULL: scratch [2, B, n_head, T, hs] of cache_dtype */
+} mi355_attn_args;
+
+int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream);
+
+/* torch.roll(cache, -1, dims=2) of lit_llama/model.py:217-218, in place, for both caches */
+int mi355_kv_roll(void* kcache, void* vcache, int cache_dtype, int B, int n_head, int S, int hs,
+                  mi355_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LLM.int8 (Linear8bitLt, lit_llama/quantization.py:38-77 + bitsandbytes MatMul8bitLt).
+ * ---------------------------------------------------------------------------------------- */
+
+/* bnb.functional.double_quant(W) as used at lit_llama/quantization.py:69-77:
+ * SCB[n] = max_k |W[n,k]| (f32), CB[n,k] = rint(127 * W[n,k] / SCB[n]); W is [N,K] of dtype (rounded to f16 first) */
+int mi355_int8_quant_rows(const void* w, int dtype, int N, int K, int8_t* cb, float* scb, mi355_stream_t stream);
+
+typedef struct mi355_int8_args {
+    const int8_t* w;    /* I8 stream (mi355_i8_repack) */
+    const float* scb;   /* [N] */
+    int32_t N, K;
+    const void* x;      /* [M, ldx] */
+    int32_t x_dtype;
+    int32_t M;
+    int64_t ldx;
+    const void* norm_scale;
+    int32_t norm_dtype;
+    float eps;
+    float threshold;    /* 6.0 */
+    int32_t R;
+    const void* bias;   /* [N] f16-valued, dtype bias_dtype, or NULL */
+    int32_t bias_dtype;
+    int32_t epi;        /* STORE / ACCUM / SWIGLU (scb2 for the second matrix) */
+    const float* scb2;
+    void* y;
+    int32_t y_dtype;
+    int32_t waves;
+    int64_t ldy;
+    int32_t grid;
+    int32_t prefetch;
+} mi355_int8_args;
+
+int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-forward entry: LLaMA.forward (lit_llama/model.py:76-122) for B = 1, T <= 16 tokens with
+ * KV cache, entered once per call; the T = 1 step can be captured in a hipGraph and replayed
+ * (positions / token ids live in device memory so the graph is static).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mi355_weight {
+    int32_t fmt;        /* MI355_W_* */
+    int32_t R;
+    const void* w;
+    int32_t N, K;
+    const void* scales;
+    const void* zeros;
+    const void* scales2;
+    const void* zeros2;
+    const float* scb;   /* I8 */
+    const float* scb2;
+    int32_t sz_dtype;
+    int32_t waves;
+    int32_t grid;
+    int32_t prefetch;
+} mi355_weight;
+
+typedef struct mi355_layer {
+    const void* rms1;
+    const void* rms2;
+    mi355_weight attn;   /* c_attn   [3C, C] */
+    mi355_weight proj;   /* c_proj   [C, C]  */
+    mi355_weight fc;     /* c_fc1/c_fc2 interleaved, N = n_hidden */
+    mi355_weight mproj;  /* mlp.c_proj [C, n_hidden] */
+    void* kcache;
+    void* vcache;
+} mi355_layer;
+
+typedef struct mi355_model {
+    int32_t n_layer, n_head, n_embd, hs, n_hidden, vocab, S, block_size;
+    int32_t param_dtype;  /* dtype of wte, norm scales */
+    int32_t cache_dtype;
+    int32_t tp_world;     /* >1: the caller all-reduces between segments (see mi355_model_segment) */
+    int32_t max_T;
+    float eps;
+    float int8_threshold;
+    const void* wte;
+    const void* ln_f;
+    mi355_weight lm_head;
+    const float* rope;
+    const mi355_layer* layers; /* host pointer to n_layer entries */
+    /* device scratch owned by the caller */
+    float* x;             /* [max_T, C] residual stream (f32) */
+    float* qkv;           /* [max_T, 3C] */
+    void* att;            /* [max_T, C] bf16 */
+    void* hbuf;           /* [max_T, n_hidden] bf16 */
+    float* partial;       /* [max_T, C] row-parallel partial sums (tensor parallel only) */
+    float* logits;        /* [max_T, vocab] */
+    int32_t* tokens;      /* [max_T] */
+    int32_t* pos;         /* [max_T] */
+    int32_t* next_token;  /* [1] */
+    int32_t* out_tokens;  /* [block_size + 1] generated ids, indexed by pos + 1, or NULL */
+} mi355_model;
+
+/* copy token ids / positions into the model's device slots (tiny kernel; arguments travel by value) */
+int mi355_set_step(const mi355_model* m, const void* idx, int idx_is_i64, int T, int pos0, int from_next_token,
+                   mi355_stream_t stream);
+
+/* enqueue one forward over T tokens already placed by mi355_set_step.
+ * logits_mode: 0 none, 1 last token only (row 0 of m->logits), 2 all T rows; argmax != 0 appends greedy sampling */
+int mi355_forward(const mi355_model* m, int T, int logits_mode, int argmax, mi355_stream_t stream);
+
+/* The same forward cut into pieces, for callers that must interleave collectives (tensor parallel):
+ *   mi355_forward_embed: x = wte[tokens]
+ *   mi355_forward_segment(layer, seg_begin, seg_end): segments 0 = RMSNorm + c_attn + RoPE/KV/attention,
+ *     1 = attn.c_proj, 2 = RMSNorm + c_fc1/c_fc2 + SwiGLU, 3 = mlp.c_proj.  With tp_world > 1 segments 1 and 3
+ *     store the rank's partial sums in m->partial (row-parallel linears, shard_dims of
+ *     scripts/convert_checkpoint.py:57-65); the caller all-reduces `partial` and calls mi355_residual_add.
+ *   mi355_forward_head: ln_f + lm_head (+ greedy argmax when not sharded). */
+int mi355_forward_embed(const mi355_model* m, int T, mi355_stream_t stream);
+int mi355_forward_segment(const mi355_model* m, int T, int layer, int seg_begin, int seg_end, mi355_stream_t stream);
+int mi355_residual_add(const mi355_model* m, int T, mi355_stream_t stream);
+int mi355_forward_head(const mi355_model* m, int T, int logits_mode, int argmax, mi355_stream_t stream);
+
+/* hipGraph of the T = 1 step (logits_mode 1).  capture/destroy synchronise the stream. */
+typedef struct mi355_graph mi355_graph;
+int mi355_graph_capture(const mi355_model* m, int argmax, mi355_stream_t stream, mi355_graph** out);
+int mi355_graph_launch(mi355_graph* g, mi355_stream_t stream);
+int mi355_graph_destroy(mi355_graph* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_LLAMA_H */

@@ -1,0 +1,129 @@
+// Shared device/host helpers for libmi355llama (gfx950 only; no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mi355_llama.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef uint16_t f16_t;   // raw f16 bits
+
+// ---------------------------------------------------------------- error plumbing (host)
+void mi355_set_error(const char* fmt, ...);
+
+#define MI355_CHECK_ARG(cond, code, ...)          \
+    do {                                          \
+        if (!(cond)) {                            \
+            mi355_set_error(__VA_ARGS__);         \
+            return (code);                        \
+        }                                         \
+    } while (0)
+
+#define MI355_HIP(expr)                                                                    \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            mi355_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (int)e__;                                                               \
+        }                                                                                  \
+    } while (0)
+
+#define MI355_LAUNCH_CHECK()                                                               \
+    do {                                                                                   \
+        hipError_t e__ = hipGetLastError();                                                \
+        if (e__ != hipSuccess) {                                                           \
+            mi355_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (int)e__;                                                               \
+        }                                                                                  \
+    } while (0)
+
+// ---------------------------------------------------------------- scalar conversions (device)
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even, NaN preserved (same rule as torch's float -> bfloat16)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float f16_to_f32(f16_t h) {
+    _Float16 v;
+    __builtin_memcpy(&v, &h, 2);
+    return (float)v;
+}
+__device__ __forceinline__ f16_t f32_to_f16(float f) {
+    _Float16 v = (_Float16)f;  // v_cvt_f16_f32: RNE
+    f16_t h;
+    __builtin_memcpy(&h, &v, 2);
+    return h;
+}
+
+// element load/store by runtime dtype code (MI355_F32 / BF16 / F16); dtype is wave-uniform
+__device__ __forceinline__ float ld_as_f32(const void* p, int64_t i, int dtype) {
+    if (dtype == MI355_F32) return ((const float*)p)[i];
+    if (dtype == MI355_BF16) return bf16_to_f32(((const bf16_t*)p)[i]);
+    return f16_to_f32(((const f16_t*)p)[i]);
+}
+__device__ __forceinline__ void st_from_f32(void* p, int64_t i, int dtype, float v) {
+    if (dtype == MI355_F32)
+        ((float*)p)[i] = v;
+    else if (dtype == MI355_BF16)
+        ((bf16_t*)p)[i] = f32_to_bf16(v);
+    else
+        ((f16_t*)p)[i] = f32_to_f16(v);
+}
+// round a float through the storage dtype (what a torch tensor of that dtype would hold)
+__device__ __forceinline__ float round_to(float v, int dtype) {
+    if (dtype == MI355_F32) return v;
+    if (dtype == MI355_BF16) return bf16_to_f32(f32_to_bf16(v));
+    return f16_to_f32(f32_to_f16(v));
+}
+
+__host__ __device__ __forceinline__ int dtype_size(int dtype) { return dtype == MI355_F32 ? 4 : 2; }
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum; `red` is LDS scratch of >= 32 floats; result broadcast to all threads.
+// Fixed lane->wave->serial order, so the result is reproducible run to run.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();  // protect `red` against a previous use
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t += red[w];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int w = 1; w < nw; ++w) t = fmaxf(t, red[w]);
+    return t;
+}
+
+// silu(a) * b in f32 (F.silu: a * sigmoid(a))
+__device__ __forceinline__ float swiglu_f32(float a, float b) { return (a / (1.0f + expf(-a))) * b; }

@@ -1,0 +1,263 @@
+// Whole-forward entry of libmi355llama: LLaMA.forward (/root/reference lit_llama/model.py:76-122) for
+// B = 1 and T <= max_T tokens with KV cache, entered ONCE per call from the host and, for the T = 1
+// decode step, captured in a hipGraph and replayed.
+//
+// The reference walks 32 Blocks from Python with ~20 ATen launches each and one device->host sync per
+// layer (model.py:214).  Here a layer is five launches:
+//     [RMSNorm -> c_attn]  ->  [RoPE + KV write + attention]  ->  [attn.c_proj + residual]
+//     -> [RMSNorm -> c_fc1/c_fc2 -> SwiGLU]  ->  [mlp.c_proj + residual]
+// and token ids / positions live in device memory (mi355_set_step writes them), so the captured graph
+// is static and nothing on the host depends on device results.
+#include "common.h"
+
+// implemented in int8.hip: the LLM.int8 linear driven from a mi355_weight descriptor
+int mi355_linear_int8_from_weight(const mi355_weight* w, const mi355_model* m, const void* x, int x_dtype, int M,
+                                  int64_t ldx, const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy,
+                                  hipStream_t stream);
+
+namespace {
+
+__global__ void set_step_kernel(int32_t* tokens, int32_t* pos, const void* idx, int idx_is_i64, int T, int pos0,
+                                const int32_t* next_token, int from_next) {
+    const int t = threadIdx.x;
+    if (t < T) {
+        int32_t tok;
+        if (from_next)
+            tok = next_token[0];
+        else
+            tok = idx_is_i64 ? (int32_t)((const int64_t*)idx)[t] : ((const int32_t*)idx)[t];
+        tokens[t] = tok;
+        pos[t] = pos0 + t;
+    }
+}
+
+__global__ void add_f32_kernel(float* x, const float* p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] += p[i];
+}
+
+int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x_dtype, int M, int64_t ldx,
+               const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy, hipStream_t s) {
+    if (w.fmt == MI355_W_I8) {
+        return mi355_linear_int8_from_weight(&w, m, x, x_dtype, M, ldx, norm_scale, epi, y, y_dtype, ldy, s);
+    }
+    mi355_linear_args a;
+    memset(&a, 0, sizeof(a));
+    a.fmt = w.fmt;
+    a.R = w.R;
+    a.w = w.w;
+    a.N = w.N;
+    a.K = w.K;
+    a.x = x;
+    a.x_dtype = x_dtype;
+    a.M = M;
+    a.ldx = ldx;
+    a.norm_scale = norm_scale;
+    a.norm_dtype = m->param_dtype;
+    a.eps = m->eps;
+    a.scales = w.scales;
+    a.zeros = w.zeros;
+    a.scales2 = w.scales2;
+    a.zeros2 = w.zeros2;
+    a.sz_dtype = w.sz_dtype;
+    a.epi = epi;
+    a.bias = nullptr;
+    a.y = y;
+    a.y_dtype = y_dtype;
+    a.ldy = ldy;
+    a.waves = w.waves;
+    a.grid = w.grid;
+    a.prefetch = w.prefetch;
+    a.flags = 0;
+    return mi355_linear_fast(&a, s);
+}
+
+}  // namespace
+
+extern "C" int mi355_set_step(const mi355_model* m, const void* idx, int idx_is_i64, int T, int pos0,
+                              int from_next_token, mi355_stream_t stream) {
+    MI355_CHECK_ARG(m != nullptr && m->tokens && m->pos, MI355_E_ARG, "set_step: null model/slots");
+    MI355_CHECK_ARG(T >= 1 && T <= m->max_T && T <= 64, MI355_E_SHAPE, "set_step: T=%d outside 1..%d", T, m->max_T);
+    MI355_CHECK_ARG(from_next_token ? (m->next_token != nullptr && T == 1) : (idx != nullptr), MI355_E_ARG,
+                    "set_step: no token source");
+    MI355_CHECK_ARG(pos0 >= 0 && pos0 + T <= m->block_size, MI355_E_SHAPE,
+                    "set_step: positions %d..%d exceed block_size %d (RoPE table)", pos0, pos0 + T - 1, m->block_size);
+    hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, m->tokens, m->pos, idx, idx_is_i64,
+                       T, pos0, m->next_token, from_next_token);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi355_forward(const mi355_model* m, int T, int logits_mode, int argmax, mi355_stream_t stream) {
+    MI355_CHECK_ARG(m != nullptr && m->layers != nullptr, MI355_E_ARG, "forward: null model");
+    MI355_CHECK_ARG(T >= 1 && T <= m->max_T, MI355_E_SHAPE, "forward: T=%d outside 1..%d", T, m->max_T);
+    MI355_CHECK_ARG(logits_mode >= 0 && logits_mode <= 2, MI355_E_ARG, "forward: bad logits_mode");
+    MI355_CHECK_ARG(!argmax || logits_mode != 0, MI355_E_ARG, "forward: argmax needs logits");
+    MI355_CHECK_ARG(m->x && m->qkv && m->att && m->hbuf && m->tokens && m->pos, MI355_E_ARG, "forward: null scratch");
+    MI355_CHECK_ARG(m->tp_world <= 1 || m->partial != nullptr, MI355_E_ARG, "forward: tensor parallel needs `partial`");
+    MI355_CHECK_ARG(m->tp_world <= 1, MI355_E_STATE,
+                    "forward: tensor-parallel models are driven segment by segment (mi355_forward_segment)");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = m->n_embd;
+
+    if (int rc = mi355_embedding(m->tokens, 0, m->wte, m->param_dtype, m->x, MI355_F32, T, C, m->vocab, s)) return rc;
+
+    for (int l = 0; l < m->n_layer; ++l) {
+        if (int rc = mi355_forward_segment(m, T, l, 0, 4, s)) return rc;
+    }
+    return mi355_forward_head(m, T, logits_mode, argmax, s);
+}
+
+// segments of layer l: 0 = RMSNorm + c_attn + attention, 1 = attn.c_proj, 2 = RMSNorm + fc + SwiGLU, 3 = mlp.c_proj.
+// With tp_world > 1 segments 1 and 3 write the rank's partial sum to m->partial (the caller all-reduces it and
+// calls mi355_residual_add); with tp_world == 1 they accumulate into the residual stream directly.
+extern "C" int mi355_forward_segment(const mi355_model* m, int T, int layer, int seg_begin, int seg_end,
+                                     mi355_stream_t stream) {
+    MI355_CHECK_ARG(m != nullptr && m->layers != nullptr, MI355_E_ARG, "forward_segment: null model");
+    MI355_CHECK_ARG(layer >= 0 && layer < m->n_layer, MI355_E_ARG, "forward_segment: bad layer %d", layer);
+    MI355_CHECK_ARG(seg_begin >= 0 && seg_end <= 4 && seg_begin < seg_end, MI355_E_ARG, "forward_segment: bad range");
+    MI355_CHECK_ARG(T >= 1 && T <= m->max_T, MI355_E_SHAPE, "forward_segment: T=%d outside 1..%d", T, m->max_T);
+    hipStream_t s = (hipStream_t)stream;
+    const mi355_layer& L = m->layers[layer];
+    const int C = m->n_embd;
+    const int Cl = m->n_head * m->hs;  // local attention width (== C unless tensor parallel)
+    const bool tp = m->tp_world > 1;
+    for (int seg = seg_begin; seg < seg_end; ++seg) {
+        switch (seg) {
+            case 0: {
+                if (int rc = run_linear(m, L.attn, m->x, MI355_F32, T, C, L.rms1, MI355_EPI_STORE, m->qkv, MI355_F32,
+                                        3 * Cl, s))
+                    return rc;
+                mi355_attn_args a;
+                memset(&a, 0, sizeof(a));
+                a.qkv = m->qkv;
+                a.qkv_dtype = MI355_F32;
+                a.B = 1;
+                a.ld_qkv = 3 * Cl;
+                a.rope = m->rope;
+                a.pos = m->pos;
+                a.kcache = L.kcache;
+                a.vcache = L.vcache;
+                a.cache_dtype = m->cache_dtype;
+                a.T = T;
+                a.n_head = m->n_head;
+                a.hs = m->hs;
+                a.S = m->S;
+                a.y_dtype = MI355_BF16;
+                a.y = m->att;
+                a.ldy = Cl;
+                if (int rc = mi355_attention(&a, s)) return rc;
+                break;
+            }
+            case 1:
+                if (int rc = run_linear(m, L.proj, m->att, MI355_BF16, T, Cl, nullptr,
+                                        tp ? MI355_EPI_STORE : MI355_EPI_ACCUM, tp ? m->partial : m->x, MI355_F32, C, s))
+                    return rc;
+                break;
+            case 2:
+                if (int rc = run_linear(m, L.fc, m->x, MI355_F32, T, C, L.rms2, MI355_EPI_SWIGLU, m->hbuf, MI355_BF16,
+                                        m->n_hidden, s))
+                    return rc;
+                break;
+            case 3:
+                if (int rc = run_linear(m, L.mproj, m->hbuf, MI355_BF16, T, m->n_hidden, nullptr,
+                                        tp ? MI355_EPI_STORE : MI355_EPI_ACCUM, tp ? m->partial : m->x, MI355_F32, C, s))
+                    return rc;
+                break;
+        }
+    }
+    return 0;
+}
+
+extern "C" int mi355_forward_embed(const mi355_model* m, int T, mi355_stream_t stream) {
+    MI355_CHECK_ARG(m != nullptr && m->x && m->tokens, MI355_E_ARG, "forward_embed: null model");
+    MI355_CHECK_ARG(T >= 1 && T <= m->max_T, MI355_E_SHAPE, "forward_embed: T=%d outside 1..%d", T, m->max_T);
+    return mi355_embedding(m->tokens, 0, m->wte, m->param_dtype, m->x, MI355_F32, T, m->n_embd, m->vocab,
+                           (hipStream_t)stream);
+}
+
+extern "C" int mi355_residual_add(const mi355_model* m, int T, mi355_stream_t stream) {
+    MI355_CHECK_ARG(m != nullptr && m->x && m->partial, MI355_E_ARG, "residual_add: null model/partial");
+    const int n = T * m->n_embd;
+    hipLaunchKernelGGL(add_f32_kernel, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, m->x, m->partial, n);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi355_forward_head(const mi355_model* m, int T, int logits_mode, int argmax, mi355_stream_t stream) {
+    MI355_CHECK_ARG(m != nullptr, MI355_E_ARG, "forward_head: null model");
+    MI355_CHECK_ARG(T >= 1 && T <= m->max_T, MI355_E_SHAPE, "forward_head: T=%d outside 1..%d", T, m->max_T);
+    if (logits_mode == 0) return 0;
+    MI355_CHECK_ARG(m->logits != nullptr, MI355_E_ARG, "forward_head: null logits buffer");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = m->n_embd;
+    const int V = m->lm_head.N;  // local vocab rows (== vocab unless tensor parallel)
+    // ln_f is fused into the lm_head prologue (model.py:118-120)
+    if (logits_mode == 1) {
+        if (int rc = run_linear(m, m->lm_head, m->x + (size_t)(T - 1) * C, MI355_F32, 1, C, m->ln_f, MI355_EPI_STORE,
+                                m->logits, MI355_F32, V, s))
+            return rc;
+    } else {
+        if (int rc = run_linear(m, m->lm_head, m->x, MI355_F32, T, C, m->ln_f, MI355_EPI_STORE, m->logits, MI355_F32, V,
+                                s))
+            return rc;
+    }
+    if (argmax) {
+        MI355_CHECK_ARG(m->next_token != nullptr, MI355_E_ARG, "forward_head: argmax without next_token slot");
+        MI355_CHECK_ARG(m->tp_world <= 1, MI355_E_STATE, "forward_head: argmax over sharded logits is done by the caller");
+        const float* row = logits_mode == 1 ? m->logits : m->logits + (size_t)(T - 1) * V;
+        // generate.py:79,85: the new id lands at position input_pos[-1] + 1
+        if (int rc = mi355_argmax(row, V, m->next_token, m->out_tokens, m->out_tokens ? m->pos + (T - 1) : nullptr, s))
+            return rc;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ hipGraph of the T = 1 step
+struct mi355_graph {
+    hipGraphExec_t exec;
+};
+
+extern "C" int mi355_graph_capture(const mi355_model* m, int argmax, mi355_stream_t stream, mi355_graph** out) {
+    MI355_CHECK_ARG(m != nullptr && out != nullptr, MI355_E_ARG, "graph_capture: null argument");
+    MI355_CHECK_ARG(stream != nullptr, MI355_E_ARG,
+                    "graph_capture: the legacy default stream cannot be captured; pass a created stream");
+    hipStream_t s = (hipStream_t)stream;
+    MI355_HIP(hipStreamSynchronize(s));
+    MI355_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = mi355_forward(m, 1, 1, argmax, s);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != 0) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    if (e != hipSuccess || graph == nullptr) {
+        mi355_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        return e != hipSuccess ? (int)e : MI355_E_STATE;
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e2 != hipSuccess) {
+        mi355_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+        return (int)e2;
+    }
+    mi355_graph* g = new mi355_graph;
+    g->exec = exec;
+    *out = g;
+    return 0;
+}
+
+extern "C" int mi355_graph_launch(mi355_graph* g, mi355_stream_t stream) {
+    MI355_CHECK_ARG(g != nullptr && g->exec != nullptr, MI355_E_ARG, "graph_launch: null graph");
+    MI355_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int mi355_graph_destroy(mi355_graph* g) {
+    if (g == nullptr) return 0;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    delete g;
+    return 0;
+}

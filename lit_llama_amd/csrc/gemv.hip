@@ -1,0 +1,639 @@
+// Skinny (M <= 16) weight-streaming linear for gfx950: the decode hot kernel.
+//
+// Replaces, for decode shapes, the reference's Triton `linear_kernel_4bit_weight`
+// (/root/reference lit_llama/quantization.py:187-333, reached from
+// ColBlockQuantizedLinear.forward :413-421) and the dense F.linear of lit_llama/model.py.
+//
+// Design:
+//  * HBM-bound: each weight byte is read exactly once, as fully coalesced 1-KiB wave loads
+//    (64 lanes x 16 B, non-temporal) from a load-time repacked stream
+//    [tile][unit][r][lane][16 B] — straight into VGPRs, no LDS round trip for weights
+//    (they are not shared between waves), a P-deep register ring keeps P KiB per wave in flight
+//    across tile boundaries and across the block-level reduction.
+//  * The multiply runs on the matrix pipe, which is otherwise idle in a GEMV:
+//    v_mfma_f32_16x16x32_bf16 with A = 16 weight rows x 32 k, B = the (<= 16) activation rows.
+//    int4 weights become bf16 MFMA operands with 7 VALU ops per 8 weights:
+//    (w >> 4i) & 0x000F000F | 0x43004300 is the bf16 pair (128 + q_a, 128 + q_b) exactly;
+//    the +128 and the GPTQ zero point are removed in the epilogue:
+//        y[n] = scale[n] * (acc[n] - (128 + zero[n]) * sum_k x[k]).
+//  * The activation vector (optionally RMSNorm'ed on the fly) is staged once per workgroup
+//    into LDS as bf16; B fragments are 16-B LDS broadcasts.
+//  * K is split over the waves of a workgroup; partial 16x16 tiles are combined through LDS in
+//    a fixed order (deterministic), then the epilogue (dequant, bias, residual accumulate or
+//    SwiGLU of an interleaved c_fc1/c_fc2 pair) writes the 16*R outputs of the tile.
+#include <mutex>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kUnitK = 128;        // input columns per stream unit
+constexpr int kMaxM = 16;
+constexpr int kLdsHeader = 512;    // red[64] + sx[16] floats (+pad)
+constexpr int kMaxLds = 160 * 1024;
+
+struct GemvParams {
+    const uint8_t* w;
+    const void* x;
+    const void* norm_scale;
+    const void* scales;
+    const void* zeros;
+    const void* scales2;
+    const void* zeros2;
+    const void* bias;
+    void* y;
+    int64_t ldx, ldy;
+    int N, K, M, n_tiles, units;
+    int x_dtype, norm_dtype, sz_dtype, y_dtype, epi;
+    int xs_stride;  // bytes per LDS activation row
+    float eps;
+};
+
+template <int FMT>
+struct Fmt;
+template <>
+struct Fmt<MI355_W_Q4> {
+    static constexpr int kPieces = 1;  // 16-B pieces per (unit, r) per lane
+};
+template <>
+struct Fmt<MI355_W_BF16> {
+    static constexpr int kPieces = 4;
+};
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// f32 / bf16 only (keeps the unrolled hot loop small; f16 tensors go through the generic operators)
+__device__ __forceinline__ float ld2(const void* p, int64_t i, int dtype) {
+    return dtype == MI355_F32 ? ((const float*)p)[i] : bf16_to_f32(((const bf16_t*)p)[i]);
+}
+__device__ __forceinline__ void st2(void* p, int64_t i, int dtype, float v) {
+    if (dtype == MI355_F32)
+        ((float*)p)[i] = v;
+    else
+        ((bf16_t*)p)[i] = f32_to_bf16(v);
+}
+
+template <bool NT>
+__device__ __forceinline__ u32x4 ldw(const uint8_t* p) {
+    if constexpr (NT)
+        return __builtin_nontemporal_load((const u32x4*)p);
+    else
+        return *(const u32x4*)p;
+}
+
+// Stage activations into LDS as bf16 (optionally RMSNorm'ed), and the per-row sums needed to undo
+// the +128 / zero-point offsets.  lit_llama/model.py:270-277 for the norm arithmetic.
+// Columns K..units*128 are zero-filled (the stream pads K up to a whole unit).
+__device__ __forceinline__ void stage_x(const GemvParams& p, char* xs, float* sx, float* red) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int Kp = p.units * kUnitK;
+    for (int m = 0; m < p.M; ++m) {
+        const int64_t base = (int64_t)m * p.ldx;
+        float rinv = 1.f;
+        if (p.norm_scale != nullptr) {
+            float ss = 0.f;
+            for (int k = tid; k < p.K; k += nt) {
+                const float v = ld2(p.x, base + k, p.x_dtype);
+                ss += v * v;
+            }
+            ss = block_sum(ss, red);
+            rinv = rsqrtf(ss / (float)p.K + p.eps);
+        }
+        bf16_t* row = (bf16_t*)(xs + (size_t)m * p.xs_stride);
+        float s = 0.f;
+        for (int k = tid; k < Kp; k += nt) {
+            bf16_t b = 0;
+            if (k < p.K) {
+                float v = ld2(p.x, base + k, p.x_dtype);
+                if (p.norm_scale != nullptr) v = ld2(p.norm_scale, k, p.norm_dtype) * (v * rinv);
+                b = f32_to_bf16(v);
+            }
+            row[k] = b;
+            s += bf16_to_f32(b);
+        }
+        s = block_sum(s, red);
+        if (tid == 0) sx[m] = s;
+    }
+    __syncthreads();
+}
+
+// Per-output operands of one tile's epilogue, owned by thread (e_row, e_col) of the first 256 threads and
+// fetched ONE TILE AHEAD: an epilogue that issued its own loads would have to wait for them with vmcnt(0),
+// draining the weight ring at every tile.
+// The loads are kept as RAW bits (converted at use): converting right after the load would make hipcc wait
+// for it on the spot.
+template <int R>
+struct EpiOps {
+    uint32_t s[R], z[R];   // Q4 scale / zero of the output row (sz_dtype bits)
+    uint32_t bias[R];      // sz_dtype bits
+    uint32_t old[R];       // y_dtype bits of the value to accumulate into
+};
+
+__device__ __forceinline__ uint32_t ld2_raw(const void* p, int64_t i, int dtype) {
+    return dtype == MI355_F32 ? ((const uint32_t*)p)[i] : (uint32_t)((const uint16_t*)p)[i];
+}
+__device__ __forceinline__ float cvt2(uint32_t raw, int dtype) {
+    return dtype == MI355_F32 ? __uint_as_float(raw) : __uint_as_float(raw << 16);
+}
+
+template <int FMT, int R>
+__device__ __forceinline__ void load_epi(const GemvParams& p, int tile, int e_row, int e_col, bool e_owner,
+                                         EpiOps<R>& o) {
+    if (e_owner && tile < p.n_tiles) {
+        const bool sw = p.epi == MI355_EPI_SWIGLU;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = sw ? tile * 16 + e_row : (tile * R + r) * 16 + e_row;
+            if (n < p.N) {
+                if constexpr (FMT == MI355_W_Q4) {
+                    o.s[r] = ld2_raw((sw && r == 1) ? p.scales2 : p.scales, n, p.sz_dtype);
+                    o.z[r] = ld2_raw((sw && r == 1) ? p.zeros2 : p.zeros, n, p.sz_dtype);
+                }
+                if (!sw) {
+                    if (p.bias != nullptr) o.bias[r] = ld2_raw(p.bias, n, p.sz_dtype);
+                    if (p.epi == MI355_EPI_ACCUM) o.old[r] = ld2_raw(p.y, (int64_t)e_col * p.ldy + n, p.y_dtype);
+                }
+            }
+        }
+    }
+}
+
+// Combine the W partial 16x16 tiles of `buf` in wave order and write the tile's outputs (stores only).
+template <int FMT, int R>
+__device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* part, int buf, int W, int tile,
+                                              int e_row, int e_col, const EpiOps<R>& o, const float* sx) {
+    // D layout of mfma_f32_16x16x32: lane (row >> 2) * 16 + col holds D[row][col] in register (row & 3)
+    const int src = ((e_row >> 2) << 4) | e_col;
+    const float* base = (const float*)(part + (size_t)(buf * W * R) * 1024) + src * 4 + (e_row & 3);
+    float v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+        for (int w = 0; w < W; ++w) s += base[(w * R + r) * 256];
+        if constexpr (FMT == MI355_W_Q4)
+            s = cvt2(o.s[r], p.sz_dtype) * (s - (128.f + cvt2(o.z[r], p.sz_dtype)) * sx[e_col]);
+        v[r] = s;
+    }
+    if (p.epi == MI355_EPI_SWIGLU) {
+        if constexpr (R == 2) {
+            const int n = tile * 16 + e_row;
+            if (n < p.N) st2(p.y, (int64_t)e_col * p.ldy + n, p.y_dtype, swiglu_f32(v[0], v[1]));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = (tile * R + r) * 16 + e_row;
+            if (n < p.N) {
+                float out = v[r];
+                if (p.bias != nullptr) out += cvt2(o.bias[r], p.sz_dtype);
+                if (p.epi == MI355_EPI_ACCUM) out += cvt2(o.old[r], p.y_dtype);
+                st2(p.y, (int64_t)e_col * p.ldy + n, p.y_dtype, out);
+            }
+        }
+    }
+}
+
+template <int FMT, int R, int P, bool NT>
+__global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)smem;
+    float* sx = (float*)(smem + 256);
+    char* part = smem + kLdsHeader;
+
+    constexpr int kPieces = Fmt<FMT>::kPieces;
+    constexpr int kSlot = R * kPieces;  // 16-B pieces per lane per unit
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    char* xs = part + 2 * W * R * 1024;
+
+    const int units = p.units;
+    const int u0 = (units * wave) / W, u1 = (units * (wave + 1)) / W;
+    const int nu = u1 - u0;
+    const int bid = blockIdx.x, nb = gridDim.x;
+    const int my_tiles = (p.n_tiles > bid) ? (p.n_tiles - bid + nb - 1) / nb : 0;
+    const int total = my_tiles * nu;
+
+    const int64_t unit_bytes = (int64_t)kSlot * 1024;
+    const uint8_t* wl = p.w + lane * 16;
+
+    // ---- weight prefetch ring: P units in flight per wave.
+    // Every refill is an UNCONDITIONAL load (past the end of the wave's work it re-reads the first KiB of
+    // the stream, an L2 hit): a conditional refill makes the ring registers phi nodes, and hipcc then drains
+    // the whole ring with s_waitcnt vmcnt(0) at the loop back-edge to copy them.
+    u32x4 ring[P][kSlot];
+    int pf_tile = bid, pf_u = u0, pf_n = 0;
+#define MI355_ISSUE(slot)                                                                                       \
+    do {                                                                                                        \
+        const bool ok__ = pf_n < total;                                                                         \
+        const uint8_t* src__ = ok__ ? wl + ((int64_t)pf_tile * units + pf_u) * unit_bytes : wl;                 \
+        _Pragma("unroll") for (int s__ = 0; s__ < kSlot; ++s__) ring[slot][s__] = ldw<NT>(src__ + s__ * 1024);  \
+        ++pf_n;                                                                                                 \
+        if (ok__ && ++pf_u == u1) {                                                                             \
+            pf_u = u0;                                                                                          \
+            pf_tile += nb;                                                                                      \
+        }                                                                                                       \
+    } while (0)
+
+#pragma unroll
+    for (int j = 0; j < P; ++j) MI355_ISSUE(j);
+
+    // ---- per-tile epilogue operands, fetched one tile ahead (threads < 256 own output (row, col))
+    const int e_row = (threadIdx.x >> 4) & 15, e_col = threadIdx.x & 15;
+    const bool e_owner = threadIdx.x < 256 && e_col < p.M;
+    EpiOps<R> eo;
+#pragma unroll
+    for (int r = 0; r < R; ++r) eo.s[r] = eo.z[r] = eo.bias[r] = eo.old[r] = 0u;
+    load_epi<FMT, R>(p, bid, e_row, e_col, e_owner, eo);
+
+    stage_x(p, xs, sx, red);
+
+    f32x4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int tile = bid, buf = 0;
+
+    if (nu == 0) {
+        // more waves than units: this wave only takes part in the combine
+        for (int i = 0; i < my_tiles; ++i) {
+            f32x4* pp = (f32x4*)(part + (size_t)((buf * W + wave) * R) * 1024) + lane;
+#pragma unroll
+            for (int r = 0; r < R; ++r) pp[r * 64] = acc[r];
+            __syncthreads();
+            if (e_owner) tile_epilogue<FMT, R>(p, part, buf, W, tile, e_row, e_col, eo, sx);
+            tile += nb;
+            buf ^= 1;
+            load_epi<FMT, R>(p, tile, e_row, e_col, e_owner, eo);
+        }
+        return;
+    }
+
+    // ---- main loop
+    const int g = lane >> 4, c = lane & 15;
+    const int xrow = c < p.M ? c : p.M - 1;
+    const char* xl = xs + (size_t)xrow * p.xs_stride + g * 64;
+    int uu = 0;
+
+    for (int t = 0; t < total; t += P) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            if (t + j < total) {
+                const char* xb = xl + (u0 + uu) * (kUnitK * 2);
+                bf16x8 b[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) b[d] = *(const bf16x8*)(xb + 16 * d);
+
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if constexpr (FMT == MI355_W_Q4) {
+                        const u32x4 q = ring[j][r];
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const uint32_t v = q[d];
+                            u32x4 a;
+                            a[0] = (v & 0x000F000Fu) | 0x43004300u;
+                            a[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
+                            a[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
+                            a[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), b[d], acc[r], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d)
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ring[j][r * kPieces + d]), b[d],
+                                                                             acc[r], 0, 0, 0);
+                    }
+                }
+
+                if (++uu == nu) {
+                    // tile done for this wave: publish the partial 16x16 tiles, combine, epilogue
+                    uu = 0;
+                    f32x4* pp = (f32x4*)(part + (size_t)((buf * W + wave) * R) * 1024) + lane;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        pp[r * 64] = acc[r];
+                        acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    __syncthreads();
+                    if (e_owner) tile_epilogue<FMT, R>(p, part, buf, W, tile, e_row, e_col, eo, sx);
+                    tile += nb;
+                    buf ^= 1;
+                    load_epi<FMT, R>(p, tile, e_row, e_col, e_owner, eo);
+                }
+            }
+            MI355_ISSUE(j);  // refill the slot just consumed (dummy source once the work is exhausted)
+        }
+    }
+#undef MI355_ISSUE
+}
+
+// ------------------------------------------------------------------------------------ repack kernels
+// Rows >= N and columns >= K of the padded stream are written as zero (nibble 0 / bf16 0 / int8 0): the
+// staged activations are zero there too, so padding contributes exactly 0 to every accumulator.
+
+__global__ void q4_repack_kernel(const uint8_t* q0, const uint8_t* q1, int64_t stride_n, int64_t stride_kb, int N,
+                                 int K, int R, uint32_t* out, int64_t n_dwords) {
+    const int units = (K + kUnitK - 1) / kUnitK;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dwords;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i & 3);
+        const int lane = (int)((i >> 2) & 63);
+        int64_t rest = i >> 8;
+        const int r = (int)(rest % R);
+        rest /= R;
+        const int u = (int)(rest % units);
+        const int tile = (int)(rest / units);
+        const int g = lane >> 4, row = lane & 15;
+        const uint8_t* src;
+        int n;
+        if (q1 != nullptr) {
+            src = r == 0 ? q0 : q1;
+            n = tile * 16 + row;
+        } else {
+            src = q0;
+            n = (tile * R + r) * 16 + row;
+        }
+        uint32_t o = 0;
+        if (n < N) {
+#pragma unroll
+            for (int pnib = 0; pnib < 8; ++pnib) {
+                const int j = 2 * (pnib & 3) + (pnib >> 2);
+                const int k = kUnitK * u + 32 * g + 8 * d + j;
+                if (k < K) {
+                    const uint8_t byte = src[(int64_t)n * stride_n + (int64_t)(k >> 1) * stride_kb];
+                    const uint32_t nib = (k & 1) ? (byte >> 4) : (byte & 0xF);
+                    o |= nib << (4 * pnib);
+                }
+            }
+        }
+        out[i] = o;
+    }
+}
+
+// one thread per 16-B piece of 8 bf16
+__global__ void bf16_repack_kernel(const void* w0, const void* w1, int dtype, int N, int K, int R, u32x4* out,
+                                   int64_t n_pieces) {
+    const int units = (K + kUnitK - 1) / kUnitK;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pieces;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const int d = (int)((i >> 6) & 3);
+        int64_t rest = i >> 8;
+        const int r = (int)(rest % R);
+        rest /= R;
+        const int u = (int)(rest % units);
+        const int tile = (int)(rest / units);
+        const int g = lane >> 4, row = lane & 15;
+        const void* src;
+        int n;
+        if (w1 != nullptr) {
+            src = r == 0 ? w0 : w1;
+            n = tile * 16 + row;
+        } else {
+            src = w0;
+            n = (tile * R + r) * 16 + row;
+        }
+        const int k0 = kUnitK * u + 32 * g + 8 * d;
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (n < N) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ka = k0 + 2 * q, kb = ka + 1;
+                const bf16_t lo = ka < K ? f32_to_bf16(ld_as_f32(src, (int64_t)n * K + ka, dtype)) : (bf16_t)0;
+                const bf16_t hi = kb < K ? f32_to_bf16(ld_as_f32(src, (int64_t)n * K + kb, dtype)) : (bf16_t)0;
+                o[q] = (uint32_t)lo | ((uint32_t)hi << 16);
+            }
+        }
+        out[i] = o;
+    }
+}
+
+// one thread per 16-B piece of 16 int8
+__global__ void i8_repack_kernel(const int8_t* c0, const int8_t* c1, int N, int K, int R, u32x4* out,
+                                 int64_t n_pieces) {
+    const int units = (K + kUnitK - 1) / kUnitK;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pieces;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const int e = (int)((i >> 6) & 1);
+        int64_t rest = i >> 7;
+        const int r = (int)(rest % R);
+        rest /= R;
+        const int u = (int)(rest % units);
+        const int tile = (int)(rest / units);
+        const int g = lane >> 4, row = lane & 15;
+        const int8_t* src;
+        int n;
+        if (c1 != nullptr) {
+            src = r == 0 ? c0 : c1;
+            n = tile * 16 + row;
+        } else {
+            src = c0;
+            n = (tile * R + r) * 16 + row;
+        }
+        const int k0 = kUnitK * u + 64 * e + 16 * g;
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (n < N) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int bidx = 0; bidx < 4; ++bidx) {
+                    const int k = k0 + 4 * q + bidx;
+                    if (k < K) v |= (uint32_t)(uint8_t)src[(int64_t)n * K + k] << (8 * bidx);
+                }
+                o[q] = v;
+            }
+        }
+        out[i] = o;
+    }
+}
+
+template <int FMT, int R, int P, bool NT>
+int launch_gemv(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, NT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    });
+    if (attr_err != hipSuccess) {
+        mi355_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(attr_err));
+        return (int)attr_err;
+    }
+    hipLaunchKernelGGL((gemv_kernel<FMT, R, P, NT>), dim3(grid), dim3(waves * 64), lds, stream, p);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int FMT, int R>
+int dispatch_pnt(const GemvParams& p, int prefetch, bool nt, int grid, int waves, size_t lds, hipStream_t s) {
+    constexpr int PA = FMT == MI355_W_Q4 ? 4 : 2;
+    constexpr int PB = FMT == MI355_W_Q4 ? 8 : 4;
+    const bool deep = prefetch >= PB;
+    if (deep) {
+        if constexpr (FMT == MI355_W_BF16 && R == 2) {
+            // 4 units x 8 pieces would need 128 VGPRs of ring alone; cap at the shallow ring
+            return nt ? launch_gemv<FMT, R, PA, true>(p, grid, waves, lds, s)
+                      : launch_gemv<FMT, R, PA, false>(p, grid, waves, lds, s);
+        } else {
+            return nt ? launch_gemv<FMT, R, PB, true>(p, grid, waves, lds, s)
+                      : launch_gemv<FMT, R, PB, false>(p, grid, waves, lds, s);
+        }
+    }
+    return nt ? launch_gemv<FMT, R, PA, true>(p, grid, waves, lds, s)
+              : launch_gemv<FMT, R, PA, false>(p, grid, waves, lds, s);
+}
+
+int g_num_cus = 0;
+
+}  // namespace
+
+extern "C" int mi355_num_cus(void) {
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        g_num_cus = prop.multiProcessorCount;
+    }
+    return g_num_cus;
+}
+
+static inline int64_t padded_rows(int N, int R, bool pair) {
+    const int rows_per_tile = pair ? 16 : 16 * R;
+    const int64_t tiles = ((int64_t)N + rows_per_tile - 1) / rows_per_tile;
+    return tiles * (pair ? 32 : rows_per_tile);  // a pair stream carries 2 x 16 rows per tile
+}
+static inline int64_t padded_cols(int K) { return ((int64_t)K + kUnitK - 1) / kUnitK * kUnitK; }
+
+extern "C" size_t mi355_packed_bytes(int fmt, int N, int K, int R, int pair) {
+    if (N <= 0 || K <= 0 || (R != 1 && R != 2) || (pair && R != 2)) return 0;
+    const int64_t elems = padded_rows(N, R, pair != 0) * padded_cols(K);
+    switch (fmt) {
+        case MI355_W_Q4: return (size_t)(elems / 2);
+        case MI355_W_BF16: return (size_t)(elems * 2);
+        case MI355_W_I8: return (size_t)elems;
+        default: return 0;
+    }
+}
+
+static int check_repack(int N, int K, int R, bool pair) {
+    MI355_CHECK_ARG(R == 1 || R == 2, MI355_E_ARG, "repack: R must be 1 or 2 (got %d)", R);
+    MI355_CHECK_ARG(!pair || R == 2, MI355_E_ARG, "repack: interleaving two matrices needs R == 2");
+    MI355_CHECK_ARG(N > 0 && K > 0, MI355_E_SHAPE, "repack: N=%d K=%d must be positive", N, K);
+    return 0;
+}
+
+static inline int repack_grid(int64_t n) {
+    const int64_t b = (n + 255) / 256;
+    return (int)(b > 262144 ? 262144 : b);
+}
+
+extern "C" int mi355_q4_repack(const uint8_t* q0, const uint8_t* q1, int64_t stride_n, int64_t stride_kb, int N, int K,
+                               int R, uint8_t* out, mi355_stream_t stream) {
+    MI355_CHECK_ARG(q0 && out, MI355_E_ARG, "q4_repack: null pointer");
+    MI355_CHECK_ARG(K % 2 == 0, MI355_E_SHAPE, "q4_repack: K=%d must be even (two entries per byte)", K);
+    if (int rc = check_repack(N, K, R, q1 != nullptr)) return rc;
+    const int64_t n_dwords = padded_rows(N, R, q1 != nullptr) * padded_cols(K) / 8;
+    hipLaunchKernelGGL(q4_repack_kernel, dim3(repack_grid(n_dwords)), dim3(256), 0, (hipStream_t)stream, q0, q1,
+                       stride_n, stride_kb, N, K, R, (uint32_t*)out, n_dwords);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi355_bf16_repack(const void* w0, const void* w1, int dtype, int N, int K, int R, void* out,
+                                 mi355_stream_t stream) {
+    MI355_CHECK_ARG(w0 && out, MI355_E_ARG, "bf16_repack: null pointer");
+    MI355_CHECK_ARG(dtype == MI355_F32 || dtype == MI355_BF16, MI355_E_DTYPE, "bf16_repack: dtype must be f32 or bf16");
+    if (int rc = check_repack(N, K, R, w1 != nullptr)) return rc;
+    const int64_t n_pieces = padded_rows(N, R, w1 != nullptr) * padded_cols(K) / 8;
+    hipLaunchKernelGGL(bf16_repack_kernel, dim3(repack_grid(n_pieces)), dim3(256), 0, (hipStream_t)stream, w0, w1,
+                       dtype, N, K, R, (u32x4*)out, n_pieces);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi355_i8_repack(const int8_t* cb0, const int8_t* cb1, int N, int K, int R, int8_t* out,
+                               mi355_stream_t stream) {
+    MI355_CHECK_ARG(cb0 && out, MI355_E_ARG, "i8_repack: null pointer");
+    if (int rc = check_repack(N, K, R, cb1 != nullptr)) return rc;
+    const int64_t n_pieces = padded_rows(N, R, cb1 != nullptr) * padded_cols(K) / 16;
+    hipLaunchKernelGGL(i8_repack_kernel, dim3(repack_grid(n_pieces)), dim3(256), 0, (hipStream_t)stream, cb0, cb1, N,
+                       K, R, (u32x4*)out, n_pieces);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stream) {
+    MI355_CHECK_ARG(a != nullptr, MI355_E_ARG, "linear_fast: null args");
+    MI355_CHECK_ARG(a->fmt == MI355_W_Q4 || a->fmt == MI355_W_BF16, MI355_E_ARG,
+                    "linear_fast: fmt %d not handled here (int8 goes through mi355_linear_int8)", a->fmt);
+    MI355_CHECK_ARG(a->R == 1 || a->R == 2, MI355_E_ARG, "linear_fast: R must be 1 or 2");
+    MI355_CHECK_ARG(a->w && a->x && a->y, MI355_E_ARG, "linear_fast: null w/x/y");
+    MI355_CHECK_ARG(a->M >= 1 && a->M <= kMaxM, MI355_E_SHAPE, "linear_fast: M=%d outside 1..%d", a->M, kMaxM);
+    MI355_CHECK_ARG(a->K > 0 && a->N > 0, MI355_E_SHAPE, "linear_fast: N=%d K=%d must be positive", a->N, a->K);
+    const bool swiglu = a->epi == MI355_EPI_SWIGLU;
+    MI355_CHECK_ARG(a->epi >= MI355_EPI_STORE && a->epi <= MI355_EPI_SWIGLU, MI355_E_ARG, "linear_fast: bad epi");
+    MI355_CHECK_ARG(!swiglu || a->R == 2, MI355_E_ARG, "linear_fast: SwiGLU epilogue needs the interleaved R=2 stream");
+    const int rows_per_tile = swiglu ? 16 : 16 * a->R;
+    if (a->fmt == MI355_W_Q4) {
+        MI355_CHECK_ARG(a->scales && a->zeros, MI355_E_ARG, "linear_fast: Q4 needs scales and zeros");
+        MI355_CHECK_ARG(!swiglu || (a->scales2 && a->zeros2), MI355_E_ARG, "linear_fast: SwiGLU Q4 needs scales2/zeros2");
+    }
+    auto two = [](int d) { return d == MI355_F32 || d == MI355_BF16; };
+    MI355_CHECK_ARG(two(a->x_dtype) && two(a->y_dtype), MI355_E_DTYPE, "linear_fast: x/y dtype must be f32 or bf16");
+    MI355_CHECK_ARG(a->norm_scale == nullptr || two(a->norm_dtype), MI355_E_DTYPE,
+                    "linear_fast: norm scale dtype must be f32 or bf16");
+    MI355_CHECK_ARG(a->fmt != MI355_W_Q4 || two(a->sz_dtype), MI355_E_DTYPE,
+                    "linear_fast: scales/zeros dtype must be f32 or bf16");
+    MI355_CHECK_ARG(a->ldx >= a->K || a->M == 1, MI355_E_SHAPE, "linear_fast: ldx < K");
+
+    GemvParams p;
+    p.w = (const uint8_t*)a->w;
+    p.x = a->x;
+    p.norm_scale = a->norm_scale;
+    p.scales = a->scales;
+    p.zeros = a->zeros;
+    p.scales2 = a->scales2;
+    p.zeros2 = a->zeros2;
+    p.bias = swiglu ? nullptr : a->bias;
+    p.y = a->y;
+    p.ldx = a->ldx;
+    p.ldy = a->ldy;
+    p.N = a->N;
+    p.K = a->K;
+    p.M = a->M;
+    p.n_tiles = (a->N + rows_per_tile - 1) / rows_per_tile;
+    p.units = (a->K + kUnitK - 1) / kUnitK;
+    p.x_dtype = a->x_dtype;
+    p.norm_dtype = a->norm_dtype;
+    p.sz_dtype = a->sz_dtype;
+    p.y_dtype = a->y_dtype;
+    p.epi = a->epi;
+    p.xs_stride = p.units * kUnitK * 2 + 16;
+    p.eps = a->eps;
+
+    int waves = a->waves > 0 ? a->waves : 8;
+    if (waves > 8) waves = 8;
+    if (waves < 4) waves = 4;  // the combine step needs 256 owner threads
+    const size_t lds = kLdsHeader + (size_t)2 * waves * a->R * 1024 + (size_t)a->M * p.xs_stride;
+    MI355_CHECK_ARG(lds <= (size_t)kMaxLds, MI355_E_SHAPE,
+                    "linear_fast: M=%d x K=%d activations do not fit LDS (%zu B > %d B); chunk M", a->M, a->K, lds,
+                    kMaxLds);
+    int grid = a->grid;
+    if (grid <= 0) {
+        const int cus = mi355_num_cus() > 0 ? mi355_num_cus() : 256;
+        grid = cus * 2;
+    }
+    if (grid > p.n_tiles) grid = p.n_tiles;
+    const bool nt = (a->flags & 1) == 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->fmt == MI355_W_Q4) {
+        return a->R == 1 ? dispatch_pnt<MI355_W_Q4, 1>(p, a->prefetch, nt, grid, waves, lds, s)
+                         : dispatch_pnt<MI355_W_Q4, 2>(p, a->prefetch, nt, grid, waves, lds, s);
+    }
+    return a->R == 1 ? dispatch_pnt<MI355_W_BF16, 1>(p, a->prefetch, nt, grid, waves, lds, s)
+                     : dispatch_pnt<MI355_W_BF16, 2>(p, a->prefetch, nt, grid, waves, lds, s);
+}
