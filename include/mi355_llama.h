@@ -169,6 +169,7 @@ int mi355_argmax(const float* logits, int V, int32_t* out, int32_t* out2, const 
  * (lit_llama/model.py:199-232): split q,k,v ([Q;K;V] along the feature dim, :197), RoPE on q,k in f32
  * (:204-205), cache write at slot min(pos, S-1) (:217-220; the roll of :214-218 is mi355_kv_roll),
  * softmax(q k^T / sqrt(hs)) v over slots [0, slot] (:230 with the causal mask of :93-99).
+ *   rope   f32 [block_size, hs/2, 2] (cos, sin) table indexed by position, or see rope_gathered
  *   qkv    [B*T, ld_qkv]: q at column h*hs, k at C + h*hs, v at 2C + h*hs (C = n_head*hs)
  *   pos    device int32 [T]: absolute positions (RoPE row, cache slot)
  *   cache  [B, n_head, S, hs] each, dtype cache_dtype; may be NULL (no cache: keys are the T new tokens)
@@ -192,6 +193,9 @@ typedef struct mi355_attn_args {
     void* y;
     int64_t ldy;
     void* kv_tmp;       /* when cache == NULL: scratch [2, B, n_head, T, hs] of cache_dtype */
+    int32_t rope_gathered; /* != 0: `rope` holds the T rows already selected (rope_cache.index_select(0, input_pos),
+                              lit_llama/model.py:94), row t is used for token t instead of row pos[t] */
+    int32_t reserved0;
 } mi355_attn_args;
 
 int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream);
@@ -319,6 +323,10 @@ typedef struct mi355_graph mi355_graph;
 int mi355_graph_capture(const mi355_model* m, int argmax, mi355_stream_t stream, mi355_graph** out);
 int mi355_graph_launch(mi355_graph* g, mi355_stream_t stream);
 int mi355_graph_destroy(mi355_graph* g);
+
+/* sizeof() of the ABI structs, for binding self-checks: 0 linear_args, 1 attn_args, 2 int8_args, 3 weight,
+ * 4 layer, 5 model; -1 for an unknown index */
+int mi355_sizeof(int which);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ struct AttnParams {
     int qkv_dtype, y_dtype;
     int B, T, n_head, hs, S;
     int fused;  // 1: this kernel writes the (single) new K/V row itself
+    int rope_gathered;  // rope row of token t is t (rows pre-selected by the caller), not pos[t]
     float scale;
 };
 
@@ -93,7 +94,7 @@ __global__ void rope_kv_write_kernel(const AttnParams p) {
         const float a = ld_as_f32(p.qkv, row + C + h * hs + 2 * pi, p.qkv_dtype);
         const float bb = ld_as_f32(p.qkv, row + C + h * hs + 2 * pi + 1, p.qkv_dtype);
         float oa, ob;
-        rope_pair(p.rope, pos, half, pi, a, bb, oa, ob);
+        rope_pair(p.rope, p.rope_gathered ? t : pos, half, pi, a, bb, oa, ob);
         kc[2 * pi] = f32_to_ct<CT>(oa);
         kc[2 * pi + 1] = f32_to_ct<CT>(ob);
     }
@@ -131,13 +132,14 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         const float a = ld_as_f32(p.qkv, row + h * hs + 2 * pi, p.qkv_dtype);
         const float bb = ld_as_f32(p.qkv, row + h * hs + 2 * pi + 1, p.qkv_dtype);
         float oa, ob;
-        rope_pair(p.rope, pos, half, pi, a, bb, oa, ob);
+        const int rrow = p.rope_gathered ? t : pos;
+        rope_pair(p.rope, rrow, half, pi, a, bb, oa, ob);
         qs[2 * pi] = oa;
         qs[2 * pi + 1] = ob;
         if (p.fused) {
             const float ka = ld_as_f32(p.qkv, row + C + h * hs + 2 * pi, p.qkv_dtype);
             const float kb = ld_as_f32(p.qkv, row + C + h * hs + 2 * pi + 1, p.qkv_dtype);
-            rope_pair(p.rope, pos, half, pi, ka, kb, oa, ob);
+            rope_pair(p.rope, rrow, half, pi, ka, kb, oa, ob);
             const CT ca = f32_to_ct<CT>(oa), cb = f32_to_ct<CT>(ob);
             CT* kw = (CT*)p.kcache + (((int64_t)b * p.n_head + h) * p.S + slot) * hs;
             kw[2 * pi] = ca;
@@ -320,6 +322,7 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
         p.S = a->T;
     }
     p.fused = (has_cache && a->T == 1) ? 1 : 0;
+    p.rope_gathered = a->rope_gathered;
 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(a->n_head, a->T, a->B);

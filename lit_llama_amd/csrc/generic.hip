@@ -20,6 +20,17 @@ void mi355_set_error(const char* fmt, ...) {
 
 extern "C" const char* mi355_last_error(void) { return g_err; }
 extern "C" int mi355_version(void) { return MI355_ABI_VERSION; }
+extern "C" int mi355_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(mi355_linear_args);
+        case 1: return (int)sizeof(mi355_attn_args);
+        case 2: return (int)sizeof(mi355_int8_args);
+        case 3: return (int)sizeof(mi355_weight);
+        case 4: return (int)sizeof(mi355_layer);
+        case 5: return (int)sizeof(mi355_model);
+        default: return -1;
+    }
+}
 
 namespace {
 

@@ -1,0 +1,342 @@
+"""Native whole-forward engine behind `LLaMA.forward` (B = 1, KV cache).
+
+Builds the `mi355_model` descriptor (include/mi355_llama.h) from the module's parameters / buffers:
+repacked weight streams, scratch, RoPE table, in-place KV caches; `forward` then costs one tiny
+`mi355_set_step` launch plus either a hipGraph replay (T == 1) or one `mi355_forward` call per chunk of
+<= max_T prompt tokens.  Replaces the per-token Python walk of generate.py:63-91 -> model.py:76-122.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _native as nat
+from . import ops
+from ._native import BF16, F32, W_BF16, W_I8, W_Q4, Layer, Model, Weight, check, dtype_code, lib, ptr
+
+
+class EngineUnavailable(RuntimeError):
+    pass
+
+
+def _env_int(name: str, default: int) -> int:
+    try:
+        return int(os.environ.get(name, default))
+    except ValueError:
+        return default
+
+
+class _PackedWeight:
+    """One entry of the model descriptor + the tensors that must stay alive for it."""
+
+    def __init__(self):
+        self.desc = Weight()
+        self.keep: List[torch.Tensor] = []
+        self.stream_bytes = 0
+        self.side_bytes = 0
+
+
+def _kind(mod: nn.Module) -> str:
+    from .quantization import ColBlockQuantizedLinear, Linear8bitLt
+
+    if isinstance(mod, ColBlockQuantizedLinear):
+        return "q4"
+    if isinstance(mod, Linear8bitLt):
+        return "i8"
+    if type(mod) is nn.Linear:
+        return "bf16"
+    raise EngineUnavailable(f"unsupported linear type {type(mod).__name__}")
+
+
+def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: Optional[dict] = None) -> _PackedWeight:
+    """Repack one linear (or the c_fc1 / c_fc2 pair) into the weight stream of its format."""
+    from .quantization import ColBlockQuantizedLinear, Linear8bitLt
+
+    kind = _kind(mod)
+    if pair is not None and _kind(pair) != kind:
+        raise EngineUnavailable("c_fc1 / c_fc2 use different linear types")
+    pw = _PackedWeight()
+    d = pw.desc
+    d.R = 2 if pair is not None else R
+    tune = tune or {}
+    d.waves, d.grid, d.prefetch = tune.get("waves", 0), tune.get("grid", 0), tune.get("prefetch", 0)
+    if kind == "q4":
+        assert isinstance(mod, ColBlockQuantizedLinear)
+        if not mod.fast_eligible(torch.bfloat16):
+            raise EngineUnavailable("ColBlockQuantizedLinear layout not handled by the fast kernel "
+                                    f"(bits={mod.bits}, groups={mod.scales.shape[1]}, scales {mod.scales.dtype})")
+        if mod.bias is not None:
+            raise EngineUnavailable("bias on a quantised linear")
+        N, K = mod.out_features, mod.in_features
+        stream = ops.repack_q4(mod.quant_weight, pair.quant_weight if pair is not None else None, N, K, d.R)
+        s0, z0 = mod.scales.reshape(-1).contiguous(), mod.zeros.reshape(-1).contiguous()
+        d.fmt, d.w, d.N, d.K = W_Q4, ptr(stream), N, K
+        d.scales, d.zeros, d.sz_dtype = ptr(s0), ptr(z0), dtype_code(s0.dtype)
+        pw.keep += [stream, s0, z0]
+        pw.side_bytes = 2 * N * s0.element_size()
+        if pair is not None:
+            s1, z1 = pair.scales.reshape(-1).contiguous(), pair.zeros.reshape(-1).contiguous()
+            if s1.dtype != s0.dtype:
+                raise EngineUnavailable("c_fc1 / c_fc2 scales differ in dtype")
+            d.scales2, d.zeros2 = ptr(s1), ptr(z1)
+            pw.keep += [s1, z1]
+            pw.side_bytes *= 2
+    elif kind == "i8":
+        assert isinstance(mod, Linear8bitLt)
+        if mod.bias is not None:
+            raise EngineUnavailable("bias on a quantised linear")
+        if not hasattr(mod.weight, "CB"):
+            raise EngineUnavailable("Linear8bitLt weight not quantised yet")
+        N, K = mod.out_features, mod.in_features
+        stream = ops.repack_i8(mod.weight.CB, pair.weight.CB if pair is not None else None, d.R)
+        d.fmt, d.w, d.N, d.K = W_I8, ptr(stream), N, K
+        d.scb = ptr(mod.weight.SCB)
+        pw.keep += [stream, mod.weight.SCB]
+        pw.side_bytes = 4 * N
+        if pair is not None:
+            d.scb2 = ptr(pair.weight.SCB)
+            pw.keep.append(pair.weight.SCB)
+            pw.side_bytes *= 2
+    else:
+        if mod.bias is not None:
+            raise EngineUnavailable("bias on a hot-path linear")
+        if mod.weight.dtype != torch.bfloat16:
+            raise EngineUnavailable(f"dense weights are {mod.weight.dtype}; the MFMA path needs bf16")
+        N, K = mod.weight.shape
+        stream = ops.repack_bf16(mod.weight.detach(), pair.weight.detach() if pair is not None else None, d.R)
+        d.fmt, d.w, d.N, d.K = W_BF16, ptr(stream), N, K
+        pw.keep.append(stream)
+    pw.stream_bytes = pw.keep[0].numel()
+    return pw
+
+
+class DecodeEngine:
+    """Owns everything `mi355_forward` needs for one `LLaMA` instance."""
+
+    def __init__(self, model: "nn.Module", *, tp_rank: int = 0, tp_world: int = 1, tune: Optional[dict] = None):
+        cfg = model.config
+        wte = model.transformer.wte.weight
+        if wte.device.type != "cuda":
+            raise EngineUnavailable(f"model is on {wte.device}")
+        if wte.dtype != torch.bfloat16:
+            raise EngineUnavailable(f"model dtype {wte.dtype}: the engine computes with bf16 MFMA operands; "
+                                    "f32 models run op by op through the exact f32 kernels")
+        self.model = model
+        self.device = wte.device
+        self.cfg = cfg
+        self.tp_world = tp_world
+        self.tune = tune or {}
+        self.stream = torch.cuda.Stream(device=self.device)  # capturable (the legacy default stream is not)
+        self.use_graph = _env_int("MI355_GRAPH", 1) != 0
+        self._graphs = {}  # argmax flag -> graph handle
+        self._keep: List[object] = []
+
+        C_, hs, nh = cfg.n_embd, cfg.n_embd // cfg.n_head, cfg.n_head
+        with torch.cuda.device(self.device):
+            first = model.transformer.h[0]
+            self.n_hidden = first.mlp.c_fc1.out_features
+            self.packed = []
+            layers = (Layer * cfg.n_layer)()
+            for i, blk in enumerate(model.transformer.h):
+                attn = pack_linear(blk.attn.c_attn, 2, tune=self.tune.get("attn"))
+                proj = pack_linear(blk.attn.c_proj, 1, tune=self.tune.get("proj"))
+                fc = pack_linear(blk.mlp.c_fc1, 2, pair=blk.mlp.c_fc2, tune=self.tune.get("fc"))
+                mproj = pack_linear(blk.mlp.c_proj, 1, tune=self.tune.get("mproj"))
+                self.packed += [attn, proj, fc, mproj]
+                L = layers[i]
+                L.rms1, L.rms2 = ptr(blk.rms_1.scale.detach()), ptr(blk.rms_2.scale.detach())
+                L.attn, L.proj, L.fc, L.mproj = attn.desc, proj.desc, fc.desc, mproj.desc
+            head = pack_linear(model.lm_head, 2, tune=self.tune.get("lm_head"))
+            self.packed.append(head)
+            self.layers = layers
+
+            # LDS bound on the rows one launch can stage (see ops.fast_linear_max_m)
+            fmts = {p.desc.fmt for p in self.packed}
+            worst_fmt = W_I8 if W_I8 in fmts else W_Q4
+            max_T = min(16, ops.fast_linear_max_m(self.n_hidden, 1, worst_fmt), ops.fast_linear_max_m(C_, 2, worst_fmt))
+            if max_T < 1:
+                raise EngineUnavailable("hidden size does not fit LDS")
+            self.max_T = max_T
+
+            local_heads = first.attn.c_attn.out_features // (3 * hs)
+            self.local_heads = local_heads
+            Cl = local_heads * hs
+            V = model.lm_head.out_features
+            dev = self.device
+            self.x = torch.zeros((max_T, C_), dtype=torch.float32, device=dev)
+            self.qkv = torch.zeros((max_T, 3 * Cl), dtype=torch.float32, device=dev)
+            self.att = torch.zeros((max_T, Cl), dtype=torch.bfloat16, device=dev)
+            self.hbuf = torch.zeros((max_T, self.n_hidden), dtype=torch.bfloat16, device=dev)
+            self.partial = torch.zeros((max_T, C_), dtype=torch.float32, device=dev)
+            self.logits = torch.zeros((max_T, V), dtype=torch.float32, device=dev)
+            self.tokens = torch.zeros((max_T,), dtype=torch.int32, device=dev)
+            self.pos = torch.zeros((max_T,), dtype=torch.int32, device=dev)
+            self.next_token = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self.out_tokens = torch.zeros((cfg.block_size + 1,), dtype=torch.int32, device=dev)
+            if model.rope_cache is None or model.rope_cache.dtype != torch.float32:
+                from .model import build_rope_cache
+
+                rope = build_rope_cache(cfg.block_size, hs, torch.int64, dev)
+            else:
+                rope = model.rope_cache
+            self.rope = rope.to(device=dev, dtype=torch.float32).contiguous()
+
+        m = Model()
+        m.n_layer, m.n_head, m.n_embd, m.hs = cfg.n_layer, local_heads, C_, hs
+        m.n_hidden, m.vocab, m.S, m.block_size = self.n_hidden, wte.shape[0], 0, cfg.block_size
+        m.param_dtype, m.cache_dtype = dtype_code(wte.dtype), BF16
+        m.tp_world, m.max_T = tp_world, max_T
+        m.eps = float(model.transformer.ln_f.eps)
+        m.int8_threshold = 6.0
+        m.wte, m.ln_f = ptr(wte.detach()), ptr(model.transformer.ln_f.scale.detach())
+        m.lm_head = head.desc
+        m.rope = ptr(self.rope)
+        m.layers = C.cast(self.layers, C.POINTER(Layer))
+        m.x, m.qkv, m.att, m.hbuf = ptr(self.x), ptr(self.qkv), ptr(self.att), ptr(self.hbuf)
+        m.partial, m.logits = ptr(self.partial), ptr(self.logits)
+        m.tokens, m.pos, m.next_token = ptr(self.tokens), ptr(self.pos), ptr(self.next_token)
+        m.out_tokens = ptr(self.out_tokens)
+        self.m = m
+        self.S = 0
+        self._cache_pool = {}  # S -> list of (k, v): kept across reset_cache() so captured graphs stay valid
+
+    # ---- bookkeeping ---------------------------------------------------------------------------------
+    def weight_stream_bytes(self) -> int:
+        return sum(p.stream_bytes for p in self.packed)
+
+    def side_bytes(self) -> int:
+        return sum(p.side_bytes for p in self.packed)
+
+    def _destroy_graphs(self) -> None:
+        for g in self._graphs.values():
+            lib().mi355_graph_destroy(g)
+        self._graphs = {}
+
+    def __del__(self):
+        try:
+            self._destroy_graphs()
+        except Exception:
+            pass
+
+    def reset_cache(self) -> None:
+        """`LLaMA.reset_cache()`: the next forward starts from zeroed caches (model.py:140-145)."""
+        self.S = 0
+
+    def _ensure_cache(self, S: int) -> None:
+        if self.S == S and self.model.kv_caches:
+            return
+        cfg = self.cfg
+        hs = cfg.n_embd // cfg.n_head
+        pool = self._cache_pool.get(S)
+        if pool is None:
+            self._destroy_graphs()  # captured kernels hold the old cache pointers / S by value
+            shape = (1, self.local_heads, S, hs)
+            pool = [(torch.zeros(shape, dtype=torch.bfloat16, device=self.device),
+                     torch.zeros(shape, dtype=torch.bfloat16, device=self.device)) for _ in range(cfg.n_layer)]
+            self._cache_pool = {S: pool}  # one cache geometry at a time
+        else:
+            for k, v in pool:
+                k.zero_()
+                v.zero_()
+        for i, (k, v) in enumerate(pool):
+            self.layers[i].kcache, self.layers[i].vcache = ptr(k), ptr(v)
+        self.model.kv_caches = list(pool)
+        self.m.S = S
+        self.S = S
+
+    # ---- execution -----------------------------------------------------------------------------------
+    def _host_pos0(self, input_pos: torch.Tensor, T: int) -> Optional[int]:
+        hint = getattr(input_pos, "_mi355_pos0", None)
+        if hint is not None:
+            return int(hint)
+        ends = input_pos[[0, -1]].tolist()  # one device->host sync for callers that do not pass the hint
+        if ends[1] - ends[0] != T - 1:
+            return None
+        return int(ends[0])
+
+    def step_graph(self, argmax: bool):
+        key = 1 if argmax else 0
+        g = self._graphs.get(key)
+        if g is None:
+            handle = C.c_void_p()
+            check(lib().mi355_graph_capture(C.byref(self.m), key, self.stream.cuda_stream, C.byref(handle)),
+                  "mi355_graph_capture")
+            g = handle
+            self._graphs[key] = g
+        return g
+
+    def _warm_step(self, argmax: bool) -> None:
+        # one eager pass before the first capture: the launchers set per-kernel attributes
+        # (hipFuncSetAttribute) lazily, which must not happen while the stream is capturing.  It recomputes
+        # exactly what the captured step will compute again, so the state is unchanged.
+        check(lib().mi355_forward(C.byref(self.m), 1, 1, 1 if argmax else 0, self.stream.cuda_stream),
+              "mi355_forward (warm-up)")
+
+    def run_step(self, argmax: bool) -> None:
+        """One T = 1 forward on self.stream (tokens / positions already placed by set_step)."""
+        s = self.stream.cuda_stream
+        if self.use_graph:
+            try:
+                if (1 if argmax else 0) not in self._graphs:
+                    self._warm_step(argmax)
+                g = self.step_graph(argmax)
+            except nat.NativeError:
+                if _env_int("MI355_GRAPH_STRICT", 0):
+                    raise
+                self.use_graph = False
+                g = None
+            if g is not None:
+                check(lib().mi355_graph_launch(g, s), "mi355_graph_launch")
+                return
+        check(lib().mi355_forward(C.byref(self.m), 1, 1, 1 if argmax else 0, s), "mi355_forward")
+
+    def set_step(self, idx: Optional[torch.Tensor], T: int, pos0: int, from_next: bool = False) -> None:
+        is64 = 1 if (idx is not None and idx.dtype == torch.int64) else 0
+        check(lib().mi355_set_step(C.byref(self.m), ptr(idx), is64, T, pos0, 1 if from_next else 0,
+                                   self.stream.cuda_stream), "mi355_set_step")
+
+    def prefill(self, idx: torch.Tensor, pos0: int, *, all_logits: bool, argmax: bool = False) -> Optional[torch.Tensor]:
+        """Feed T prompt tokens starting at position pos0 (chunks of max_T); returns logits [T, V] if asked,
+        otherwise leaves the last token's logits in self.logits[0]."""
+        T = idx.numel()
+        flat = idx.reshape(-1)
+        out = torch.empty((T, self.logits.shape[1]), dtype=torch.float32, device=self.device) if all_logits else None
+        s = self.stream.cuda_stream
+        for t0 in range(0, T, self.max_T):
+            n = min(self.max_T, T - t0)
+            last = t0 + n == T
+            self.set_step(flat[t0:t0 + n], n, pos0 + t0)
+            mode = 2 if all_logits else (1 if last else 0)
+            if n == 1 and mode == 1:
+                self.run_step(argmax)
+            else:
+                check(lib().mi355_forward(C.byref(self.m), n, mode, 1 if (argmax and last) else 0, s), "mi355_forward")
+            if all_logits:
+                out[t0:t0 + n].copy_(self.logits[:n])
+        return out
+
+    def forward(self, idx: torch.Tensor, max_seq_length: int, input_pos: torch.Tensor) -> Optional[torch.Tensor]:
+        """`LLaMA.forward` for B == 1 with a KV cache; returns logits [1, T, V] (f32) or None if the positions
+        are not a contiguous run (then the caller takes the op-by-op path)."""
+        T = idx.shape[1]
+        pos0 = self._host_pos0(input_pos, T)
+        if pos0 is None:
+            return None
+        if pos0 + T > max_seq_length:
+            return None  # cache-roll regime (model.py:214-218): handled by the op-by-op path
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._ensure_cache(max_seq_length)
+            if T == 1:
+                self.set_step(idx.reshape(-1), 1, pos0)
+                self.run_step(False)  # hipGraph replay; logits land in row 0
+                logits = self.logits[:1].clone()
+            else:
+                logits = self.prefill(idx, pos0, all_logits=True)
+        cur.wait_stream(self.stream)
+        return logits.view(1, T, -1)

@@ -1,0 +1,102 @@
+"""Token sampling loop with the signature of /root/reference generate.py:20-91.
+
+`generate(model, idx, max_new_tokens, *, max_seq_length, temperature, top_k, eos_id)` returns the prompt
+followed by the generated ids, like the reference.  Two ways through it:
+
+  * greedy (`top_k == 1`, which is how the reference spells greedy: generate.py:70-76 leaves a single finite
+    logit) on an engine-backed model: prefill once, then per token one `set_step` launch + one hipGraph replay
+    whose last node is the on-device argmax that feeds the next step.  The host never reads a device value
+    inside the loop (the reference syncs once per layer per token, model.py:214), so launches run ahead of
+    the GPU;
+  * everything else: the reference's loop, calling `model(x, max_seq_length, input_pos)` and sampling with
+    torch ops on the returned logits.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+
+def _host_pos(t: torch.Tensor, pos0: int) -> torch.Tensor:
+    """Attach the host-known first position so the engine needs no device->host sync to learn it."""
+    t._mi355_pos0 = pos0
+    return t
+
+
+@torch.no_grad()
+def generate(
+    model,
+    idx: torch.Tensor,
+    max_new_tokens: int,
+    *,
+    max_seq_length: Optional[int] = None,
+    temperature: float = 1.0,
+    top_k: Optional[int] = None,
+    eos_id: Optional[int] = None,
+) -> torch.Tensor:
+    T = idx.size(0)
+    T_new = T + max_new_tokens
+    if max_seq_length is None:
+        max_seq_length = min(T_new, model.config.block_size)
+    device, dtype = idx.device, idx.dtype
+
+    eng = model.engine() if (getattr(model, "use_engine", False) and device.type == "cuda") else None
+    if eng is not None and top_k == 1 and T_new <= max_seq_length and max_new_tokens > 0:
+        return _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id)
+
+    # ---- reference loop (generate.py:45-91)
+    empty = torch.empty(T_new, dtype=dtype, device=device)
+    empty[:T] = idx
+    idx = empty
+    pos_host = 0
+    input_pos = _host_pos(torch.arange(0, T, device=device), 0)
+    for _ in range(max_new_tokens):
+        x = idx.index_select(0, input_pos).view(1, -1)
+        logits = model(x, max_seq_length, input_pos)
+        logits = logits[0, -1] / temperature
+        if top_k is not None:
+            v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
+            logits = torch.where(logits < v[[-1]], -float("Inf"), logits)
+        probs = torch.nn.functional.softmax(logits, dim=-1)
+        idx_next = torch.multinomial(probs, num_samples=1).to(dtype=dtype)
+        pos_host = pos_host + input_pos.numel() if input_pos.numel() > 1 else pos_host + 1
+        input_pos = _host_pos(input_pos[-1:] + 1, pos_host)
+        idx = idx.index_copy(0, input_pos, idx_next)
+        if eos_id is not None and idx_next == eos_id:
+            # generate.py:88-89 returns `idx[:input_pos]`: despite its comment the slice stops BEFORE the
+            # EOS position; kept as is so callers see the same length as with the reference
+            return idx[:input_pos]
+    return idx
+
+
+def _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id):
+    """Greedy decode entirely on the device: out[pos + 1] = argmax(logits(pos))."""
+    device, dtype = idx.device, idx.dtype
+    T = idx.size(0)
+    cur = torch.cuda.current_stream(device)
+    eng.stream.wait_stream(cur)
+    with torch.cuda.stream(eng.stream):
+        eng._ensure_cache(max_seq_length)
+        eng.out_tokens[:T].copy_(idx.to(torch.int32))
+        # prompt: all but the last token without logits, then the last one with logits + argmax
+        eng.prefill(idx, 0, all_logits=False, argmax=True)
+        done = 1
+        while done < max_new_tokens:
+            # next token id is read from the device slot written by the previous argmax node
+            eng.set_step(None, 1, T + done - 1, from_next=True)
+            eng.run_step(True)
+            done += 1
+            if eos_id is not None and (done % 16 == 0 or done == max_new_tokens):
+                # bounded-lag EOS check: the reference tests every token (generate.py:88-89) and pays a
+                # device->host sync for it; here the sync is amortised and the tail is cut off afterwards
+                toks = eng.out_tokens[T:T + done].tolist()
+                if eos_id in toks:
+                    break
+        out = eng.out_tokens[:T + done].to(dtype).clone()
+    cur.wait_stream(eng.stream)
+    if eos_id is not None:
+        gen = out[T:].tolist()
+        if eos_id in gen:
+            out = out[: T + gen.index(eos_id)]  # same cut as the reference's `idx[:input_pos]`
+    return out

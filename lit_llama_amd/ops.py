@@ -1,0 +1,362 @@
+"""Tensor-level wrappers over the C ABI (one call = one or two HIP kernel launches on the current stream).
+
+PyTorch is used for device memory and streams only; nothing here computes on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as nat
+from ._native import (BF16, EPI_ACCUM, EPI_STORE, EPI_SWIGLU, F32, W_BF16, W_I8, W_Q4, AttnArgs, Int8Args, LinearArgs,
+                      check, dtype_code, lib, ptr, require_gpu, stream_ptr)
+
+MAX_M = 16
+_LDS_BUDGET = 160 * 1024
+
+
+def fast_linear_max_m(K: int, R: int, fmt: int = W_Q4, waves: int = 8) -> int:
+    """Largest M whose staged activations fit the 160 KiB LDS of one workgroup (see gemv.hip)."""
+    kp = (K + 127) // 128 * 128
+    if fmt == W_I8:
+        fixed = 512 + 2 * waves * R * 1024 + kp * 2 + 16
+        per_m = (kp + 16) + kp * 2
+    else:
+        fixed = 512 + 2 * waves * R * 1024
+        per_m = kp * 2 + 16
+    return max(0, min(MAX_M, (_LDS_BUDGET - fixed) // per_m))
+
+
+# ------------------------------------------------------------------------------------------ repack
+def packed_bytes(fmt: int, N: int, K: int, R: int, pair: bool) -> int:
+    n = int(lib().mi355_packed_bytes(fmt, N, K, R, 1 if pair else 0))
+    if n <= 0:
+        raise nat.NativeError(f"packed_bytes: bad shape fmt={fmt} N={N} K={K} R={R}")
+    return n
+
+
+def repack_q4(q0: torch.Tensor, q1: Optional[torch.Tensor], N: int, K: int, R: int) -> torch.Tensor:
+    """quant_weight [N, K/2] uint8 (any strides) -> Q4 stream (uint8 1-D)."""
+    require_gpu(q0, "repack_q4")
+    assert q0.dtype == torch.uint8 and q0.shape == (N, K // 2)
+    if q1 is not None:
+        assert q1.dtype == torch.uint8 and q1.shape == q0.shape and q1.stride() == q0.stride()
+    out = torch.empty(packed_bytes(W_Q4, N, K, R, q1 is not None), dtype=torch.uint8, device=q0.device)
+    check(lib().mi355_q4_repack(ptr(q0), ptr(q1), q0.stride(0), q0.stride(1), N, K, R, ptr(out), stream_ptr()),
+          "mi355_q4_repack")
+    return out
+
+
+def repack_bf16(w0: torch.Tensor, w1: Optional[torch.Tensor], R: int) -> torch.Tensor:
+    require_gpu(w0, "repack_bf16")
+    N, K = w0.shape
+    w0 = w0.contiguous()
+    if w1 is not None:
+        w1 = w1.contiguous()
+        assert w1.shape == w0.shape and w1.dtype == w0.dtype
+    out = torch.empty(packed_bytes(W_BF16, N, K, R, w1 is not None), dtype=torch.uint8, device=w0.device)
+    check(lib().mi355_bf16_repack(ptr(w0), ptr(w1), dtype_code(w0.dtype), N, K, R, ptr(out), stream_ptr()),
+          "mi355_bf16_repack")
+    return out
+
+
+def repack_i8(c0: torch.Tensor, c1: Optional[torch.Tensor], R: int) -> torch.Tensor:
+    require_gpu(c0, "repack_i8")
+    N, K = c0.shape
+    assert c0.dtype == torch.int8
+    c0 = c0.contiguous()
+    if c1 is not None:
+        c1 = c1.contiguous()
+    out = torch.empty(packed_bytes(W_I8, N, K, R, c1 is not None), dtype=torch.uint8, device=c0.device)
+    check(lib().mi355_i8_repack(ptr(c0), ptr(c1), N, K, R, ptr(out), stream_ptr()), "mi355_i8_repack")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ linears
+def linear_fast(
+    x2d: torch.Tensor,
+    stream: torch.Tensor,
+    fmt: int,
+    R: int,
+    N: int,
+    K: int,
+    *,
+    scales: Optional[torch.Tensor] = None,
+    zeros: Optional[torch.Tensor] = None,
+    scales2: Optional[torch.Tensor] = None,
+    zeros2: Optional[torch.Tensor] = None,
+    norm_scale: Optional[torch.Tensor] = None,
+    eps: float = 1e-5,
+    bias: Optional[torch.Tensor] = None,
+    epi: int = EPI_STORE,
+    out: Optional[torch.Tensor] = None,
+    out_dtype: Optional[torch.dtype] = None,
+    waves: int = 0,
+    grid: int = 0,
+    prefetch: int = 0,
+    flags: int = 0,
+) -> torch.Tensor:
+    """y[M, N] = epi(x2d[M, K] . W^T) through the MFMA weight-streaming kernel; M is chunked to fit LDS."""
+    require_gpu(x2d, "linear_fast")
+    assert x2d.dim() == 2 and x2d.shape[1] == K and x2d.stride(1) == 1
+    M = x2d.shape[0]
+    if out is None:
+        assert epi != EPI_ACCUM, "accumulate epilogue needs `out`"
+        out = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    a = LinearArgs()
+    a.fmt, a.R, a.w, a.N, a.K = fmt, R, ptr(stream), N, K
+    a.x_dtype = dtype_code(x2d.dtype)
+    a.ldx = x2d.stride(0)
+    a.norm_scale = ptr(norm_scale)
+    a.norm_dtype = dtype_code(norm_scale.dtype) if norm_scale is not None else F32
+    a.eps = eps
+    a.scales, a.zeros, a.scales2, a.zeros2 = ptr(scales), ptr(zeros), ptr(scales2), ptr(zeros2)
+    a.sz_dtype = dtype_code(scales.dtype) if scales is not None else (dtype_code(bias.dtype) if bias is not None else F32)
+    a.epi = epi
+    a.bias = ptr(bias)
+    a.y_dtype = dtype_code(out.dtype)
+    a.ldy = out.stride(0)
+    a.waves, a.grid, a.prefetch, a.flags = waves, grid, prefetch, flags
+    step = fast_linear_max_m(K, R, fmt, waves or 8)
+    if step < 1:
+        raise nat.NativeError(f"linear_fast: K={K} does not fit LDS even for M=1")
+    s = stream_ptr()
+    esz_x, esz_y = x2d.element_size(), out.element_size()
+    for m0 in range(0, M, step):
+        a.M = min(step, M - m0)
+        a.x = x2d.data_ptr() + m0 * x2d.stride(0) * esz_x
+        a.y = out.data_ptr() + m0 * out.stride(0) * esz_y
+        check(lib().mi355_linear_fast(C.byref(a), s), "mi355_linear_fast")
+    return out
+
+
+def linear_int8(
+    x2d: torch.Tensor,
+    stream: torch.Tensor,
+    scb: torch.Tensor,
+    R: int,
+    N: int,
+    K: int,
+    *,
+    scb2: Optional[torch.Tensor] = None,
+    norm_scale: Optional[torch.Tensor] = None,
+    eps: float = 1e-5,
+    threshold: float = 6.0,
+    bias: Optional[torch.Tensor] = None,
+    epi: int = EPI_STORE,
+    out: Optional[torch.Tensor] = None,
+    out_dtype: Optional[torch.dtype] = None,
+    waves: int = 0,
+    grid: int = 0,
+    prefetch: int = 0,
+) -> torch.Tensor:
+    require_gpu(x2d, "linear_int8")
+    assert x2d.dim() == 2 and x2d.shape[1] == K and x2d.stride(1) == 1
+    assert scb.dtype == torch.float32
+    M = x2d.shape[0]
+    if out is None:
+        assert epi != EPI_ACCUM
+        out = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
+    a = Int8Args()
+    a.w, a.scb, a.N, a.K = ptr(stream), ptr(scb), N, K
+    a.x_dtype = dtype_code(x2d.dtype)
+    a.ldx = x2d.stride(0)
+    a.norm_scale = ptr(norm_scale)
+    a.norm_dtype = dtype_code(norm_scale.dtype) if norm_scale is not None else F32
+    a.eps, a.threshold, a.R = eps, threshold, R
+    a.bias = ptr(bias)
+    a.bias_dtype = dtype_code(bias.dtype) if bias is not None else F32
+    a.epi = epi
+    a.scb2 = ptr(scb2)
+    a.y_dtype = dtype_code(out.dtype)
+    a.ldy = out.stride(0)
+    a.waves, a.grid, a.prefetch = waves, grid, prefetch
+    step = fast_linear_max_m(K, R, W_I8, waves or 8)
+    if step < 1:
+        raise nat.NativeError(f"linear_int8: K={K} does not fit LDS even for M=1")
+    s = stream_ptr()
+    for m0 in range(0, M, step):
+        a.M = min(step, M - m0)
+        a.x = x2d.data_ptr() + m0 * x2d.stride(0) * x2d.element_size()
+        a.y = out.data_ptr() + m0 * out.stride(0) * out.element_size()
+        check(lib().mi355_linear_int8(C.byref(a), s), "mi355_linear_int8")
+    return out
+
+
+def int8_quant_rows(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """bnb.functional.double_quant(W)[0], [2]: (CB int8 [N,K], SCB f32 [N])."""
+    require_gpu(w, "int8_quant_rows")
+    w = w.contiguous()
+    N, K = w.shape
+    cb = torch.empty((N, K), dtype=torch.int8, device=w.device)
+    scb = torch.empty((N,), dtype=torch.float32, device=w.device)
+    check(lib().mi355_int8_quant_rows(ptr(w), dtype_code(w.dtype), N, K, ptr(cb), ptr(scb), stream_ptr()),
+          "mi355_int8_quant_rows")
+    return cb, scb
+
+
+def linear_dense(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    require_gpu(x2d, "linear_dense")
+    assert x2d.dtype == w.dtype and x2d.stride(1) == 1
+    w = w.contiguous()
+    M, K = x2d.shape
+    N = w.shape[0]
+    if bias is not None:
+        bias = bias.to(x2d.dtype).contiguous()
+    out = torch.empty((M, N), dtype=x2d.dtype, device=x2d.device)
+    s = stream_ptr()
+    for m0 in range(0, M, 32768):
+        m = min(32768, M - m0)
+        check(lib().mi355_linear_dense(x2d.data_ptr() + m0 * x2d.stride(0) * x2d.element_size(), x2d.stride(0), ptr(w),
+                                       ptr(bias), out.data_ptr() + m0 * N * out.element_size(), N, m, N, K,
+                                       dtype_code(x2d.dtype), s), "mi355_linear_dense")
+    return out
+
+
+def linear_colblock(x2d: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, bits: int,
+                    tile_cols: int, bias: Optional[torch.Tensor], K: int) -> torch.Tensor:
+    require_gpu(x2d, "linear_colblock")
+    M = x2d.shape[0]
+    N = qweight.shape[0]
+    scales = scales.contiguous()
+    zeros = zeros.contiguous()
+    assert scales.dtype == zeros.dtype
+    if bias is not None:
+        bias = bias.to(scales.dtype).contiguous()
+    out = torch.empty((M, N), dtype=x2d.dtype, device=x2d.device)
+    s = stream_ptr()
+    for m0 in range(0, M, 32768):
+        m = min(32768, M - m0)
+        check(lib().mi355_linear_colblock(x2d.data_ptr() + m0 * x2d.stride(0) * x2d.element_size(), x2d.stride(0),
+                                          ptr(qweight), qweight.stride(0), qweight.stride(1), ptr(scales), ptr(zeros),
+                                          dtype_code(scales.dtype), scales.shape[1], tile_cols, bits, ptr(bias),
+                                          out.data_ptr() + m0 * N * out.element_size(), N, m, N, K,
+                                          dtype_code(x2d.dtype), s), "mi355_linear_colblock")
+    return out
+
+
+def colblock_dequant(qweight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, bits: int, tile_cols: int,
+                     K: int, dtype: torch.dtype) -> torch.Tensor:
+    require_gpu(qweight, "colblock_dequant")
+    N = qweight.shape[0]
+    scales = scales.contiguous()
+    zeros = zeros.contiguous()
+    out = torch.empty((N, K), dtype=dtype, device=qweight.device)
+    check(lib().mi355_colblock_dequant(ptr(qweight), qweight.stride(0), qweight.stride(1), ptr(scales), ptr(zeros),
+                                       dtype_code(scales.dtype), scales.shape[1], tile_cols, bits, ptr(out),
+                                       dtype_code(dtype), N, K, stream_ptr()), "mi355_colblock_dequant")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ small ops
+def rmsnorm(x: torch.Tensor, scale: torch.Tensor, eps: float, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    require_gpu(x, "rmsnorm")
+    C_ = x.shape[-1]
+    x2 = x.reshape(-1, C_)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    out = torch.empty(x2.shape, dtype=out_dtype or x.dtype, device=x.device)
+    check(lib().mi355_rmsnorm(ptr(x2), x2.stride(0), ptr(scale), dtype_code(scale.dtype), eps, ptr(out), C_,
+                              x2.shape[0], C_, dtype_code(x2.dtype), dtype_code(out.dtype), stream_ptr()),
+          "mi355_rmsnorm")
+    return out.view(x.shape)
+
+
+def apply_rope(x: torch.Tensor, rope: torch.Tensor) -> torch.Tensor:
+    require_gpu(x, "apply_rope")
+    B, T, nh, hs = x.shape
+    xc = x.contiguous()
+    rope = rope[:T].to(torch.float32).contiguous()
+    out = torch.empty_like(xc)
+    check(lib().mi355_apply_rope(ptr(xc), ptr(rope), ptr(out), B, T, nh, hs, dtype_code(x.dtype), stream_ptr()),
+          "mi355_apply_rope")
+    return out
+
+
+def swiglu(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    require_gpu(a, "swiglu")
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    check(lib().mi355_swiglu(ptr(a), ptr(b), ptr(out), a.numel(), dtype_code(a.dtype), stream_ptr()), "mi355_swiglu")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    require_gpu(a, "add")
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    check(lib().mi355_add(ptr(a), ptr(b), ptr(out), a.numel(), dtype_code(a.dtype), stream_ptr()), "mi355_add")
+    return out
+
+
+def embedding(idx: torch.Tensor, wte: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    require_gpu(wte, "embedding")
+    assert idx.dtype in (torch.int32, torch.int64)
+    flat = idx.reshape(-1).contiguous()
+    wte = wte.contiguous()
+    V, C_ = wte.shape
+    out = torch.empty((flat.numel(), C_), dtype=out_dtype or wte.dtype, device=wte.device)
+    check(lib().mi355_embedding(ptr(flat), 1 if idx.dtype == torch.int64 else 0, ptr(wte), dtype_code(wte.dtype),
+                                ptr(out), dtype_code(out.dtype), flat.numel(), C_, V, stream_ptr()), "mi355_embedding")
+    return out.view(*idx.shape, C_)
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    require_gpu(logits, "argmax")
+    assert logits.dim() == 1 and logits.dtype == torch.float32
+    logits = logits.contiguous()
+    out = torch.empty((1,), dtype=torch.int32, device=logits.device)
+    check(lib().mi355_argmax(ptr(logits), logits.numel(), ptr(out), None, None, stream_ptr()), "mi355_argmax")
+    return out
+
+
+def attention(
+    qkv: torch.Tensor,
+    rope: torch.Tensor,
+    n_head: int,
+    *,
+    pos: Optional[torch.Tensor] = None,
+    kv_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+    rope_gathered: bool = False,
+    out_dtype: Optional[torch.dtype] = None,
+) -> torch.Tensor:
+    """qkv [B, T, 3C] -> y [B, T, C]; RoPE + (in-place) cache write + causal attention."""
+    require_gpu(qkv, "attention")
+    B, T, C3 = qkv.shape
+    Cw = C3 // 3
+    hs = Cw // n_head
+    qkv = qkv.contiguous()
+    assert rope.dtype == torch.float32 and rope.is_contiguous()
+    y = torch.empty((B, T, Cw), dtype=out_dtype or qkv.dtype, device=qkv.device)
+    a = AttnArgs()
+    a.qkv, a.qkv_dtype, a.B, a.ld_qkv = ptr(qkv), dtype_code(qkv.dtype), B, C3
+    a.rope = ptr(rope)
+    a.T, a.n_head, a.hs = T, n_head, hs
+    a.y, a.y_dtype, a.ldy = ptr(y), dtype_code(y.dtype), Cw
+    a.rope_gathered = 1 if rope_gathered else 0
+    keep = []
+    if kv_cache is not None:
+        k, v = kv_cache
+        assert k.is_contiguous() and v.is_contiguous() and k.shape == v.shape and k.shape[0] == B
+        assert k.shape[1] == n_head and k.shape[3] == hs and k.dtype == v.dtype
+        assert pos is not None and pos.numel() == T
+        p32 = pos.to(torch.int32).contiguous()
+        keep.append(p32)
+        a.pos, a.kcache, a.vcache, a.cache_dtype, a.S = ptr(p32), ptr(k), ptr(v), dtype_code(k.dtype), k.shape[2]
+    else:
+        cdt = qkv.dtype if qkv.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        tmp = torch.empty((2, B, n_head, T, hs), dtype=cdt, device=qkv.device)
+        keep.append(tmp)
+        a.kv_tmp, a.cache_dtype, a.S = ptr(tmp), dtype_code(cdt), T
+    check(lib().mi355_attention(C.byref(a), stream_ptr()), "mi355_attention")
+    return y
+
+
+def kv_roll(k: torch.Tensor, v: torch.Tensor) -> None:
+    require_gpu(k, "kv_roll")
+    B, nh, S, hs = k.shape
+    check(lib().mi355_kv_roll(ptr(k), ptr(v), dtype_code(k.dtype), B, nh, S, hs, stream_ptr()), "mi355_kv_roll")

@@ -1,0 +1,194 @@
+"""Drop-in operator plug-ins: `ColBlockQuantizedLinear` (GPTQ int4 / int8) and `Linear8bitLt` (LLM.int8).
+
+Same constructor signatures, registered buffers, state-dict keys, `pack_weight` / `get_weight` / `forward`
+contract as /root/reference lit_llama/quantization.py:38-77 and :340-423, so `quantization(mode)` +
+`LLaMA.from_name` + `load_state_dict` of a reference checkpoint work unchanged.
+`forward` runs hand-written gfx950 kernels through the C ABI; there is neither Triton, nor bitsandbytes,
+nor a CPU fallback behind it.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _native as nat
+from . import ops
+
+
+class ColBlockQuantizedLinear(torch.nn.Module):
+    """k-bit (4 or 8) linear with per-row x per-column-tile scale / zero.
+
+    Buffers (lit_llama/quantization.py:350-374):
+      quant_weight uint8 [out, in * bits / 8] stored column-major (stride (1, out));
+      byte j of row n = q[n, 2j] | q[n, 2j + 1] << 4 for bits = 4 (:387-390);
+      scales, zeros [out, ceil(in / tile_cols)]; bias [out] or None.
+    """
+
+    def __init__(self, in_features, out_features, bias: bool, *, bits, tile_cols):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.tile_cols = tile_cols if tile_cols != -1 else self.in_features
+        self.bits = bits
+        self.entries_per_byte = 8 // bits
+        assert self.entries_per_byte > 0 and self.entries_per_byte * self.bits == 8
+        assert in_features % self.entries_per_byte == 0
+        self.register_buffer(
+            "quant_weight",
+            torch.empty((self.out_features, self.in_features // self.entries_per_byte), dtype=torch.uint8)
+            .t()
+            .contiguous()
+            .t(),
+        )
+        n_groups = (self.in_features + self.tile_cols - 1) // self.tile_cols
+        self.register_buffer("scales", torch.empty((self.out_features, n_groups)))
+        self.register_buffer("zeros", torch.empty_like(self.scales))
+        assert isinstance(bias, bool)
+        if bias:
+            self.register_buffer("bias", torch.empty((self.out_features,)))
+        else:
+            self.register_buffer("bias", None)
+        self._stream: Optional[torch.Tensor] = None  # repacked weight stream (fast path)
+        self._stream_key = None
+
+    # ---- format utilities (device agnostic tensor reshuffling; not on the hot path) -----------------
+    def pack_weight(self, weight):
+        """Quantise `weight` with the current scales / zeros and pack it (lit_llama/quantization.py:376-390),
+        including the reference's truncating float -> uint8 conversion."""
+        weight = weight.to(device=self.quant_weight.device, copy=True)
+        for j in range(self.scales.size(1)):
+            sl = slice(j * self.tile_cols, (j + 1) * self.tile_cols)
+            weight[:, sl] /= self.scales[:, j : j + 1]
+            weight[:, sl] += self.zeros[:, j : j + 1]
+        weight = weight.clamp_(min=0, max=2**self.bits - 1).to(dtype=torch.uint8)
+        self.quant_weight.zero_()
+        for nr in range(self.entries_per_byte):
+            self.quant_weight += weight[:, nr :: self.entries_per_byte] << (nr * self.bits)
+        self._stream = None
+
+    def get_weight(self, dtype=torch.float):
+        """Dequantised [out, in] weight (lit_llama/quantization.py:392-411)."""
+        if self.quant_weight.device.type == "cuda":
+            return ops.colblock_dequant(self.quant_weight, self.scales, self.zeros, self.bits, self.tile_cols,
+                                        self.in_features, dtype)
+        # host-side format utility (checkpoint tooling); same arithmetic as the reference
+        weight = torch.empty((self.out_features, self.in_features), device=self.quant_weight.device, dtype=dtype)
+        mask = (1 << self.bits) - 1
+        for nr in range(self.entries_per_byte):
+            weight[:, nr :: self.entries_per_byte] = ((self.quant_weight >> (nr * self.bits)) & mask).float()
+        for j in range(self.scales.size(1)):
+            sl = slice(j * self.tile_cols, (j + 1) * self.tile_cols)
+            weight[:, sl] -= self.zeros[:, j : j + 1]
+            weight[:, sl] *= self.scales[:, j : j + 1]
+        return weight
+
+    # ---- hot path -----------------------------------------------------------------------------------
+    def fast_eligible(self, dtype: torch.dtype) -> bool:
+        """MFMA weight-streaming kernel: 4 bits, one scale/zero per row (gptq.int4's tile_cols = -1), bf16 I/O."""
+        return (
+            self.bits == 4
+            and self.scales.shape[1] == 1
+            and dtype == torch.bfloat16
+            and self.scales.dtype in (torch.bfloat16, torch.float32)
+            and self.in_features % 2 == 0
+        )
+
+    def weight_stream(self, R: int = 1) -> torch.Tensor:
+        key = (self.quant_weight.data_ptr(), self.quant_weight._version, R)
+        if self._stream is None or self._stream_key != key:
+            self._stream = ops.repack_q4(self.quant_weight, None, self.out_features, self.in_features, R)
+            self._stream_key = key
+        return self._stream
+
+    def forward(self, inp):
+        nat.require_gpu(inp, "ColBlockQuantizedLinear.forward")
+        nat.require_gpu(self.quant_weight, "ColBlockQuantizedLinear.forward (module buffers)")
+        x2d = inp.reshape(-1, inp.shape[-1])
+        if x2d.stride(-1) != 1:
+            x2d = x2d.contiguous()
+        if self.fast_eligible(inp.dtype):
+            R = 2 if self.out_features % 32 == 0 and self.out_features >= 16384 else 1
+            y = ops.linear_fast(
+                x2d, self.weight_stream(R), nat.W_Q4, R, self.out_features, self.in_features,
+                scales=self.scales.reshape(-1), zeros=self.zeros.reshape(-1),
+                bias=None if self.bias is None else self.bias.to(self.scales.dtype),
+                out_dtype=inp.dtype,
+            )
+        else:
+            y = ops.linear_colblock(x2d, self.quant_weight, self.scales, self.zeros, self.bits, self.tile_cols,
+                                    self.bias, self.in_features)
+        return y.view(*inp.shape[:-1], self.out_features)
+
+
+class Linear8bitLt(torch.nn.Linear):
+    """LLM.int8 linear for inference: int8 row-quantised weight (`weight.CB`, `weight.SCB`), quantised at
+    construction and re-quantised when a float checkpoint is loaded (lit_llama/quantization.py:38-77).
+    `threshold = 6.0`, `has_fp16_weights = False` as in the reference."""
+
+    threshold = 6.0
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.weight.requires_grad_(False)
+        if self.bias is not None:
+            self.bias.requires_grad_(False)
+        self._stream: Optional[torch.Tensor] = None
+        self._stream_key = None
+        self._pending_fp: Optional[torch.Tensor] = None
+        self._quantize_weight(self.weight.data)
+
+    def _load_from_state_dict(self, local_state_dict, *args, **kwargs):
+        # exactly one key ends with `weight`; the other possible one is the bias (:52-67)
+        weight_key = next((name for name in local_state_dict.keys() if name.endswith("weight")), None)
+        if weight_key is None:
+            return
+        weight = local_state_dict.pop(weight_key)
+        self._quantize_weight(weight)
+        if local_state_dict:
+            super()._load_from_state_dict(local_state_dict, *args, **kwargs)
+
+    def _quantize_weight(self, weight: torch.Tensor) -> None:
+        """`bnb.functional.double_quant(weight.half().cuda())` -> CB, SCB (:69-77), on the module's GPU."""
+        dev = self.weight.device
+        if dev.type != "cuda":
+            # the reference cannot even construct this module off-GPU; keep the float weight until `.to(cuda)`
+            self._pending_fp = weight.detach()
+            return
+        w = weight.detach().to(device=dev)
+        if w.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            w = w.float()
+        CB, SCB = ops.int8_quant_rows(w.contiguous())
+        self.weight.data = CB
+        setattr(self.weight, "CB", CB)
+        setattr(self.weight, "SCB", SCB)
+        self._pending_fp = None
+        self._stream = None
+
+    def _apply(self, fn, recurse=True):
+        pending = self._pending_fp
+        out = super()._apply(fn, recurse)
+        if pending is not None and self.weight.device.type == "cuda":
+            self._quantize_weight(pending.to(self.weight.device))
+        return out
+
+    def weight_stream(self, R: int = 1) -> torch.Tensor:
+        CB = self.weight.CB
+        key = (CB.data_ptr(), CB._version, R)
+        if self._stream is None or self._stream_key != key:
+            self._stream = ops.repack_i8(CB, None, R)
+            self._stream_key = key
+        return self._stream
+
+    def forward(self, x):
+        nat.require_gpu(x, "Linear8bitLt.forward")
+        if not hasattr(self.weight, "CB"):
+            raise nat.NativeError("Linear8bitLt: weight is not quantised (module was never moved to the GPU)")
+        x2d = x.reshape(-1, x.shape[-1])
+        if x2d.stride(-1) != 1:
+            x2d = x2d.contiguous()
+        y = ops.linear_int8(
+            x2d, self.weight_stream(1), self.weight.SCB, 1, self.out_features, self.in_features,
+            threshold=self.threshold, bias=self.bias, out_dtype=x.dtype,
+        )
+        return y.view(*x.shape[:-1], self.out_features)

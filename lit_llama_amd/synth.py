@@ -1,0 +1,141 @@
+"""Deterministic synthetic checkpoints and prompts — there are no LLaMA weights offline.
+
+State dicts use the reference's key names (scripts/convert_checkpoint.py:24-53) and buffer layouts, so they
+load into `lit_llama.LLaMA` (the reference, in tests) and `lit_llama_amd.LLaMA` alike:
+
+  fp          : every Linear W ~ N(0, 1/K); embedding ~ N(0, 1); RMSNorm scales 1 + 0.1 N(0, 1)
+  gptq.int4   : the fp weights quantised per output row, asymmetric min/max round-to-nearest exactly as
+                GPTQQuantizer.find_params_weight / quantize_weight (lit_llama/quantization.py:472-513, perchannel,
+                not sym); integer levels written straight into the packed column-major buffer (:350-359,
+                :387-390); scales are rounded to bf16 ONCE here, so the bf16 GPU buffers and the f32 oracle
+                dequantise identical weights; zeros are small integers (exact in any dtype)
+  llm.int8    : fp weights with a few input channels of the embedding / norm scales boosted so activations cross
+                the |x| >= 6 outlier threshold
+
+`device="cuda"` generates directly in HBM with the torch CUDA generator (bench); the CPU generator (tests) is
+what the golden fixtures were produced from.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .model import LLaMAConfig
+
+
+def linear_shapes(cfg: LLaMAConfig):
+    """(state-dict prefix, out_features, in_features) of every linear, in module order."""
+    C, H, V = cfg.n_embd, cfg.n_hidden, cfg.padded_vocab_size
+    out = [("lm_head", V, C)]
+    for i in range(cfg.n_layer):
+        p = f"transformer.h.{i}."
+        out += [(p + "attn.c_attn", 3 * C, C), (p + "attn.c_proj", C, C), (p + "mlp.c_fc1", H, C),
+                (p + "mlp.c_fc2", H, C), (p + "mlp.c_proj", C, H)]
+    return out
+
+
+def rtn_quantize_rows(w: torch.Tensor, bits: int = 4):
+    """Per-row asymmetric round-to-nearest: returns (q uint8 [N, K], scale f32 [N], zero f32 [N])."""
+    maxq = 2**bits - 1
+    w = w.float()
+    zero_t = torch.zeros(w.shape[0], device=w.device)
+    xmin = torch.minimum(w.min(1)[0], zero_t)
+    xmax = torch.maximum(w.max(1)[0], zero_t)
+    flat = (xmin == 0) & (xmax == 0)
+    xmin[flat] = -1
+    xmax[flat] = +1
+    scale = (xmax - xmin) / maxq
+    zero = torch.round(-xmin / scale)
+    q = torch.clamp(torch.round(w / scale[:, None]) + zero[:, None], 0, maxq).to(torch.uint8)
+    return q, scale, zero
+
+
+def pack_colblock(q: torch.Tensor, bits: int = 4) -> torch.Tensor:
+    """q [N, K] uint8 levels -> quant_weight [N, K * bits / 8] uint8 with stride (1, N)."""
+    epb = 8 // bits
+    N, K = q.shape
+    packed = torch.zeros((N, K // epb), dtype=torch.uint8, device=q.device)
+    for nr in range(epb):
+        packed |= q[:, nr::epb] << (nr * bits)
+    return packed.t().contiguous().t()
+
+
+def _randn(shape, gen, device, std=1.0):
+    return torch.randn(shape, generator=gen, device=device, dtype=torch.float32) * std
+
+
+def make_state_dict(
+    cfg: LLaMAConfig,
+    *,
+    seed: int = 0,
+    mode: Optional[str] = None,
+    dtype: torch.dtype = torch.float32,
+    device: str = "cpu",
+    outlier_channels: int = 0,
+) -> Dict[str, torch.Tensor]:
+    """Synthetic checkpoint.  mode None / "llm.int8": float weights in `dtype`; "gptq.int4": packed buffers with
+    scales / zeros in `dtype`."""
+    assert mode in (None, "gptq.int4", "llm.int8")
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    C = cfg.n_embd
+    sd: Dict[str, torch.Tensor] = {}
+    wte = _randn((cfg.padded_vocab_size, C), gen, device)
+    ln = lambda: 1.0 + 0.1 * _randn((C,), gen, device)  # noqa: E731
+    norms = {"transformer.ln_f.scale": ln()}
+    for i in range(cfg.n_layer):
+        norms[f"transformer.h.{i}.rms_1.scale"] = ln()
+        norms[f"transformer.h.{i}.rms_2.scale"] = ln()
+    if outlier_channels:
+        # fixed channels x20: after RMSNorm these exceed the LLM.int8 threshold of 6
+        ch = torch.arange(outlier_channels, device=device) * (C // max(outlier_channels, 1)) + 3
+        for k in norms:
+            norms[k][ch] *= 20.0
+    sd["transformer.wte.weight"] = wte.to(dtype)
+    for k, v in norms.items():
+        sd[k] = v.to(dtype)
+    for prefix, N, K in linear_shapes(cfg):
+        w = _randn((N, K), gen, device, std=K**-0.5)
+        if mode == "gptq.int4":
+            q, scale, zero = rtn_quantize_rows(w, 4)
+            scale = scale.to(torch.bfloat16).float()  # rounded once; identical on both sides
+            sd[prefix + ".quant_weight"] = pack_colblock(q, 4)
+            sd[prefix + ".scales"] = scale[:, None].to(dtype)
+            sd[prefix + ".zeros"] = zero[:, None].to(dtype)
+        else:
+            sd[prefix + ".weight"] = w.to(dtype)
+    return sd
+
+
+def make_prompt(length: int, vocab: int = 32000, seed: int = 1234, device: str = "cpu") -> torch.Tensor:
+    """BOS (id 1) followed by uniform ids, int32 1-D (tokenizer.py:43 returns torch.int)."""
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(seed)
+    ids = torch.randint(0, vocab, (length,), generator=gen, dtype=torch.int64)
+    ids[0] = 1
+    return ids.to(torch.int32).to(device)
+
+
+def fill_model_random_int4(model, seed: int = 0) -> None:
+    """Bench-only shortcut for multi-GB models: fill every ColBlockQuantizedLinear of a GPU model in place with
+    uniformly random levels, scales (max - min) / 15 of a N(0, 1/K) row (~ 7.2 / sqrt(K) / 15) and zero 8, and
+    the embedding / norm scales as in make_state_dict — without materialising fp32 weights first."""
+    from .quantization import ColBlockQuantizedLinear
+
+    dev = model.transformer.wte.weight.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    with torch.no_grad():
+        model.transformer.wte.weight.copy_(_randn(tuple(model.transformer.wte.weight.shape), gen, dev))
+        for name, mod in model.named_modules():
+            if isinstance(mod, ColBlockQuantizedLinear):
+                N, Kb = mod.quant_weight.shape
+                raw = torch.randint(0, 256, (Kb, N), generator=gen, device=dev, dtype=torch.uint8)
+                mod.quant_weight.copy_(raw.t())
+                K = mod.in_features
+                s = (7.2 / 15.0) * K**-0.5 * (1.0 + 0.1 * torch.rand((N, 1), generator=gen, device=dev))
+                mod.scales.copy_(s.to(mod.scales.dtype))
+                mod.zeros.fill_(8.0)
+            elif name.endswith(("rms_1", "rms_2", "ln_f")):
+                mod.scale.copy_((1.0 + 0.1 * _randn(tuple(mod.scale.shape), gen, dev)).to(mod.scale.dtype))

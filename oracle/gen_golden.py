@@ -1,0 +1,202 @@
+"""Produce tests/golden/*.npz by running the UNMODIFIED reference (/root/reference) in this container.
+
+    python oracle/gen_golden.py            # needs /root/reference; run in the build container only
+
+The reference imports `lightning` at module import time (lit_llama/utils.py:15, generate.py:9); that package is
+absent here, so oracle/_stubs/lightning provides the two names touched at import.  Nothing under
+/root/reference is modified or copied.  Weights are NOT stored: they are re-created from a seed by
+lit_llama_amd/synth.py (torch's CPU generator is deterministic for a given torch build), only inputs and the
+reference's outputs are written.  The script also checks oracle/oracle.py (the restatement) against the same
+runs and refuses to write fixtures the restatement does not reproduce.
+"""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference")
+sys.path[:0] = [str(ROOT / "oracle" / "_stubs"), str(REF), str(ROOT)]
+
+import generate as ref_generate  # noqa: E402  (reference generate.py)
+import lit_llama as ref  # noqa: E402
+from lit_llama.quantization import ColBlockQuantizedLinear as RefColBlock  # noqa: E402
+from lit_llama.utils import quantization as ref_quantization  # noqa: E402
+
+from lit_llama_amd import synth  # noqa: E402
+from lit_llama_amd.model import LLaMAConfig as OurConfig  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+PROBES = 64  # logit columns stored per step
+
+
+def probe_index(vocab: int) -> np.ndarray:
+    return (np.arange(PROBES) * (vocab // PROBES) + 7) % vocab
+
+
+@torch.no_grad()
+def ref_teacher_forced(model, tokens, prompt_len, max_seq_length):
+    model.reset_cache() if model.mask_cache is not None else None
+    out = []
+    input_pos = torch.arange(0, prompt_len)
+    for _ in range(tokens.numel() - prompt_len):
+        x = tokens.index_select(0, input_pos).view(1, -1)
+        out.append(model(x, max_seq_length, input_pos)[0, -1].float())
+        input_pos = input_pos[-1:] + 1
+    model.reset_cache()
+    return torch.stack(out)
+
+
+def summarize(logits: torch.Tensor, vocab: int):
+    top2 = torch.topk(logits, 2, dim=-1)
+    return dict(
+        argmax=top2.indices[:, 0].numpy().astype(np.int32),
+        margin=(top2.values[:, 0] - top2.values[:, 1]).numpy().astype(np.float32),
+        probes=logits[:, torch.from_numpy(probe_index(vocab))].numpy().astype(np.float32),
+        std=logits.std(dim=-1).numpy().astype(np.float32),
+        mean=logits.mean(dim=-1).numpy().astype(np.float32),
+    )
+
+
+def model_case(name, cfg_kwargs, mode, prompt_len, new_tokens, max_seq_length=None, seed=0):
+    torch.manual_seed(1234)
+    ref_cfg = ref.LLaMAConfig(**cfg_kwargs)
+    our_cfg = OurConfig(**cfg_kwargs)
+    sd = synth.make_state_dict(our_cfg, seed=seed, mode=mode)
+    with ref_quantization(mode):
+        model = ref.LLaMA(ref_cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    prompt = synth.make_prompt(prompt_len, vocab=ref_cfg.vocab_size)
+    toks = ref_generate.generate(model, prompt, new_tokens, top_k=1, max_seq_length=max_seq_length)
+    model.reset_cache()
+    S = max_seq_length if max_seq_length is not None else min(prompt_len + new_tokens, ref_cfg.block_size)
+    rolled = prompt_len + new_tokens > S
+    fix = dict(tokens=toks.numpy().astype(np.int32), prompt_len=np.int32(prompt_len), seed=np.int32(seed),
+               max_seq_length=np.int32(S))
+    if not rolled:
+        logits = ref_teacher_forced(model, toks, prompt_len, S)
+        fix.update(summarize(logits, ref_cfg.padded_vocab_size))
+        # no-cache full forward over the finished sequence (evaluate/full.py:120-129 shape of call)
+        with torch.no_grad():
+            full = model(toks[:-1].view(1, -1).long())[0].float()
+        fix["nocache_argmax"] = full.argmax(-1).numpy().astype(np.int32)
+        fix["nocache_probes"] = full[:, torch.from_numpy(probe_index(ref_cfg.padded_vocab_size))].numpy().astype(np.float32)
+        model.reset_cache()
+
+    # ---- pin the restatement on the very same run
+    om = oracle.Model(oracle.Config(**cfg_kwargs), {k: v.clone() for k, v in sd.items()}, mode=mode)
+    otoks = oracle.generate(om, prompt, new_tokens, top_k=1, max_seq_length=max_seq_length)
+    assert torch.equal(otoks, toks), f"{name}: oracle tokens differ from the reference"
+    if not rolled:
+        ologits = oracle.teacher_forced_logits(om, toks, prompt_len, S)
+        err = (ologits - logits).abs().max().item()
+        assert err <= 1e-5 * max(1.0, logits.abs().max().item()), f"{name}: oracle logits off by {err}"
+        print(f"  {name}: oracle == reference (tokens equal, max |dlogit| {err:.2e}, min margin {fix['margin'].min():.3e})")
+    else:
+        print(f"  {name}: oracle == reference (tokens equal, cache-roll regime)")
+    np.savez_compressed(OUT / f"{name}.npz", **fix)
+
+
+def colblock_cases():
+    fix = {}
+    gen = torch.Generator().manual_seed(7)
+    for tag, (N, K, bits, tile_cols) in {"b4_row": (96, 256, 4, -1), "b4_g64": (48, 256, 4, 64),
+                                          "b8_row": (32, 128, 8, -1)}.items():
+        mod = RefColBlock(K, N, bias=False, bits=bits, tile_cols=tile_cols)
+        w = torch.randn((N, K), generator=gen) * K**-0.5
+        tc = mod.tile_cols
+        G = mod.scales.shape[1]
+        maxq = 2**bits - 1
+        scales, zeros = torch.empty((N, G)), torch.empty((N, G))
+        for g in range(G):
+            blk = w[:, g * tc:(g + 1) * tc]
+            xmin = torch.minimum(blk.min(1)[0], torch.zeros(N))
+            xmax = torch.maximum(blk.max(1)[0], torch.zeros(N))
+            scales[:, g] = (xmax - xmin) / maxq
+            zeros[:, g] = torch.round(-xmin / scales[:, g])
+        mod.scales.copy_(scales)
+        mod.zeros.copy_(zeros)
+        mod.pack_weight(w)
+        x = torch.randn((3, K), generator=gen)
+        y = mod(x)
+        wdq = mod.get_weight()
+        # restatement pin
+        oq = oracle.colblock_pack(w, scales, zeros, bits, tc)
+        assert torch.equal(oq, mod.quant_weight), f"colblock {tag}: pack differs"
+        assert torch.equal(oracle.colblock_get_weight(oq, scales, zeros, bits, tc), wdq), f"colblock {tag}: dequant differs"
+        assert torch.equal(oracle.colblock_linear(x, oq, scales, zeros, bits, tc), y), f"colblock {tag}: forward differs"
+        fix.update({f"{tag}_w": w.numpy(), f"{tag}_q": mod.quant_weight.contiguous().numpy(),
+                    f"{tag}_scales": scales.numpy(), f"{tag}_zeros": zeros.numpy(), f"{tag}_x": x.numpy(),
+                    f"{tag}_y": y.numpy(), f"{tag}_wdq": wdq.numpy(),
+                    f"{tag}_meta": np.array([N, K, bits, tc], dtype=np.int32),
+                    f"{tag}_qstride": np.array(mod.quant_weight.stride(), dtype=np.int64)})
+    print("  colblock: oracle == reference (pack / get_weight / forward bit-equal)")
+    np.savez_compressed(OUT / "colblock.npz", **fix)
+
+
+def block_cases():
+    """RMSNorm, RoPE, Block forward (no cache, B = 3) and attention with cache on small dims, like the shapes of
+    tests/test_model.py:37-102, tests/test_rope.py, tests/test_rmsnorm.py of the reference."""
+    torch.manual_seed(11)
+    fix = {}
+    x = torch.randn(2, 16, 16)
+    norm = ref.RMSNorm(16, eps=1e-6)
+    norm.scale.data = 1 + 0.1 * torch.randn(16)
+    fix.update(rms_x=x.numpy(), rms_scale=norm.scale.detach().numpy(), rms_y=norm(x).detach().numpy())
+    assert torch.equal(oracle.rmsnorm(x, norm.scale.detach(), 1e-6), norm(x).detach())
+
+    rc = ref.build_rope_cache(seq_len=6, n_elem=4, dtype=torch.float32, device="cpu")
+    xr = torch.randn(1, 6, 2, 4)
+    fix.update(rope_cache=rc.numpy(), rope_x=xr.numpy(), rope_y=ref.apply_rope(xr, rc).numpy())
+    big = ref.build_rope_cache(seq_len=2048, n_elem=128, dtype=torch.int64, device="cpu")
+    assert torch.equal(oracle.build_rope_cache(2048, 128, dtype=torch.int64), big)
+    fix.update(rope_big_rows=big[[0, 1, 17, 511, 2047]].numpy())
+
+    cfg = ref.LLaMAConfig(block_size=64, vocab_size=100, n_layer=2, n_head=4, n_embd=32)
+    model = ref.LLaMA(cfg)
+    model.apply(model._init_weights)
+    for p_ in model.parameters():
+        p_.data = torch.randn_like(p_) * (0.3 if p_.dim() > 1 else 0.1) + (0 if p_.dim() > 1 else 1)
+    model.eval()
+    idx = torch.randint(0, 100, (3, 9))
+    with torch.no_grad():
+        logits = model(idx)
+        logits_pos = model(idx[:1], 12, torch.arange(9))
+        kc, vc = model.kv_caches[1]
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    om = oracle.Model(oracle.Config(block_size=64, vocab_size=100, n_layer=2, n_head=4, n_embd=32), sd)
+    with torch.no_grad():
+        assert torch.allclose(om(idx), logits, atol=1e-6), "block: oracle no-cache forward differs"
+        ol = om(idx[:1], 12, torch.arange(9))
+        assert torch.allclose(ol, logits_pos, atol=1e-6), "block: oracle cached forward differs"
+        assert torch.allclose(om.kv_caches[1][0], kc, atol=1e-6)
+    fix.update({f"blk_sd::{k}": v.numpy() for k, v in sd.items()})
+    fix.update(blk_idx=idx.numpy().astype(np.int64), blk_logits=logits.numpy(), blk_logits_pos=logits_pos.numpy(),
+               blk_kcache=kc.numpy(), blk_vcache=vc.numpy())
+    print("  rmsnorm / rope / block: oracle == reference")
+    np.savez_compressed(OUT / "blocks.npz", **fix)
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(8)
+    print("generating golden fixtures from", REF)
+    colblock_cases()
+    block_cases()
+    cfg1 = dict(n_layer=2, n_head=4, n_embd=256)
+    model_case("cfg1_fp32", cfg1, None, prompt_len=8, new_tokens=24)
+    model_case("cfg1_int4", cfg1, "gptq.int4", prompt_len=8, new_tokens=24)
+    # the cache-roll regime of tests/test_generate.py:26-54 (max_seq_length < T + max_new_tokens)
+    tiny = dict(block_size=128, vocab_size=16, n_layer=1, n_head=4, n_embd=8)
+    model_case("tiny_roll", tiny, None, prompt_len=5, new_tokens=20, max_seq_length=10)
+    model_case("tiny_noroll", tiny, None, prompt_len=5, new_tokens=20)
+    print("done ->", OUT)
+
+
+if __name__ == "__main__":
+    main()
