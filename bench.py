@@ -1,0 +1,297 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: LLaMA-7B `gptq.int4`, batch 1, greedy decode on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one decoded token: one pass of the whole forward (32 layers x 5 launches + lm_head + on-device
+argmax, replayed from a hipGraph) over synthetic random-init weights of the 7B architecture, with the
+prompt already prefilled and everything resident in HBM when the timed region starts.  W untimed steps, then
+EXACTLY K timed steps between (barrier +) torch.cuda.synchronize() on both sides; MAX over ranks; rank 0 prints
+ONE JSON line.  With N > 1 every GPU decodes its own independent stream (the bs=1 7B path does not shard —
+SURVEY.md §8e: "replicas only"), so scaling is "weak" and `value` is the sum over ranks.
+
+Extra objects on the same line:
+  roofline     — the dominant kernel (c_fc1/c_fc2 + SwiGLU int4 weight-streaming launch): algorithmic bytes per
+                 launch / average launch duration, measured with events on the launch stream over all 32 layers'
+                 weights (1.4 GB, larger than the 256 MiB Infinity Cache), vs the 8.0 TB/s HBM peak;
+  cpu_baseline — oracle/oracle.py (a port of the reference's CPU path, which dequantises every weight on every
+                 call) timed on the host cores over a bounded sample, extrapolated to 32 layers.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+METRIC = "decode tokens/sec/GPU LLaMA-7B gptq.int4 bs=1; % HBM roofline"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--prompt-len", type=int, default=128)
+    ap.add_argument("--model", default="7B")
+    ap.add_argument("--quantize", default="gptq.int4", choices=["gptq.int4", "llm.int8", "none"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--tune", default=None, help="JSON dict of per-linear launch tuning (engine.DecodeEngine tune)")
+    return ap.parse_args()
+
+
+def bytes_per_token(cfg, mode: str):
+    """Algorithmic HBM bytes of one decode step: every linear weight once + its per-row
+    scale/zero + norm scales + one embedding row; KV traffic is reported separately (position dependent)."""
+    C_, H, V, L = cfg.n_embd, cfg.n_hidden, cfg.padded_vocab_size, cfg.n_layer
+    params = L * (3 * C_ * C_ + C_ * C_ + 3 * C_ * H) + V * C_
+    rows = L * (3 * C_ + C_ + 2 * H + C_) + V
+    wbytes = {"gptq.int4": params // 2, "llm.int8": params, "none": params * 2}[mode]
+    side = {"gptq.int4": rows * 4, "llm.int8": rows * 4, "none": 0}[mode]
+    other = (2 * L + 1) * C_ * 2 + C_ * 2
+    return dict(weights=wbytes, total=wbytes + side + other, kv_per_pos=2 * L * C_ * 2)
+
+
+def build_model(args, dev):
+    from lit_llama_amd import synth
+    from lit_llama_amd.model import LLaMA, LLaMAConfig
+    from lit_llama_amd.utils import EmptyInitOnDevice
+
+    cfg = LLaMAConfig.from_name(args.model)
+    mode = None if args.quantize == "none" else args.quantize
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode=mode):
+        model = LLaMA(cfg)
+    model.eval()
+    if mode == "gptq.int4":
+        synth.fill_model_random_int4(model, seed=0)
+    else:
+        gen = torch.Generator(device=dev).manual_seed(0)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if name.endswith("scale"):
+                    p.copy_((1 + 0.1 * torch.randn(p.shape, generator=gen, device=dev)).to(p.dtype))
+                elif name.endswith("wte.weight"):
+                    p.copy_(torch.randn(p.shape, generator=gen, device=dev).to(p.dtype))
+            for mod in model.modules():
+                if isinstance(mod, torch.nn.Linear):
+                    w = torch.randn(mod.weight.shape, generator=gen, device=dev) * mod.in_features**-0.5
+                    if mode == "llm.int8":
+                        mod._quantize_weight(w)
+                    else:
+                        mod.weight.data.copy_(w.to(mod.weight.dtype))
+    if args.tune:
+        model._engine = None
+        from lit_llama_amd.engine import DecodeEngine
+
+        model._engine = DecodeEngine(model, tune=json.loads(args.tune))
+    return model, cfg
+
+
+def measure_dominant_kernel(eng, reps: int = 3):
+    """Average duration of the c_fc1/c_fc2 + SwiGLU launch (segment 2 of every layer), events on eng.stream."""
+    from lit_llama_amd._native import check, lib
+
+    n_layer = eng.cfg.n_layer
+    s = eng.stream.cuda_stream
+    evs = []
+    with torch.cuda.stream(eng.stream):
+        for _ in range(reps):
+            for l in range(n_layer):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib().mi355_forward_segment(C.byref(eng.m), 1, l, 2, 3, s), "forward_segment")
+                e1.record()
+                evs.append((e0, e1))
+    eng.stream.synchronize()
+    times = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs[n_layer:])  # first pass = warm-up
+    return sum(times) / len(times), times[len(times) // 2]
+
+
+def cpu_baseline(cfg, mode: str):
+    """The oracle (port of the reference CPU path) on a bounded sample: ONE 7B-width layer + lm_head, 10 decode
+    steps after a 1-token prompt (~10 s); per-token time extrapolated to n_layer layers."""
+    from lit_llama_amd import synth
+    from lit_llama_amd.model import LLaMAConfig
+    from oracle import oracle
+
+    small = LLaMAConfig(n_layer=1, n_head=cfg.n_head, n_embd=cfg.n_embd)
+    sd = synth.make_state_dict(small, seed=0, mode=mode if mode != "none" else None)
+    om = oracle.Model(oracle.Config(n_layer=1, n_head=cfg.n_head, n_embd=cfg.n_embd), sd,
+                      mode=mode if mode != "none" else None)
+    idx = torch.tensor([[1]], dtype=torch.int64)
+    with torch.no_grad():
+        om(idx, 16, torch.tensor([0]))  # prefill (also builds caches)
+        t_layer = t_head = 0.0
+        steps = 10
+        for i in range(steps):
+            x = torch.randn(1, 1, cfg.n_embd)
+            rope = om.rope_cache.index_select(0, torch.tensor([1 + i]))
+            mask = om.mask_cache.index_select(2, torch.tensor([1 + i]))[:, :, :, :16]
+            t0 = time.perf_counter()
+            x, om.kv_caches[0] = om.block(0, x, rope, mask, 16, torch.tensor([1 + i]), om.kv_caches[0])
+            t1 = time.perf_counter()
+            oracle.linear(om.sd, "lm_head", oracle.rmsnorm(x, om.p("transformer.ln_f.scale")), om.mode)
+            t2 = time.perf_counter()
+            t_layer += (t1 - t0) / steps
+            t_head += (t2 - t1) / steps
+    per_token = cfg.n_layer * t_layer + t_head
+    return dict(value=1.0 / per_token, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/oracle.py (reference CPU path restated), 1 of {cfg.n_layer} layers at {args_model_name(cfg)} "
+                       f"width + lm_head, {steps} decode steps ({steps * (t_layer + t_head):.1f} s measured), "
+                       f"extrapolated: {cfg.n_layer} x {t_layer:.2f} s + {t_head:.2f} s per token")
+
+
+def args_model_name(cfg):
+    return {4096: "7B", 5120: "13B", 6656: "30B", 8192: "65B"}.get(cfg.n_embd, f"n_embd={cfg.n_embd}")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback for the hot path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.no_graph:
+        os.environ["MI355_GRAPH"] = "0"
+
+    from lit_llama_amd import synth
+
+    model, cfg = build_model(args, dev)
+    eng = model.engine()
+    if eng is None:
+        raise SystemExit(f"native engine unavailable: {model._engine_failed}")
+    T, W, K = args.prompt_len, args.warmup, args.steps
+    S = T + W + K + 1
+    if S > cfg.block_size:
+        raise SystemExit(f"prompt + warmup + steps + 1 = {S} exceeds block_size {cfg.block_size}")
+    prompt = synth.make_prompt(T, vocab=cfg.vocab_size, seed=1234 + rank).to(dev)
+
+    with torch.cuda.stream(eng.stream):
+        eng._ensure_cache(S)
+        eng.out_tokens[:T].copy_(prompt)
+        t_pf0 = time.perf_counter()
+        eng.prefill(prompt, 0, all_logits=False, argmax=True)
+        eng.stream.synchronize()
+        t_prefill = time.perf_counter() - t_pf0
+        pos = T
+        for _ in range(W):
+            eng.set_step(None, 1, pos, from_next=True)
+            eng.run_step(True)
+            pos += 1
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            eng.set_step(None, 1, pos, from_next=True)
+            eng.run_step(True)
+            pos += 1
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tokens = eng.out_tokens[: pos + 1].tolist()
+    assert all(0 <= t_ < cfg.padded_vocab_size for t_ in tokens), "decode produced invalid ids"
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    bpt = bytes_per_token(cfg, args.quantize)
+    tok_s_gpu = K / elapsed
+    mean_pos = T + W + K / 2
+    # ---- dominant kernel roofline (c_fc1/c_fc2 + SwiGLU)
+    C_, H = cfg.n_embd, cfg.n_hidden
+    wb = {"gptq.int4": C_ * H, "llm.int8": 2 * C_ * H, "none": 4 * C_ * H}[args.quantize]
+    side = {"gptq.int4": 2 * 2 * H * 2, "llm.int8": 2 * H * 4, "none": 0}[args.quantize]
+    algo = wb + side + C_ * 4 + C_ * 2 + H * 2
+    avg_s, med_s = measure_dominant_kernel(eng)
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_traffic.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get("fc_swiglu_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": METRIC,
+        "value": round(tok_s_gpu * world, 2),
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": round(1e3 * elapsed / K, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"LLaMA-{args.model} {args.quantize} bs=1 greedy decode (configs[2]), random-init weights, "
+                        f"prompt {T} tokens, positions {T + W}..{T + W + K - 1}",
+            "prompt_len": T,
+            "max_seq_length": S,
+            "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (bs=1 path does not shard)",
+            "hipgraph": bool(eng.use_graph and eng._graphs),
+            "launches_per_token": cfg.n_layer * 5 + 3,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "gemv_kernel<Q4,R=2,SwiGLU> (c_fc1/c_fc2 pair)" if args.quantize == "gptq.int4" else "fc pair",
+            "achieved": round(algo / avg_s / 1e9, 1),
+            "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s",
+            "frac": round(algo / avg_s / HBM_PEAK, 4),
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": algo,
+            "avg_launch_us": round(avg_s * 1e6, 2),
+            "median_launch_us": round(med_s * 1e6, 2),
+        },
+        "decode_roofline": {
+            "bytes_per_token_weights": bpt["weights"],
+            "bytes_per_token_total": bpt["total"] + int(bpt["kv_per_pos"] * (mean_pos + 2)),
+            "tokens_per_s_at_100pct": round(HBM_PEAK / bpt["weights"], 1),
+            "frac_of_int4_weight_roofline": round(tok_s_gpu * bpt["weights"] / HBM_PEAK, 4),
+        },
+        "prefill_s": round(t_prefill, 4),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.quantize)
+        except Exception as e:  # the baseline must never take the headline down with it
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"failed: {e!r}"}
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -136,11 +136,11 @@ __device__ __forceinline__ float cvt2(uint32_t raw, int dtype) {
     return dtype == MI355_F32 ? __uint_as_float(raw) : __uint_as_float(raw << 16);
 }
 
-template <int FMT, int R>
+template <int FMT, int R, int EPI>
 __device__ __forceinline__ void load_epi(const GemvParams& p, int tile, int e_row, int e_col, bool e_owner,
                                          EpiOps<R>& o) {
     if (e_owner && tile < p.n_tiles) {
-        const bool sw = p.epi == MI355_EPI_SWIGLU;
+        constexpr bool sw = EPI == MI355_EPI_SWIGLU;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int n = sw ? tile * 16 + e_row : (tile * R + r) * 16 + e_row;
@@ -151,7 +151,7 @@ __device__ __forceinline__ void load_epi(const GemvParams& p, int tile, int e_ro
                 }
                 if (!sw) {
                     if (p.bias != nullptr) o.bias[r] = ld2_raw(p.bias, n, p.sz_dtype);
-                    if (p.epi == MI355_EPI_ACCUM) o.old[r] = ld2_raw(p.y, (int64_t)e_col * p.ldy + n, p.y_dtype);
+                    if (EPI == MI355_EPI_ACCUM) o.old[r] = ld2_raw(p.y, (int64_t)e_col * p.ldy + n, p.y_dtype);
                 }
             }
         }
@@ -159,7 +159,7 @@ __device__ __forceinline__ void load_epi(const GemvParams& p, int tile, int e_ro
 }
 
 // Combine the W partial 16x16 tiles of `buf` in wave order and write the tile's outputs (stores only).
-template <int FMT, int R>
+template <int FMT, int R, int EPI>
 __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* part, int buf, int W, int tile,
                                               int e_row, int e_col, const EpiOps<R>& o, const float* sx) {
     // D layout of mfma_f32_16x16x32: lane (row >> 2) * 16 + col holds D[row][col] in register (row & 3)
@@ -174,7 +174,7 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
             s = cvt2(o.s[r], p.sz_dtype) * (s - (128.f + cvt2(o.z[r], p.sz_dtype)) * sx[e_col]);
         v[r] = s;
     }
-    if (p.epi == MI355_EPI_SWIGLU) {
+    if constexpr (EPI == MI355_EPI_SWIGLU) {
         if constexpr (R == 2) {
             const int n = tile * 16 + e_row;
             if (n < p.N) st2(p.y, (int64_t)e_col * p.ldy + n, p.y_dtype, swiglu_f32(v[0], v[1]));
@@ -186,14 +186,16 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
             if (n < p.N) {
                 float out = v[r];
                 if (p.bias != nullptr) out += cvt2(o.bias[r], p.sz_dtype);
-                if (p.epi == MI355_EPI_ACCUM) out += cvt2(o.old[r], p.y_dtype);
+                if (EPI == MI355_EPI_ACCUM) out += cvt2(o.old[r], p.y_dtype);
                 st2(p.y, (int64_t)e_col * p.ldy + n, p.y_dtype, out);
             }
         }
     }
 }
 
-template <int FMT, int R, int P, bool NT>
+// EPI is a template parameter so that the SwiGLU pair kernel (c_fc1/c_fc2: the largest launch of a decode
+// step) is its own symbol in profiles, and the epilogue carries no runtime switch.
+template <int FMT, int R, int P, bool NT, int EPI>
 __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     EpiOps<R> eo;
 #pragma unroll
     for (int r = 0; r < R; ++r) eo.s[r] = eo.z[r] = eo.bias[r] = eo.old[r] = 0u;
-    load_epi<FMT, R>(p, bid, e_row, e_col, e_owner, eo);
+    load_epi<FMT, R, EPI>(p, bid, e_row, e_col, e_owner, eo);
 
     stage_x(p, xs, sx, red);
 
@@ -262,10 +264,10 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
 #pragma unroll
             for (int r = 0; r < R; ++r) pp[r * 64] = acc[r];
             __syncthreads();
-            if (e_owner) tile_epilogue<FMT, R>(p, part, buf, W, tile, e_row, e_col, eo, sx);
+            if (e_owner) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, sx);
             tile += nb;
             buf ^= 1;
-            load_epi<FMT, R>(p, tile, e_row, e_col, e_owner, eo);
+            load_epi<FMT, R, EPI>(p, tile, e_row, e_col, e_owner, eo);
         }
         return;
     }
@@ -317,10 +319,10 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
                         acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                     __syncthreads();
-                    if (e_owner) tile_epilogue<FMT, R>(p, part, buf, W, tile, e_row, e_col, eo, sx);
+                    if (e_owner) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, sx);
                     tile += nb;
                     buf ^= 1;
-                    load_epi<FMT, R>(p, tile, e_row, e_col, e_owner, eo);
+                    load_epi<FMT, R, EPI>(p, tile, e_row, e_col, e_owner, eo);
                 }
             }
             MI355_ISSUE(j);  // refill the slot just consumed (dummy source once the work is exhausted)
@@ -451,21 +453,33 @@ __global__ void i8_repack_kernel(const int8_t* c0, const int8_t* c1, int N, int 
     }
 }
 
-template <int FMT, int R, int P, bool NT>
-int launch_gemv(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
+template <int FMT, int R, int P, bool NT, int EPI>
+int launch_gemv_epi(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, NT>,
+        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, NT, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     });
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    hipLaunchKernelGGL((gemv_kernel<FMT, R, P, NT>), dim3(grid), dim3(waves * 64), lds, stream, p);
+    hipLaunchKernelGGL((gemv_kernel<FMT, R, P, NT, EPI>), dim3(grid), dim3(waves * 64), lds, stream, p);
     MI355_LAUNCH_CHECK();
     return 0;
+}
+
+template <int FMT, int R, int P, bool NT>
+int launch_gemv(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
+    switch (p.epi) {
+        case MI355_EPI_STORE: return launch_gemv_epi<FMT, R, P, NT, MI355_EPI_STORE>(p, grid, waves, lds, stream);
+        case MI355_EPI_ACCUM: return launch_gemv_epi<FMT, R, P, NT, MI355_EPI_ACCUM>(p, grid, waves, lds, stream);
+        default:
+            if constexpr (R == 2) return launch_gemv_epi<FMT, R, P, NT, MI355_EPI_SWIGLU>(p, grid, waves, lds, stream);
+            mi355_set_error("SwiGLU epilogue needs R == 2");
+            return MI355_E_ARG;
+    }
 }
 
 template <int FMT, int R>

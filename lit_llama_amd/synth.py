@@ -73,9 +73,11 @@ def make_state_dict(
     dtype: torch.dtype = torch.float32,
     device: str = "cpu",
     outlier_channels: int = 0,
+    bf16_exact: bool = True,
 ) -> Dict[str, torch.Tensor]:
     """Synthetic checkpoint.  mode None / "llm.int8": float weights in `dtype`; "gptq.int4": packed buffers with
-    scales / zeros in `dtype`."""
+    scales / zeros in `dtype`.  With `bf16_exact` every float value is rounded to bf16 once at generation time
+    (and stored in `dtype`), so a bf16 GPU model and the f32 CPU oracle hold identical parameters."""
     assert mode in (None, "gptq.int4", "llm.int8")
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -92,9 +94,10 @@ def make_state_dict(
         ch = torch.arange(outlier_channels, device=device) * (C // max(outlier_channels, 1)) + 3
         for k in norms:
             norms[k][ch] *= 20.0
-    sd["transformer.wte.weight"] = wte.to(dtype)
+    rnd = (lambda t: t.to(torch.bfloat16).float()) if bf16_exact else (lambda t: t)  # noqa: E731
+    sd["transformer.wte.weight"] = rnd(wte).to(dtype)
     for k, v in norms.items():
-        sd[k] = v.to(dtype)
+        sd[k] = rnd(v).to(dtype)
     for prefix, N, K in linear_shapes(cfg):
         w = _randn((N, K), gen, device, std=K**-0.5)
         if mode == "gptq.int4":
@@ -104,7 +107,7 @@ def make_state_dict(
             sd[prefix + ".scales"] = scale[:, None].to(dtype)
             sd[prefix + ".zeros"] = zero[:, None].to(dtype)
         else:
-            sd[prefix + ".weight"] = w.to(dtype)
+            sd[prefix + ".weight"] = rnd(w).to(dtype)
     return sd
 
 

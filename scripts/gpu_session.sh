@@ -1,0 +1,49 @@
+#!/bin/bash
+# One gpurun call = tests + smoke + bench + rocprof summary + tuning sweep; everything lands in gpurun_out/.
+# Usage (from the build container):  gpurun --timeout 2400 -- 'bash scripts/gpu_session.sh [stage ...]'
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+OUT=gpurun_out
+mkdir -p $OUT
+STAGES="${*:-tests smoke bench prof sweep}"
+echo "stages: $STAGES" | tee $OUT/session.log
+rocm-smi --showproductname 2>/dev/null | head -8 >> $OUT/session.log
+for st in $STAGES; do
+  echo "=== $st $(date +%T)" | tee -a $OUT/session.log
+  case $st in
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q -rA -p no:cacheprovider --timeout=900 > $OUT/pytest_gpu.log 2>&1
+      echo "pytest exit $?" | tee -a $OUT/session.log; tail -60 $OUT/pytest_gpu.log ;;
+    smoke)
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+      echo "smoke exit $?" | tee -a $OUT/session.log; tail -5 $OUT/smoke.log ;;
+    bench)
+      timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+      echo "bench exit $?" | tee -a $OUT/session.log; cat $OUT/bench.json; tail -5 $OUT/bench.err
+      timeout 600 python bench.py --no-graph --no-cpu-baseline --steps 64 > $OUT/bench_nograph.json 2>> $OUT/bench.err
+      cat $OUT/bench_nograph.json ;;
+    prof)
+      rm -rf $OUT/prof
+      timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o run -- python bench.py --steps 64 --warmup 8 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
+      echo "rocprof exit $?" | tee -a $OUT/session.log
+      find $OUT/prof -name '*stats*' | head; f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
+      [ -n "$f" ] && { cp "$f" $OUT/kernel_stats.csv; head -30 "$f"; }
+      # keep the merge-back small: drop the raw trace, keep the stats
+      find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete ;;
+    pmc)
+      rm -rf $OUT/pmc
+      timeout 900 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc -o fetch -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/pmc_bench.json 2> $OUT/pmc.err
+      echo "pmc exit $?" | tee -a $OUT/session.log
+      f=$(find $OUT/pmc -name '*counter_collection.csv' | head -1)
+      [ -n "$f" ] && python scripts/pmc_summary.py "$f" > $OUT/pmc_summary.txt 2>&1 && cat $OUT/pmc_summary.txt
+      find $OUT/pmc -name '*.csv' -size +20M -delete ;;
+    sweep)
+      timeout 1200 python scripts/sweep_gemv.py --out $OUT/sweep_best.json > $OUT/sweep.log 2>&1
+      echo "sweep exit $?" | tee -a $OUT/session.log; grep BEST $OUT/sweep.log ;;
+    sweepq)
+      timeout 600 python scripts/sweep_gemv.py --quick --out $OUT/sweep_best.json > $OUT/sweep.log 2>&1
+      echo "sweep exit $?" | tee -a $OUT/session.log; grep BEST $OUT/sweep.log ;;
+  esac
+done
+echo "=== done $(date +%T)" | tee -a $OUT/session.log

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""On-box tuning sweep of the weight-streaming linear: per-shape launch duration over (waves, grid, prefetch, nt),
+cycling through enough distinct weight buffers that nothing is served from the 256 MiB Infinity Cache.
+
+    python scripts/sweep_gemv.py [--fmt q4] [--quick]   ->  one line per configuration + a best-of table
+"""
+import argparse
+import itertools
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from lit_llama_amd import _native as nat  # noqa: E402
+from lit_llama_amd import ops  # noqa: E402
+
+SHAPES_7B = {
+    # name: (N, K, R, epi)
+    "attn": (12288, 4096, 2, nat.EPI_STORE),
+    "proj": (4096, 4096, 1, nat.EPI_ACCUM),
+    "fc": (11008, 4096, 2, nat.EPI_SWIGLU),
+    "mproj": (4096, 11008, 1, nat.EPI_ACCUM),
+    "lm_head": (32000, 4096, 2, nat.EPI_STORE),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--shapes", default="attn,proj,fc,mproj,lm_head")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(0)
+    cus = nat.num_cus()
+    results = {}
+    for name in args.shapes.split(","):
+        N, K, R, epi = SHAPES_7B[name]
+        pair = epi == nat.EPI_SWIGLU
+        nbytes = ops.packed_bytes(nat.W_Q4, N, K, R, pair)
+        n_buf = max(2, int(600e6 // nbytes) + 1)  # > 2x the Infinity Cache in rotation
+        streams = [torch.randint(0, 256, (nbytes,), generator=gen, device=dev, dtype=torch.uint8) for _ in range(n_buf)]
+        sc = (0.005 + 0.005 * torch.rand(N, generator=gen, device=dev)).to(torch.bfloat16)
+        ze = torch.full((N,), 8.0, device=dev, dtype=torch.bfloat16)
+        x = torch.randn((1, K), generator=gen, device=dev).to(torch.bfloat16 if epi == nat.EPI_ACCUM else torch.float32)
+        norm = None if epi == nat.EPI_ACCUM else (1 + 0.1 * torch.randn(K, generator=gen, device=dev)).to(torch.bfloat16)
+        out = torch.zeros((1, N), device=dev, dtype=torch.float32 if epi != nat.EPI_SWIGLU else torch.bfloat16)
+        n_tiles = (N + (16 if pair else 16 * R) - 1) // (16 if pair else 16 * R)
+        grids = sorted({g for g in (n_tiles, cus, 2 * cus, 3 * cus, 4 * cus, 8 * cus) if g <= n_tiles})
+        waves_l, pf_l, nt_l = (4, 8), (4, 8), (0, 1)
+        if args.quick:
+            grids, waves_l, pf_l, nt_l = grids[-3:], (8,), (4, 8), (0,)
+        best = None
+        for waves, grid, pf, flags in itertools.product(waves_l, grids, pf_l, nt_l):
+            kw = dict(scales=sc, zeros=ze, scales2=sc if pair else None, zeros2=ze if pair else None, norm_scale=norm,
+                      epi=epi, out=out, waves=waves, grid=grid, prefetch=pf, flags=flags)
+            for s in streams[:2]:
+                ops.linear_fast(x, s, nat.W_Q4, R, N, K, **kw)
+            torch.cuda.synchronize()
+            reps = 3
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                for s in streams:
+                    ops.linear_fast(x, s, nat.W_Q4, R, N, K, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (reps * n_buf)
+            gbs = nbytes / us / 1e3
+            rec = dict(shape=name, waves=waves, grid=grid, prefetch=pf, nt=1 - flags, us=round(us, 2), GBps=round(gbs, 1))
+            print(json.dumps(rec), flush=True)
+            if best is None or us < best["us"]:
+                best = rec
+        results[name] = best
+        del streams
+        torch.cuda.empty_cache()
+    print("BEST " + json.dumps(results), flush=True)
+    if args.out:
+        Path(args.out).write_text(json.dumps(results, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,185 @@
+"""Host-side logic on CPU: drop-in module contract (ctor signatures, buffers, state-dict keys, layouts), the
+`quantization()` selector, format utilities against the reference's golden vectors, synthetic checkpoints, and the
+rule that the product path refuses to compute off-GPU (no silent CPU fallback)."""
+import numpy as np
+import pytest
+import torch
+
+import lit_llama_amd
+from lit_llama_amd import _native as nat
+from lit_llama_amd import ops, synth
+from lit_llama_amd.model import LLaMA, LLaMAConfig, build_rope_cache
+from lit_llama_amd.quantization import ColBlockQuantizedLinear, Linear8bitLt
+from lit_llama_amd.utils import EmptyInitOnDevice, find_multiple, llama_model_lookup, quantization
+
+CFG1 = dict(n_layer=2, n_head=4, n_embd=256)
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_config_and_shapes():
+    cfg = LLaMAConfig.from_name("7B")
+    assert (cfg.n_layer, cfg.n_head, cfg.n_embd, cfg.padded_vocab_size, cfg.n_hidden) == (32, 32, 4096, 32000, 11008)
+    assert LLaMAConfig.from_name("65B").n_hidden == 22016
+    assert LLaMAConfig(vocab_size=16).padded_vocab_size == 64
+    assert find_multiple(10, 8) == 16 and find_multiple(16, 8) == 16
+    assert llama_model_lookup({"transformer.wte.weight": torch.empty(10, 8192)}) == "65B"
+
+
+def test_quantization_context_swaps_linear_and_restores():
+    stock = torch.nn.Linear
+    with quantization("gptq.int4"):
+        model = LLaMA(LLaMAConfig(n_layer=1, n_head=4, n_embd=256))
+        assert torch.nn.Linear is not stock
+    assert torch.nn.Linear is stock
+    mods = dict(model.named_modules())
+    for name in ("lm_head", "transformer.h.0.attn.c_attn", "transformer.h.0.attn.c_proj", "transformer.h.0.mlp.c_fc1",
+                 "transformer.h.0.mlp.c_fc2", "transformer.h.0.mlp.c_proj"):
+        assert isinstance(mods[name], ColBlockQuantizedLinear) and mods[name].bits == 4
+        assert mods[name].tile_cols == mods[name].in_features  # tile_cols = -1 -> one group per row
+    assert isinstance(model.transformer.wte, torch.nn.Embedding)
+    with pytest.raises(ValueError):
+        with quantization("nope"):
+            pass
+    with pytest.raises(ValueError):
+        EmptyInitOnDevice(torch.device("cpu"), quantization_mode="llm.int8")
+    with quantization("llm.int8"):
+        assert torch.nn.Linear is Linear8bitLt
+    assert torch.nn.Linear is stock
+
+
+def test_colblock_buffers_match_reference_layout():
+    m = ColBlockQuantizedLinear(64, 16, False, bits=4, tile_cols=-1)
+    assert m.quant_weight.shape == (16, 32) and m.quant_weight.stride() == (1, 16) and m.quant_weight.dtype == torch.uint8
+    assert m.scales.shape == (16, 1) and m.zeros.shape == (16, 1) and m.bias is None
+    assert set(m.state_dict().keys()) == {"quant_weight", "scales", "zeros"}
+    g = ColBlockQuantizedLinear(256, 48, True, bits=4, tile_cols=64)
+    assert g.scales.shape == (48, 4) and g.bias.shape == (48,)
+    e = ColBlockQuantizedLinear(128, 32, False, bits=8, tile_cols=-1)
+    assert e.quant_weight.shape == (32, 128) and e.entries_per_byte == 1
+    with pytest.raises(AssertionError):
+        ColBlockQuantizedLinear(64, 16, False, bits=3, tile_cols=-1)
+
+
+def test_pack_and_get_weight_against_reference_golden(golden):
+    g = golden("colblock")
+    for tag in ("b4_row", "b4_g64", "b8_row"):
+        N, K, bits, tc = (int(v) for v in g[f"{tag}_meta"])
+        mod = ColBlockQuantizedLinear(K, N, False, bits=bits, tile_cols=tc if tc != K else -1)
+        mod.scales.copy_(_t(g[f"{tag}_scales"]))
+        mod.zeros.copy_(_t(g[f"{tag}_zeros"]))
+        mod.pack_weight(_t(g[f"{tag}_w"]))
+        assert torch.equal(mod.quant_weight, _t(g[f"{tag}_q"]))
+        assert tuple(mod.quant_weight.stride()) == tuple(int(v) for v in g[f"{tag}_qstride"])
+        assert torch.equal(mod.get_weight(), _t(g[f"{tag}_wdq"]))
+
+
+def test_reference_state_dict_loads_and_round_trips():
+    cfg = LLaMAConfig(**CFG1)
+    sd = synth.make_state_dict(cfg, seed=0, mode="gptq.int4")
+    with quantization("gptq.int4"):
+        model = LLaMA(cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    out = model.state_dict()
+    assert set(out.keys()) == set(sd.keys())
+    for k in sd:
+        assert torch.equal(out[k], sd[k]), k
+    qw = out["transformer.h.1.mlp.c_proj.quant_weight"]
+    assert qw.shape == (256, cfg.n_hidden // 2)
+    fp = synth.make_state_dict(cfg, seed=0)
+    LLaMA(cfg).load_state_dict(fp, strict=True)
+    assert set(fp.keys()) == set(LLaMA(cfg).state_dict().keys())
+
+
+def test_synth_is_deterministic_and_quantisation_exact():
+    cfg = LLaMAConfig(**CFG1)
+    a = synth.make_state_dict(cfg, seed=0, mode="gptq.int4")
+    b = synth.make_state_dict(cfg, seed=0, mode="gptq.int4")
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    w = torch.randn(8, 64)
+    q, s, z = synth.rtn_quantize_rows(w)
+    assert q.max() <= 15 and torch.all(z == torch.round(z)) and torch.all((z >= 0) & (z <= 15))
+    packed = synth.pack_colblock(q)
+    assert packed.stride() == (1, 8)
+    assert torch.equal(packed & 0xF, q[:, 0::2]) and torch.equal(packed >> 4, q[:, 1::2])
+    # scales survive a bf16 round trip exactly (both sides dequantise identical weights)
+    sc = a["lm_head.scales"]
+    assert torch.equal(sc.to(torch.bfloat16).float(), sc)
+    p = synth.make_prompt(8)
+    assert p.dtype == torch.int32 and int(p[0]) == 1 and torch.equal(p, synth.make_prompt(8))
+
+
+def test_rope_table_is_bit_identical_to_reference(golden):
+    g = golden("blocks")
+    big = build_rope_cache(2048, 128, torch.int64, torch.device("cpu"))
+    assert torch.equal(big[[0, 1, 17, 511, 2047]], _t(g["rope_big_rows"]))
+    assert torch.equal(build_rope_cache(6, 4, torch.float32, torch.device("cpu")), _t(g["rope_cache"]))
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No CPU fallback: every compute entry point raises instead of silently running somewhere else."""
+    cfg = LLaMAConfig(n_layer=1, n_head=2, n_embd=64, vocab_size=64)
+    model = LLaMA(cfg)
+    idx = torch.zeros((1, 4), dtype=torch.int64)
+    with pytest.raises(nat.NativeError, match="GPU only"):
+        model(idx)
+    with pytest.raises(nat.NativeError):
+        model.transformer.ln_f(torch.zeros(1, 4, 64))
+    with pytest.raises(nat.NativeError):
+        ColBlockQuantizedLinear(64, 16, False, bits=4, tile_cols=-1)(torch.zeros(2, 64))
+    with pytest.raises(nat.NativeError):
+        ops.rmsnorm(torch.zeros(2, 8), torch.ones(8), 1e-5)
+    with pytest.raises(nat.NativeError):
+        lit_llama_amd.apply_rope(torch.zeros(1, 2, 2, 4), torch.zeros(2, 2, 2))
+    with pytest.raises(nat.NativeError):
+        lit_llama_amd.generate(model, torch.zeros(4, dtype=torch.int32), 2, top_k=1)
+
+
+def test_linear8bit_defers_quantisation_off_gpu():
+    lin = Linear8bitLt(32, 8, bias=False)
+    assert lin._pending_fp is not None and not hasattr(lin.weight, "CB")
+    lin.load_state_dict({"weight": torch.randn(8, 32)})
+    assert lin._pending_fp.shape == (8, 32)
+    with pytest.raises(nat.NativeError):
+        lin(torch.zeros(1, 32))
+
+
+def test_fast_linear_lds_budget():
+    assert ops.fast_linear_max_m(4096, 2) == 14 or ops.fast_linear_max_m(4096, 2) == 15 or ops.fast_linear_max_m(4096, 2) == 16
+    assert 1 <= ops.fast_linear_max_m(11008, 1) <= 7
+    assert 1 <= ops.fast_linear_max_m(22016, 1) <= 3
+    assert ops.fast_linear_max_m(11008, 1, nat.W_I8) >= 1
+
+
+def test_stream_layout_statements_are_self_consistent():
+    """tests/layouts.py (the numpy statement of include/mi355_llama.h's stream layouts) round-trips; the GPU tests
+    compare the repack kernels with it bit for bit."""
+    import layouts
+
+    rng = np.random.default_rng(0)
+    for N, K, R in [(64, 256, 1), (96, 384, 2), (40, 200, 1)]:
+        q = rng.integers(0, 16, size=(N, K), dtype=np.uint8)
+        s = layouts.q4_levels_to_stream(q, None, R)
+        assert s.size == nat.lib().mi355_packed_bytes(nat.W_Q4, N, K, R, 0)
+        assert np.array_equal(layouts.q4_stream_to_levels(s, N, K, R, False)[0], q)
+    q0, q1 = rng.integers(0, 16, size=(48, 256), dtype=np.uint8), rng.integers(0, 16, size=(48, 256), dtype=np.uint8)
+    s = layouts.q4_levels_to_stream(q0, q1, 2)
+    assert s.size == nat.lib().mi355_packed_bytes(nat.W_Q4, 48, 256, 2, 1)
+    back = layouts.q4_stream_to_levels(s, 48, 256, 2, True)
+    assert np.array_equal(back[0], q0) and np.array_equal(back[1], q1)
+    assert layouts.bf16_bits_to_stream(np.zeros((40, 200), np.uint16), 2).size == nat.lib().mi355_packed_bytes(nat.W_BF16, 40, 200, 2, 0)
+    assert layouts.i8_to_stream(np.zeros((48, 256), np.int8), 1).size == nat.lib().mi355_packed_bytes(nat.W_I8, 48, 256, 1, 0)
+    # the nibble order is what makes `(w >> 4i) & 0x000F000F | 0x43004300` an MFMA A fragment:
+    # VGPR i of the fragment = bf16 pair (slot 2i, slot 2i+1) = (128 + q[k0 + 2i], 128 + q[k0 + 2i + 1])
+    q = np.arange(16, dtype=np.uint8)[None, :].repeat(16, 0) % 16
+    qq = np.zeros((16, 128), np.uint8)
+    qq[:, :8] = q[:, :8]
+    w0 = layouts.q4_levels_to_stream(qq, None, 1).view(np.uint32).reshape(64, 4)[0, 0]  # lane 0 (g=0,row=0), dword 0
+    for i in range(4):
+        pair = ((int(w0) >> (4 * i)) & 0x000F000F) | 0x43004300
+        lo = np.array([pair & 0xFFFF], dtype=np.uint32) << 16
+        hi = np.array([pair & 0xFFFF0000], dtype=np.uint32)
+        assert lo.view(np.float32)[0] == 128.0 + qq[0, 2 * i] and hi.view(np.float32)[0] == 128.0 + qq[0, 2 * i + 1]

@@ -1,0 +1,372 @@
+"""GPU parity tests of the individual kernels, through the C ABI, against the oracle on the same seeded inputs.
+
+Tolerances (written next to each check):
+  * integer / byte work (repack layouts, int8 accumulation, argmax, embedding gather): bit-exact;
+  * f32 generic kernels: |err| <= 2e-5 * scale (different summation order than torch's CPU matmul);
+  * MFMA bf16-operand kernels with f32 output: |err| <= 1e-3 * rms(y) against an f64 product of the SAME
+    bf16-rounded activations (what remains is f32 accumulation order and the +128 offset cancellation);
+  * bf16 outputs: additionally one bf16 rounding, |err| <= 2^-8 |y|.
+"""
+import numpy as np
+import pytest
+import torch
+
+from lit_llama_amd import _native as nat
+from lit_llama_amd import ops, synth
+from oracle import oracle
+
+import layouts  # tests/layouts.py
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _rms(t):
+    return float(t.double().pow(2).mean().sqrt())
+
+
+# ---------------------------------------------------------------------------------------------- stream layouts
+@pytest.mark.parametrize("N,K,R", [(64, 256, 1), (96, 384, 2), (40, 200, 1)])
+def test_q4_repack_layout_is_the_documented_one(dev, N, K, R):
+    gen = torch.Generator().manual_seed(N + K)
+    q = torch.randint(0, 16, (N, K), generator=gen, dtype=torch.uint8)
+    packed = synth.pack_colblock(q).to(dev)
+    stream = ops.repack_q4(packed, None, N, K, R).cpu().numpy()
+    assert np.array_equal(stream, layouts.q4_levels_to_stream(q.numpy(), None, R))  # bit-exact
+    assert np.array_equal(layouts.q4_stream_to_levels(stream, N, K, R, False)[0], q.numpy())
+    # row-major packed input (different strides) must give the same stream
+    stream2 = ops.repack_q4(packed.contiguous(), None, N, K, R).cpu().numpy()
+    assert np.array_equal(stream, stream2)
+
+
+def test_q4_repack_pair_interleaves_two_matrices(dev):
+    N, K = 48, 256
+    gen = torch.Generator().manual_seed(5)
+    q0 = torch.randint(0, 16, (N, K), generator=gen, dtype=torch.uint8)
+    q1 = torch.randint(0, 16, (N, K), generator=gen, dtype=torch.uint8)
+    s = ops.repack_q4(synth.pack_colblock(q0).to(dev), synth.pack_colblock(q1).to(dev), N, K, 2).cpu().numpy()
+    assert np.array_equal(s, layouts.q4_levels_to_stream(q0.numpy(), q1.numpy(), 2))
+
+
+def test_bf16_and_i8_repack_layouts(dev):
+    gen = torch.Generator().manual_seed(6)
+    w = torch.randn((40, 200), generator=gen).to(torch.bfloat16)
+    for R in (1, 2):
+        s = ops.repack_bf16(w.to(dev), None, R).cpu().numpy()
+        assert np.array_equal(s, layouts.bf16_bits_to_stream(w.view(torch.int16).numpy().view(np.uint16), R))
+    cb = torch.randint(-127, 128, (48, 256), generator=gen, dtype=torch.int8)
+    for R in (1, 2):
+        s = ops.repack_i8(cb.to(dev), None, R).cpu().numpy()
+        assert np.array_equal(s, layouts.i8_to_stream(cb.numpy(), R))
+
+
+# ---------------------------------------------------------------------------------------------- int4 fast linear
+def _q4_problem(N, K, M, seed, dev, x_scale=1.0):
+    gen = torch.Generator().manual_seed(seed)
+    w = torch.randn((N, K), generator=gen) * K**-0.5
+    q, scale, zero = synth.rtn_quantize_rows(w)
+    scale = scale.to(torch.bfloat16).float()
+    x = torch.randn((M, K), generator=gen) * x_scale
+    wdq = (q.float() - zero[:, None]) * scale[:, None]
+    return dict(q=q, packed=synth.pack_colblock(q).to(dev), scale=scale, zero=zero, x=x, wdq=wdq)
+
+
+Q4_SHAPES = [
+    # N, K, M, R, waves, grid, prefetch
+    (64, 128, 1, 1, 0, 0, 0),       # one unit: 7 of 8 waves have no work (combine-only path)
+    (96, 256, 3, 2, 4, 0, 0),
+    (48, 384, 2, 2, 8, 0, 8),       # N not a multiple of 32: padded tile
+    (40, 200, 1, 1, 0, 0, 0),       # K and N both padded
+    (512, 1024, 16, 1, 8, 3, 4),    # 3 workgroups loop over 32 tiles (persistent path), M = 16
+    (4096, 4096, 1, 1, 0, 0, 0),    # 7B attn.c_proj
+    (4096, 4096, 1, 1, 4, 128, 8),
+    (12288, 4096, 2, 2, 0, 0, 0),   # 7B c_attn
+    (4096, 11008, 1, 1, 0, 0, 0),   # 7B mlp.c_proj: 86 units over 8 waves (uneven split)
+    (4096, 11008, 5, 1, 8, 200, 8),
+    (32000, 4096, 1, 2, 0, 0, 0),   # lm_head
+    (8192, 2752, 1, 1, 0, 0, 0),    # 65B TP=8 mlp.c_proj shard: K = 21.5 units
+]
+
+
+@pytest.mark.parametrize("N,K,M,R,waves,grid,prefetch", Q4_SHAPES)
+def test_q4_linear_matches_oracle(dev, N, K, M, R, waves, grid, prefetch):
+    p = _q4_problem(N, K, M, seed=N * 7 + K + M, dev=dev)
+    xb = p["x"].to(torch.bfloat16)
+    stream = ops.repack_q4(p["packed"], None, N, K, R)
+    sc, ze = p["scale"].to(torch.bfloat16).to(dev), p["zero"].to(torch.bfloat16).to(dev)
+    y = ops.linear_fast(xb.to(dev), stream, nat.W_Q4, R, N, K, scales=sc, zeros=ze, out_dtype=torch.float32,
+                        waves=waves, grid=grid, prefetch=prefetch).cpu()
+    ref64 = xb.double() @ p["wdq"].double().t()
+    err = (y.double() - ref64).abs().max().item()
+    assert err <= 1e-3 * _rms(ref64), f"max err {err:.3e} vs rms {_rms(ref64):.3e}"
+    # and the oracle's own forward (reference CPU path: full dequant + F.linear) on the same inputs
+    yo = oracle.colblock_linear(xb.float(), synth.pack_colblock(p["q"]).contiguous(), p["scale"][:, None],
+                                p["zero"][:, None], 4, K)
+    assert (y - yo).abs().max().item() <= 1e-3 * _rms(ref64)
+    # bf16 output = one extra rounding
+    yb = ops.linear_fast(xb.to(dev), stream, nat.W_Q4, R, N, K, scales=sc, zeros=ze, out_dtype=torch.bfloat16,
+                         waves=waves, grid=grid, prefetch=prefetch).cpu().double()
+    assert bool(((yb - ref64).abs() <= 2.0**-8 * ref64.abs() + 1e-3 * _rms(ref64)).all())
+
+
+def test_q4_linear_f32_scales_nt_flag_and_determinism(dev):
+    N, K, M = 1024, 2048, 4
+    p = _q4_problem(N, K, M, seed=99, dev=dev)
+    xb = p["x"].to(torch.bfloat16).to(dev)
+    stream = ops.repack_q4(p["packed"], None, N, K, 1)
+    kw = dict(scales=p["scale"].to(dev), zeros=p["zero"].to(dev), out_dtype=torch.float32)
+    y0 = ops.linear_fast(xb, stream, nat.W_Q4, 1, N, K, **kw)
+    y1 = ops.linear_fast(xb, stream, nat.W_Q4, 1, N, K, flags=1, **kw)   # plain (temporal) weight loads
+    y2 = ops.linear_fast(xb, stream, nat.W_Q4, 1, N, K, **kw)
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)  # bit-reproducible, independent of the cache policy
+    ref64 = xb.cpu().double() @ p["wdq"].double().t()
+    assert (y0.cpu().double() - ref64).abs().max().item() <= 1e-3 * _rms(ref64)
+    # an f32 activation is rounded to bf16 exactly once
+    y3 = ops.linear_fast(xb.float(), stream, nat.W_Q4, 1, N, K, **kw)
+    assert torch.equal(y0, y3)
+
+
+def test_q4_linear_fused_rmsnorm_accumulate_and_bias(dev):
+    N, K, M = 256, 512, 3
+    p = _q4_problem(N, K, M, seed=3, dev=dev, x_scale=3.0)
+    gen = torch.Generator().manual_seed(8)
+    nscale = (1 + 0.1 * torch.randn(K, generator=gen)).to(torch.bfloat16)
+    bias = torch.randn(N, generator=gen).to(torch.bfloat16)
+    resid = torch.randn((M, N), generator=gen)
+    stream = ops.repack_q4(p["packed"], None, N, K, 1)
+    sc, ze = p["scale"].to(torch.bfloat16).to(dev), p["zero"].to(torch.bfloat16).to(dev)
+    out = resid.clone().to(dev)
+    ops.linear_fast(p["x"].to(dev), stream, nat.W_Q4, 1, N, K, scales=sc, zeros=ze, norm_scale=nscale.to(dev), eps=1e-5,
+                    bias=bias.to(dev), epi=nat.EPI_ACCUM, out=out)
+    xn = oracle.rmsnorm(p["x"], nscale.float(), 1e-5).to(torch.bfloat16)
+    ref64 = xn.double() @ p["wdq"].double().t() + bias.double() + resid.double()
+    # RMSNorm in f32 then ONE bf16 rounding: a value on a rounding boundary may land one bf16 ulp away
+    xn_dev = ops.rmsnorm(p["x"].to(dev), nscale.to(dev), 1e-5, out_dtype=torch.bfloat16).cpu()
+    assert (xn_dev.float() - xn.float()).abs().max() <= 2.0**-7 * xn.float().abs().max()
+    ref_dev = xn_dev.double() @ p["wdq"].double().t() + bias.double() + resid.double()
+    err = (out.cpu().double() - ref_dev).abs().max().item()
+    assert err <= 1e-3 * _rms(ref64), err
+
+
+def test_q4_linear_swiglu_pair(dev):
+    N, K, M = 11008, 4096, 2   # 7B c_fc1 / c_fc2
+    a = _q4_problem(N, K, M, seed=41, dev=dev)
+    b = _q4_problem(N, K, M, seed=42, dev=dev)
+    x = a["x"].to(torch.bfloat16)
+    stream = ops.repack_q4(a["packed"], b["packed"], N, K, 2)
+    bf = lambda t: t.to(torch.bfloat16).to(dev)  # noqa: E731
+    y = ops.linear_fast(x.to(dev), stream, nat.W_Q4, 2, N, K, scales=bf(a["scale"]), zeros=bf(a["zero"]),
+                        scales2=bf(b["scale"]), zeros2=bf(b["zero"]), epi=nat.EPI_SWIGLU, out_dtype=torch.float32).cpu()
+    h1 = x.double() @ a["wdq"].double().t()
+    h2 = x.double() @ b["wdq"].double().t()
+    ref = torch.nn.functional.silu(h1) * h2
+    assert (y.double() - ref).abs().max().item() <= 2e-3 * _rms(ref)
+
+
+def test_q4_fast_kernel_agrees_with_generic_kernel_at_full_size(dev):
+    """Two independent HIP implementations (MFMA stream kernel on the repacked layout vs the scalar kernel on
+    the reference layout) on a 7B-sized matrix, plus linearity — size-independent checks at BASELINE sizes."""
+    N, K = 11008, 4096
+    gen = torch.Generator(device=dev).manual_seed(1)
+    packed = torch.randint(0, 256, (K // 2, N), generator=gen, device=dev, dtype=torch.uint8).t()
+    scales = (0.005 + 0.005 * torch.rand((N, 1), generator=gen, device=dev)).to(torch.bfloat16)
+    zeros = torch.randint(0, 16, (N, 1), generator=gen, device=dev).to(torch.bfloat16)
+    x = torch.randn((2, K), generator=gen, device=dev).to(torch.bfloat16)
+    stream = ops.repack_q4(packed, None, N, K, 2)
+    fast = ops.linear_fast(x, stream, nat.W_Q4, 2, N, K, scales=scales.reshape(-1), zeros=zeros.reshape(-1),
+                           out_dtype=torch.float32)
+    slow = ops.linear_colblock(x.float(), packed, scales.float(), zeros.float(), 4, K, None, K)
+    assert (fast - slow).abs().max().item() <= 1e-3 * _rms(slow)
+    # linearity in x (exact inputs: powers of two keep bf16 products exact)
+    y2 = ops.linear_fast((x.float() * 2).to(torch.bfloat16), stream, nat.W_Q4, 2, N, K, scales=scales.reshape(-1),
+                         zeros=zeros.reshape(-1), out_dtype=torch.float32)
+    assert (y2 - 2 * fast).abs().max().item() <= 1e-3 * _rms(slow)
+
+
+# ---------------------------------------------------------------------------------------------- bf16 fast linear
+@pytest.mark.parametrize("N,K,M,R,grid", [(64, 128, 1, 1, 0), (96, 384, 4, 2, 0), (4096, 4096, 1, 1, 0),
+                                          (4096, 11008, 2, 1, 100), (32000, 4096, 1, 2, 0), (40, 200, 2, 1, 0)])
+def test_bf16_linear_matches_oracle(dev, N, K, M, R, grid):
+    gen = torch.Generator().manual_seed(N + K + M)
+    w = (torch.randn((N, K), generator=gen) * K**-0.5).to(torch.bfloat16)
+    x = torch.randn((M, K), generator=gen).to(torch.bfloat16)
+    stream = ops.repack_bf16(w.to(dev), None, R)
+    y = ops.linear_fast(x.to(dev), stream, nat.W_BF16, R, N, K, out_dtype=torch.float32, grid=grid).cpu()
+    ref64 = x.double() @ w.double().t()
+    assert (y.double() - ref64).abs().max().item() <= 2e-5 * max(1.0, _rms(ref64)) * 10  # plain f32 accumulation
+    # repack from f32 weights rounds them once to bf16
+    stream32 = ops.repack_bf16(w.float().to(dev), None, R)
+    assert torch.equal(stream32, stream)
+
+
+# ---------------------------------------------------------------------------------------------- generic kernels
+def test_colblock_generic_kernels_match_reference_golden(dev, golden):
+    g = golden("colblock")
+    for tag in ("b4_row", "b4_g64", "b8_row"):
+        N, K, bits, tc = (int(v) for v in g[f"{tag}_meta"])
+        q = _t(g[f"{tag}_q"]).t().contiguous().t().to(dev)  # reference (column-major) storage
+        scales, zeros = _t(g[f"{tag}_scales"]).to(dev), _t(g[f"{tag}_zeros"]).to(dev)
+        wdq = ops.colblock_dequant(q, scales, zeros, bits, tc, K, torch.float32).cpu()
+        assert torch.equal(wdq, _t(g[f"{tag}_wdq"]))  # (q - z) * s in f32: bit-exact
+        y = ops.linear_colblock(_t(g[f"{tag}_x"]).to(dev), q, scales, zeros, bits, tc, None, K).cpu()
+        ref = _t(g[f"{tag}_y"])
+        assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_dense_rmsnorm_rope_swiglu_add_embedding_argmax(dev, golden):
+    g = golden("blocks")
+    # RMSNorm / RoPE against the reference's own outputs
+    y = ops.rmsnorm(_t(g["rms_x"]).to(dev), _t(g["rms_scale"]).to(dev), 1e-6).cpu()
+    assert (y - _t(g["rms_y"])).abs().max().item() <= 2e-6
+    yr = ops.apply_rope(_t(g["rope_x"]).to(dev), _t(g["rope_cache"]).to(dev)).cpu()
+    assert (yr - _t(g["rope_y"])).abs().max().item() <= 1e-6
+    gen = torch.Generator().manual_seed(2)
+    x, w, b = torch.randn((5, 200), generator=gen), torch.randn((33, 200), generator=gen), torch.randn(33, generator=gen)
+    yd = ops.linear_dense(x.to(dev), w.to(dev), b.to(dev)).cpu()
+    ref = torch.nn.functional.linear(x, w, b)
+    assert (yd - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    a, c = torch.randn((3, 77), generator=gen), torch.randn((3, 77), generator=gen)
+    assert (ops.swiglu(a.to(dev), c.to(dev)).cpu() - torch.nn.functional.silu(a) * c).abs().max().item() <= 1e-6
+    assert torch.equal(ops.add(a.to(dev), c.to(dev)).cpu(), a + c)
+    ab, cb = a.to(torch.bfloat16), c.to(torch.bfloat16)
+    assert torch.equal(ops.add(ab.to(dev), cb.to(dev)).cpu(), ab + cb)
+    wte = torch.randn((50, 16), generator=gen)
+    idx = torch.tensor([[3, 49, 0], [7, 7, 12]])
+    assert torch.equal(ops.embedding(idx.to(dev), wte.to(dev)).cpu(), wte[idx])
+    assert torch.equal(ops.embedding(idx.int().to(dev), wte.to(dev)).cpu(), wte[idx])
+    logits = torch.randn(32000, generator=gen)
+    logits[[123, 31999]] = logits.max() + 1.0  # tie: lowest index wins
+    assert int(ops.argmax(logits.to(dev)).item()) == 123
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def _oracle_attention_steps(qkv_steps, n_head, rope, S, prompt):
+    """Run the oracle's CausalSelfAttention core (rope, cache, SDPA) over a prompt + single-token steps."""
+    C = qkv_steps.shape[-1] // 3
+    hs = C // n_head
+    cache = (torch.zeros(1, n_head, S, hs), torch.zeros(1, n_head, S, hs))
+    mask_cache = torch.tril(torch.ones(rope.shape[0], rope.shape[0], dtype=torch.bool))[None, None]
+    outs, pos = [], 0
+    chunks = [qkv_steps[:prompt]] + [qkv_steps[i:i + 1] for i in range(prompt, qkv_steps.shape[0])]
+    for ch in chunks:
+        T = ch.shape[0]
+        input_pos = torch.arange(pos, pos + T)
+        q, k, v = ch.view(1, T, 3 * C).split(C, dim=2)
+        q = oracle.apply_rope(q.view(1, T, n_head, hs), rope.index_select(0, input_pos)).transpose(1, 2)
+        k = oracle.apply_rope(k.view(1, T, n_head, hs), rope.index_select(0, input_pos)).transpose(1, 2)
+        v = v.view(1, T, n_head, hs).transpose(1, 2)
+        ck, cv = cache
+        ip = input_pos
+        if input_pos[-1] >= S:
+            ip = torch.tensor(S - 1)
+            ck, cv = torch.roll(ck, -1, dims=2), torch.roll(cv, -1, dims=2)
+        ck, cv = ck.index_copy(2, ip, k), cv.index_copy(2, ip, v)
+        cache = (ck, cv)
+        mask = mask_cache.index_select(2, input_pos)[:, :, :, :S]
+        y = torch.nn.functional.scaled_dot_product_attention(q, ck, cv, attn_mask=mask)
+        outs.append(y.transpose(1, 2).reshape(T, C))
+        pos += T
+    return torch.cat(outs), cache
+
+
+@pytest.mark.parametrize("n_head,hs,cache_dtype,tol", [(4, 64, torch.float32, 2e-5), (2, 128, torch.float32, 2e-5),
+                                                       (4, 2, torch.float32, 2e-5), (2, 128, torch.bfloat16, 2e-2)])
+def test_attention_with_cache_prefill_decode_and_roll(dev, n_head, hs, cache_dtype, tol):
+    S, prompt, steps = 12, 5, 11   # positions 0..15: the last 4 steps run in the cache-roll regime
+    C = n_head * hs
+    gen = torch.Generator().manual_seed(hs)
+    qkv = torch.randn((prompt + steps, 3 * C), generator=gen)
+    rope = oracle.build_rope_cache(64, hs, dtype=torch.int64)
+    ref, (rk, rv) = _oracle_attention_steps(qkv, n_head, rope, S, prompt)
+    k = torch.zeros((1, n_head, S, hs), dtype=cache_dtype, device=dev)
+    v = torch.zeros_like(k)
+    rope_d = rope.to(dev)
+    outs, pos = [], 0
+    for T in [prompt] + [1] * steps:
+        ip = torch.arange(pos, pos + T, device=dev)
+        if pos + T - 1 >= S:
+            ops.kv_roll(k, v)
+        y = ops.attention(qkv[pos:pos + T].view(1, T, 3 * C).to(dev), rope_d, n_head, pos=ip, kv_cache=(k, v))
+        outs.append(y.view(T, C).float().cpu())
+        pos += T
+    got = torch.cat(outs)
+    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert (k.float().cpu() - rk).abs().max().item() <= tol * max(1.0, rk.abs().max().item())
+    assert (v.float().cpu() - rv).abs().max().item() <= tol * max(1.0, rv.abs().max().item())
+
+
+def test_attention_without_cache_batched(dev):
+    B, T, n_head, hs = 3, 9, 4, 8
+    C = n_head * hs
+    gen = torch.Generator().manual_seed(12)
+    qkv = torch.randn((B, T, 3 * C), generator=gen)
+    rope = oracle.build_rope_cache(T, hs, dtype=torch.int64)
+    q, k, v = qkv.split(C, dim=2)
+    q = oracle.apply_rope(q.view(B, T, n_head, hs), rope).transpose(1, 2)
+    k = oracle.apply_rope(k.view(B, T, n_head, hs), rope).transpose(1, 2)
+    v = v.view(B, T, n_head, hs).transpose(1, 2)
+    mask = torch.tril(torch.ones(T, T, dtype=torch.bool))[None, None]
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=mask).transpose(1, 2).reshape(B, T, C)
+    got = ops.attention(qkv.to(dev), rope.to(dev), n_head, rope_gathered=True).cpu()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_attention_long_context_decode_bf16(dev):
+    """7B head geometry at a long position: 32 heads x 128, cache bf16, position 1500."""
+    n_head, hs, S, pos = 32, 128, 2048, 1500
+    C = n_head * hs
+    gen = torch.Generator(device=dev).manual_seed(4)
+    k = (torch.randn((1, n_head, S, hs), generator=gen, device=dev)).to(torch.bfloat16)
+    v = (torch.randn((1, n_head, S, hs), generator=gen, device=dev)).to(torch.bfloat16)
+    qkv = torch.randn((1, 1, 3 * C), generator=gen, device=dev)
+    rope = oracle.build_rope_cache(2048, hs, dtype=torch.int64)
+    y = ops.attention(qkv, rope.to(dev), n_head, pos=torch.tensor([pos], device=dev), kv_cache=(k, v),
+                      out_dtype=torch.float32).cpu()
+    kc, vc = k.float().cpu(), v.float().cpu()  # includes the row the kernel wrote at `pos`
+    q = oracle.apply_rope(qkv.cpu()[..., :C].view(1, 1, n_head, hs), rope[pos:pos + 1]).transpose(1, 2)
+    att = torch.softmax((q @ kc[:, :, :pos + 1].transpose(-1, -2)) / hs**0.5, dim=-1) @ vc[:, :, :pos + 1]
+    ref = att.transpose(1, 2).reshape(1, 1, C)
+    assert (y - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    knew = oracle.apply_rope(qkv.cpu()[..., C:2 * C].view(1, 1, n_head, hs), rope[pos:pos + 1])
+    assert torch.equal(kc[0, :, pos], knew[0, 0].to(torch.bfloat16).float())
+
+
+# ---------------------------------------------------------------------------------------------- LLM.int8
+def test_int8_weight_quantisation_is_bit_exact(dev):
+    gen = torch.Generator().manual_seed(21)
+    w = torch.randn((96, 512), generator=gen) * 0.05
+    cb, scb = ops.int8_quant_rows(w.to(dev))
+    ocb, oscb = oracle.int8_quant_rows(w)
+    assert torch.equal(scb.cpu(), oscb)
+    assert torch.equal(cb.cpu(), ocb)
+    cb16, scb16 = ops.int8_quant_rows(w.to(torch.bfloat16).to(dev))
+    ocb16, oscb16 = oracle.int8_quant_rows(w.to(torch.bfloat16))
+    assert torch.equal(cb16.cpu(), ocb16) and torch.equal(scb16.cpu(), oscb16)
+
+
+@pytest.mark.parametrize("N,K,M,R,outliers", [(64, 128, 1, 1, 0), (96, 512, 3, 2, 2), (4096, 4096, 1, 1, 5),
+                                              (4096, 11008, 2, 1, 7), (40, 200, 2, 1, 1)])
+def test_int8_linear_matches_oracle(dev, N, K, M, R, outliers):
+    gen = torch.Generator().manual_seed(N + K)
+    w = torch.randn((N, K), generator=gen) * K**-0.5
+    x = torch.randn((M, K), generator=gen)
+    for i in range(outliers):
+        x[i % M, (37 * i + 5) % K] = 6.0 + i  # |x| >= 6: outlier columns
+    x = x.to(torch.bfloat16)
+    ocb, oscb = oracle.int8_quant_rows(w)
+    ref = oracle.llm_int8_linear(x, ocb, oscb).float()
+    cb, scb = ops.int8_quant_rows(w.to(dev))
+    stream = ops.repack_i8(cb, None, R)
+    y = ops.linear_int8(x.to(dev), stream, scb, R, N, K, out_dtype=torch.bfloat16).float().cpu()
+    # integer accumulation and every f16 rounding are restated exactly; the f16 outlier side product is summed
+    # in a different order than torch's matmul -> allow one f16 ulp on those rows
+    close = (y - ref).abs() <= 2.0**-9 * ref.abs() + 1e-6
+    assert bool(close.all()), f"{int((~close).sum())} of {close.numel()} outputs differ"
+    if outliers == 0:
+        assert torch.equal(y, ref)
+    # sanity: the quantised product tracks the fp product
+    fp = x.float() @ w.t()
+    assert (y - fp).abs().max().item() <= 5e-2 * fp.abs().max().item()
