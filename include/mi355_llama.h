@@ -117,6 +117,8 @@ typedef struct mi355_linear_args {
 } mi355_linear_args;
 
 int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stream);
+/* `count` launches back to back from one host call (tuning / measurement loops that must not be host bound) */
+int mi355_linear_fast_batch(const mi355_linear_args* a, int count, mi355_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Generic (any shape, any M, f32 / bf16 / f16 activations) operators.  They follow the

@@ -651,3 +651,10 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     return a->R == 1 ? dispatch_pnt<MI355_W_BF16, 1>(p, a->prefetch, nt, grid, waves, lds, s)
                      : dispatch_pnt<MI355_W_BF16, 2>(p, a->prefetch, nt, grid, waves, lds, s);
 }
+
+extern "C" int mi355_linear_fast_batch(const mi355_linear_args* a, int count, mi355_stream_t stream) {
+    MI355_CHECK_ARG(a != nullptr && count >= 0, MI355_E_ARG, "linear_fast_batch: bad argument");
+    for (int i = 0; i < count; ++i)
+        if (int rc = mi355_linear_fast(a + i, stream)) return rc;
+    return 0;
+}

@@ -53,18 +53,33 @@ def main():
         if args.quick:
             grids, waves_l, pf_l, nt_l = grids[-3:], (8,), (4, 8), (0,)
         best = None
+        import ctypes as C
+
+        def make_args(stream, waves, grid, pf, flags):
+            a = nat.LinearArgs()
+            a.fmt, a.R, a.w, a.N, a.K = nat.W_Q4, R, stream.data_ptr(), N, K
+            a.x, a.x_dtype, a.M, a.ldx = x.data_ptr(), nat.dtype_code(x.dtype), 1, K
+            a.norm_scale = None if norm is None else norm.data_ptr()
+            a.norm_dtype, a.eps = nat.BF16, 1e-5
+            a.scales, a.zeros = sc.data_ptr(), ze.data_ptr()
+            if pair:
+                a.scales2, a.zeros2 = sc.data_ptr(), ze.data_ptr()
+            a.sz_dtype, a.epi = nat.BF16, epi
+            a.y, a.y_dtype, a.ldy = out.data_ptr(), nat.dtype_code(out.dtype), N
+            a.waves, a.grid, a.prefetch, a.flags = waves, grid, pf, flags
+            return a
+
+        reps = 4
         for waves, grid, pf, flags in itertools.product(waves_l, grids, pf_l, nt_l):
-            kw = dict(scales=sc, zeros=ze, scales2=sc if pair else None, zeros2=ze if pair else None, norm_scale=norm,
-                      epi=epi, out=out, waves=waves, grid=grid, prefetch=pf, flags=flags)
-            for s in streams[:2]:
-                ops.linear_fast(x, s, nat.W_Q4, R, N, K, **kw)
+            arr = (nat.LinearArgs * (reps * n_buf))()
+            for i in range(reps * n_buf):
+                arr[i] = make_args(streams[i % n_buf], waves, grid, pf, flags)
+            sp = nat.stream_ptr()
+            nat.check(nat.lib().mi355_linear_fast_batch(arr, n_buf, sp), "warm-up")
             torch.cuda.synchronize()
-            reps = 3
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(reps):
-                for s in streams:
-                    ops.linear_fast(x, s, nat.W_Q4, R, N, K, **kw)
+            nat.check(nat.lib().mi355_linear_fast_batch(arr, reps * n_buf, sp), "batch")
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (reps * n_buf)
