@@ -102,11 +102,18 @@ __global__ void rope_kv_write_kernel(const AttnParams p) {
         vc[d] = f32_to_ct<CT>(ld_as_f32(p.qkv, row + 2 * C + h * hs + d, p.qkv_dtype));
 }
 
-// Dynamic LDS: qs[hs] kcur[hs] vcur[hs] opart[nw][hs] red[32] scores[len]
+// Dynamic LDS: qs[hs] kcur[hs] vcur[hs] | per wave: m, l | opart[nw][hs]
+//
+// Single pass, flash-decoding style inside one workgroup: every wave walks a strided subset of the cached
+// rows with the K row and the V row of each position loaded together (8 x 16-B loads in flight per lane), keeps a
+// running (max, sum, weighted V) per row group, merges the row groups with wavefront shuffles and the waves
+// through LDS once.  One barrier before and one after the stream — the previous three-phase version (scores ->
+// softmax -> PV, five barriers, two dependent sweeps over HBM/L2) spent ~12 us on a 150-row context.
 template <typename CT>
 __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int VEC = Vec16<CT>::kN;
+    constexpr float kNegBig = -1.0e30f;
     const int h = blockIdx.x, t = blockIdx.y, b = blockIdx.z;
     const int hs = p.hs, half = hs >> 1, C = p.n_head * hs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -114,9 +121,10 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     float* qs = (float*)smem;
     float* kcur = qs + hs;
     float* vcur = kcur + hs;
-    float* opart = vcur + hs;
-    float* red = opart + nw * hs;
-    float* scores = red + 32;
+    float* wm = vcur + hs;        // [nw] running max per wave
+    float* wl = wm + nw;          // [nw] running sum per wave
+    float* scur = wl + nw;        // [4] score of the current position (fused)
+    float* opart = scur + 4;      // [nw][hs]
 
     const int pos = p.pos ? p.pos[t] : t;
     const int slot = pos < p.S - 1 ? pos : p.S - 1;
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     const CT* kc = (const CT*)p.kcache + ((int64_t)b * p.n_head + h) * p.S * hs;
     const CT* vc = (const CT*)p.vcache + ((int64_t)b * p.n_head + h) * p.S * hs;
 
-    // ---- phase 0: q (and, fused, the new k / v row) through RoPE into LDS
+    // ---- q (and, fused, the new k / v row) through RoPE into LDS
     for (int pi = tid; pi < half; pi += blockDim.x) {
         const float a = ld_as_f32(p.qkv, row + h * hs + 2 * pi, p.qkv_dtype);
         const float bb = ld_as_f32(p.qkv, row + h * hs + 2 * pi + 1, p.qkv_dtype);
@@ -158,116 +166,131 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     __syncthreads();
 
     const int row_bytes = hs * (int)sizeof(CT);
-    const bool vec_ok = (row_bytes % 16 == 0) && ((row_bytes / 16) <= 64) && (((row_bytes / 16) & ((row_bytes / 16) - 1)) == 0);
-    const int LPR = vec_ok ? row_bytes / 16 : 64;  // lanes per row
-    const int rpw = 64 / LPR;                      // rows per wave instruction
-    const int li = lane % LPR, lr = lane / LPR;
+    const int n16 = row_bytes / 16;
+    const bool vec_ok = (row_bytes % 16 == 0) && (n16 <= 64) && ((n16 & (n16 - 1)) == 0);
 
-    // ---- phase 1: scores[s] = scale * <q, K[s]>
     if (vec_ok) {
+        const int LPR = n16;        // lanes per row
+        const int rpw = 64 / LPR;   // rows per wave instruction
+        const int li = lane % LPR, lr = lane / LPR;
         float qf[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) qf[j] = qs[li * VEC + j];
-        const int stride = nw * rpw;
-        // wave-uniform trip count: the shuffles below need every lane of a row group in the loop
-        for (int base = 0; base < n_glob; base += stride * 4) {
-            const int s0 = base + wave * rpw + lr;
-            u32x4 raw[4];
+        float m_run = kNegBig, l_run = 0.f, of[VEC];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+        for (int j = 0; j < VEC; ++j) of[j] = 0.f;
+        const int stride = nw * rpw;
+        constexpr int U = 4;
+        // wave-uniform trip count: the shuffles below need every lane of a row group in the loop
+        for (int base = 0; base < n_glob; base += stride * U) {
+            const int s0 = base + wave * rpw + lr;
+            u32x4 kr[U], vr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
                 const int s = s0 + u * stride;
-                if (s < n_glob) raw[u] = *(const u32x4*)((const char*)kc + (int64_t)s * row_bytes + li * 16);
+                if (s < n_glob) {
+                    kr[u] = *(const u32x4*)((const char*)kc + (int64_t)s * row_bytes + li * 16);
+                    vr[u] = *(const u32x4*)((const char*)vc + (int64_t)s * row_bytes + li * 16);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int s = s0 + u * stride;
+                const bool valid = s < n_glob;
                 float dot = 0.f;
-                if (s < n_glob) {
+                float vf[VEC];
+                if (valid) {
                     float kf[VEC];
-                    unpack16<CT>(raw[u], kf);
+                    unpack16<CT>(kr[u], kf);
+                    unpack16<CT>(vr[u], vf);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) dot += qf[j] * kf[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) vf[j] = 0.f;
                 }
                 for (int o = LPR >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-                if (s < n_glob && li == 0) scores[s] = dot * p.scale;
+                const float sc = valid ? dot * p.scale : kNegBig;
+                const float m_new = fmaxf(m_run, sc);
+                const float corr = expf(m_run - m_new);
+                const float pr = valid ? expf(sc - m_new) : 0.f;
+                l_run = l_run * corr + pr;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) of[j] = of[j] * corr + pr * vf[j];
+                m_run = m_new;
+            }
+        }
+        // merge the rpw row groups of the wave (lanes with equal li)
+        for (int o = LPR; o < 64; o <<= 1) {
+            const float m_o = __shfl_xor(m_run, o, 64), l_o = __shfl_xor(l_run, o, 64);
+            const float m_new = fmaxf(m_run, m_o);
+            const float ca = expf(m_run - m_new), cb = expf(m_o - m_new);
+            l_run = l_run * ca + l_o * cb;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) of[j] = of[j] * ca + __shfl_xor(of[j], o, 64) * cb;
+            m_run = m_new;
+        }
+        if (lr == 0) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) opart[wave * hs + li * VEC + j] = of[j];
+            if (li == 0) {
+                wm[wave] = m_run;
+                wl[wave] = l_run;
             }
         }
     } else {
+        // odd head sizes (tiny test models): one row per wave step, lanes stride the head dimension
+        float m_run = kNegBig, l_run = 0.f;
+        float oacc[4] = {0.f, 0.f, 0.f, 0.f};  // d = lane + 64 j, hs <= 256
         for (int s = wave; s < n_glob; s += nw) {
             float dot = 0.f;
             for (int d = lane; d < hs; d += 64) dot += qs[d] * ct_to_f32<CT>(kc[(int64_t)s * hs + d]);
-            dot = wave_sum(dot);
-            if (lane == 0) scores[s] = dot * p.scale;
+            dot = wave_sum(dot) * p.scale;
+            const float m_new = fmaxf(m_run, dot);
+            const float corr = expf(m_run - m_new), pr = expf(dot - m_new);
+            l_run = l_run * corr + pr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = lane + 64 * j;
+                if (d < hs) oacc[j] = oacc[j] * corr + pr * ct_to_f32<CT>(vc[(int64_t)s * hs + d]);
+            }
+            m_run = m_new;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = lane + 64 * j;
+            if (d < hs) opart[wave * hs + d] = oacc[j];
+        }
+        if (lane == 0) {
+            wm[wave] = m_run;
+            wl[wave] = l_run;
         }
     }
     if (p.fused && wave == nw - 1) {
         float dot = 0.f;
         for (int d = lane; d < hs; d += 64) dot += qs[d] * kcur[d];
         dot = wave_sum(dot);
-        if (lane == 0) scores[slot] = dot * p.scale;
+        if (lane == 0) scur[0] = dot * p.scale;
     }
     __syncthreads();
 
-    // ---- phase 2: softmax over [0, len)
-    float mx = -INFINITY;
-    for (int s = tid; s < len; s += blockDim.x) mx = fmaxf(mx, scores[s]);
-    mx = block_max(mx, red);
-    float sum = 0.f;
-    for (int s = tid; s < len; s += blockDim.x) {
-        const float e = expf(scores[s] - mx);
-        scores[s] = e;
-        sum += e;
+    // ---- combine the waves (fixed order) and, fused, the current position from its LDS copy
+    float m_all = kNegBig;
+    for (int w = 0; w < nw; ++w) m_all = fmaxf(m_all, wm[w]);
+    float s_cur = kNegBig;
+    if (p.fused) {
+        s_cur = scur[0];
+        m_all = fmaxf(m_all, s_cur);
     }
-    sum = block_sum(sum, red);  // includes the barriers that publish scores[]
-    const float inv = 1.0f / sum;
-
-    // ---- phase 3: o[d] = sum_s p[s] V[s][d]
-    if (vec_ok) {
-        float of[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) of[j] = 0.f;
-        const int stride = nw * rpw;
-        for (int base = 0; base < n_glob; base += stride * 4) {
-            const int s0 = base + wave * rpw + lr;
-            u32x4 raw[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = s0 + u * stride;
-                if (s < n_glob) raw[u] = *(const u32x4*)((const char*)vc + (int64_t)s * row_bytes + li * 16);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = s0 + u * stride;
-                if (s < n_glob) {
-                    float vf[VEC];
-                    unpack16<CT>(raw[u], vf);
-                    const float pr = scores[s];
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) of[j] += pr * vf[j];
-                }
-            }
-        }
-        // combine the rpw row groups of the wave (lanes with equal li)
-        for (int o = LPR; o < 64; o <<= 1) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) of[j] += __shfl_xor(of[j], o, 64);
-        }
-        if (lr == 0) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) opart[wave * hs + li * VEC + j] = of[j];
-        }
-    } else {
-        for (int d = lane; d < hs; d += 64) {
-            float o = 0.f;
-            for (int s = wave; s < n_glob; s += nw) o += scores[s] * ct_to_f32<CT>(vc[(int64_t)s * hs + d]);
-            opart[wave * hs + d] = o;
-        }
-    }
-    __syncthreads();
+    float l_all = 0.f;
+    for (int w = 0; w < nw; ++w) l_all += wl[w] * expf(wm[w] - m_all);
+    const float p_cur = p.fused ? expf(s_cur - m_all) : 0.f;
+    l_all += p_cur;
+    const float inv = 1.0f / l_all;
     for (int d = tid; d < hs; d += blockDim.x) {
         float o = 0.f;
-        for (int w = 0; w < nw; ++w) o += opart[w * hs + d];
-        if (p.fused) o += scores[slot] * vcur[d];
+        for (int w = 0; w < nw; ++w) o += opart[w * hs + d] * expf(wm[w] - m_all);
+        if (p.fused) o += p_cur * vcur[d];
         st_from_f32(p.y, ((int64_t)b * p.T + t) * p.ldy + h * hs + d, p.y_dtype, o * inv);
     }
 }
@@ -335,8 +358,9 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
         MI355_LAUNCH_CHECK();
     }
     const int threads = 512, nw = threads / 64;
-    const size_t lds = (size_t)(3 * a->hs + nw * a->hs + 32 + p.S) * sizeof(float) + 16;
-    MI355_CHECK_ARG(lds <= 160 * 1024, MI355_E_SHAPE, "attention: S=%d hs=%d needs %zu B of LDS", p.S, a->hs, lds);
+    const size_t lds = (size_t)(3 * a->hs + 2 * nw + 4 + nw * a->hs) * sizeof(float) + 16;
+    MI355_CHECK_ARG(a->hs <= 256 || (a->hs * esz) % 16 == 0, MI355_E_SHAPE, "attention: head size %d unsupported", a->hs);
+    MI355_CHECK_ARG(lds <= 160 * 1024, MI355_E_SHAPE, "attention: hs=%d needs %zu B of LDS", a->hs, lds);
     static bool attr_done = false;
     if (!attr_done) {
         MI355_HIP(hipFuncSetAttribute((const void*)attn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,

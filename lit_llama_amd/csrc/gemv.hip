@@ -46,6 +46,7 @@ struct GemvParams {
     int N, K, M, n_tiles, units;
     int x_dtype, norm_dtype, sz_dtype, y_dtype, epi;
     int xs_stride;  // bytes per LDS activation row
+    int vec_ok;     // x rows (and the norm scale) are 16-B aligned: vectorised staging
     float eps;
 };
 
@@ -81,16 +82,95 @@ __device__ __forceinline__ u32x4 ldw(const uint8_t* p) {
         return *(const u32x4*)p;
 }
 
+// 8 consecutive activations (k0 .. k0+7, zero beyond K) as floats, with 16-B loads
+__device__ __forceinline__ void load8(const void* base, int64_t off, int k0, int K, int dtype, float (&v)[8]) {
+    if (k0 + 8 <= K) {
+        if (dtype == MI355_F32) {
+            const f32x4 a = *(const f32x4*)((const float*)base + off), b = *(const f32x4*)((const float*)base + off + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = a[i];
+                v[4 + i] = b[i];
+            }
+        } else {
+            const u32x4 r = *(const u32x4*)((const bf16_t*)base + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] = __uint_as_float(r[i] << 16);
+                v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (k0 + i < K) ? ld2(base, off + i, dtype) : 0.f;
+    }
+}
+
 // Stage activations into LDS as bf16 (optionally RMSNorm'ed), and the per-row sums needed to undo
 // the +128 / zero-point offsets.  lit_llama/model.py:270-277 for the norm arithmetic.
 // Columns K..units*128 are zero-filled (the stream pads K up to a whole unit).
+// Fast path (p.vec_ok, at most 4 x 8 elements per thread): every load of a row is issued at once and the row
+// stays in registers across the norm reduction — one L2 round trip instead of a dependent chain per element,
+// which dominated these few-microsecond kernels.
 __device__ __forceinline__ void stage_x(const GemvParams& p, char* xs, float* sx, float* red) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int Kp = p.units * kUnitK;
+    const int nvec = Kp >> 3;
+    const bool norm = p.norm_scale != nullptr;
+    if (p.vec_ok && nvec <= 4 * nt) {
+        for (int m = 0; m < p.M; ++m) {
+            const int64_t base = (int64_t)m * p.ldx;
+            float xv[4][8], nv[4][8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int v = tid + c * nt;
+                if (v < nvec) {
+                    load8(p.x, base + v * 8, v * 8, p.K, p.x_dtype, xv[c]);
+                    if (norm) load8(p.norm_scale, v * 8, v * 8, p.K, p.norm_dtype, nv[c]);
+                }
+            }
+            float rinv = 1.f;
+            if (norm) {
+                float ss = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (tid + c * nt < nvec) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) ss += xv[c][i] * xv[c][i];
+                    }
+                ss = block_sum(ss, red);
+                rinv = rsqrtf(ss / (float)p.K + p.eps);
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int v = tid + c * nt;
+                if (v < nvec) {
+                    u32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float a = xv[c][2 * i], b = xv[c][2 * i + 1];
+                        if (norm) {
+                            a = nv[c][2 * i] * (a * rinv);
+                            b = nv[c][2 * i + 1] * (b * rinv);
+                        }
+                        const bf16_t ab = f32_to_bf16(a), bb = f32_to_bf16(b);
+                        s += bf16_to_f32(ab) + bf16_to_f32(bb);
+                        o[i] = (uint32_t)ab | ((uint32_t)bb << 16);
+                    }
+                    *(u32x4*)(xs + (size_t)m * p.xs_stride + v * 16) = o;
+                }
+            }
+            s = block_sum(s, red);
+            if (tid == 0) sx[m] = s;
+        }
+        __syncthreads();
+        return;
+    }
     for (int m = 0; m < p.M; ++m) {
         const int64_t base = (int64_t)m * p.ldx;
         float rinv = 1.f;
-        if (p.norm_scale != nullptr) {
+        if (norm) {
             float ss = 0.f;
             for (int k = tid; k < p.K; k += nt) {
                 const float v = ld2(p.x, base + k, p.x_dtype);
@@ -105,7 +185,7 @@ __device__ __forceinline__ void stage_x(const GemvParams& p, char* xs, float* sx
             bf16_t b = 0;
             if (k < p.K) {
                 float v = ld2(p.x, base + k, p.x_dtype);
-                if (p.norm_scale != nullptr) v = ld2(p.norm_scale, k, p.norm_dtype) * (v * rinv);
+                if (norm) v = ld2(p.norm_scale, k, p.norm_dtype) * (v * rinv);
                 b = f32_to_bf16(v);
             }
             row[k] = b;
@@ -628,6 +708,12 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     p.epi = a->epi;
     p.xs_stride = p.units * kUnitK * 2 + 16;
     p.eps = a->eps;
+    {
+        const int esz = a->x_dtype == MI355_F32 ? 4 : 2;
+        bool ok = ((uintptr_t)a->x % 16 == 0) && ((a->ldx * esz) % 16 == 0 || a->M == 1);
+        if (a->norm_scale != nullptr) ok = ok && ((uintptr_t)a->norm_scale % 16 == 0);
+        p.vec_ok = ok ? 1 : 0;
+    }
 
     int waves = a->waves > 0 ? a->waves : 8;
     if (waves > 8) waves = 8;

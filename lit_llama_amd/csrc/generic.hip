@@ -157,6 +157,27 @@ __global__ void embedding_kernel(const void* idx, int idx_is_i64, const void* wt
     int64_t tok = idx_is_i64 ? ((const int64_t*)idx)[m] : (int64_t)((const int32_t*)idx)[m];
     if (tok < 0) tok = 0;
     if (tok >= vocab) tok = vocab - 1;
+    if (w_dtype == MI355_BF16 && y_dtype == MI355_F32 && (C & 7) == 0 && ((uintptr_t)wte & 15) == 0 &&
+        ((uintptr_t)y & 15) == 0) {
+        // decode path: one 16-B load (8 bf16) -> two 16-B stores (8 f32) per thread step
+        const u32x4* src = (const u32x4*)((const bf16_t*)wte + tok * C);
+        f32x4* dst = (f32x4*)((float*)y + (int64_t)m * C);
+        for (int v = threadIdx.x; v < (C >> 3); v += blockDim.x) {
+            const u32x4 r = src[v];
+            f32x4 a, b;
+            a[0] = __uint_as_float(r[0] << 16);
+            a[1] = __uint_as_float(r[0] & 0xffff0000u);
+            a[2] = __uint_as_float(r[1] << 16);
+            a[3] = __uint_as_float(r[1] & 0xffff0000u);
+            b[0] = __uint_as_float(r[2] << 16);
+            b[1] = __uint_as_float(r[2] & 0xffff0000u);
+            b[2] = __uint_as_float(r[3] << 16);
+            b[3] = __uint_as_float(r[3] & 0xffff0000u);
+            dst[2 * v] = a;
+            dst[2 * v + 1] = b;
+        }
+        return;
+    }
     for (int k = threadIdx.x; k < C; k += blockDim.x)
         st_from_f32(y, (int64_t)m * C + k, y_dtype, ld_as_f32(wte, tok * C + k, w_dtype));
 }
@@ -167,12 +188,33 @@ __global__ void argmax_kernel(const float* logits, int V, int32_t* out, int32_t*
     __shared__ int si[16];
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
-        const float v = logits[i];
+    auto upd = [&](float v, int i) {
         if (v > best || (v == best && i < bi)) {
             best = v;
             bi = i;
         }
+    };
+    if ((V & 3) == 0 && ((uintptr_t)logits & 15) == 0) {
+        // 8 x 16-B loads per thread in flight (a dependent scalar chain took ~14 us for 32000 logits)
+        const int nv = V >> 2;
+        for (int base = 0; base < nv; base += blockDim.x * 8) {
+            f32x4 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = base + u * blockDim.x + threadIdx.x;
+                if (v < nv) r[u] = ((const f32x4*)logits)[v];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = base + u * blockDim.x + threadIdx.x;
+                if (v < nv) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) upd(r[u][q], 4 * v + q);
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < V; i += blockDim.x) upd(logits[i], i);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

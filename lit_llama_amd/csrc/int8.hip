@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
             for (int m = 0; m < p.M; ++m) out |= fabsf(f16_to_f32(xh[(size_t)m * Kp + k])) >= p.threshold;
         for (int m = 0; m < p.M; ++m) {
             const float s = sca[m];
-            const float inv = s > 0.f ? 127.0f / s : 0.f;
+            const float inv = s > 0.f ? __fdiv_rn(127.0f, s) : 0.f;  // IEEE division: bit parity with the oracle
             const float q = out ? 0.f : rintf(f16_to_f32(xh[(size_t)m * Kp + k]) * inv);
             ((int8_t*)(xq + (size_t)m * p.xq_stride))[k] = (int8_t)q;
         }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
                     const int64_t off =
                         ((((int64_t)tile * units + u) * R + r) * 2 + e) * 1024 + (g * 16 + e_row) * 16 + j;
                     const float cb = (float)(int8_t)p.w[off];
-                    const float sub = f16r((cb * scb) / 127.0f);
+                    const float sub = f16r(__fdiv_rn(cb * scb, 127.0f));
                     o += f16_to_f32(xh[(size_t)e_col * Kp + k]) * sub;
                     any = true;
                 }
@@ -300,7 +300,7 @@ __global__ void int8_quant_rows_kernel(const void* w, int dtype, int K, int8_t* 
         amax = fmaxf(amax, fabsf(f16_to_f32(f32_to_f16(ld_as_f32(w, (int64_t)n * K + k, dtype)))));
     amax = block_max(amax, red);
     if (threadIdx.x == 0) scb[n] = amax;
-    const float inv = amax > 0.f ? 127.0f / amax : 0.f;
+    const float inv = amax > 0.f ? __fdiv_rn(127.0f, amax) : 0.f;  // IEEE division: bit parity with the oracle
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         const float v = f16_to_f32(f32_to_f16(ld_as_f32(w, (int64_t)n * K + k, dtype)));
         cb[(int64_t)n * K + k] = (int8_t)rintf(v * inv);

@@ -70,6 +70,11 @@ llama_configs = {
 }
 
 
+def _tp(config) -> int:
+    """Tensor-parallel degree of a rank-local model built by tp.build_local_model (1 for ordinary models)."""
+    return int(getattr(config, "tp_world", 1))
+
+
 def _linear(mod: nn.Module, x: torch.Tensor) -> torch.Tensor:
     """Apply one of the hot-path linears.  Quantised plug-ins carry their own kernels; a stock `nn.Linear`
     (no-quant configs) goes to the bf16 weight-streaming kernel for skinny inputs, to the exact f32 kernel for
@@ -114,7 +119,7 @@ class RMSNorm(nn.Module):
 class MLP(nn.Module):
     def __init__(self, config: LLaMAConfig) -> None:
         super().__init__()
-        n_hidden = config.n_hidden
+        n_hidden = config.n_hidden // _tp(config)  # rank-local rows under tensor parallelism (tp.py)
         self.c_fc1 = nn.Linear(config.n_embd, n_hidden, bias=False)
         self.c_fc2 = nn.Linear(config.n_embd, n_hidden, bias=False)
         self.c_proj = nn.Linear(n_hidden, config.n_embd, bias=False)
@@ -128,9 +133,10 @@ class CausalSelfAttention(nn.Module):
     def __init__(self, config: LLaMAConfig) -> None:
         super().__init__()
         assert config.n_embd % config.n_head == 0
-        self.c_attn = nn.Linear(config.n_embd, 3 * config.n_embd, bias=False)  # [Q; K; V] stacked on dim 0
-        self.c_proj = nn.Linear(config.n_embd, config.n_embd, bias=False)
-        self.n_head = config.n_head
+        tp = _tp(config)
+        self.c_attn = nn.Linear(config.n_embd, 3 * config.n_embd // tp, bias=False)  # [Q; K; V] stacked on dim 0
+        self.c_proj = nn.Linear(config.n_embd // tp, config.n_embd, bias=False)
+        self.n_head = config.n_head // tp
         self.n_embd = config.n_embd
         self.block_size = config.block_size
 
@@ -187,7 +193,7 @@ class LLaMA(nn.Module):
         super().__init__()
         assert config.padded_vocab_size is not None
         self.config = config
-        self.lm_head = nn.Linear(config.n_embd, config.padded_vocab_size, bias=False)
+        self.lm_head = nn.Linear(config.n_embd, config.padded_vocab_size // _tp(config), bias=False)
         self.transformer = nn.ModuleDict(
             dict(
                 wte=nn.Embedding(config.padded_vocab_size, config.n_embd),
@@ -259,6 +265,8 @@ class LLaMA(nn.Module):
         if self.mask_cache is None:
             self.mask_cache = self.build_mask_cache(idx)
 
+        if _tp(self.config) > 1:
+            raise nat.NativeError("a rank-local tensor-parallel model is driven through tp.TPDecoder / tp.tp_forward")
         if input_pos is not None and B == 1 and self.use_engine:
             eng = self.engine()
             if eng is not None:

@@ -138,15 +138,21 @@ class Linear8bitLt(torch.nn.Linear):
         self._pending_fp: Optional[torch.Tensor] = None
         self._quantize_weight(self.weight.data)
 
-    def _load_from_state_dict(self, local_state_dict, *args, **kwargs):
-        # exactly one key ends with `weight`; the other possible one is the bias (:52-67)
-        weight_key = next((name for name in local_state_dict.keys() if name.endswith("weight")), None)
-        if weight_key is None:
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # Re-quantise the float `<prefix>weight` of the checkpoint on the GPU and let nn.Module load the bias
+        # (lit_llama/quantization.py:52-67; the reference looks the key up by its `weight` suffix, here it is
+        # addressed by the module prefix so the order of the checkpoint's keys does not matter).
+        weight_key = prefix + "weight"
+        if weight_key not in state_dict:
             return
-        weight = local_state_dict.pop(weight_key)
+        weight = state_dict.pop(weight_key)
         self._quantize_weight(weight)
-        if local_state_dict:
-            super()._load_from_state_dict(local_state_dict, *args, **kwargs)
+        if prefix + "bias" in state_dict:
+            stash = self._parameters.pop("weight")
+            try:
+                super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+            finally:
+                self._parameters["weight"] = stash
 
     def _quantize_weight(self, weight: torch.Tensor) -> None:
         """`bnb.functional.double_quant(weight.half().cuda())` -> CB, SCB (:69-77), on the module's GPU."""

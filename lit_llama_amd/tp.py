@@ -1,0 +1,243 @@
+"""Tensor parallelism for the decode path (BASELINE.json configs[4]: LLaMA-65B gptq.int4, TP = 8 over xGMI).
+
+The reference has no tensor parallelism; the partition is the one Meta's checkpoints use and the reference
+records when it MERGES them — `shard_dims` in /root/reference scripts/convert_checkpoint.py:57-65:
+
+    c_attn   dim 0 (per head, inside each of the stacked Q / K / V thirds, lit_llama/model.py:197)
+    c_proj   dim 1        c_fc1 / c_fc2  dim 0        mlp.c_proj  dim 1        lm_head  dim 0
+    wte      replicated here (524 MB in bf16 for 65B; a column split would add an all-gather per token)
+
+Per layer two row-parallel linears produce partial sums -> one all-reduce(sum) of [T, n_embd] f32 each
+(RCCL over xGMI through torch.distributed, backend "nccl"), plus one all-gather of the [V / world] logit shards
+per step.  int4 per-row scale / zero shard with the rows of column-parallel linears and are replicated for
+row-parallel ones (y = s (sum_k x_k q_k - z sum_k x_k) is additive over K shards).
+
+`tp_forward` is the protocol (which collective where); it drives a list of `LocalShard`s: one `EngineShard` per
+process under torch.distributed, or several on ONE GPU with `LoopbackComm` (how the protocol is tested on the
+1-GPU box), or CPU stand-ins in the gloo tests.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .model import LLaMA, LLaMAConfig
+
+SHARD_DIMS = {
+    "attn.c_attn": 0, "attn.c_proj": 1, "mlp.c_fc1": 0, "mlp.c_fc2": 0, "mlp.c_proj": 1, "lm_head": 0,
+}
+
+
+def check_divisible(cfg: LLaMAConfig, world: int) -> None:
+    if cfg.n_head % world or cfg.n_hidden % world or cfg.padded_vocab_size % world:
+        raise ValueError(f"TP={world} does not divide n_head={cfg.n_head}, n_hidden={cfg.n_hidden} or "
+                         f"vocab={cfg.padded_vocab_size}")
+    if (cfg.n_hidden // world) % 2 or (cfg.n_embd // world) % 2:
+        raise ValueError("int4 packing needs an even number of input columns per shard")
+
+
+def _shard_rows(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    n = t.shape[0] // world
+    return t[rank * n:(rank + 1) * n]
+
+
+def _shard_qkv_rows(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """rows [Q; K; V] -> [Q_r; K_r; V_r] (heads are contiguous inside each third)."""
+    third = t.shape[0] // 3
+    n = third // world
+    return torch.cat([t[i * third + rank * n: i * third + (rank + 1) * n] for i in range(3)], dim=0)
+
+
+def _shard_cols(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    n = t.shape[1] // world
+    return t[:, rank * n:(rank + 1) * n]
+
+
+def shard_state_dict(sd: Dict[str, torch.Tensor], cfg: LLaMAConfig, rank: int, world: int) -> Dict[str, torch.Tensor]:
+    """Rank-local view of a full (fp or gptq.int4) checkpoint with the reference's key names."""
+    check_divisible(cfg, world)
+    out: Dict[str, torch.Tensor] = {}
+    for key, t in sd.items():
+        name = next((n for n in SHARD_DIMS if (n + ".") in key), None)
+        if name is None:  # wte, norm scales
+            out[key] = t
+            continue
+        dim = SHARD_DIMS[name]
+        leaf = key.rsplit(".", 1)[1]
+        if dim == 0:
+            if leaf == "bias":
+                raise ValueError("hot-path linears have no bias")
+            cut = _shard_qkv_rows if name == "attn.c_attn" else _shard_rows
+            piece = cut(t, rank, world)
+        else:
+            # row-parallel: weights / packed bytes split along the input dim, per-row scale / zero replicated
+            piece = t if leaf in ("scales", "zeros") else _shard_cols(t, rank, world)
+        if leaf == "quant_weight":
+            piece = piece.t().contiguous().t()  # keep the reference's column-major storage
+        else:
+            piece = piece.contiguous()
+        out[key] = piece
+    return out
+
+
+def build_local_model(cfg: LLaMAConfig, world: int, *, device, dtype=torch.bfloat16, mode: Optional[str] = None) -> LLaMA:
+    """An (empty) LLaMA whose linears have the rank-local shapes; fill it with `shard_state_dict` output."""
+    from .utils import EmptyInitOnDevice
+
+    check_divisible(cfg, world)
+    local = LLaMAConfig(block_size=cfg.block_size, vocab_size=cfg.vocab_size, padded_vocab_size=cfg.padded_vocab_size,
+                        n_layer=cfg.n_layer, n_head=cfg.n_head, n_embd=cfg.n_embd)
+    local.tp_world = world
+    with EmptyInitOnDevice(device=device, dtype=dtype, quantization_mode=mode):
+        model = LLaMA(local)
+    model.eval()
+    return model
+
+
+# ------------------------------------------------------------------------------------------------ communicators
+class DistComm:
+    """torch.distributed (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+
+    def all_reduce_sum(self, tensors: Sequence[torch.Tensor]) -> None:
+        assert len(tensors) == 1
+        self.dist.all_reduce(tensors[0], op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather_cols(self, tensors: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        assert len(tensors) == 1
+        t = tensors[0].contiguous()
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t, group=self.group)
+        return [torch.cat(parts, dim=-1)]
+
+
+class LoopbackComm:
+    """All ranks live in this process (one GPU): the 'collective' is a local sum / concat, in rank order."""
+
+    def __init__(self, world: int):
+        self.world = world
+
+    def all_reduce_sum(self, tensors: Sequence[torch.Tensor]) -> None:
+        assert len(tensors) == self.world
+        total = tensors[0].clone()
+        for t in tensors[1:]:
+            total += t
+        for t in tensors:
+            t.copy_(total)
+
+    def all_gather_cols(self, tensors: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        assert len(tensors) == self.world
+        full = torch.cat(list(tensors), dim=-1)
+        return [full.clone() for _ in tensors]
+
+
+# ------------------------------------------------------------------------------------------------ protocol
+def tp_forward(shards: Sequence, comm, T: int, n_layer: int, want_logits: bool = True) -> Optional[List[torch.Tensor]]:
+    """One forward over T tokens already placed in every shard.  Returns the full logits per shard
+    ([rows, vocab], rows = whatever `head()` produced)."""
+    for s in shards:
+        s.embed(T)
+    for l in range(n_layer):
+        for s in shards:
+            s.attn_part(l, T)          # RMSNorm + c_attn shard + local heads + c_proj shard -> partial
+        comm.all_reduce_sum([s.partial_view(T) for s in shards])
+        for s in shards:
+            s.residual_add(T)
+            s.mlp_part(l, T)           # RMSNorm + fc shard + SwiGLU + mlp.c_proj shard -> partial
+        comm.all_reduce_sum([s.partial_view(T) for s in shards])
+        for s in shards:
+            s.residual_add(T)
+    if not want_logits:
+        return None
+    return comm.all_gather_cols([s.head(T) for s in shards])
+
+
+class EngineShard:
+    """`LocalShard` on the native engine: the rank's `mi355_model` driven segment by segment."""
+
+    def __init__(self, model: LLaMA, world: int, tune: Optional[dict] = None):
+        from .engine import DecodeEngine
+
+        self.eng = DecodeEngine(model, tp_world=world, tune=tune)
+        model._engine = self.eng
+        self.model = model
+
+    def _call(self, fn, *args):
+        from ._native import check, lib
+
+        check(getattr(lib(), fn)(C.byref(self.eng.m), *args, self.eng.stream.cuda_stream), fn)
+
+    def embed(self, T):
+        self._call("mi355_forward_embed", T)
+
+    def attn_part(self, l, T):
+        self._call("mi355_forward_segment", T, l, 0, 2)
+
+    def mlp_part(self, l, T):
+        self._call("mi355_forward_segment", T, l, 2, 4)
+
+    def residual_add(self, T):
+        self._call("mi355_residual_add", T)
+
+    def partial_view(self, T):
+        return self.eng.partial[:T]
+
+    def head(self, T):
+        self._call("mi355_forward_head", T, 1, 0)  # last token only
+        return self.eng.logits[:1, : self.eng.m.lm_head.N]
+
+
+class TPDecoder:
+    """Greedy decode of ONE stream across `world` shards (list of EngineShard; length 1 per process under
+    torch.distributed, length `world` with LoopbackComm)."""
+
+    def __init__(self, shards: Sequence[EngineShard], comm, cfg: LLaMAConfig):
+        self.shards, self.comm, self.cfg = list(shards), comm, cfg
+
+    def _streams(self):
+        return [s.eng.stream for s in self.shards]
+
+    @torch.no_grad()
+    def generate(self, prompt: torch.Tensor, max_new_tokens: int, max_seq_length: Optional[int] = None) -> torch.Tensor:
+        from .ops import argmax
+
+        T = prompt.numel()
+        S = max_seq_length or min(T + max_new_tokens, self.cfg.block_size)
+        dev = prompt.device
+        out = torch.empty(T + max_new_tokens, dtype=prompt.dtype, device=dev)
+        out[:T] = prompt
+        eng0 = self.shards[0].eng
+        cur = torch.cuda.current_stream(dev)
+        for st in self._streams():
+            st.wait_stream(cur)
+        # the loopback shards share one GPU: run everything on shard 0's stream so the order is total
+        run_stream = eng0.stream
+        for s in self.shards:
+            s.eng.stream = run_stream
+        with torch.cuda.stream(run_stream):
+            for s in self.shards:
+                s.eng._ensure_cache(S)
+            pos, logits = 0, None
+            while pos < T:  # prompt in chunks every shard can stage
+                n = min(min(s.eng.max_T for s in self.shards), T - pos)
+                for s in self.shards:
+                    s.eng.set_step(prompt[pos:pos + n], n, pos)
+                logits = tp_forward(self.shards, self.comm, n, self.cfg.n_layer, want_logits=(pos + n == T))
+                pos += n
+            for i in range(max_new_tokens):
+                nxt = argmax(logits[0].reshape(-1).float().contiguous())
+                out[T + i: T + i + 1] = nxt.to(out.dtype)
+                if i + 1 == max_new_tokens:
+                    break
+                for s in self.shards:
+                    s.eng.set_step(nxt, 1, T + i)
+                logits = tp_forward(self.shards, self.comm, 1, self.cfg.n_layer)
+        cur.wait_stream(run_stream)
+        return out

@@ -25,12 +25,13 @@ for st in $STAGES; do
       cat $OUT/bench_nograph.json ;;
     prof)
       rm -rf $OUT/prof
-      timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o run -- python bench.py --steps 64 --warmup 8 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
+      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python bench.py --steps 64 --warmup 8 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
       echo "rocprof exit $?" | tee -a $OUT/session.log
-      find $OUT/prof -name '*stats*' | head; f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
-      [ -n "$f" ] && { cp "$f" $OUT/kernel_stats.csv; head -30 "$f"; }
-      # keep the merge-back small: drop the raw trace, keep the stats
-      find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete ;;
+      ls $OUT/prof | head
+      f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv
+      t=$(find $OUT/prof -name '*kernel_trace.csv' | head -1)
+      [ -n "$t" ] && python scripts/prof_summary.py "$t" > $OUT/prof_summary.txt 2>&1 && cat $OUT/prof_summary.txt
+      find $OUT/prof -name '*kernel_trace.csv' -size +30M -delete ;;
     pmc)
       rm -rf $OUT/pmc
       timeout 900 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc -o fetch -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/pmc_bench.json 2> $OUT/pmc.err
