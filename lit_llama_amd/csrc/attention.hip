@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) of[j] = 0.f;
         const int stride = nw * rpw;
-        constexpr int U = 4;
+        constexpr int U = 8;  // 16 x 16-B loads in flight per lane: a 512-row context is one round trip
         // wave-uniform trip count: the shuffles below need every lane of a row group in the loop
         for (int base = 0; base < n_glob; base += stride * U) {
             const int s0 = base + wave * rpw + lr;

@@ -46,7 +46,8 @@ struct GemvParams {
     int N, K, M, n_tiles, units;
     int x_dtype, norm_dtype, sz_dtype, y_dtype, epi;
     int xs_stride;  // bytes per LDS activation row
-    int vec_ok;     // x rows (and the norm scale) are 16-B aligned: vectorised staging
+    int vec_mode;   // 0 scalar staging, 1 f32 + bf16-scale RMSNorm vectorised, 2 bf16 copy vectorised
+    unsigned w_bytes;  // size of the weight stream (buffer descriptor bound)
     float eps;
 };
 
@@ -82,85 +83,93 @@ __device__ __forceinline__ u32x4 ldw(const uint8_t* p) {
         return *(const u32x4*)p;
 }
 
-// 8 consecutive activations (k0 .. k0+7, zero beyond K) as floats, with 16-B loads
-__device__ __forceinline__ void load8(const void* base, int64_t off, int k0, int K, int dtype, float (&v)[8]) {
-    if (k0 + 8 <= K) {
-        if (dtype == MI355_F32) {
-            const f32x4 a = *(const f32x4*)((const float*)base + off), b = *(const f32x4*)((const float*)base + off + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = a[i];
-                v[4 + i] = b[i];
-            }
-        } else {
-            const u32x4 r = *(const u32x4*)((const bf16_t*)base + off);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[2 * i] = __uint_as_float(r[i] << 16);
-                v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (k0 + i < K) ? ld2(base, off + i, dtype) : 0.f;
-    }
-}
-
 // Stage activations into LDS as bf16 (optionally RMSNorm'ed), and the per-row sums needed to undo
 // the +128 / zero-point offsets.  lit_llama/model.py:270-277 for the norm arithmetic.
 // Columns K..units*128 are zero-filled (the stream pads K up to a whole unit).
-// Fast path (p.vec_ok, at most 4 x 8 elements per thread): every load of a row is issued at once and the row
-// stays in registers across the norm reduction — one L2 round trip instead of a dependent chain per element,
-// which dominated these few-microsecond kernels.
+//
+// Two vectorised paths cover the decode step (p.vec_mode, chosen on the host):
+//   1: x f32 + RMSNorm with a bf16 scale, K % 8 == 0, at most 2 x 8 elements per thread — the row is loaded
+//      once (16-B loads, all issued up front), kept in registers across the reduction, normalised, stored;
+//   2: x bf16, no norm, K % 8 == 0 — 16-B copies straight into LDS.
+// A per-element loop with a dependent load per iteration (the first version) cost ~5 us per launch, more than
+// streaming the weights of a 4096 x 4096 int4 matrix.
 __device__ __forceinline__ void stage_x(const GemvParams& p, char* xs, float* sx, float* red) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int Kp = p.units * kUnitK;
-    const int nvec = Kp >> 3;
     const bool norm = p.norm_scale != nullptr;
-    if (p.vec_ok && nvec <= 4 * nt) {
+    if (p.vec_mode == 1) {
+        const int nvec = p.K >> 3;
         for (int m = 0; m < p.M; ++m) {
-            const int64_t base = (int64_t)m * p.ldx;
-            float xv[4][8], nv[4][8];
+            const float* xrow = (const float*)p.x + (int64_t)m * p.ldx;
+            f32x4 xa[2], xb[2];
+            u32x4 ns[2];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 2; ++c) {
                 const int v = tid + c * nt;
                 if (v < nvec) {
-                    load8(p.x, base + v * 8, v * 8, p.K, p.x_dtype, xv[c]);
-                    if (norm) load8(p.norm_scale, v * 8, v * 8, p.K, p.norm_dtype, nv[c]);
+                    xa[c] = *(const f32x4*)(xrow + v * 8);
+                    xb[c] = *(const f32x4*)(xrow + v * 8 + 4);
+                    ns[c] = *(const u32x4*)((const bf16_t*)p.norm_scale + v * 8);
                 }
             }
-            float rinv = 1.f;
-            if (norm) {
-                float ss = 0.f;
+            float ss = 0.f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (tid + c * nt < nvec) {
+            for (int c = 0; c < 2; ++c)
+                if (tid + c * nt < nvec) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) ss += xv[c][i] * xv[c][i];
-                    }
-                ss = block_sum(ss, red);
-                rinv = rsqrtf(ss / (float)p.K + p.eps);
-            }
+                    for (int i = 0; i < 4; ++i) ss += xa[c][i] * xa[c][i] + xb[c][i] * xb[c][i];
+                }
+            ss = block_sum(ss, red);
+            const float rinv = rsqrtf(ss / (float)p.K + p.eps);
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 2; ++c) {
                 const int v = tid + c * nt;
                 if (v < nvec) {
                     u32x4 o;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float a = xv[c][2 * i], b = xv[c][2 * i + 1];
-                        if (norm) {
-                            a = nv[c][2 * i] * (a * rinv);
-                            b = nv[c][2 * i + 1] * (b * rinv);
-                        }
-                        const bf16_t ab = f32_to_bf16(a), bb = f32_to_bf16(b);
-                        s += bf16_to_f32(ab) + bf16_to_f32(bb);
-                        o[i] = (uint32_t)ab | ((uint32_t)bb << 16);
+                        const float x0 = i < 2 ? xa[c][2 * i] : xb[c][2 * i - 4];
+                        const float x1 = i < 2 ? xa[c][2 * i + 1] : xb[c][2 * i - 3];
+                        const bf16_t a = f32_to_bf16(__uint_as_float(ns[c][i] << 16) * (x0 * rinv));
+                        const bf16_t b = f32_to_bf16(__uint_as_float(ns[c][i] & 0xffff0000u) * (x1 * rinv));
+                        s += bf16_to_f32(a) + bf16_to_f32(b);
+                        o[i] = (uint32_t)a | ((uint32_t)b << 16);
                     }
                     *(u32x4*)(xs + (size_t)m * p.xs_stride + v * 16) = o;
                 }
             }
+            for (int k = p.K + tid; k < Kp; k += nt) ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;
+            s = block_sum(s, red);
+            if (tid == 0) sx[m] = s;
+        }
+        __syncthreads();
+        return;
+    }
+    if (p.vec_mode == 2) {
+        const int nvec = p.K >> 3;
+        for (int m = 0; m < p.M; ++m) {
+            const bf16_t* xrow = (const bf16_t*)p.x + (int64_t)m * p.ldx;
+            float s = 0.f;
+            for (int v0 = 0; v0 < nvec; v0 += 4 * nt) {
+                u32x4 r[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int v = v0 + tid + c * nt;
+                    if (v < nvec) r[c] = *(const u32x4*)(xrow + v * 8);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int v = v0 + tid + c * nt;
+                    if (v < nvec) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            s += __uint_as_float(r[c][i] << 16) + __uint_as_float(r[c][i] & 0xffff0000u);
+                        *(u32x4*)(xs + (size_t)m * p.xs_stride + v * 16) = r[c];
+                    }
+                }
+            }
+            for (int k = p.K + tid; k < Kp; k += nt) ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;
             s = block_sum(s, red);
             if (tid == 0) sx[m] = s;
         }
@@ -297,20 +306,25 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     const int my_tiles = (p.n_tiles > bid) ? (p.n_tiles - bid + nb - 1) / nb : 0;
     const int total = my_tiles * nu;
 
-    const int64_t unit_bytes = (int64_t)kSlot * 1024;
-    const uint8_t* wl = p.w + lane * 16;
 
     // ---- weight prefetch ring: P units in flight per wave.
-    // Every refill is an UNCONDITIONAL load (past the end of the wave's work it re-reads the first KiB of
-    // the stream, an L2 hit): a conditional refill makes the ring registers phi nodes, and hipcc then drains
-    // the whole ring with s_waitcnt vmcnt(0) at the loop back-edge to copy them.
+    // Every refill is an UNCONDITIONAL load: a conditional refill makes the ring registers phi nodes, and hipcc
+    // then drains the whole ring with s_waitcnt vmcnt(0) at the loop back-edge to copy them.  Past the end of the
+    // wave's work the offset is pushed beyond the buffer descriptor's bound: the hardware returns zeros and
+    // issues NO memory request.  (Re-reading a fixed dummy address instead funnels every wave of the chip into
+    // one L2 channel: measured ~8 us of a 16 us launch.)
     u32x4 ring[P][kSlot];
     int pf_tile = bid, pf_u = u0, pf_n = 0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const unsigned lane_off = lane * 16;
+    const unsigned unit_bytes32 = (unsigned)kSlot * 1024u;
 #define MI355_ISSUE(slot)                                                                                       \
     do {                                                                                                        \
         const bool ok__ = pf_n < total;                                                                         \
-        const uint8_t* src__ = ok__ ? wl + ((int64_t)pf_tile * units + pf_u) * unit_bytes : wl;                 \
-        _Pragma("unroll") for (int s__ = 0; s__ < kSlot; ++s__) ring[slot][s__] = ldw<NT>(src__ + s__ * 1024);  \
+        const unsigned off__ = ok__ ? ((unsigned)pf_tile * (unsigned)units + (unsigned)pf_u) * unit_bytes32 + lane_off \
+                                    : 0xFFFFF000u;                                                              \
+        _Pragma("unroll") for (int s__ = 0; s__ < kSlot; ++s__) ring[slot][s__] = __builtin_bit_cast(           \
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off__ + s__ * 1024, 0, NT ? 2 : 0));             \
         ++pf_n;                                                                                                 \
         if (ok__ && ++pf_u == u1) {                                                                             \
             pf_u = u0;                                                                                          \
@@ -708,16 +722,25 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     p.epi = a->epi;
     p.xs_stride = p.units * kUnitK * 2 + 16;
     p.eps = a->eps;
-    {
-        const int esz = a->x_dtype == MI355_F32 ? 4 : 2;
-        bool ok = ((uintptr_t)a->x % 16 == 0) && ((a->ldx * esz) % 16 == 0 || a->M == 1);
-        if (a->norm_scale != nullptr) ok = ok && ((uintptr_t)a->norm_scale % 16 == 0);
-        p.vec_ok = ok ? 1 : 0;
-    }
-
     int waves = a->waves > 0 ? a->waves : 8;
     if (waves > 8) waves = 8;
     if (waves < 4) waves = 4;  // the combine step needs 256 owner threads
+    {
+        const int esz = a->x_dtype == MI355_F32 ? 4 : 2;
+        const bool aligned = ((uintptr_t)a->x % 16 == 0) && ((a->ldx * esz) % 16 == 0 || a->M == 1) && a->K % 8 == 0;
+        p.vec_mode = 0;
+        if (aligned && a->norm_scale != nullptr && a->x_dtype == MI355_F32 && a->norm_dtype == MI355_BF16 &&
+            (uintptr_t)a->norm_scale % 16 == 0 && a->K / 8 <= 2 * waves * 64)
+            p.vec_mode = 1;
+        else if (aligned && a->norm_scale == nullptr && a->x_dtype == MI355_BF16)
+            p.vec_mode = 2;
+    }
+    {
+        const size_t wb = mi355_packed_bytes(a->fmt, a->N, a->K, a->R, swiglu ? 1 : 0);
+        MI355_CHECK_ARG(wb > 0 && wb < 0xFFFFFFF0ull, MI355_E_SHAPE, "linear_fast: weight stream of %zu B exceeds 4 GiB", wb);
+        p.w_bytes = (unsigned)wb;
+    }
+
     const size_t lds = kLdsHeader + (size_t)2 * waves * a->R * 1024 + (size_t)a->M * p.xs_stride;
     MI355_CHECK_ARG(lds <= (size_t)kMaxLds, MI355_E_SHAPE,
                     "linear_fast: M=%d x K=%d activations do not fit LDS (%zu B > %d B); chunk M", a->M, a->K, lds,

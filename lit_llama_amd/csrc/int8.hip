@@ -34,6 +34,7 @@ struct I8Params {
     int N, K, M, n_tiles, units;
     int x_dtype, norm_dtype, bias_dtype, y_dtype, epi;
     int xq_stride;  // bytes per int8 activation row in LDS
+    unsigned w_bytes;  // size of the weight stream (buffer descriptor bound)
     float eps, threshold;
 };
 
@@ -63,23 +64,25 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
     const int total = my_tiles * nu;
 
     constexpr int kSlot = R * 2;
-    const int64_t unit_bytes = (int64_t)kSlot * 1024;
-    const uint8_t* wl = p.w + lane * 16;
 
-    // unconditional refills (dummy source past the end), see gemv.hip
+    // unconditional refills through a buffer descriptor (out-of-range -> zeros, no memory request), see gemv.hip
     u32x4 ring[P][kSlot];
     int pf_tile = bid, pf_u = u0, pf_n = 0;
-#define MI355_ISSUE(slot)                                                                          \
-    do {                                                                                           \
-        const bool ok__ = pf_n < total;                                                            \
-        const uint8_t* src__ = ok__ ? wl + ((int64_t)pf_tile * units + pf_u) * unit_bytes : wl;    \
-        _Pragma("unroll") for (int s__ = 0; s__ < kSlot; ++s__) ring[slot][s__] =                  \
-            __builtin_nontemporal_load((const u32x4*)(src__ + s__ * 1024));                        \
-        ++pf_n;                                                                                    \
-        if (ok__ && ++pf_u == u1) {                                                                \
-            pf_u = u0;                                                                             \
-            pf_tile += nb;                                                                         \
-        }                                                                                          \
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const unsigned lane_off = lane * 16;
+    const unsigned unit_bytes32 = (unsigned)kSlot * 1024u;
+#define MI355_ISSUE(slot)                                                                                       \
+    do {                                                                                                        \
+        const bool ok__ = pf_n < total;                                                                         \
+        const unsigned off__ = ok__ ? ((unsigned)pf_tile * (unsigned)units + (unsigned)pf_u) * unit_bytes32 + lane_off \
+                                    : 0xFFFFF000u;                                                              \
+        _Pragma("unroll") for (int s__ = 0; s__ < kSlot; ++s__) ring[slot][s__] = __builtin_bit_cast(           \
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off__ + s__ * 1024, 0, 2));                      \
+        ++pf_n;                                                                                                 \
+        if (ok__ && ++pf_u == u1) {                                                                             \
+            pf_u = u0;                                                                                          \
+            pf_tile += nb;                                                                                      \
+        }                                                                                                       \
     } while (0)
 #pragma unroll
     for (int j = 0; j < P; ++j) MI355_ISSUE(j);
@@ -370,6 +373,11 @@ extern "C" int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream
     p.xq_stride = Kp + 16;
     p.eps = a->eps;
     p.threshold = a->threshold;
+    {
+        const size_t wb = mi355_packed_bytes(MI355_W_I8, a->N, a->K, a->R, swiglu ? 1 : 0);
+        MI355_CHECK_ARG(wb > 0 && wb < 0xFFFFFFF0ull, MI355_E_SHAPE, "linear_int8: weight stream of %zu B exceeds 4 GiB", wb);
+        p.w_bytes = (unsigned)wb;
+    }
 
     int waves = a->waves > 0 ? a->waves : 8;
     if (waves > 8) waves = 8;
