@@ -114,6 +114,13 @@ typedef struct mi355_linear_args {
     int32_t grid;       /* workgroups (persistent loop over tiles) */
     int32_t prefetch;   /* ring depth variant (4 or 8) */
     int32_t flags;      /* bit0: non-temporal weight loads off */
+    /* activations given as split-attention partial records instead of x (x may be NULL): the prologue combines
+     * them (K = attn_heads * attn_hs); layout as written by mi355_attention with n_split = attn_splits */
+    const float* attn_partials;
+    int32_t attn_splits;
+    int32_t attn_heads;
+    int32_t attn_hs;
+    int32_t reserved1;
 } mi355_linear_args;
 
 int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stream);
@@ -197,10 +204,18 @@ typedef struct mi355_attn_args {
     void* kv_tmp;       /* when cache == NULL: scratch [2, B, n_head, T, hs] of cache_dtype */
     int32_t rope_gathered; /* != 0: `rope` holds the T rows already selected (rope_cache.index_select(0, input_pos),
                               lit_llama/model.py:94), row t is used for token t instead of row pos[t] */
-    int32_t reserved0;
+    int32_t n_split;    /* > 1: flash-decoding, n_split workgroups per head write un-normalised partial records
+                           [B*T][n_head][n_split][hs + 4] f32 = (max, sum, 0, 0, o[hs]) to `partials` and y is NOT
+                           written: combine with mi355_attn_combine or let the following mi355_linear_fast do it
+                           (attn_partials); 0 / 1: single workgroup per head writes y */
+    float* partials;
 } mi355_attn_args;
 
 int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream);
+
+/* y[r, h*hs + d] from the partial records of a split attention (rows = B*T) */
+int mi355_attn_combine(const float* partials, int n_split, int rows, int n_head, int hs, void* y, int y_dtype,
+                       int64_t ldy, mi355_stream_t stream);
 
 /* torch.roll(cache, -1, dims=2) of lit_llama/model.py:217-218, in place, for both caches */
 int mi355_kv_roll(void* kcache, void* vcache, int cache_dtype, int B, int n_head, int S, int hs,
@@ -298,6 +313,9 @@ typedef struct mi355_model {
     int32_t* pos;         /* [max_T] */
     int32_t* next_token;  /* [1] */
     int32_t* out_tokens;  /* [block_size + 1] generated ids, indexed by pos + 1, or NULL */
+    float* attn_part;     /* [n_head][attn_splits][hs + 4] partial records of the split decode attention, or NULL */
+    int32_t attn_splits;  /* > 1: T == 1 steps run the attention over attn_splits workgroups per head */
+    int32_t reserved0;
 } mi355_model;
 
 /* copy token ids / positions into the model's device slots (tiny kernel; arguments travel by value) */

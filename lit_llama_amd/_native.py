@@ -37,6 +37,8 @@ class LinearArgs(C.Structure):
         ("sz_dtype", c_int32), ("epi", c_int32), ("bias", c_void_p),
         ("y", c_void_p), ("y_dtype", c_int32), ("reserved0", c_int32), ("ldy", c_int64),
         ("waves", c_int32), ("grid", c_int32), ("prefetch", c_int32), ("flags", c_int32),
+        ("attn_partials", c_void_p), ("attn_splits", c_int32), ("attn_heads", c_int32), ("attn_hs", c_int32),
+        ("reserved1", c_int32),
     ]
 
 
@@ -46,7 +48,7 @@ class AttnArgs(C.Structure):
         ("rope", c_void_p), ("pos", c_void_p), ("kcache", c_void_p), ("vcache", c_void_p),
         ("cache_dtype", c_int32), ("T", c_int32), ("n_head", c_int32), ("hs", c_int32),
         ("S", c_int32), ("y_dtype", c_int32), ("y", c_void_p), ("ldy", c_int64),
-        ("kv_tmp", c_void_p), ("rope_gathered", c_int32), ("reserved0", c_int32),
+        ("kv_tmp", c_void_p), ("rope_gathered", c_int32), ("n_split", c_int32), ("partials", c_void_p),
     ]
 
 
@@ -89,6 +91,7 @@ class Model(C.Structure):
         ("x", c_void_p), ("qkv", c_void_p), ("att", c_void_p), ("hbuf", c_void_p),
         ("partial", c_void_p), ("logits", c_void_p),
         ("tokens", c_void_p), ("pos", c_void_p), ("next_token", c_void_p), ("out_tokens", c_void_p),
+        ("attn_part", c_void_p), ("attn_splits", c_int32), ("reserved0", c_int32),
     ]
 
 
@@ -118,6 +121,7 @@ PROTOTYPES = {
     "mi355_embedding": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mi355_argmax": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mi355_attention": (c_int, [C.POINTER(AttnArgs), c_void_p]),
+    "mi355_attn_combine": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "mi355_kv_roll": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mi355_int8_quant_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mi355_linear_int8": (c_int, [C.POINTER(Int8Args), c_void_p]),

@@ -28,6 +28,8 @@ struct AttnParams {
     int B, T, n_head, hs, S;
     int fused;  // 1: this kernel writes the (single) new K/V row itself
     int rope_gathered;  // rope row of token t is t (rows pre-selected by the caller), not pos[t]
+    int n_split;        // workgroups per head (flash-decoding); > 1 writes partial records to `part`
+    float* part;
     float scale;
 };
 
@@ -102,19 +104,27 @@ __global__ void rope_kv_write_kernel(const AttnParams p) {
         vc[d] = f32_to_ct<CT>(ld_as_f32(p.qkv, row + 2 * C + h * hs + d, p.qkv_dtype));
 }
 
-// Dynamic LDS: qs[hs] kcur[hs] vcur[hs] | per wave: m, l | opart[nw][hs]
+// Dynamic LDS: qs[hs] kcur[hs] vcur[hs] | per wave: m, l | scur | opart[nw][hs]
 //
-// Single pass, flash-decoding style inside one workgroup: every wave walks a strided subset of the cached
-// rows with the K row and the V row of each position loaded together (8 x 16-B loads in flight per lane), keeps a
-// running (max, sum, weighted V) per row group, merges the row groups with wavefront shuffles and the waves
-// through LDS once.  One barrier before and one after the stream — the previous three-phase version (scores ->
-// softmax -> PV, five barriers, two dependent sweeps over HBM/L2) spent ~12 us on a 150-row context.
+// Flash-decoding: grid (head, token, batch x n_split).  A head's cached rows are cut into n_split contiguous
+// chunks so that several CUs pull one head's K/V (one CU sustains only ~50-100 GB/s; 32 heads on 32 CUs left
+// 7/8 of the chip idle and cost ~12-16 us per layer).  Inside a workgroup every wave walks a strided subset
+// of its chunk with the K row and the V row of a position loaded together (16 x 16-B loads in flight per lane),
+// keeps a running (max, sum, weighted V) per row group, merges row groups with wavefront shuffles and waves
+// through LDS.  The first batch of K/V loads is issued BEFORE the q / RoPE prologue: they do not depend on it,
+// so the two memory round trips overlap.
+//   n_split == 1: the workgroup normalises and writes y.
+//   n_split  > 1: it writes its un-normalised partial (m, l, o[hs]) to `part`; the consumer combines them
+//                 (mi355_attn_combine, or the prologue of the following c_proj linear — see gemv.hip).
 template <typename CT>
 __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int VEC = Vec16<CT>::kN;
     constexpr float kNegBig = -1.0e30f;
-    const int h = blockIdx.x, t = blockIdx.y, b = blockIdx.z;
+    constexpr int U = 8;
+    const int h = blockIdx.x, t = blockIdx.y;
+    const int ns = p.n_split;
+    const int b = blockIdx.z / ns, sj = blockIdx.z % ns;
     const int hs = p.hs, half = hs >> 1, C = p.n_head * hs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
 
@@ -130,10 +140,36 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     const int slot = pos < p.S - 1 ? pos : p.S - 1;
     const int len = slot + 1;
     const int n_glob = p.fused ? slot : len;  // rows read from the cache in global memory
+    const int chunk = (n_glob + ns - 1) / ns;
+    const int s_begin = sj * chunk;
+    const int s_end = (s_begin + chunk < n_glob) ? s_begin + chunk : n_glob;
+    const bool own_cur = p.fused && sj == ns - 1;  // the split that folds in the new token
 
     const int64_t row = ((int64_t)b * p.T + t) * p.ld_qkv;
     const CT* kc = (const CT*)p.kcache + ((int64_t)b * p.n_head + h) * p.S * hs;
     const CT* vc = (const CT*)p.vcache + ((int64_t)b * p.n_head + h) * p.S * hs;
+
+    const int row_bytes = hs * (int)sizeof(CT);
+    const int n16 = row_bytes / 16;
+    const bool vec_ok = (row_bytes % 16 == 0) && (n16 <= 64) && ((n16 & (n16 - 1)) == 0);
+    const int LPR = vec_ok ? n16 : 64;  // lanes per row
+    const int rpw = 64 / LPR;           // rows per wave instruction
+    const int li = lane % LPR, lr = lane / LPR;
+    const int stride = nw * rpw;
+
+    // ---- first batch of K/V rows: in flight while q is prepared
+    u32x4 kr[U], vr[U];
+    if (vec_ok) {
+        const int s0 = s_begin + wave * rpw + lr;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = s0 + u * stride;
+            if (s < s_end) {
+                kr[u] = *(const u32x4*)((const char*)kc + (int64_t)s * row_bytes + li * 16);
+                vr[u] = *(const u32x4*)((const char*)vc + (int64_t)s * row_bytes + li * 16);
+            }
+        }
+    }
 
     // ---- q (and, fused, the new k / v row) through RoPE into LDS
     for (int pi = tid; pi < half; pi += blockDim.x) {
@@ -144,7 +180,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         rope_pair(p.rope, rrow, half, pi, a, bb, oa, ob);
         qs[2 * pi] = oa;
         qs[2 * pi + 1] = ob;
-        if (p.fused) {
+        if (own_cur) {
             const float ka = ld_as_f32(p.qkv, row + C + h * hs + 2 * pi, p.qkv_dtype);
             const float kb = ld_as_f32(p.qkv, row + C + h * hs + 2 * pi + 1, p.qkv_dtype);
             rope_pair(p.rope, rrow, half, pi, ka, kb, oa, ob);
@@ -156,7 +192,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
             kcur[2 * pi + 1] = ct_to_f32<CT>(cb);
         }
     }
-    if (p.fused) {
+    if (own_cur) {
         for (int d = tid; d < hs; d += blockDim.x) {
             const CT cv = f32_to_ct<CT>(ld_as_f32(p.qkv, row + 2 * C + h * hs + d, p.qkv_dtype));
             ((CT*)p.vcache)[(((int64_t)b * p.n_head + h) * p.S + slot) * hs + d] = cv;
@@ -165,38 +201,20 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     }
     __syncthreads();
 
-    const int row_bytes = hs * (int)sizeof(CT);
-    const int n16 = row_bytes / 16;
-    const bool vec_ok = (row_bytes % 16 == 0) && (n16 <= 64) && ((n16 & (n16 - 1)) == 0);
-
     if (vec_ok) {
-        const int LPR = n16;        // lanes per row
-        const int rpw = 64 / LPR;   // rows per wave instruction
-        const int li = lane % LPR, lr = lane / LPR;
         float qf[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) qf[j] = qs[li * VEC + j];
         float m_run = kNegBig, l_run = 0.f, of[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) of[j] = 0.f;
-        const int stride = nw * rpw;
-        constexpr int U = 8;  // 16 x 16-B loads in flight per lane: a 512-row context is one round trip
         // wave-uniform trip count: the shuffles below need every lane of a row group in the loop
-        for (int base = 0; base < n_glob; base += stride * U) {
+        for (int base = s_begin; base < s_end; base += stride * U) {
             const int s0 = base + wave * rpw + lr;
-            u32x4 kr[U], vr[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int s = s0 + u * stride;
-                if (s < n_glob) {
-                    kr[u] = *(const u32x4*)((const char*)kc + (int64_t)s * row_bytes + li * 16);
-                    vr[u] = *(const u32x4*)((const char*)vc + (int64_t)s * row_bytes + li * 16);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int s = s0 + u * stride;
-                const bool valid = s < n_glob;
+                const bool valid = s < s_end;
                 float dot = 0.f;
                 float vf[VEC];
                 if (valid) {
@@ -218,6 +236,16 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) of[j] = of[j] * corr + pr * vf[j];
                 m_run = m_new;
+            }
+            // next batch (only long contexts get here)
+            const int n0 = s0 + stride * U;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = n0 + u * stride;
+                if (s < s_end) {
+                    kr[u] = *(const u32x4*)((const char*)kc + (int64_t)s * row_bytes + li * 16);
+                    vr[u] = *(const u32x4*)((const char*)vc + (int64_t)s * row_bytes + li * 16);
+                }
             }
         }
         // merge the rpw row groups of the wave (lanes with equal li)
@@ -242,7 +270,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         // odd head sizes (tiny test models): one row per wave step, lanes stride the head dimension
         float m_run = kNegBig, l_run = 0.f;
         float oacc[4] = {0.f, 0.f, 0.f, 0.f};  // d = lane + 64 j, hs <= 256
-        for (int s = wave; s < n_glob; s += nw) {
+        for (int s = s_begin + wave; s < s_end; s += nw) {
             float dot = 0.f;
             for (int d = lane; d < hs; d += 64) dot += qs[d] * ct_to_f32<CT>(kc[(int64_t)s * hs + d]);
             dot = wave_sum(dot) * p.scale;
@@ -266,7 +294,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
             wl[wave] = l_run;
         }
     }
-    if (p.fused && wave == nw - 1) {
+    if (own_cur && wave == nw - 1) {
         float dot = 0.f;
         for (int d = lane; d < hs; d += 64) dot += qs[d] * kcur[d];
         dot = wave_sum(dot);
@@ -278,20 +306,54 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     float m_all = kNegBig;
     for (int w = 0; w < nw; ++w) m_all = fmaxf(m_all, wm[w]);
     float s_cur = kNegBig;
-    if (p.fused) {
+    if (own_cur) {
         s_cur = scur[0];
         m_all = fmaxf(m_all, s_cur);
     }
     float l_all = 0.f;
     for (int w = 0; w < nw; ++w) l_all += wl[w] * expf(wm[w] - m_all);
-    const float p_cur = p.fused ? expf(s_cur - m_all) : 0.f;
+    const float p_cur = own_cur ? expf(s_cur - m_all) : 0.f;
     l_all += p_cur;
-    const float inv = 1.0f / l_all;
-    for (int d = tid; d < hs; d += blockDim.x) {
+    if (ns == 1) {
+        const float inv = 1.0f / l_all;
+        for (int d = tid; d < hs; d += blockDim.x) {
+            float o = 0.f;
+            for (int w = 0; w < nw; ++w) o += opart[w * hs + d] * expf(wm[w] - m_all);
+            if (own_cur) o += p_cur * vcur[d];
+            st_from_f32(p.y, ((int64_t)b * p.T + t) * p.ldy + h * hs + d, p.y_dtype, o * inv);
+        }
+    } else {
+        // partial record: [m, l, 0, 0, o[hs]] (un-normalised), one per (token row, head, split)
+        float* rec = p.part + ((((int64_t)b * p.T + t) * p.n_head + h) * ns + sj) * (hs + 4);
+        if (tid == 0) {
+            rec[0] = m_all;
+            rec[1] = l_all;
+            rec[2] = 0.f;
+            rec[3] = 0.f;
+        }
+        for (int d = tid; d < hs; d += blockDim.x) {
+            float o = 0.f;
+            for (int w = 0; w < nw; ++w) o += opart[w * hs + d] * expf(wm[w] - m_all);
+            if (own_cur) o += p_cur * vcur[d];
+            rec[4 + d] = o;
+        }
+    }
+}
+
+// y[row, h*hs + d] = sum_j e^{m_j - M} o_j[d] / sum_j e^{m_j - M} l_j  over the n_split partial records
+__global__ void attn_combine_kernel(const float* part, int n_split, int n_head, int hs, void* y, int y_dtype,
+                                    int64_t ldy) {
+    const int r = blockIdx.y, h = blockIdx.x;
+    const float* rec = part + (((int64_t)r * n_head + h) * n_split) * (hs + 4);
+    float M = -1.0e30f;
+    for (int j = 0; j < n_split; ++j) M = fmaxf(M, rec[j * (hs + 4)]);
+    float L = 0.f;
+    for (int j = 0; j < n_split; ++j) L += rec[j * (hs + 4) + 1] * expf(rec[j * (hs + 4)] - M);
+    const float inv = 1.0f / L;
+    for (int d = threadIdx.x; d < hs; d += blockDim.x) {
         float o = 0.f;
-        for (int w = 0; w < nw; ++w) o += opart[w * hs + d] * expf(wm[w] - m_all);
-        if (p.fused) o += p_cur * vcur[d];
-        st_from_f32(p.y, ((int64_t)b * p.T + t) * p.ldy + h * hs + d, p.y_dtype, o * inv);
+        for (int j = 0; j < n_split; ++j) o += rec[j * (hs + 4) + 4 + d] * expf(rec[j * (hs + 4)] - M);
+        st_from_f32(y, (int64_t)r * ldy + h * hs + d, y_dtype, o * inv);
     }
 }
 
@@ -357,7 +419,12 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
             hipLaunchKernelGGL(rope_kv_write_kernel<bf16_t>, grid, dim3(thr), 0, s, p);
         MI355_LAUNCH_CHECK();
     }
-    const int threads = 512, nw = threads / 64;
+    int ns = a->n_split > 1 ? a->n_split : 1;
+    MI355_CHECK_ARG(ns == 1 || a->partials != nullptr, MI355_E_ARG, "attention: n_split > 1 needs a partials buffer");
+    MI355_CHECK_ARG(ns <= 64 && (int64_t)a->B * ns <= 65535, MI355_E_SHAPE, "attention: n_split too large");
+    p.n_split = ns;
+    p.part = (float*)a->partials;
+    const int threads = ns > 1 ? 256 : 512, nw = threads / 64;
     const size_t lds = (size_t)(3 * a->hs + 2 * nw + 4 + nw * a->hs) * sizeof(float) + 16;
     MI355_CHECK_ARG(a->hs <= 256 || (a->hs * esz) % 16 == 0, MI355_E_SHAPE, "attention: head size %d unsupported", a->hs);
     MI355_CHECK_ARG(lds <= 160 * 1024, MI355_E_SHAPE, "attention: hs=%d needs %zu B of LDS", a->hs, lds);
@@ -369,10 +436,22 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
                                       160 * 1024));
         attr_done = true;
     }
+    const dim3 agrid(a->n_head, a->T, a->B * ns);
     if (esz == 4)
-        hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(threads), lds, s, p);
+        hipLaunchKernelGGL(attn_kernel<float>, agrid, dim3(threads), lds, s, p);
     else
-        hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, dim3(threads), lds, s, p);
+        hipLaunchKernelGGL(attn_kernel<bf16_t>, agrid, dim3(threads), lds, s, p);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi355_attn_combine(const float* partials, int n_split, int rows, int n_head, int hs, void* y,
+                                  int y_dtype, int64_t ldy, mi355_stream_t stream) {
+    MI355_CHECK_ARG(partials && y, MI355_E_ARG, "attn_combine: null pointer");
+    MI355_CHECK_ARG(n_split >= 1 && rows >= 1 && rows <= 65535 && n_head >= 1 && hs >= 1, MI355_E_SHAPE,
+                    "attn_combine: bad shape");
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(n_head, rows), dim3(hs >= 128 ? 128 : 64), 0, (hipStream_t)stream,
+                       partials, n_split, n_head, hs, y, y_dtype, ldy);
     MI355_LAUNCH_CHECK();
     return 0;
 }

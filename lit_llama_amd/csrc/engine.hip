@@ -36,7 +36,8 @@ __global__ void add_f32_kernel(float* x, const float* p, int n) {
 }
 
 int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x_dtype, int M, int64_t ldx,
-               const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy, hipStream_t s) {
+               const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy, hipStream_t s,
+               const float* attn_partials = nullptr) {
     if (w.fmt == MI355_W_I8) {
         return mi355_linear_int8_from_weight(&w, m, x, x_dtype, M, ldx, norm_scale, epi, y, y_dtype, ldy, s);
     }
@@ -68,6 +69,12 @@ int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x
     a.grid = w.grid;
     a.prefetch = w.prefetch;
     a.flags = 0;
+    if (attn_partials != nullptr) {
+        a.attn_partials = attn_partials;
+        a.attn_splits = m->attn_splits;
+        a.attn_heads = m->n_head;
+        a.attn_hs = m->hs;
+    }
     return mi355_linear_fast(&a, s);
 }
 
@@ -121,6 +128,8 @@ extern "C" int mi355_forward_segment(const mi355_model* m, int T, int layer, int
     const int C = m->n_embd;
     const int Cl = m->n_head * m->hs;  // local attention width (== C unless tensor parallel)
     const bool tp = m->tp_world > 1;
+    // decode steps spread each head's K/V over attn_splits workgroups; the c_proj prologue combines the partials
+    const bool split = T == 1 && m->attn_splits > 1 && m->attn_part != nullptr && L.proj.fmt != MI355_W_I8;
     for (int seg = seg_begin; seg < seg_end; ++seg) {
         switch (seg) {
             case 0: {
@@ -145,12 +154,17 @@ extern "C" int mi355_forward_segment(const mi355_model* m, int T, int layer, int
                 a.y_dtype = MI355_BF16;
                 a.y = m->att;
                 a.ldy = Cl;
+                if (split) {
+                    a.n_split = m->attn_splits;
+                    a.partials = m->attn_part;
+                }
                 if (int rc = mi355_attention(&a, s)) return rc;
                 break;
             }
             case 1:
                 if (int rc = run_linear(m, L.proj, m->att, MI355_BF16, T, Cl, nullptr,
-                                        tp ? MI355_EPI_STORE : MI355_EPI_ACCUM, tp ? m->partial : m->x, MI355_F32, C, s))
+                                        tp ? MI355_EPI_STORE : MI355_EPI_ACCUM, tp ? m->partial : m->x, MI355_F32, C, s,
+                                        split ? m->attn_part : nullptr))
                     return rc;
                 break;
             case 2:

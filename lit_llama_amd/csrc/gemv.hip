@@ -48,6 +48,8 @@ struct GemvParams {
     int xs_stride;  // bytes per LDS activation row
     int vec_mode;   // 0 scalar staging, 1 f32 + bf16-scale RMSNorm vectorised, 2 bf16 copy vectorised
     unsigned w_bytes;  // size of the weight stream (buffer descriptor bound)
+    const float* attn_part;  // vec_mode 3: activations = combine of split-attention partial records
+    int attn_splits, attn_heads, attn_hs;
     float eps;
 };
 
@@ -93,10 +95,68 @@ __device__ __forceinline__ u32x4 ldw(const uint8_t* p) {
 //   2: x bf16, no norm, K % 8 == 0 — 16-B copies straight into LDS.
 // A per-element loop with a dependent load per iteration (the first version) cost ~5 us per launch, more than
 // streaming the weights of a 4096 x 4096 int4 matrix.
+template <bool kAttnCombine>
 __device__ __forceinline__ void stage_x(const GemvParams& p, char* xs, float* sx, float* red) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int Kp = p.units * kUnitK;
     const bool norm = p.norm_scale != nullptr;
+    if constexpr (kAttnCombine) {
+        if (p.vec_mode == 3) {
+            // x[m, h*hs + d] = sum_j e^{m_j - M} o_j[d] / sum_j e^{m_j - M} l_j over the n_split partial records the
+            // split attention kernel left behind (attention.hip): the flash-decoding combine costs no launch.
+            const int hs = p.attn_hs, ns = p.attn_splits, rs = hs + 4;
+            const int nvec = p.K >> 3;
+            for (int m = 0; m < p.M; ++m) {
+                float s = 0.f;
+                for (int v = tid; v < nvec; v += nt) {
+                    const int k0 = v * 8, h = k0 / hs, d0 = k0 - h * hs;
+                    const float* rec = p.attn_part + ((int64_t)m * p.attn_heads + h) * ns * rs;
+                    float M_ = -1.0e30f, L = 0.f;
+                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (int j0 = 0; j0 < ns; j0 += 4) {
+                        float mj[4], lj[4];
+                        f32x4 oa[4], ob[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j0 + j < ns) {
+                                const float* r = rec + (j0 + j) * rs;
+                                mj[j] = r[0];
+                                lj[j] = r[1];
+                                oa[j] = *(const f32x4*)(r + 4 + d0);
+                                ob[j] = *(const f32x4*)(r + 8 + d0);
+                            }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j0 + j < ns) {
+                                const float Mn = fmaxf(M_, mj[j]);
+                                const float c_old = expf(M_ - Mn), c_new = expf(mj[j] - Mn);
+                                L = L * c_old + lj[j] * c_new;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    acc[i] = acc[i] * c_old + oa[j][i] * c_new;
+                                    acc[4 + i] = acc[4 + i] * c_old + ob[j][i] * c_new;
+                                }
+                                M_ = Mn;
+                            }
+                    }
+                    const float inv = 1.0f / L;
+                    u32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bf16_t a = f32_to_bf16(acc[2 * i] * inv), b = f32_to_bf16(acc[2 * i + 1] * inv);
+                        s += bf16_to_f32(a) + bf16_to_f32(b);
+                        o[i] = (uint32_t)a | ((uint32_t)b << 16);
+                    }
+                    *(u32x4*)(xs + (size_t)m * p.xs_stride + v * 16) = o;
+                }
+                for (int k = p.K + tid; k < Kp; k += nt) ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;
+                s = block_sum(s, red);
+                if (tid == 0) sx[m] = s;
+            }
+            __syncthreads();
+            return;
+        }
+    }
     if (p.vec_mode == 1) {
         const int nvec = p.K >> 3;
         for (int m = 0; m < p.M; ++m) {
@@ -343,7 +403,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     for (int r = 0; r < R; ++r) eo.s[r] = eo.z[r] = eo.bias[r] = eo.old[r] = 0u;
     load_epi<FMT, R, EPI>(p, bid, e_row, e_col, e_owner, eo);
 
-    stage_x(p, xs, sx, red);
+    stage_x<EPI != MI355_EPI_SWIGLU>(p, xs, sx, red);
 
     f32x4 acc[R];
 #pragma unroll
@@ -679,7 +739,12 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     MI355_CHECK_ARG(a->fmt == MI355_W_Q4 || a->fmt == MI355_W_BF16, MI355_E_ARG,
                     "linear_fast: fmt %d not handled here (int8 goes through mi355_linear_int8)", a->fmt);
     MI355_CHECK_ARG(a->R == 1 || a->R == 2, MI355_E_ARG, "linear_fast: R must be 1 or 2");
-    MI355_CHECK_ARG(a->w && a->x && a->y, MI355_E_ARG, "linear_fast: null w/x/y");
+    MI355_CHECK_ARG(a->w && (a->x || a->attn_partials) && a->y, MI355_E_ARG, "linear_fast: null w/x/y");
+    if (a->attn_partials != nullptr) {
+        MI355_CHECK_ARG(a->attn_splits >= 1 && a->attn_heads >= 1 && a->attn_hs % 8 == 0 && a->norm_scale == nullptr &&
+                            a->K == a->attn_heads * a->attn_hs && a->epi != MI355_EPI_SWIGLU,
+                        MI355_E_ARG, "linear_fast: bad split-attention activation spec");
+    }
     MI355_CHECK_ARG(a->M >= 1 && a->M <= kMaxM, MI355_E_SHAPE, "linear_fast: M=%d outside 1..%d", a->M, kMaxM);
     MI355_CHECK_ARG(a->K > 0 && a->N > 0, MI355_E_SHAPE, "linear_fast: N=%d K=%d must be positive", a->N, a->K);
     const bool swiglu = a->epi == MI355_EPI_SWIGLU;
@@ -696,7 +761,7 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
                     "linear_fast: norm scale dtype must be f32 or bf16");
     MI355_CHECK_ARG(a->fmt != MI355_W_Q4 || two(a->sz_dtype), MI355_E_DTYPE,
                     "linear_fast: scales/zeros dtype must be f32 or bf16");
-    MI355_CHECK_ARG(a->ldx >= a->K || a->M == 1, MI355_E_SHAPE, "linear_fast: ldx < K");
+    MI355_CHECK_ARG(a->ldx >= a->K || a->M == 1 || a->attn_partials, MI355_E_SHAPE, "linear_fast: ldx < K");
 
     GemvParams p;
     p.w = (const uint8_t*)a->w;
@@ -727,13 +792,18 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     if (waves < 4) waves = 4;  // the combine step needs 256 owner threads
     {
         const int esz = a->x_dtype == MI355_F32 ? 4 : 2;
-        const bool aligned = ((uintptr_t)a->x % 16 == 0) && ((a->ldx * esz) % 16 == 0 || a->M == 1) && a->K % 8 == 0;
+        const bool aligned = a->x != nullptr && ((uintptr_t)a->x % 16 == 0) && ((a->ldx * esz) % 16 == 0 || a->M == 1) && a->K % 8 == 0;
         p.vec_mode = 0;
         if (aligned && a->norm_scale != nullptr && a->x_dtype == MI355_F32 && a->norm_dtype == MI355_BF16 &&
             (uintptr_t)a->norm_scale % 16 == 0 && a->K / 8 <= 2 * waves * 64)
             p.vec_mode = 1;
         else if (aligned && a->norm_scale == nullptr && a->x_dtype == MI355_BF16)
             p.vec_mode = 2;
+        if (a->attn_partials != nullptr) p.vec_mode = 3;
+        p.attn_part = a->attn_partials;
+        p.attn_splits = a->attn_splits;
+        p.attn_heads = a->attn_heads;
+        p.attn_hs = a->attn_hs;
     }
     {
         const size_t wb = mi355_packed_bytes(a->fmt, a->N, a->K, a->R, swiglu ? 1 : 0);

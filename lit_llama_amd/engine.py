@@ -177,6 +177,8 @@ class DecodeEngine:
             self.pos = torch.zeros((max_T,), dtype=torch.int32, device=dev)
             self.next_token = torch.zeros((1,), dtype=torch.int32, device=dev)
             self.out_tokens = torch.zeros((cfg.block_size + 1,), dtype=torch.int32, device=dev)
+            self.attn_splits = max(1, int(self.tune.get("attn_splits", _env_int("MI355_ATTN_SPLITS", 4))))
+            self.attn_part = torch.zeros((local_heads, self.attn_splits, hs + 4), dtype=torch.float32, device=dev)
             if model.rope_cache is None or model.rope_cache.dtype != torch.float32:
                 from .model import build_rope_cache
 
@@ -200,6 +202,7 @@ class DecodeEngine:
         m.partial, m.logits = ptr(self.partial), ptr(self.logits)
         m.tokens, m.pos, m.next_token = ptr(self.tokens), ptr(self.pos), ptr(self.next_token)
         m.out_tokens = ptr(self.out_tokens)
+        m.attn_part, m.attn_splits = ptr(self.attn_part), self.attn_splits
         self.m = m
         self.S = 0
         self._cache_pool = {}  # S -> list of (k, v): kept across reset_cache() so captured graphs stay valid

@@ -98,8 +98,11 @@ def linear_fast(
     grid: int = 0,
     prefetch: int = 0,
     flags: int = 0,
+    attn_partials: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
-    """y[M, N] = epi(x2d[M, K] . W^T) through the MFMA weight-streaming kernel; M is chunked to fit LDS."""
+    """y[M, N] = epi(x2d[M, K] . W^T) through the MFMA weight-streaming kernel; M is chunked to fit LDS.
+    With `attn_partials` ([M, heads, splits, hs + 4] f32 records of a split attention) the activations are the
+    combined attention output and x2d only provides M / dtype / device (it is not read)."""
     require_gpu(x2d, "linear_fast")
     assert x2d.dim() == 2 and x2d.shape[1] == K and x2d.stride(1) == 1
     M = x2d.shape[0]
@@ -126,10 +129,16 @@ def linear_fast(
         raise nat.NativeError(f"linear_fast: K={K} does not fit LDS even for M=1")
     s = stream_ptr()
     esz_x, esz_y = x2d.element_size(), out.element_size()
+    if attn_partials is not None:
+        assert attn_partials.dtype == torch.float32 and attn_partials.is_contiguous() and attn_partials.shape[0] == M
+        _, a.attn_heads, a.attn_splits, rec = attn_partials.shape
+        a.attn_hs = rec - 4
     for m0 in range(0, M, step):
         a.M = min(step, M - m0)
         a.x = x2d.data_ptr() + m0 * x2d.stride(0) * esz_x
         a.y = out.data_ptr() + m0 * out.stride(0) * esz_y
+        if attn_partials is not None:
+            a.attn_partials = attn_partials.data_ptr() + m0 * attn_partials.stride(0) * 4
         check(lib().mi355_linear_fast(C.byref(a), s), "mi355_linear_fast")
     return out
 
@@ -323,8 +332,12 @@ def attention(
     kv_cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
     rope_gathered: bool = False,
     out_dtype: Optional[torch.dtype] = None,
+    n_split: int = 1,
+    return_partials: bool = False,
 ) -> torch.Tensor:
-    """qkv [B, T, 3C] -> y [B, T, C]; RoPE + (in-place) cache write + causal attention."""
+    """qkv [B, T, 3C] -> y [B, T, C]; RoPE + (in-place) cache write + causal attention.  n_split > 1 spreads each
+    head over n_split workgroups (flash-decoding) and combines the partial records with mi355_attn_combine, or
+    returns them ([B*T, heads, n_split, hs + 4]) for a consumer that combines on the fly."""
     require_gpu(qkv, "attention")
     B, T, C3 = qkv.shape
     Cw = C3 // 3
@@ -352,7 +365,16 @@ def attention(
         tmp = torch.empty((2, B, n_head, T, hs), dtype=cdt, device=qkv.device)
         keep.append(tmp)
         a.kv_tmp, a.cache_dtype, a.S = ptr(tmp), dtype_code(cdt), T
+    parts = None
+    if n_split > 1:
+        parts = torch.empty((B * T, n_head, n_split, hs + 4), dtype=torch.float32, device=qkv.device)
+        a.n_split, a.partials = n_split, ptr(parts)
     check(lib().mi355_attention(C.byref(a), stream_ptr()), "mi355_attention")
+    if parts is not None:
+        if return_partials:
+            return parts
+        check(lib().mi355_attn_combine(ptr(parts), n_split, B * T, n_head, hs, ptr(y), dtype_code(y.dtype), Cw,
+                                       stream_ptr()), "mi355_attn_combine")
     return y
 
 

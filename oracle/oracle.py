@@ -117,7 +117,8 @@ def int8_quant_rows(w: torch.Tensor):
     SCB[n] = max_k |W[n,k]| (f16 values, f32 statistic), CB = rint(W * (127 / SCB))."""
     wh = w.half().float()
     scb = wh.abs().amax(dim=1)
-    inv = torch.where(scb > 0, 127.0 / scb, torch.zeros_like(scb))
+    # IEEE division (a Python float divided by a tensor would be reciprocal-then-multiply: two roundings)
+    inv = torch.where(scb > 0, torch.full_like(scb, 127.0) / scb, torch.zeros_like(scb))
     cb = torch.round(wh * inv[:, None]).to(torch.int8)  # torch.round = round half to even = rintf
     return cb, scb
 
@@ -135,7 +136,7 @@ def llm_int8_linear(x: torch.Tensor, cb: torch.Tensor, scb: torch.Tensor, bias=N
         outlier_cols = torch.zeros(xh.shape[1], dtype=torch.bool)
         stat = absx
     sca = stat.amax(dim=1)  # row absmax over sub-threshold entries
-    inv = torch.where(sca > 0, 127.0 / sca, torch.zeros_like(sca))
+    inv = torch.where(sca > 0, torch.full_like(sca, 127.0) / sca, torch.zeros_like(sca))
     ca = torch.round(xh * inv[:, None])
     ca[:, outlier_cols] = 0  # CA[:, idx] = 0
     acc = (ca.to(torch.float64) @ cb.to(torch.float64).t()).to(torch.int64)  # exact int32 accumulation
@@ -145,7 +146,8 @@ def llm_int8_linear(x: torch.Tensor, cb: torch.Tensor, scb: torch.Tensor, bias=N
     out = out.half().float()
     if bool(outlier_cols.any()):
         sub_a = xh[:, outlier_cols]  # fp16 values
-        sub_b = ((cb[:, outlier_cols].float() * scb[:, None]) / 127.0).half().float()  # [N, n_out]
+        sub_b = (cb[:, outlier_cols].float() * scb[:, None])
+        sub_b = (sub_b / torch.full_like(sub_b, 127.0)).half().float()  # [N, n_out]
         mm = (sub_a @ sub_b.t()).half().float()  # fp16 GEMM, fp32 accumulate, rounded once
         out = (out + mm).half().float()
     return out.to(x.dtype).reshape(*shape[:-1], cb.shape[0])

@@ -42,6 +42,9 @@ for st in $STAGES; do
     sweep)
       timeout 1200 python scripts/sweep_gemv.py --out $OUT/sweep_best.json > $OUT/sweep.log 2>&1
       echo "sweep exit $?" | tee -a $OUT/session.log; grep BEST $OUT/sweep.log ;;
+    sweepres)
+      timeout 600 python scripts/sweep_gemv.py --quick --bufs 1 > $OUT/sweep_resident.log 2>&1
+      echo "sweep(resident) exit $?" | tee -a $OUT/session.log; grep BEST $OUT/sweep_resident.log ;;
     sweepq)
       timeout 600 python scripts/sweep_gemv.py --quick --out $OUT/sweep_best.json > $OUT/sweep.log 2>&1
       echo "sweep exit $?" | tee -a $OUT/session.log; grep BEST $OUT/sweep.log ;;

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--shapes", default="attn,proj,fc,mproj,lm_head")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--bufs", type=int, default=0, help="distinct weight buffers in rotation (0: enough to defeat "
+                    "the 256 MiB Infinity Cache; 1: one buffer, i.e. cache-resident weights)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev).manual_seed(0)
@@ -40,7 +42,7 @@ def main():
         N, K, R, epi = SHAPES_7B[name]
         pair = epi == nat.EPI_SWIGLU
         nbytes = ops.packed_bytes(nat.W_Q4, N, K, R, pair)
-        n_buf = max(2, int(600e6 // nbytes) + 1)  # > 2x the Infinity Cache in rotation
+        n_buf = args.bufs if args.bufs > 0 else max(2, int(600e6 // nbytes) + 1)  # > 2x the Infinity Cache
         streams = [torch.randint(0, 256, (nbytes,), generator=gen, device=dev, dtype=torch.uint8) for _ in range(n_buf)]
         sc = (0.005 + 0.005 * torch.rand(N, generator=gen, device=dev)).to(torch.bfloat16)
         ze = torch.full((N,), 8.0, device=dev, dtype=torch.bfloat16)
@@ -69,7 +71,7 @@ def main():
             a.waves, a.grid, a.prefetch, a.flags = waves, grid, pf, flags
             return a
 
-        reps = 4
+        reps = 4 if args.bufs == 0 else max(4, 64 // n_buf)
         for waves, grid, pf, flags in itertools.product(waves_l, grids, pf_l, nt_l):
             arr = (nat.LinearArgs * (reps * n_buf))()
             for i in range(reps * n_buf):
