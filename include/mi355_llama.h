@@ -121,6 +121,9 @@ typedef struct mi355_linear_args {
     int32_t attn_heads;
     int32_t attn_hs;
     int32_t reserved1;
+    /* optional profiling aid: uint64 [grid][8] wall-clock stamps (100 MHz) written by wave 0 of every workgroup:
+     * 0 entry, 1 ring issued, 2 activations staged, 3 first tile's loop done, 4 first epilogue done, 5 exit */
+    uint64_t* debug_stamps;
 } mi355_linear_args;
 
 int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stream);

@@ -38,7 +38,7 @@ class LinearArgs(C.Structure):
         ("y", c_void_p), ("y_dtype", c_int32), ("reserved0", c_int32), ("ldy", c_int64),
         ("waves", c_int32), ("grid", c_int32), ("prefetch", c_int32), ("flags", c_int32),
         ("attn_partials", c_void_p), ("attn_splits", c_int32), ("attn_heads", c_int32), ("attn_hs", c_int32),
-        ("reserved1", c_int32),
+        ("reserved1", c_int32), ("debug_stamps", c_void_p),
     ]
 
 

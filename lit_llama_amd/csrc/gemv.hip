@@ -50,6 +50,7 @@ struct GemvParams {
     unsigned w_bytes;  // size of the weight stream (buffer descriptor bound)
     const float* attn_part;  // vec_mode 3: activations = combine of split-attention partial records
     int attn_splits, attn_heads, attn_hs;
+    unsigned long long* dbg;  // optional wall-clock stamps [grid][8]
     float eps;
 };
 
@@ -358,6 +359,11 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = blockDim.x >> 6;
     char* xs = part + 2 * W * R * 1024;
+#define MI355_STAMP(i)                                                                   \
+    do {                                                                                 \
+        if (p.dbg != nullptr && threadIdx.x == 0) p.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+    MI355_STAMP(0);
 
     const int units = p.units;
     const int u0 = (units * wave) / W, u1 = (units * (wave + 1)) / W;
@@ -394,6 +400,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
 
 #pragma unroll
     for (int j = 0; j < P; ++j) MI355_ISSUE(j);
+    MI355_STAMP(1);
 
     // ---- per-tile epilogue operands, fetched one tile ahead (threads < 256 own output (row, col))
     const int e_row = (threadIdx.x >> 4) & 15, e_col = threadIdx.x & 15;
@@ -404,6 +411,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     load_epi<FMT, R, EPI>(p, bid, e_row, e_col, e_owner, eo);
 
     stage_x<EPI != MI355_EPI_SWIGLU>(p, xs, sx, red);
+    MI355_STAMP(2);
 
     f32x4 acc[R];
 #pragma unroll
@@ -472,8 +480,10 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
                         pp[r * 64] = acc[r];
                         acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
+                    if (tile == bid) MI355_STAMP(3);
                     __syncthreads();
                     if (e_owner) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, sx);
+                    if (tile == bid) MI355_STAMP(4);
                     tile += nb;
                     buf ^= 1;
                     load_epi<FMT, R, EPI>(p, tile, e_row, e_col, e_owner, eo);
@@ -482,7 +492,9 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
             MI355_ISSUE(j);  // refill the slot just consumed (dummy source once the work is exhausted)
         }
     }
+    MI355_STAMP(5);
 #undef MI355_ISSUE
+#undef MI355_STAMP
 }
 
 // ------------------------------------------------------------------------------------ repack kernels
@@ -804,6 +816,7 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
         p.attn_splits = a->attn_splits;
         p.attn_heads = a->attn_heads;
         p.attn_hs = a->attn_hs;
+        p.dbg = (unsigned long long*)a->debug_stamps;
     }
     {
         const size_t wb = mi355_packed_bytes(a->fmt, a->N, a->K, a->R, swiglu ? 1 : 0);
