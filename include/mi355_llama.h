@@ -113,7 +113,7 @@ typedef struct mi355_linear_args {
     int32_t waves;      /* waves per workgroup (split of K) */
     int32_t grid;       /* workgroups (persistent loop over tiles) */
     int32_t prefetch;   /* ring depth variant (4 or 8) */
-    int32_t flags;      /* bit0: non-temporal weight loads off */
+    int32_t flags;      /* reserved (0) */
     /* activations given as split-attention partial records instead of x (x may be NULL): the prologue combines
      * them (K = attn_heads * attn_hs); layout as written by mi355_attention with n_split = attn_splits */
     const float* attn_partials;

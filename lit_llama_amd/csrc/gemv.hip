@@ -29,7 +29,7 @@ namespace {
 
 constexpr int kUnitK = 128;        // input columns per stream unit
 constexpr int kMaxM = 16;
-constexpr int kLdsHeader = 512;    // red[64] + sx[16] floats (+pad)
+constexpr int kLdsHeader = 1024;   // wss[8][16] floats (+pad)
 constexpr int kMaxLds = 160 * 1024;
 
 struct GemvParams {
@@ -86,186 +86,163 @@ __device__ __forceinline__ u32x4 ldw(const uint8_t* p) {
         return *(const u32x4*)p;
 }
 
-// Stage activations into LDS as bf16 (optionally RMSNorm'ed), and the per-row sums needed to undo
-// the +128 / zero-point offsets.  lit_llama/model.py:270-277 for the norm arithmetic.
-// Columns K..units*128 are zero-filled (the stream pads K up to a whole unit).
-//
-// Two vectorised paths cover the decode step (p.vec_mode, chosen on the host):
-//   1: x f32 + RMSNorm with a bf16 scale, K % 8 == 0, at most 2 x 8 elements per thread — the row is loaded
-//      once (16-B loads, all issued up front), kept in registers across the reduction, normalised, stored;
-//   2: x bf16, no norm, K % 8 == 0 — 16-B copies straight into LDS.
-// A per-element loop with a dependent load per iteration (the first version) cost ~5 us per launch, more than
-// streaming the weights of a 4096 x 4096 int4 matrix.
-template <bool kAttnCombine>
-__device__ __forceinline__ void stage_x(const GemvParams& p, char* xs, float* sx, float* red) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int Kp = p.units * kUnitK;
-    const bool norm = p.norm_scale != nullptr;
-    if constexpr (kAttnCombine) {
-        if (p.vec_mode == 3) {
-            // x[m, h*hs + d] = sum_j e^{m_j - M} o_j[d] / sum_j e^{m_j - M} l_j over the n_split partial records the
-            // split attention kernel left behind (attention.hip): the flash-decoding combine costs no launch.
-            const int hs = p.attn_hs, ns = p.attn_splits, rs = hs + 4;
-            const int nvec = p.K >> 3;
-            for (int m = 0; m < p.M; ++m) {
-                float s = 0.f;
-                for (int v = tid; v < nvec; v += nt) {
-                    const int k0 = v * 8, h = k0 / hs, d0 = k0 - h * hs;
-                    const float* rec = p.attn_part + ((int64_t)m * p.attn_heads + h) * ns * rs;
-                    float M_ = -1.0e30f, L = 0.f;
-                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    for (int j0 = 0; j0 < ns; j0 += 4) {
-                        float mj[4], lj[4];
-                        f32x4 oa[4], ob[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j0 + j < ns) {
-                                const float* r = rec + (j0 + j) * rs;
-                                mj[j] = r[0];
-                                lj[j] = r[1];
-                                oa[j] = *(const f32x4*)(r + 4 + d0);
-                                ob[j] = *(const f32x4*)(r + 8 + d0);
-                            }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j0 + j < ns) {
-                                const float Mn = fmaxf(M_, mj[j]);
-                                const float c_old = expf(M_ - Mn), c_new = expf(mj[j] - Mn);
-                                L = L * c_old + lj[j] * c_new;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    acc[i] = acc[i] * c_old + oa[j][i] * c_new;
-                                    acc[4 + i] = acc[4 + i] * c_old + ob[j][i] * c_new;
-                                }
-                                M_ = Mn;
-                            }
-                    }
-                    const float inv = 1.0f / L;
-                    u32x4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const bf16_t a = f32_to_bf16(acc[2 * i] * inv), b = f32_to_bf16(acc[2 * i + 1] * inv);
-                        s += bf16_to_f32(a) + bf16_to_f32(b);
-                        o[i] = (uint32_t)a | ((uint32_t)b << 16);
-                    }
-                    *(u32x4*)(xs + (size_t)m * p.xs_stride + v * 16) = o;
-                }
-                for (int k = p.K + tid; k < Kp; k += nt) ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;
-                s = block_sum(s, red);
-                if (tid == 0) sx[m] = s;
-            }
-            __syncthreads();
-            return;
-        }
-    }
-    if (p.vec_mode == 1) {
-        const int nvec = p.K >> 3;
-        for (int m = 0; m < p.M; ++m) {
-            const float* xrow = (const float*)p.x + (int64_t)m * p.ldx;
-            f32x4 xa[2], xb[2];
-            u32x4 ns[2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int v = tid + c * nt;
-                if (v < nvec) {
-                    xa[c] = *(const f32x4*)(xrow + v * 8);
-                    xb[c] = *(const f32x4*)(xrow + v * 8 + 4);
-                    ns[c] = *(const u32x4*)((const bf16_t*)p.norm_scale + v * 8);
-                }
-            }
-            float ss = 0.f;
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-                if (tid + c * nt < nvec) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) ss += xa[c][i] * xa[c][i] + xb[c][i] * xb[c][i];
-                }
-            ss = block_sum(ss, red);
-            const float rinv = rsqrtf(ss / (float)p.K + p.eps);
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int v = tid + c * nt;
-                if (v < nvec) {
-                    u32x4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float x0 = i < 2 ? xa[c][2 * i] : xb[c][2 * i - 4];
-                        const float x1 = i < 2 ? xa[c][2 * i + 1] : xb[c][2 * i - 3];
-                        const bf16_t a = f32_to_bf16(__uint_as_float(ns[c][i] << 16) * (x0 * rinv));
-                        const bf16_t b = f32_to_bf16(__uint_as_float(ns[c][i] & 0xffff0000u) * (x1 * rinv));
-                        s += bf16_to_f32(a) + bf16_to_f32(b);
-                        o[i] = (uint32_t)a | ((uint32_t)b << 16);
-                    }
-                    *(u32x4*)(xs + (size_t)m * p.xs_stride + v * 16) = o;
-                }
-            }
-            for (int k = p.K + tid; k < Kp; k += nt) ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;
-            s = block_sum(s, red);
-            if (tid == 0) sx[m] = s;
-        }
-        __syncthreads();
-        return;
-    }
-    if (p.vec_mode == 2) {
-        const int nvec = p.K >> 3;
-        for (int m = 0; m < p.M; ++m) {
-            const bf16_t* xrow = (const bf16_t*)p.x + (int64_t)m * p.ldx;
-            float s = 0.f;
-            for (int v0 = 0; v0 < nvec; v0 += 4 * nt) {
-                u32x4 r[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int v = v0 + tid + c * nt;
-                    if (v < nvec) r[c] = *(const u32x4*)(xrow + v * 8);
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int v = v0 + tid + c * nt;
-                    if (v < nvec) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            s += __uint_as_float(r[c][i] << 16) + __uint_as_float(r[c][i] & 0xffff0000u);
-                        *(u32x4*)(xs + (size_t)m * p.xs_stride + v * 16) = r[c];
-                    }
-                }
-            }
-            for (int k = p.K + tid; k < Kp; k += nt) ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;
-            s = block_sum(s, red);
-            if (tid == 0) sx[m] = s;
-        }
-        __syncthreads();
-        return;
-    }
-    for (int m = 0; m < p.M; ++m) {
+// ------------------------------------------------------------------------------------ activation staging
+// The activation rows go to LDS as bf16 (the MFMA B operand).  What the timeline stamps showed for the first
+// version (load -> block reduce -> normalise -> block reduce -> barrier, issued AFTER the weight ring): ~4 us of a
+// 12-14 us launch before the first MFMA.  So:
+//   * RMSNorm's 1/rms is a per-row scalar and commutes with the linear map: rows are staged as bf16(scale_k x_k)
+//     and the epilogue multiplies by rsqrt(mean(x^2) + eps) (lit_llama/model.py:274-277, same arithmetic up to
+//     where the one bf16 rounding sits).  The sum of squares needs no barrier of its own: per-wave partials are
+//     published together with the staged row.
+//   * the row sum needed to undo the +128 / zero-point offset comes out of the matrix pipe: one extra MFMA per
+//     k-step with an all-ones A fragment yields sum_k x_k of exactly the rounded operands.
+//   * the row's loads are issued BEFORE the weight ring: VMEM returns in order, so loads queued behind 4-8 KiB
+//     of HBM weight traffic per wave would only be usable when that traffic has landed.
+// Vectorised modes (p.vec_mode, chosen on the host; all need K % 8 == 0 and 16-B aligned rows):
+//   1: x f32 with a bf16 norm scale, <= 2 x 8 elements per thread      (decode: c_attn, c_fc1/c_fc2, lm_head)
+//   2: x bf16, no norm, <= 4 x 8 elements per thread                   (decode: mlp.c_proj; attn.c_proj unsplit)
+//   3: x = combine of split-attention partial records, <= 8 elements per thread, <= 4 splits   (attn.c_proj)
+//   0: any dtype / shape, element loop.
+template <int VMODE>
+struct Stager;
+
+template <>
+struct Stager<0> {  // element loop, any dtype
+    __device__ __forceinline__ void load(const GemvParams&, int) {}
+    __device__ __forceinline__ float store(const GemvParams& p, int m, char* xs) {
+        const int tid = threadIdx.x, nt = blockDim.x;
+        const bool norm = p.norm_scale != nullptr;
         const int64_t base = (int64_t)m * p.ldx;
-        float rinv = 1.f;
-        if (norm) {
-            float ss = 0.f;
-            for (int k = tid; k < p.K; k += nt) {
-                const float v = ld2(p.x, base + k, p.x_dtype);
-                ss += v * v;
-            }
-            ss = block_sum(ss, red);
-            rinv = rsqrtf(ss / (float)p.K + p.eps);
-        }
         bf16_t* row = (bf16_t*)(xs + (size_t)m * p.xs_stride);
-        float s = 0.f;
-        for (int k = tid; k < Kp; k += nt) {
-            bf16_t b = 0;
-            if (k < p.K) {
-                float v = ld2(p.x, base + k, p.x_dtype);
-                if (norm) v = ld2(p.norm_scale, k, p.norm_dtype) * (v * rinv);
-                b = f32_to_bf16(v);
+        float ss = 0.f;
+        for (int k = tid; k < p.K; k += nt) {
+            float v = ld2(p.x, base + k, p.x_dtype);
+            if (norm) {
+                ss += v * v;
+                v = ld2(p.norm_scale, k, p.norm_dtype) * v;
             }
-            row[k] = b;
-            s += bf16_to_f32(b);
+            row[k] = f32_to_bf16(v);
         }
-        s = block_sum(s, red);
-        if (tid == 0) sx[m] = s;
+        return ss;
     }
-    __syncthreads();
-}
+};
+
+template <>
+struct Stager<1> {  // f32 row, bf16 norm scale, <= 2 x 8 elements per thread
+    f32x4 xa[2], xb[2];
+    u32x4 ns[2];
+    __device__ __forceinline__ void load(const GemvParams& p, int m) {
+        const int tid = threadIdx.x, nt = blockDim.x, nvec = p.K >> 3;
+        const float* xrow = (const float*)p.x + (int64_t)m * p.ldx;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int v = tid + c * nt;
+            if (v < nvec) {
+                xa[c] = *(const f32x4*)(xrow + v * 8);
+                xb[c] = *(const f32x4*)(xrow + v * 8 + 4);
+                ns[c] = *(const u32x4*)((const bf16_t*)p.norm_scale + v * 8);
+            }
+        }
+    }
+    __device__ __forceinline__ float store(const GemvParams& p, int m, char* xs) {
+        const int tid = threadIdx.x, nt = blockDim.x, nvec = p.K >> 3;
+        char* row = xs + (size_t)m * p.xs_stride;
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int v = tid + c * nt;
+            if (v < nvec) {
+                u32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x0 = i < 2 ? xa[c][2 * i] : xb[c][2 * i - 4];
+                    const float x1 = i < 2 ? xa[c][2 * i + 1] : xb[c][2 * i - 3];
+                    ss += x0 * x0 + x1 * x1;
+                    const bf16_t a = f32_to_bf16(__uint_as_float(ns[c][i] << 16) * x0);
+                    const bf16_t b = f32_to_bf16(__uint_as_float(ns[c][i] & 0xffff0000u) * x1);
+                    o[i] = (uint32_t)a | ((uint32_t)b << 16);
+                }
+                *(u32x4*)(row + v * 16) = o;
+            }
+        }
+        return ss;
+    }
+};
+
+template <>
+struct Stager<2> {  // bf16 row, no norm, <= 4 x 8 elements per thread
+    u32x4 r[4];
+    __device__ __forceinline__ void load(const GemvParams& p, int m) {
+        const int tid = threadIdx.x, nt = blockDim.x, nvec = p.K >> 3;
+        const bf16_t* xrow = (const bf16_t*)p.x + (int64_t)m * p.ldx;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int v = tid + c * nt;
+            if (v < nvec) r[c] = *(const u32x4*)(xrow + v * 8);
+        }
+    }
+    __device__ __forceinline__ float store(const GemvParams& p, int m, char* xs) {
+        const int tid = threadIdx.x, nt = blockDim.x, nvec = p.K >> 3;
+        char* row = xs + (size_t)m * p.xs_stride;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int v = tid + c * nt;
+            if (v < nvec) *(u32x4*)(row + v * 16) = r[c];
+        }
+        return 0.f;
+    }
+};
+
+template <>
+struct Stager<3> {  // split-attention partial records, <= 8 elements per thread, <= 4 splits
+    float mj[4], lj[4];
+    f32x4 oa[4], ob[4];
+    __device__ __forceinline__ void load(const GemvParams& p, int m) {
+        const int tid = threadIdx.x, nvec = p.K >> 3;
+        if (tid < nvec) {
+            const int hs = p.attn_hs, rs = hs + 4;
+            const int k0 = tid * 8, h = k0 / hs, d0 = k0 - h * hs;
+            const float* rec = p.attn_part + ((int64_t)m * p.attn_heads + h) * p.attn_splits * rs;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < p.attn_splits) {
+                    const float* q = rec + j * rs;
+                    mj[j] = q[0];
+                    lj[j] = q[1];
+                    oa[j] = *(const f32x4*)(q + 4 + d0);
+                    ob[j] = *(const f32x4*)(q + 8 + d0);
+                }
+        }
+    }
+    __device__ __forceinline__ float store(const GemvParams& p, int m, char* xs) {
+        const int tid = threadIdx.x, nvec = p.K >> 3;
+        if (tid < nvec) {
+            // x[h*hs + d] = sum_j e^{m_j - M} o_j[d] / sum_j e^{m_j - M} l_j  (flash-decoding combine)
+            float M_ = -1.0e30f, L = 0.f;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < p.attn_splits) {
+                    const float Mn = fmaxf(M_, mj[j]);
+                    const float c_old = expf(M_ - Mn), c_new = expf(mj[j] - Mn);
+                    L = L * c_old + lj[j] * c_new;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i] = acc[i] * c_old + oa[j][i] * c_new;
+                        acc[4 + i] = acc[4 + i] * c_old + ob[j][i] * c_new;
+                    }
+                    M_ = Mn;
+                }
+            const float inv = 1.0f / L;
+            u32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                o[i] = (uint32_t)f32_to_bf16(acc[2 * i] * inv) | ((uint32_t)f32_to_bf16(acc[2 * i + 1] * inv) << 16);
+            *(u32x4*)(xs + (size_t)m * p.xs_stride + tid * 16) = o;
+        }
+        return 0.f;
+    }
+};
 
 // Per-output operands of one tile's epilogue, owned by thread (e_row, e_col) of the first 256 threads and
 // fetched ONE TILE AHEAD: an epilogue that issued its own loads would have to wait for them with vmcnt(0),
@@ -309,20 +286,25 @@ __device__ __forceinline__ void load_epi(const GemvParams& p, int tile, int e_ro
 }
 
 // Combine the W partial 16x16 tiles of `buf` in wave order and write the tile's outputs (stores only).
+// RS = partial tiles per wave: R weight tiles (+ the all-ones tile carrying sum_k x_k for Q4).
 template <int FMT, int R, int EPI>
 __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* part, int buf, int W, int tile,
-                                              int e_row, int e_col, const EpiOps<R>& o, const float* sx) {
+                                              int e_row, int e_col, const EpiOps<R>& o, float rinv) {
+    constexpr int RS = R + (FMT == MI355_W_Q4 ? 1 : 0);
     // D layout of mfma_f32_16x16x32: lane (row >> 2) * 16 + col holds D[row][col] in register (row & 3)
     const int src = ((e_row >> 2) << 4) | e_col;
-    const float* base = (const float*)(part + (size_t)(buf * W * R) * 1024) + src * 4 + (e_row & 3);
+    const float* base = (const float*)(part + (size_t)(buf * W * RS) * 1024) + src * 4 + (e_row & 3);
+    float sx = 0.f;
+    if constexpr (FMT == MI355_W_Q4) {
+        for (int w = 0; w < W; ++w) sx += base[(w * RS + R) * 256];
+    }
     float v[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float s = 0.f;
-        for (int w = 0; w < W; ++w) s += base[(w * R + r) * 256];
-        if constexpr (FMT == MI355_W_Q4)
-            s = cvt2(o.s[r], p.sz_dtype) * (s - (128.f + cvt2(o.z[r], p.sz_dtype)) * sx[e_col]);
-        v[r] = s;
+        for (int w = 0; w < W; ++w) s += base[(w * RS + r) * 256];
+        if constexpr (FMT == MI355_W_Q4) s = cvt2(o.s[r], p.sz_dtype) * (s - (128.f + cvt2(o.z[r], p.sz_dtype)) * sx);
+        v[r] = s * rinv;
     }
     if constexpr (EPI == MI355_EPI_SWIGLU) {
         if constexpr (R == 2) {
@@ -345,22 +327,23 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
 
 // EPI is a template parameter so that the SwiGLU pair kernel (c_fc1/c_fc2: the largest launch of a decode
 // step) is its own symbol in profiles, and the epilogue carries no runtime switch.
-template <int FMT, int R, int P, bool NT, int EPI>
+template <int FMT, int R, int P, int EPI, int VMODE>
 __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
+    constexpr bool NT = true;  // weights are read once: non-temporal
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = (float*)smem;
-    float* sx = (float*)(smem + 256);
+    float* wss = (float*)smem;  // [W][16] per-wave partial sums of x^2 (RMSNorm)
     char* part = smem + kLdsHeader;
 
     constexpr int kPieces = Fmt<FMT>::kPieces;
     constexpr int kSlot = R * kPieces;  // 16-B pieces per lane per unit
+    constexpr int RS = R + (FMT == MI355_W_Q4 ? 1 : 0);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = blockDim.x >> 6;
-    char* xs = part + 2 * W * R * 1024;
-#define MI355_STAMP(i)                                                                   \
-    do {                                                                                 \
+    char* xs = part + 2 * W * RS * 1024;
+#define MI355_STAMP(i)                                                                          \
+    do {                                                                                        \
         if (p.dbg != nullptr && threadIdx.x == 0) p.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); \
     } while (0)
     MI355_STAMP(0);
@@ -372,6 +355,9 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     const int my_tiles = (p.n_tiles > bid) ? (p.n_tiles - bid + nb - 1) / nb : 0;
     const int total = my_tiles * nu;
 
+    // ---- row 0 of the activations: loads first (in-order VMEM return, see Stager)
+    Stager<VMODE> stager;
+    stager.load(p, 0);
 
     // ---- weight prefetch ring: P units in flight per wave.
     // Every refill is an UNCONDITIONAL load: a conditional refill makes the ring registers phi nodes, and hipcc
@@ -410,10 +396,28 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     for (int r = 0; r < R; ++r) eo.s[r] = eo.z[r] = eo.bias[r] = eo.old[r] = 0u;
     load_epi<FMT, R, EPI>(p, bid, e_row, e_col, e_owner, eo);
 
-    stage_x<EPI != MI355_EPI_SWIGLU>(p, xs, sx, red);
+    // ---- stage the activation rows; per-wave partial sums of squares ride along (no extra barrier)
+    for (int m = 0; m < p.M; ++m) {
+        if (m > 0) stager.load(p, m);
+        float ss = stager.store(p, m, xs);
+        for (int k = p.K + (int)threadIdx.x; k < p.units * kUnitK; k += blockDim.x)
+            ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;  // stream padding
+        if constexpr (VMODE == 0 || VMODE == 1) {
+            ss = wave_sum(ss);
+            if (lane == 0) wss[wave * 16 + m] = ss;
+        }
+    }
+    __syncthreads();
     MI355_STAMP(2);
 
-    f32x4 acc[R];
+    float rinv = 1.f;
+    if (p.norm_scale != nullptr && e_owner) {
+        float ss = 0.f;
+        for (int w = 0; w < W; ++w) ss += wss[w * 16 + e_col];
+        rinv = rsqrtf(ss / (float)p.K + p.eps);
+    }
+
+    f32x4 acc[R], acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -422,11 +426,11 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     if (nu == 0) {
         // more waves than units: this wave only takes part in the combine
         for (int i = 0; i < my_tiles; ++i) {
-            f32x4* pp = (f32x4*)(part + (size_t)((buf * W + wave) * R) * 1024) + lane;
+            f32x4* pp = (f32x4*)(part + (size_t)((buf * W + wave) * RS) * 1024) + lane;
 #pragma unroll
-            for (int r = 0; r < R; ++r) pp[r * 64] = acc[r];
+            for (int r = 0; r < RS; ++r) pp[r * 64] = acc1;  // zeros
             __syncthreads();
-            if (e_owner) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, sx);
+            if (e_owner) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
             tile += nb;
             buf ^= 1;
             load_epi<FMT, R, EPI>(p, tile, e_row, e_col, e_owner, eo);
@@ -438,6 +442,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     const int g = lane >> 4, c = lane & 15;
     const int xrow = c < p.M ? c : p.M - 1;
     const char* xl = xs + (size_t)xrow * p.xs_stride + g * 64;
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // 8 x bf16 1.0
     int uu = 0;
 
     for (int t = 0; t < total; t += P) {
@@ -449,6 +454,12 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
 #pragma unroll
                 for (int d = 0; d < 4; ++d) b[d] = *(const bf16x8*)(xb + 16 * d);
 
+                if constexpr (FMT == MI355_W_Q4) {
+                    // sum_k x_k of the rounded operands, from the otherwise idle matrix pipe
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ones), b[d], acc1, 0, 0, 0);
+                }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if constexpr (FMT == MI355_W_Q4) {
@@ -474,22 +485,26 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
                 if (++uu == nu) {
                     // tile done for this wave: publish the partial 16x16 tiles, combine, epilogue
                     uu = 0;
-                    f32x4* pp = (f32x4*)(part + (size_t)((buf * W + wave) * R) * 1024) + lane;
+                    f32x4* pp = (f32x4*)(part + (size_t)((buf * W + wave) * RS) * 1024) + lane;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         pp[r * 64] = acc[r];
                         acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
+                    if constexpr (FMT == MI355_W_Q4) {
+                        pp[R * 64] = acc1;
+                        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                     if (tile == bid) MI355_STAMP(3);
                     __syncthreads();
-                    if (e_owner) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, sx);
+                    if (e_owner) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
                     if (tile == bid) MI355_STAMP(4);
                     tile += nb;
                     buf ^= 1;
                     load_epi<FMT, R, EPI>(p, tile, e_row, e_col, e_owner, eo);
                 }
             }
-            MI355_ISSUE(j);  // refill the slot just consumed (dummy source once the work is exhausted)
+            MI355_ISSUE(j);  // refill the slot just consumed (offset out of range once the work is exhausted)
         }
     }
     MI355_STAMP(5);
@@ -619,52 +634,65 @@ __global__ void i8_repack_kernel(const int8_t* c0, const int8_t* c1, int N, int 
     }
 }
 
-template <int FMT, int R, int P, bool NT, int EPI>
-int launch_gemv_epi(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
+template <int FMT, int R, int P, int EPI, int VMODE>
+int launch_gemv_v(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, NT, EPI>,
+        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, EPI, VMODE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     });
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    hipLaunchKernelGGL((gemv_kernel<FMT, R, P, NT, EPI>), dim3(grid), dim3(waves * 64), lds, stream, p);
+    hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE>), dim3(grid), dim3(waves * 64), lds, stream, p);
     MI355_LAUNCH_CHECK();
     return 0;
 }
 
-template <int FMT, int R, int P, bool NT>
+template <int FMT, int R, int P, int EPI>
+int launch_gemv_epi(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
+    switch (p.vec_mode) {
+        case 1:
+            if constexpr (EPI != MI355_EPI_ACCUM) return launch_gemv_v<FMT, R, P, EPI, 1>(p, grid, waves, lds, stream);
+            break;
+        case 2:
+            if constexpr (EPI != MI355_EPI_SWIGLU) return launch_gemv_v<FMT, R, P, EPI, 2>(p, grid, waves, lds, stream);
+            break;
+        case 3:
+            if constexpr (EPI != MI355_EPI_SWIGLU) return launch_gemv_v<FMT, R, P, EPI, 3>(p, grid, waves, lds, stream);
+            break;
+        default: break;
+    }
+    if (p.vec_mode == 3) {
+        mi355_set_error("split-attention prologue is not available for this epilogue");
+        return MI355_E_ARG;
+    }
+    return launch_gemv_v<FMT, R, P, EPI, 0>(p, grid, waves, lds, stream);
+}
+
+template <int FMT, int R, int P>
 int launch_gemv(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     switch (p.epi) {
-        case MI355_EPI_STORE: return launch_gemv_epi<FMT, R, P, NT, MI355_EPI_STORE>(p, grid, waves, lds, stream);
-        case MI355_EPI_ACCUM: return launch_gemv_epi<FMT, R, P, NT, MI355_EPI_ACCUM>(p, grid, waves, lds, stream);
+        case MI355_EPI_STORE: return launch_gemv_epi<FMT, R, P, MI355_EPI_STORE>(p, grid, waves, lds, stream);
+        case MI355_EPI_ACCUM: return launch_gemv_epi<FMT, R, P, MI355_EPI_ACCUM>(p, grid, waves, lds, stream);
         default:
-            if constexpr (R == 2) return launch_gemv_epi<FMT, R, P, NT, MI355_EPI_SWIGLU>(p, grid, waves, lds, stream);
+            if constexpr (R == 2) return launch_gemv_epi<FMT, R, P, MI355_EPI_SWIGLU>(p, grid, waves, lds, stream);
             mi355_set_error("SwiGLU epilogue needs R == 2");
             return MI355_E_ARG;
     }
 }
 
 template <int FMT, int R>
-int dispatch_pnt(const GemvParams& p, int prefetch, bool nt, int grid, int waves, size_t lds, hipStream_t s) {
+int dispatch_p(const GemvParams& p, int prefetch, int grid, int waves, size_t lds, hipStream_t s) {
     constexpr int PA = FMT == MI355_W_Q4 ? 4 : 2;
     constexpr int PB = FMT == MI355_W_Q4 ? 8 : 4;
-    const bool deep = prefetch >= PB;
-    if (deep) {
-        if constexpr (FMT == MI355_W_BF16 && R == 2) {
-            // 4 units x 8 pieces would need 128 VGPRs of ring alone; cap at the shallow ring
-            return nt ? launch_gemv<FMT, R, PA, true>(p, grid, waves, lds, s)
-                      : launch_gemv<FMT, R, PA, false>(p, grid, waves, lds, s);
-        } else {
-            return nt ? launch_gemv<FMT, R, PB, true>(p, grid, waves, lds, s)
-                      : launch_gemv<FMT, R, PB, false>(p, grid, waves, lds, s);
-        }
+    if (prefetch >= PB) {
+        // BF16 R=2 at 4 units x 8 pieces would need 128 VGPRs of ring alone; cap at the shallow ring
+        if constexpr (!(FMT == MI355_W_BF16 && R == 2)) return launch_gemv<FMT, R, PB>(p, grid, waves, lds, s);
     }
-    return nt ? launch_gemv<FMT, R, PA, true>(p, grid, waves, lds, s)
-              : launch_gemv<FMT, R, PA, false>(p, grid, waves, lds, s);
+    return launch_gemv<FMT, R, PA>(p, grid, waves, lds, s);
 }
 
 int g_num_cus = 0;
@@ -806,12 +834,18 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
         const int esz = a->x_dtype == MI355_F32 ? 4 : 2;
         const bool aligned = a->x != nullptr && ((uintptr_t)a->x % 16 == 0) && ((a->ldx * esz) % 16 == 0 || a->M == 1) && a->K % 8 == 0;
         p.vec_mode = 0;
+        const int nvec = a->K / 8, nthr = waves * 64;
         if (aligned && a->norm_scale != nullptr && a->x_dtype == MI355_F32 && a->norm_dtype == MI355_BF16 &&
-            (uintptr_t)a->norm_scale % 16 == 0 && a->K / 8 <= 2 * waves * 64)
+            (uintptr_t)a->norm_scale % 16 == 0 && nvec <= 2 * nthr)
             p.vec_mode = 1;
-        else if (aligned && a->norm_scale == nullptr && a->x_dtype == MI355_BF16)
+        else if (aligned && a->norm_scale == nullptr && a->x_dtype == MI355_BF16 && nvec <= 4 * nthr)
             p.vec_mode = 2;
-        if (a->attn_partials != nullptr) p.vec_mode = 3;
+        if (a->attn_partials != nullptr) {
+            MI355_CHECK_ARG(a->attn_splits <= 4 && nvec <= nthr && ((uintptr_t)a->attn_partials % 16) == 0,
+                            MI355_E_SHAPE, "linear_fast: split-attention prologue handles <= 4 splits and K <= %d",
+                            8 * nthr);
+            p.vec_mode = 3;
+        }
         p.attn_part = a->attn_partials;
         p.attn_splits = a->attn_splits;
         p.attn_heads = a->attn_heads;
@@ -824,7 +858,8 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
         p.w_bytes = (unsigned)wb;
     }
 
-    const size_t lds = kLdsHeader + (size_t)2 * waves * a->R * 1024 + (size_t)a->M * p.xs_stride;
+    const int RS = a->R + (a->fmt == MI355_W_Q4 ? 1 : 0);
+    const size_t lds = kLdsHeader + (size_t)2 * waves * RS * 1024 + (size_t)a->M * p.xs_stride;
     MI355_CHECK_ARG(lds <= (size_t)kMaxLds, MI355_E_SHAPE,
                     "linear_fast: M=%d x K=%d activations do not fit LDS (%zu B > %d B); chunk M", a->M, a->K, lds,
                     kMaxLds);
@@ -834,14 +869,13 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
         grid = cus * 2;
     }
     if (grid > p.n_tiles) grid = p.n_tiles;
-    const bool nt = (a->flags & 1) == 0;
     hipStream_t s = (hipStream_t)stream;
     if (a->fmt == MI355_W_Q4) {
-        return a->R == 1 ? dispatch_pnt<MI355_W_Q4, 1>(p, a->prefetch, nt, grid, waves, lds, s)
-                         : dispatch_pnt<MI355_W_Q4, 2>(p, a->prefetch, nt, grid, waves, lds, s);
+        return a->R == 1 ? dispatch_p<MI355_W_Q4, 1>(p, a->prefetch, grid, waves, lds, s)
+                         : dispatch_p<MI355_W_Q4, 2>(p, a->prefetch, grid, waves, lds, s);
     }
-    return a->R == 1 ? dispatch_pnt<MI355_W_BF16, 1>(p, a->prefetch, nt, grid, waves, lds, s)
-                     : dispatch_pnt<MI355_W_BF16, 2>(p, a->prefetch, nt, grid, waves, lds, s);
+    return a->R == 1 ? dispatch_p<MI355_W_BF16, 1>(p, a->prefetch, grid, waves, lds, s)
+                     : dispatch_p<MI355_W_BF16, 2>(p, a->prefetch, grid, waves, lds, s);
 }
 
 extern "C" int mi355_linear_fast_batch(const mi355_linear_args* a, int count, mi355_stream_t stream) {

@@ -112,16 +112,16 @@ def test_q4_linear_matches_oracle(dev, N, K, M, R, waves, grid, prefetch):
     assert bool(((yb - ref64).abs() <= 2.0**-8 * ref64.abs() + 1e-3 * _rms(ref64)).all())
 
 
-def test_q4_linear_f32_scales_nt_flag_and_determinism(dev):
+def test_q4_linear_f32_scales_and_determinism(dev):
     N, K, M = 1024, 2048, 4
     p = _q4_problem(N, K, M, seed=99, dev=dev)
     xb = p["x"].to(torch.bfloat16).to(dev)
     stream = ops.repack_q4(p["packed"], None, N, K, 1)
     kw = dict(scales=p["scale"].to(dev), zeros=p["zero"].to(dev), out_dtype=torch.float32)
     y0 = ops.linear_fast(xb, stream, nat.W_Q4, 1, N, K, **kw)
-    y1 = ops.linear_fast(xb, stream, nat.W_Q4, 1, N, K, flags=1, **kw)   # plain (temporal) weight loads
+    y1 = ops.linear_fast(xb, stream, nat.W_Q4, 1, N, K, grid=7, **kw)   # other tile -> workgroup mapping
     y2 = ops.linear_fast(xb, stream, nat.W_Q4, 1, N, K, **kw)
-    assert torch.equal(y0, y1) and torch.equal(y0, y2)  # bit-reproducible, independent of the cache policy
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)  # bit-reproducible, independent of the launch geometry
     ref64 = xb.cpu().double() @ p["wdq"].double().t()
     assert (y0.cpu().double() - ref64).abs().max().item() <= 1e-3 * _rms(ref64)
     # an f32 activation is rounded to bf16 exactly once (a different staging path: only the order of the f32
