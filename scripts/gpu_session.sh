@@ -34,10 +34,11 @@ for st in $STAGES; do
       find $OUT/prof -name '*kernel_trace.csv' -size +30M -delete ;;
     pmc)
       rm -rf $OUT/pmc
-      timeout 900 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc -o fetch -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/pmc_bench.json 2> $OUT/pmc.err
+      timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o fetch -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/pmc_bench.json 2> $OUT/pmc.err
       echo "pmc exit $?" | tee -a $OUT/session.log
       f=$(find $OUT/pmc -name '*counter_collection.csv' | head -1)
-      [ -n "$f" ] && python scripts/pmc_summary.py "$f" > $OUT/pmc_summary.txt 2>&1 && cat $OUT/pmc_summary.txt
+      ls $OUT/pmc | head; [ -n "$f" ] && head -3 "$f"
+      [ -n "$f" ] && python scripts/pmc_summary.py "$f" --json $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt
       find $OUT/pmc -name '*.csv' -size +20M -delete ;;
     sweep)
       timeout 1200 python scripts/sweep_gemv.py --out $OUT/sweep_best.json > $OUT/sweep.log 2>&1
