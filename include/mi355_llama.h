@@ -212,6 +212,8 @@ typedef struct mi355_attn_args {
                            written: combine with mi355_attn_combine or let the following mi355_linear_fast do it
                            (attn_partials); 0 / 1: single workgroup per head writes y */
     float* partials;
+    uint64_t* debug_stamps; /* optional: uint64 [workgroups][8] wall-clock stamps (100 MHz): 0 entry, 1 K/V loads
+                               issued, 2 q staged, 3 rows done, 4 exit */
 } mi355_attn_args;
 
 int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream);

@@ -49,6 +49,7 @@ class AttnArgs(C.Structure):
         ("cache_dtype", c_int32), ("T", c_int32), ("n_head", c_int32), ("hs", c_int32),
         ("S", c_int32), ("y_dtype", c_int32), ("y", c_void_p), ("ldy", c_int64),
         ("kv_tmp", c_void_p), ("rope_gathered", c_int32), ("n_split", c_int32), ("partials", c_void_p),
+        ("debug_stamps", c_void_p),
     ]
 
 

@@ -30,6 +30,7 @@ struct AttnParams {
     int rope_gathered;  // rope row of token t is t (rows pre-selected by the caller), not pos[t]
     int n_split;        // workgroups per head (flash-decoding); > 1 writes partial records to `part`
     float* part;
+    unsigned long long* dbg;
     float scale;
 };
 
@@ -135,6 +136,12 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     float* wl = wm + nw;          // [nw] running sum per wave
     float* scur = wl + nw;        // [4] score of the current position (fused)
     float* opart = scur + 4;      // [nw][hs]
+    const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#define MI355_STAMP(i)                                                                  \
+    do {                                                                                \
+        if (p.dbg != nullptr && threadIdx.x == 0) p.dbg[wg * 8 + (i)] = wall_clock64(); \
+    } while (0)
+    MI355_STAMP(0);
 
     const int pos = p.pos ? p.pos[t] : t;
     const int slot = pos < p.S - 1 ? pos : p.S - 1;
@@ -171,6 +178,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         }
     }
 
+    MI355_STAMP(1);
     // ---- q (and, fused, the new k / v row) through RoPE into LDS
     for (int pi = tid; pi < half; pi += blockDim.x) {
         const float a = ld_as_f32(p.qkv, row + h * hs + 2 * pi, p.qkv_dtype);
@@ -200,6 +208,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         }
     }
     __syncthreads();
+    MI355_STAMP(2);
 
     if (vec_ok) {
         float qf[VEC];
@@ -300,6 +309,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         dot = wave_sum(dot);
         if (lane == 0) scur[0] = dot * p.scale;
     }
+    MI355_STAMP(3);
     __syncthreads();
 
     // ---- combine the waves (fixed order) and, fused, the current position from its LDS copy
@@ -338,6 +348,8 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
             rec[4 + d] = o;
         }
     }
+    MI355_STAMP(4);
+#undef MI355_STAMP
 }
 
 // y[row, h*hs + d] = sum_j e^{m_j - M} o_j[d] / sum_j e^{m_j - M} l_j  over the n_split partial records
@@ -424,6 +436,7 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
     MI355_CHECK_ARG(ns <= 64 && (int64_t)a->B * ns <= 65535, MI355_E_SHAPE, "attention: n_split too large");
     p.n_split = ns;
     p.part = (float*)a->partials;
+    p.dbg = (unsigned long long*)a->debug_stamps;
     const int threads = ns > 1 ? 256 : 512, nw = threads / 64;
     const size_t lds = (size_t)(3 * a->hs + 2 * nw + 4 + nw * a->hs) * sizeof(float) + 16;
     MI355_CHECK_ARG(a->hs <= 256 || (a->hs * esz) % 16 == 0, MI355_E_SHAPE, "attention: head size %d unsupported", a->hs);
