@@ -148,7 +148,7 @@ def test_linear8bit_defers_quantisation_off_gpu():
 
 
 def test_fast_linear_lds_budget():
-    assert ops.fast_linear_max_m(4096, 2) == 14 or ops.fast_linear_max_m(4096, 2) == 15 or ops.fast_linear_max_m(4096, 2) == 16
+    assert 12 <= ops.fast_linear_max_m(4096, 2) <= 16
     assert 1 <= ops.fast_linear_max_m(11008, 1) <= 7
     assert 1 <= ops.fast_linear_max_m(22016, 1) <= 3
     assert ops.fast_linear_max_m(11008, 1, nat.W_I8) >= 1
