@@ -75,6 +75,23 @@ __device__ __forceinline__ void unpack16(const u32x4& raw, float (&out)[Vec16<CT
     }
 }
 
+
+// Sum over aligned groups of `lpr` lanes (power of two); every lane of a group ends up with the group's sum.
+// Steps 1, 2, 4, 8 are DPP lane permutations inside quads / half rows / rows (xor-butterfly equivalents:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror — full-rate VALU).  `__shfl_xor` lowers
+// to ds_bpermute, an LDS round trip of ~120 cycles per step; a dependent chain of those per cached row was most of
+// this kernel's time.  Only groups wider than a 16-lane row use ds_bpermute for the last step(s).
+#define MI355_DPP_ADD(v, ctrl) \
+    ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, false)))
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+    if (lpr >= 2) v = MI355_DPP_ADD(v, 0xB1);
+    if (lpr >= 4) v = MI355_DPP_ADD(v, 0x4E);
+    if (lpr >= 8) v = MI355_DPP_ADD(v, 0x141);
+    if (lpr >= 16) v = MI355_DPP_ADD(v, 0x140);
+    for (int o = 16; o < lpr; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // RoPE of one interleaved pair at absolute position `pos` (lit_llama/model.py:314-318)
 __device__ __forceinline__ void rope_pair(const float* rope, int pos, int half, int pi, float a, float b, float& oa,
                                           float& ob) {
@@ -251,24 +268,35 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         // wave-uniform trip count: the shuffles below need every lane of a row group in the loop
         for (int base = s_begin; base < s_end; base += stride * U) {
             const int s0 = base + wave * rpw + lr;
+            // all U partial dot products first, then the U lane-group reductions (independent -> interleaved),
+            // then the sequential online-softmax updates
+            float dots[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = s0 + u * stride;
+                float dot = 0.f;
+                if (s < s_end) {
+                    float kf[VEC];
+                    unpack16<CT>(kr[u], kf);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) dot += qf[j] * kf[j];
+                }
+                dots[u] = dot;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) dots[u] = group_sum(dots[u], LPR);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int s = s0 + u * stride;
                 const bool valid = s < s_end;
-                float dot = 0.f;
                 float vf[VEC];
                 if (valid) {
-                    float kf[VEC];
-                    unpack16<CT>(kr[u], kf);
                     unpack16<CT>(vr[u], vf);
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) dot += qf[j] * kf[j];
                 } else {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) vf[j] = 0.f;
                 }
-                for (int o = LPR >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-                const float sc = valid ? dot * p.scale : kNegBig;
+                const float sc = valid ? dots[u] * p.scale : kNegBig;
                 const float m_new = fmaxf(m_run, sc);
                 const float corr = expf(m_run - m_new);
                 const float pr = valid ? expf(sc - m_new) : 0.f;
