@@ -113,7 +113,7 @@ typedef struct mi355_linear_args {
     int32_t waves;      /* waves per workgroup (split of K) */
     int32_t grid;       /* workgroups (persistent loop over tiles) */
     int32_t prefetch;   /* ring depth variant (4 or 8) */
-    int32_t flags;      /* reserved (0) */
+    int32_t flags;      /* bit0: stage activation row 0 before issuing the weight ring (tuning knob) */
     /* activations given as split-attention partial records instead of x (x may be NULL): the prologue combines
      * them (K = attn_heads * attn_hs); layout as written by mi355_attention with n_split = attn_splits */
     const float* attn_partials;
@@ -281,6 +281,8 @@ typedef struct mi355_weight {
     int32_t waves;
     int32_t grid;
     int32_t prefetch;
+    int32_t flags;      /* as mi355_linear_args.flags */
+    int32_t reserved0;
 } mi355_weight;
 
 typedef struct mi355_layer {

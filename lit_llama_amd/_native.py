@@ -70,6 +70,7 @@ class Weight(C.Structure):
         ("scales", c_void_p), ("zeros", c_void_p), ("scales2", c_void_p), ("zeros2", c_void_p),
         ("scb", c_void_p), ("scb2", c_void_p),
         ("sz_dtype", c_int32), ("waves", c_int32), ("grid", c_int32), ("prefetch", c_int32),
+        ("flags", c_int32), ("reserved0", c_int32),
     ]
 
 

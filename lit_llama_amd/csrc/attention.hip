@@ -269,24 +269,28 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         for (int base = s_begin; base < s_end; base += stride * U) {
             const int s0 = base + wave * rpw + lr;
             // all U partial dot products first, then the U lane-group reductions (independent -> interleaved),
-            // then the sequential online-softmax updates
+            // then the sequential online-softmax updates.  Steps whose rows are all past the end are skipped
+            // with a wave-uniform test (a 150-row context over 4 splits uses 3 of the 8 steps).
+            const int sw0 = base + wave * rpw;  // first row of this wave's step 0
             float dots[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int s = s0 + u * stride;
                 float dot = 0.f;
-                if (s < s_end) {
-                    float kf[VEC];
-                    unpack16<CT>(kr[u], kf);
+                if (sw0 + u * stride < s_end) {
+                    if (s < s_end) {
+                        float kf[VEC];
+                        unpack16<CT>(kr[u], kf);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) dot += qf[j] * kf[j];
+                        for (int j = 0; j < VEC; ++j) dot += qf[j] * kf[j];
+                    }
+                    dot = group_sum(dot, LPR);
                 }
                 dots[u] = dot;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) dots[u] = group_sum(dots[u], LPR);
-#pragma unroll
             for (int u = 0; u < U; ++u) {
+                if (sw0 + u * stride >= s_end) break;  // wave-uniform
                 const int s = s0 + u * stride;
                 const bool valid = s < s_end;
                 float vf[VEC];
@@ -298,8 +302,8 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
                 }
                 const float sc = valid ? dots[u] * p.scale : kNegBig;
                 const float m_new = fmaxf(m_run, sc);
-                const float corr = expf(m_run - m_new);
-                const float pr = valid ? expf(sc - m_new) : 0.f;
+                const float corr = __expf(m_run - m_new);
+                const float pr = valid ? __expf(sc - m_new) : 0.f;
                 l_run = l_run * corr + pr;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) of[j] = of[j] * corr + pr * vf[j];

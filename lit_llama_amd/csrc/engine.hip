@@ -68,7 +68,7 @@ int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x
     a.waves = w.waves;
     a.grid = w.grid;
     a.prefetch = w.prefetch;
-    a.flags = 0;
+    a.flags = w.flags;
     if (attn_partials != nullptr) {
         a.attn_partials = attn_partials;
         a.attn_splits = m->attn_splits;

@@ -51,6 +51,7 @@ struct GemvParams {
     const float* attn_part;  // vec_mode 3: activations = combine of split-attention partial records
     int attn_splits, attn_heads, attn_hs;
     unsigned long long* dbg;  // optional wall-clock stamps [grid][8]
+    int stage_first;  // stage activation row 0 (waits for its loads) BEFORE issuing the weight ring
     float eps;
 };
 
@@ -358,6 +359,17 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     // ---- row 0 of the activations: loads first (in-order VMEM return, see Stager)
     Stager<VMODE> stager;
     stager.load(p, 0);
+    if (p.stage_first) {
+        // With two workgroups per CU the activation loads of one queue behind the other's weight prefetch in the
+        // CU's memory pipeline and arrive 2-3 us late; consuming them before this workgroup's own ring is issued
+        // keeps the staging off the critical path (the ring then has the whole staging/barrier time to land).
+        float ss = stager.store(p, 0, xs);
+        for (int k = p.K + (int)threadIdx.x; k < p.units * kUnitK; k += blockDim.x) ((bf16_t*)xs)[k] = 0;
+        if constexpr (VMODE == 0 || VMODE == 1) {
+            ss = wave_sum(ss);
+            if (lane == 0) wss[wave * 16] = ss;
+        }
+    }
 
     // ---- weight prefetch ring: P units in flight per wave.
     // Every refill is an UNCONDITIONAL load: a conditional refill makes the ring registers phi nodes, and hipcc
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
     load_epi<FMT, R, EPI>(p, bid, e_row, e_col, e_owner, eo);
 
     // ---- stage the activation rows; per-wave partial sums of squares ride along (no extra barrier)
-    for (int m = 0; m < p.M; ++m) {
+    for (int m = p.stage_first ? 1 : 0; m < p.M; ++m) {
         if (m > 0) stager.load(p, m);
         float ss = stager.store(p, m, xs);
         for (int k = p.K + (int)threadIdx.x; k < p.units * kUnitK; k += blockDim.x)
@@ -851,6 +863,7 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
         p.attn_heads = a->attn_heads;
         p.attn_hs = a->attn_hs;
         p.dbg = (unsigned long long*)a->debug_stamps;
+        p.stage_first = (a->flags & 1) ? 1 : 0;
     }
     {
         const size_t wb = mi355_packed_bytes(a->fmt, a->N, a->K, a->R, swiglu ? 1 : 0);

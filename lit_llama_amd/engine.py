@@ -64,6 +64,7 @@ def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: 
     d.R = 2 if pair is not None else R
     tune = tune or {}
     d.waves, d.grid, d.prefetch = tune.get("waves", 0), tune.get("grid", 0), tune.get("prefetch", 0)
+    d.flags = tune.get("flags", 0)
     if kind == "q4":
         assert isinstance(mod, ColBlockQuantizedLinear)
         if not mod.fast_eligible(torch.bfloat16):

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--waves", type=int, default=8)
     ap.add_argument("--prefetch", type=int, default=4)
+    ap.add_argument("--flags", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev).manual_seed(0)
@@ -50,7 +51,7 @@ def main():
                 a.scales2, a.zeros2 = sc.data_ptr(), ze.data_ptr()
             a.sz_dtype, a.epi = nat.BF16, epi
             a.y, a.y_dtype, a.ldy = out.data_ptr(), nat.dtype_code(out.dtype), N
-            a.waves, a.grid, a.prefetch = args.waves, grid, args.prefetch
+            a.waves, a.grid, a.prefetch, a.flags = args.waves, grid, args.prefetch, args.flags
             a.debug_stamps = stamps.data_ptr() if dbg else None
             return a
 

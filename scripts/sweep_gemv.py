@@ -53,7 +53,7 @@ def main():
         grids = sorted({g for g in (n_tiles, cus, 2 * cus, 3 * cus, 4 * cus, 8 * cus) if g <= n_tiles})
         waves_l, pf_l, nt_l = (4, 8), (4, 8), (0, 1)
         if args.quick:
-            grids, waves_l, pf_l, nt_l = grids[-3:], (8,), (4, 8), (0,)
+            grids, waves_l, pf_l, nt_l = grids[-3:], (8,), (4,), (0, 1)
         best = None
         import ctypes as C
 
@@ -86,7 +86,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (reps * n_buf)
             gbs = nbytes / us / 1e3
-            rec = dict(shape=name, waves=waves, grid=grid, prefetch=pf, nt=1 - flags, us=round(us, 2), GBps=round(gbs, 1))
+            rec = dict(shape=name, waves=waves, grid=grid, prefetch=pf, stage_first=flags, us=round(us, 2), GBps=round(gbs, 1))
             print(json.dumps(rec), flush=True)
             if best is None or us < best["us"]:
                 best = rec
