@@ -142,16 +142,21 @@ class DecodeEngine:
             self.n_hidden = first.mlp.c_fc1.out_features
             self.packed = []
             layers = (Layer * cfg.n_layer)()
+            # Launch geometry: one persistent workgroup per CU looping over 16-row tiles.  Tile counts that are a
+            # multiple of the CU count keep every CU equally busy (7B: c_attn 768 tiles = 3 per CU, c_proj /
+            # mlp.c_proj 256 = 1 per CU, lm_head 2000 = 7.8); the c_fc1/c_fc2 pair is 688 tiles (2.7 per CU).
+            cus = nat.num_cus() or 256
+            dflt = lambda key: {"grid": cus, **self.tune.get(key, {})}  # noqa: E731
             for i, blk in enumerate(model.transformer.h):
-                attn = pack_linear(blk.attn.c_attn, 2, tune=self.tune.get("attn"))
-                proj = pack_linear(blk.attn.c_proj, 1, tune=self.tune.get("proj"))
-                fc = pack_linear(blk.mlp.c_fc1, 2, pair=blk.mlp.c_fc2, tune=self.tune.get("fc"))
-                mproj = pack_linear(blk.mlp.c_proj, 1, tune=self.tune.get("mproj"))
+                attn = pack_linear(blk.attn.c_attn, 1, tune=dflt("attn"))
+                proj = pack_linear(blk.attn.c_proj, 1, tune=dflt("proj"))
+                fc = pack_linear(blk.mlp.c_fc1, 2, pair=blk.mlp.c_fc2, tune=dflt("fc"))
+                mproj = pack_linear(blk.mlp.c_proj, 1, tune=dflt("mproj"))
                 self.packed += [attn, proj, fc, mproj]
                 L = layers[i]
                 L.rms1, L.rms2 = ptr(blk.rms_1.scale.detach()), ptr(blk.rms_2.scale.detach())
                 L.attn, L.proj, L.fc, L.mproj = attn.desc, proj.desc, fc.desc, mproj.desc
-            head = pack_linear(model.lm_head, 2, tune=self.tune.get("lm_head"))
+            head = pack_linear(model.lm_head, 1, tune=dflt("lm_head"))
             self.packed.append(head)
             self.layers = layers
 
