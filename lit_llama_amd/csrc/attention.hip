@@ -76,22 +76,6 @@ __device__ __forceinline__ void unpack16(const u32x4& raw, float (&out)[Vec16<CT
 }
 
 
-// Sum over aligned groups of `lpr` lanes (power of two); every lane of a group ends up with the group's sum.
-// Steps 1, 2, 4, 8 are DPP lane permutations inside quads / half rows / rows (xor-butterfly equivalents:
-// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror — full-rate VALU).  `__shfl_xor` lowers
-// to ds_bpermute, an LDS round trip of ~120 cycles per step; a dependent chain of those per cached row was most of
-// this kernel's time.  Only groups wider than a 16-lane row use ds_bpermute for the last step(s).
-#define MI355_DPP_ADD(v, ctrl) \
-    ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, false)))
-__device__ __forceinline__ float group_sum(float v, int lpr) {
-    if (lpr >= 2) v = MI355_DPP_ADD(v, 0xB1);
-    if (lpr >= 4) v = MI355_DPP_ADD(v, 0x4E);
-    if (lpr >= 8) v = MI355_DPP_ADD(v, 0x141);
-    if (lpr >= 16) v = MI355_DPP_ADD(v, 0x140);
-    for (int o = 16; o < lpr; o <<= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // RoPE of one interleaved pair at absolute position `pos` (lit_llama/model.py:314-318)
 __device__ __forceinline__ void rope_pair(const float* rope, int pos, int half, int pi, float a, float b, float& oa,
                                           float& ob) {

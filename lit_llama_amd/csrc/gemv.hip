@@ -293,17 +293,39 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
                                               int e_row, int e_col, const EpiOps<R>& o, float rinv) {
     constexpr int RS = R + (FMT == MI355_W_Q4 ? 1 : 0);
     // D layout of mfma_f32_16x16x32: lane (row >> 2) * 16 + col holds D[row][col] in register (row & 3)
-    const int src = ((e_row >> 2) << 4) | e_col;
-    const float* base = (const float*)(part + (size_t)(buf * W * RS) * 1024) + src * 4 + (e_row & 3);
     float sx = 0.f;
-    if constexpr (FMT == MI355_W_Q4) {
-        for (int w = 0; w < W; ++w) sx += base[(w * RS + R) * 256];
-    }
     float v[R];
+    if (p.M == 1) {
+        // decode: the 16 lanes of a row's group each fetch ONE wave's partial and the group is summed with DPP
+        // (fixed butterfly order -> reproducible); a serial loop over W x (R + 1) LDS reads per owner cost ~0.6 us
+        // per tile on the critical path.  Here e_col doubles as the wave index.
+        const int src = (e_row >> 2) << 4;  // column 0
+        const float* base = (const float*)(part + (size_t)(buf * W * RS) * 1024) + src * 4 + (e_row & 3);
+        float t[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) t[r] = e_col < W ? base[(e_col * RS + r) * 256] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RS; ++r) t[r] = group_sum(t[r], 16);
+        if (e_col != 0) return;
+        if constexpr (FMT == MI355_W_Q4) sx = t[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = t[r];
+    } else {
+        const int src = ((e_row >> 2) << 4) | e_col;
+        const float* base = (const float*)(part + (size_t)(buf * W * RS) * 1024) + src * 4 + (e_row & 3);
+        if constexpr (FMT == MI355_W_Q4) {
+            for (int w = 0; w < W; ++w) sx += base[(w * RS + R) * 256];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float s = 0.f;
+            for (int w = 0; w < W; ++w) s += base[(w * RS + r) * 256];
+            v[r] = s;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        float s = 0.f;
-        for (int w = 0; w < W; ++w) s += base[(w * RS + r) * 256];
+        float s = v[r];
         if constexpr (FMT == MI355_W_Q4) s = cvt2(o.s[r], p.sz_dtype) * (s - (128.f + cvt2(o.z[r], p.sz_dtype)) * sx);
         v[r] = s * rinv;
     }
@@ -442,7 +464,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
 #pragma unroll
             for (int r = 0; r < RS; ++r) pp[r * 64] = acc1;  // zeros
             __syncthreads();
-            if (e_owner) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
+            if (e_owner || (p.M == 1 && threadIdx.x < 256)) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
             tile += nb;
             buf ^= 1;
             load_epi<FMT, R, EPI>(p, tile, e_row, e_col, e_owner, eo);
@@ -509,7 +531,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
                     }
                     if (tile == bid) MI355_STAMP(3);
                     __syncthreads();
-                    if (e_owner) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
+                    if (e_owner || (p.M == 1 && threadIdx.x < 256)) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
                     if (tile == bid) MI355_STAMP(4);
                     tile += nb;
                     buf ^= 1;
