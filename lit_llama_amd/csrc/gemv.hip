@@ -29,7 +29,7 @@ namespace {
 
 constexpr int kUnitK = 128;        // input columns per stream unit
 constexpr int kMaxM = 16;
-constexpr int kLdsHeader = 1024;   // wss[8][16] floats (+pad)
+constexpr int kLdsHeader = 1024;   // wss[16][16] floats
 constexpr int kMaxLds = 160 * 1024;
 
 struct GemvParams {
@@ -350,8 +350,13 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
 
 // EPI is a template parameter so that the SwiGLU pair kernel (c_fc1/c_fc2: the largest launch of a decode
 // step) is its own symbol in profiles, and the epilogue carries no runtime switch.
+// Up to 16 waves (1024 threads) per workgroup for the lean Q4 P=4 variants (<= 128 VGPRs); the register-hungrier
+// ones (deep ring, bf16 weights: 4 pieces per unit) stay at 8 waves.
+template <int FMT, int P>
+constexpr int kMaxThreads = (FMT == MI355_W_Q4 && P <= 4) ? 1024 : 512;
+
 template <int FMT, int R, int P, int EPI, int VMODE>
-__global__ __launch_bounds__(512) void gemv_kernel(const GemvParams p) {
+__global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvParams p) {
     constexpr bool NT = true;  // weights are read once: non-temporal
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* wss = (float*)smem;  // [W][16] per-wave partial sums of x^2 (RMSNorm)
@@ -680,6 +685,7 @@ int launch_gemv_v(const GemvParams& p, int grid, int waves, size_t lds, hipStrea
         mi355_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
+    if (waves * 64 > kMaxThreads<FMT, P>) waves = kMaxThreads<FMT, P> / 64;
     hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE>), dim3(grid), dim3(waves * 64), lds, stream, p);
     MI355_LAUNCH_CHECK();
     return 0;
@@ -862,7 +868,8 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     p.xs_stride = p.units * kUnitK * 2 + 16;
     p.eps = a->eps;
     int waves = a->waves > 0 ? a->waves : 8;
-    if (waves > 8) waves = 8;
+    if (waves > 16) waves = 16;
+    if (!(a->fmt == MI355_W_Q4 && a->prefetch < 8) && waves > 8) waves = 8;  // see kMaxThreads
     if (waves < 4) waves = 4;  // the combine step needs 256 owner threads
     {
         const int esz = a->x_dtype == MI355_F32 ? 4 : 2;

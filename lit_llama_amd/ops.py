@@ -25,7 +25,7 @@ def fast_linear_max_m(K: int, R: int, fmt: int = W_Q4, waves: int = 8) -> int:
         fixed = 512 + 2 * waves * R * 1024 + kp * 2 + 16
         per_m = (kp + 16) + kp * 2
     else:
-        fixed = 1024 + 2 * waves * (R + 1) * 1024
+        fixed = 1024 + 2 * max(waves, 8) * (R + 1) * 1024
         per_m = kp * 2 + 16
     return max(0, min(MAX_M, (_LDS_BUDGET - fixed) // per_m))
 
