@@ -196,17 +196,18 @@ def main():
         eng.stream.synchronize()
         t_prefill = time.perf_counter() - t_pf0
         pos = T
+        # same loop as lit_llama_amd.generate._generate_greedy: chained greedy steps, one graph replay per token
+        eng.set_step(None, 1, pos, from_next=True)
+        eng.embed_step()
         for _ in range(W):
-            eng.set_step(None, 1, pos, from_next=True)
-            eng.run_step(True)
+            eng.run_step(3)
             pos += 1
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(K):
-            eng.set_step(None, 1, pos, from_next=True)
-            eng.run_step(True)
+            eng.run_step(3)
             pos += 1
         torch.cuda.synchronize(dev)
         if dist is not None:

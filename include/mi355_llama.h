@@ -330,7 +330,12 @@ int mi355_set_step(const mi355_model* m, const void* idx, int idx_is_i64, int T,
                    mi355_stream_t stream);
 
 /* enqueue one forward over T tokens already placed by mi355_set_step.
- * logits_mode: 0 none, 1 last token only (row 0 of m->logits), 2 all T rows; argmax != 0 appends greedy sampling */
+ * logits_mode: 0 none, 1 last token only (row 0 of m->logits), 2 all T rows.
+ * argmax: bit 0 appends greedy sampling (next_token[0], out_tokens[pos + 1]); bit 1 ("chained", T = 1 only, with
+ * bit 0) additionally skips the embedding at the start -- m->x must already hold the embedding of tokens[0], e.g.
+ * from mi355_forward_embed -- and ends the step by writing tokens[0] = argmax, pos[0] += 1 and the new token's
+ * embedding row into m->x, so consecutive chained steps (or replays of a graph captured with argmax = 3) run
+ * the greedy loop of generate.py:63-91 with no launch between them. */
 int mi355_forward(const mi355_model* m, int T, int logits_mode, int argmax, mi355_stream_t stream);
 
 /* The same forward cut into pieces, for callers that must interleave collectives (tensor parallel):

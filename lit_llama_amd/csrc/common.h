@@ -143,3 +143,66 @@ __device__ __forceinline__ float group_sum(float v, int lpr) {
 
 // silu(a) * b in f32 (F.silu: a * sigmoid(a))
 __device__ __forceinline__ float swiglu_f32(float a, float b) { return (a / (1.0f + expf(-a))) * b; }
+
+// Block-wide index of the first maximum of logits[0..V) (lowest index wins ties, as torch.topk(.., 1) /
+// argmax do on the CPU oracle); every thread gets the result.  An all-NaN row gives 0.
+__device__ inline int block_argmax_first(const float* logits, int V) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    auto upd = [&](float v, int i) {
+        if (v > best || (v == best && i < bi)) {
+            best = v;
+            bi = i;
+        }
+    };
+    if ((V & 3) == 0 && ((uintptr_t)logits & 15) == 0) {
+        // 8 x 16-B loads per thread in flight (a dependent scalar chain took ~14 us for 32000 logits)
+        const int nv = V >> 2;
+        for (int base = 0; base < nv; base += blockDim.x * 8) {
+            f32x4 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = base + u * blockDim.x + threadIdx.x;
+                if (v < nv) r[u] = ((const f32x4*)logits)[v];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = base + u * blockDim.x + threadIdx.x;
+                if (v < nv) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) upd(r[u][q], 4 * v + q);
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < V; i += blockDim.x) upd(logits[i], i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) {
+        sv[wave] = best;
+        si[wave] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+                best = sv[w];
+                bi = si[w];
+            }
+        if (bi == 0x7fffffff) bi = 0;
+        si[0] = bi;
+    }
+    __syncthreads();
+    return si[0];
+}

@@ -31,6 +31,42 @@ __global__ void set_step_kernel(int32_t* tokens, int32_t* pos, const void* idx, 
     }
 }
 
+// Greedy chaining (generate.py:79-85 with top_k = 1, on the device): the step's argmax becomes the next step's
+// token, the position advances, and the next step's embedding row (model.py:102) is written to the residual
+// stream, so a chained graph needs neither a set_step nor an embedding launch between tokens.
+__global__ void argmax_advance_kernel(const float* logits, int V, int32_t* next_token, int32_t* out_tokens,
+                                      int32_t* tokens, int32_t* pos, const void* wte, int w_dtype, float* x, int C) {
+    const int bi = block_argmax_first(logits, V);
+    const int p = pos[0];
+    if (w_dtype == MI355_BF16 && (C & 7) == 0) {
+        const u32x4* src = (const u32x4*)((const bf16_t*)wte + (int64_t)bi * C);
+        f32x4* dst = (f32x4*)x;
+        for (int v = threadIdx.x; v < (C >> 3); v += blockDim.x) {
+            const u32x4 r = src[v];
+            f32x4 a, b;
+            a[0] = __uint_as_float(r[0] << 16);
+            a[1] = __uint_as_float(r[0] & 0xffff0000u);
+            a[2] = __uint_as_float(r[1] << 16);
+            a[3] = __uint_as_float(r[1] & 0xffff0000u);
+            b[0] = __uint_as_float(r[2] << 16);
+            b[1] = __uint_as_float(r[2] & 0xffff0000u);
+            b[2] = __uint_as_float(r[3] << 16);
+            b[3] = __uint_as_float(r[3] & 0xffff0000u);
+            dst[2 * v] = a;
+            dst[2 * v + 1] = b;
+        }
+    } else {
+        for (int k = threadIdx.x; k < C; k += blockDim.x) x[k] = ld_as_f32(wte, (int64_t)bi * C + k, w_dtype);
+    }
+    __syncthreads();  // every thread has read pos[0] before it moves
+    if (threadIdx.x == 0) {
+        next_token[0] = bi;
+        if (out_tokens != nullptr) out_tokens[p + 1] = bi;
+        tokens[0] = bi;
+        pos[0] = p + 1;
+    }
+}
+
 __global__ void add_f32_kernel(float* x, const float* p, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] += p[i];
 }
@@ -106,7 +142,13 @@ extern "C" int mi355_forward(const mi355_model* m, int T, int logits_mode, int a
     hipStream_t s = (hipStream_t)stream;
     const int C = m->n_embd;
 
-    if (int rc = mi355_embedding(m->tokens, 0, m->wte, m->param_dtype, m->x, MI355_F32, T, C, m->vocab, s)) return rc;
+    // argmax bit 1 (chained greedy step): x already holds the embedding of tokens[0], written by the previous
+    // step's argmax_advance_kernel (or by mi355_forward_embed before the first chained step)
+    MI355_CHECK_ARG(!(argmax & 2) || (T == 1 && logits_mode == 1 && (argmax & 1)), MI355_E_ARG,
+                    "forward: a chained step is T = 1 with last-token logits and argmax");
+    if (!(argmax & 2)) {
+        if (int rc = mi355_embedding(m->tokens, 0, m->wte, m->param_dtype, m->x, MI355_F32, T, C, m->vocab, s)) return rc;
+    }
 
     for (int l = 0; l < m->n_layer; ++l) {
         if (int rc = mi355_forward_segment(m, T, l, 0, 4, s)) return rc;
@@ -220,6 +262,13 @@ extern "C" int mi355_forward_head(const mi355_model* m, int T, int logits_mode, 
         MI355_CHECK_ARG(m->next_token != nullptr, MI355_E_ARG, "forward_head: argmax without next_token slot");
         MI355_CHECK_ARG(m->tp_world <= 1, MI355_E_STATE, "forward_head: argmax over sharded logits is done by the caller");
         const float* row = logits_mode == 1 ? m->logits : m->logits + (size_t)(T - 1) * V;
+        if (argmax & 2) {
+            MI355_CHECK_ARG(T == 1 && m->tokens && m->pos && m->x, MI355_E_ARG, "forward_head: chained step needs T = 1");
+            hipLaunchKernelGGL(argmax_advance_kernel, dim3(1), dim3(1024), 0, s, row, V, m->next_token, m->out_tokens,
+                               m->tokens, m->pos, m->wte, m->param_dtype, m->x, C);
+            MI355_LAUNCH_CHECK();
+            return 0;
+        }
         // generate.py:79,85: the new id lands at position input_pos[-1] + 1
         if (int rc = mi355_argmax(row, V, m->next_token, m->out_tokens, m->out_tokens ? m->pos + (T - 1) : nullptr, s))
             return rc;

@@ -184,60 +184,8 @@ __global__ void embedding_kernel(const void* idx, int idx_is_i64, const void* wt
 
 // first index of the maximum (torch.topk(.., 1) / argmax tie rule is "lowest index" for the CPU oracle)
 __global__ void argmax_kernel(const float* logits, int V, int32_t* out, int32_t* out2, const int32_t* out2_pos) {
-    __shared__ float sv[16];
-    __shared__ int si[16];
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    auto upd = [&](float v, int i) {
-        if (v > best || (v == best && i < bi)) {
-            best = v;
-            bi = i;
-        }
-    };
-    if ((V & 3) == 0 && ((uintptr_t)logits & 15) == 0) {
-        // 8 x 16-B loads per thread in flight (a dependent scalar chain took ~14 us for 32000 logits)
-        const int nv = V >> 2;
-        for (int base = 0; base < nv; base += blockDim.x * 8) {
-            f32x4 r[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int v = base + u * blockDim.x + threadIdx.x;
-                if (v < nv) r[u] = ((const f32x4*)logits)[v];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int v = base + u * blockDim.x + threadIdx.x;
-                if (v < nv) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) upd(r[u][q], 4 * v + q);
-                }
-            }
-        }
-    } else {
-        for (int i = threadIdx.x; i < V; i += blockDim.x) upd(logits[i], i);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) {
-            best = ov;
-            bi = oi;
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (lane == 0) {
-        sv[wave] = best;
-        si[wave] = bi;
-    }
-    __syncthreads();
+    const int bi = block_argmax_first(logits, V);
     if (threadIdx.x == 0) {
-        for (int w = 1; w < nw; ++w)
-            if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
-                best = sv[w];
-                bi = si[w];
-            }
-        if (bi == 0x7fffffff) bi = 0;  // all-NaN row
         out[0] = bi;
         if (out2 != nullptr) out2[out2_pos != nullptr ? out2_pos[0] + 1 : 0] = bi;
     }

@@ -267,8 +267,8 @@ class DecodeEngine:
             return None
         return int(ends[0])
 
-    def step_graph(self, argmax: bool):
-        key = 1 if argmax else 0
+    def step_graph(self, argmax):
+        key = int(argmax)  # 0 logits only, 1 + greedy argmax, 3 chained greedy step (mi355_forward)
         g = self._graphs.get(key)
         if g is None:
             handle = C.c_void_p()
@@ -278,19 +278,25 @@ class DecodeEngine:
             self._graphs[key] = g
         return g
 
-    def _warm_step(self, argmax: bool) -> None:
+    def _warm_step(self, argmax) -> None:
         # one eager pass before the first capture: the launchers set per-kernel attributes
         # (hipFuncSetAttribute) lazily, which must not happen while the stream is capturing.  It recomputes
         # exactly what the captured step will compute again, so the state is unchanged.
-        check(lib().mi355_forward(C.byref(self.m), 1, 1, 1 if argmax else 0, self.stream.cuda_stream),
+        # (A chained step would advance the state, so its warm-up is the plain argmax step: same kernels plus
+        # argmax_advance_kernel, which has no lazily-set attribute.)
+        check(lib().mi355_forward(C.byref(self.m), 1, 1, int(argmax) & 1, self.stream.cuda_stream),
               "mi355_forward (warm-up)")
+        if int(argmax) & 2:
+            self.embed_step()  # the warm-up consumed the residual stream; restore the chained entry state
 
-    def run_step(self, argmax: bool) -> None:
-        """One T = 1 forward on self.stream (tokens / positions already placed by set_step)."""
+    def run_step(self, argmax) -> None:
+        """One T = 1 forward on self.stream (tokens / positions already placed by set_step).  argmax: False/0
+        logits only, True/1 greedy argmax, 3 chained greedy step (needs `embed_step()` before the first one)."""
         s = self.stream.cuda_stream
+        argmax = int(argmax)
         if self.use_graph:
             try:
-                if (1 if argmax else 0) not in self._graphs:
+                if argmax not in self._graphs:
                     self._warm_step(argmax)
                 g = self.step_graph(argmax)
             except nat.NativeError:
@@ -301,7 +307,11 @@ class DecodeEngine:
             if g is not None:
                 check(lib().mi355_graph_launch(g, s), "mi355_graph_launch")
                 return
-        check(lib().mi355_forward(C.byref(self.m), 1, 1, 1 if argmax else 0, s), "mi355_forward")
+        check(lib().mi355_forward(C.byref(self.m), 1, 1, argmax, s), "mi355_forward")
+
+    def embed_step(self) -> None:
+        """Embedding of tokens[0] into the residual stream: the entry state of a chained greedy step."""
+        check(lib().mi355_forward_embed(C.byref(self.m), 1, self.stream.cuda_stream), "mi355_forward_embed")
 
     def set_step(self, idx: Optional[torch.Tensor], T: int, pos0: int, from_next: bool = False) -> None:
         is64 = 1 if (idx is not None and idx.dtype == torch.int64) else 0

@@ -82,10 +82,13 @@ def _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id):
         # prompt: all but the last token without logits, then the last one with logits + argmax
         eng.prefill(idx, 0, all_logits=False, argmax=True)
         done = 1
+        if max_new_tokens > 1:
+            # entry state of the chained steps: token = the prompt's argmax, position T, its embedding in x.
+            # From here every step's last node writes the next token / position / embedding itself.
+            eng.set_step(None, 1, T, from_next=True)
+            eng.embed_step()
         while done < max_new_tokens:
-            # next token id is read from the device slot written by the previous argmax node
-            eng.set_step(None, 1, T + done - 1, from_next=True)
-            eng.run_step(True)
+            eng.run_step(3)
             done += 1
             if eos_id is not None and (done % 16 == 0 or done == max_new_tokens):
                 # bounded-lag EOS check: the reference tests every token (generate.py:88-89) and pays a
