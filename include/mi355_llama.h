@@ -257,6 +257,9 @@ typedef struct mi355_int8_args {
     int64_t ldy;
     int32_t grid;
     int32_t prefetch;
+    uint64_t* debug_stamps; /* optional: uint64 [workgroups][8] wall-clock stamps (100 MHz): 0 entry, 1 ring issued,
+                               2 rows staged (f16 + scales), 3 quantised + outlier list, 4 first tile streamed,
+                               5 first tile stored, 6 exit */
 } mi355_int8_args;
 
 int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream);

@@ -61,6 +61,7 @@ class Int8Args(C.Structure):
         ("threshold", c_float), ("R", c_int32), ("bias", c_void_p), ("bias_dtype", c_int32),
         ("epi", c_int32), ("scb2", c_void_p), ("y", c_void_p), ("y_dtype", c_int32),
         ("waves", c_int32), ("ldy", c_int64), ("grid", c_int32), ("prefetch", c_int32),
+        ("debug_stamps", c_void_p),
     ]
 
 

@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 typedef uint16_t bf16_t;  // raw bf16 bits
 typedef uint16_t f16_t;   // raw f16 bits
@@ -132,6 +133,8 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // this kernel's time.  Only groups wider than a 16-lane row use ds_bpermute for the last step(s).
 #define MI355_DPP_ADD(v, ctrl) \
     ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, false)))
+#define MI355_DPP_MAX(v, ctrl) \
+    fmaxf((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, false)))
 __device__ __forceinline__ float group_sum(float v, int lpr) {
     if (lpr >= 2) v = MI355_DPP_ADD(v, 0xB1);
     if (lpr >= 4) v = MI355_DPP_ADD(v, 0x4E);

@@ -203,12 +203,23 @@ extern "C" int mi355_forward_segment(const mi355_model* m, int T, int layer, int
                 if (int rc = mi355_attention(&a, s)) return rc;
                 break;
             }
-            case 1:
+            case 1: {
+                // the c_proj prologue can combine <= 4 splits of a row that fits one 16-B vector per thread
+                // (mi355_linear_fast); wider shards (13B..65B single GPU) take the stand-alone combine first
+                const int proj_threads = 64 * (L.proj.waves >= 4 && L.proj.waves < 8 ? L.proj.waves : 8);  // lower bound of
+                                                                                             // what the launcher picks
+                const bool fused = split && m->attn_splits <= 4 && Cl / 8 <= proj_threads && Cl % 8 == 0;
+                if (split && !fused) {
+                    if (int rc = mi355_attn_combine(m->attn_part, m->attn_splits, 1, m->n_head, m->hs, m->att, MI355_BF16,
+                                                    Cl, s))
+                        return rc;
+                }
                 if (int rc = run_linear(m, L.proj, m->att, MI355_BF16, T, Cl, nullptr,
                                         tp ? MI355_EPI_STORE : MI355_EPI_ACCUM, tp ? m->partial : m->x, MI355_F32, C, s,
-                                        split ? m->attn_part : nullptr))
+                                        fused ? m->attn_part : nullptr))
                     return rc;
                 break;
+            }
             case 2:
                 if (int rc = run_linear(m, L.fc, m->x, MI355_F32, T, C, L.rms2, MI355_EPI_SWIGLU, m->hbuf, MI355_BF16,
                                         m->n_hidden, s))

@@ -36,26 +36,39 @@ struct I8Params {
     int xq_stride;  // bytes per int8 activation row in LDS
     unsigned w_bytes;  // size of the weight stream (buffer descriptor bound)
     float eps, threshold;
+    uint64_t* dbg;
+    int vec;  // 1: 16-B / 8-B vector staging of x (aligned rows, bf16 norm scale), see mi355_linear_int8
 };
 
 __device__ __forceinline__ float f16r(float v) { return f16_to_f32(f32_to_f16(v)); }
 
-// LDS map: [hdr: red[64] | sca[16] | ocnt[8]] [part 2*W*R KiB] [xq M*xq_stride] [xh M*Kp f16] [olist Kp u16]
-template <int R, int P>
+constexpr int kFastOut = 8;  // outlier columns whose weight bytes are prefetched one tile ahead (registers)
+constexpr int kStageVec = 8;  // 4-column activation vectors a thread keeps in registers (decode: K <= 32 * threads)
+
+// LDS map: [hdr: red[64] | sca[16] | sinv[16] | ototal] [part 2*W*R KiB] [xq M*xq_stride] [xh M*Kp f16]
+//          [olist Kp u16: outlier columns, ascending] [obits Kp/8 B: outlier bit set]
+template <int R, int P, bool VEC>
 __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
     float* sca = (float*)(smem + 256);
-    int* ocnt = (int*)(smem + 320);
+    float* sinv = (float*)(smem + 320);
+    int* ototal = (int*)(smem + 384);
     char* part = smem + kHdr;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = blockDim.x >> 6;
+#define MI355_STAMP(i)                                                                          \
+    do {                                                                                        \
+        if (p.dbg != nullptr && threadIdx.x == 0) p.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+    MI355_STAMP(0);
     const int units = p.units, Kp = units * kUnitK;
     char* xq = part + 2 * W * R * 1024;
     f16_t* xh = (f16_t*)(xq + (size_t)p.M * p.xq_stride);
     uint16_t* olist = (uint16_t*)(xh + (size_t)p.M * Kp);
+    unsigned* obits = (unsigned*)(olist + Kp);
 
     const int u0 = (units * wave) / W, u1 = (units * (wave + 1)) / W;
     const int nu = u1 - u0;
@@ -84,75 +97,287 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
             pf_tile += nb;                                                                                      \
         }                                                                                                       \
     } while (0)
+    // Vector staging: this thread's first activation vectors (and their norm scales) are requested BEFORE the
+    // weight ring, because VMEM returns in order and the prologue must not queue behind ~32 KiB of weights.
+    constexpr int NV = kStageVec;
+    const int nthr = blockDim.x;
+    const int nvecp = Kp >> 2;
+    const bool x32 = p.x_dtype == MI355_F32;
+    // loads go through buffer descriptors: vectors past the row end return zeros without a branch (a
+    // conditional load is a separate basic block and the compiler drains vmcnt at every join)
+    [[maybe_unused]] u32x4 xr[NV];
+    [[maybe_unused]] u32x2 nr[NV];
+    const int x_esz = x32 ? 4 : 2;
+    [[maybe_unused]] auto load_chunk = [&](int m, int c) {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const char*)p.x + (int64_t)m * p.ldx * x_esz), 0, p.K * x_esz, 0x00020000);
+        if (x32) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                xr[i] = __builtin_bit_cast(
+                    u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ((c * NV + i) * nthr + tid) * 16, 0, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const u32x2 t = __builtin_bit_cast(
+                    u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, ((c * NV + i) * nthr + tid) * 8, 0, 0));
+                xr[i] = u32x4{t[0], t[1], 0u, 0u};
+            }
+        }
+    };
+    if constexpr (VEC) {
+        load_chunk(0, 0);
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.norm_scale != nullptr ? p.norm_scale : p.x), 0, p.norm_scale != nullptr ? p.K * 2 : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            nr[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rn, (i * nthr + tid) * 8, 0, 0));
+    }
 #pragma unroll
     for (int j = 0; j < P; ++j) MI355_ISSUE(j);
+    MI355_STAMP(1);
 
     // ---------------- prologue: f16 activations, outlier columns, row scales, int8 quantisation
-    for (int m = 0; m < p.M; ++m) {
-        const int64_t base = (int64_t)m * p.ldx;
-        float rinv = 1.f;
-        if (p.norm_scale != nullptr) {
-            float ss = 0.f;
-            for (int k = tid; k < p.K; k += blockDim.x) {
-                const float v = ld_as_f32(p.x, base + k, p.x_dtype);
-                ss += v * v;
-            }
-            ss = block_sum(ss, red);
-            rinv = rsqrtf(ss / (float)p.K + p.eps);
-        }
-        float amax = 0.f;
-        for (int k = tid; k < Kp; k += blockDim.x) {
-            f16_t h = 0;
-            if (k < p.K) {
-                float v = ld_as_f32(p.x, base + k, p.x_dtype);
-                if (p.norm_scale != nullptr) v = ld_as_f32(p.norm_scale, k, p.norm_dtype) * (v * rinv);
-                h = f32_to_f16(v);
-            }
-            xh[(size_t)m * Kp + k] = h;
-            const float a = fabsf(f16_to_f32(h));
-            if (!(p.threshold > 0.f) || a < p.threshold) amax = fmaxf(amax, a);
-        }
-        amax = block_max(amax, red);
-        if (tid == 0) sca[m] = amax;
-    }
+    // Outlier columns {k : |x[m,k]| >= threshold for some row m} are a bit set in LDS (atomic OR by whichever
+    // thread stages the column; there are only a handful), from which wave 0 later writes the ascending list.
+    for (int i = tid; i < (Kp >> 5); i += nthr) obits[i] = 0u;
+    if (tid == 0) ototal[0] = 0;
     __syncthreads();
-    // outlier columns of this wave's K slice, in ascending k (one ballot per 64 columns)
-    {
-        uint16_t* mylist = olist + u0 * kUnitK;
-        int cnt = 0;
-        if (p.threshold > 0.f) {
-            for (int k0 = u0 * kUnitK; k0 < u1 * kUnitK; k0 += 64) {
-                const int k = k0 + lane;
-                bool out = false;
-                for (int m = 0; m < p.M; ++m) out |= fabsf(f16_to_f32(xh[(size_t)m * Kp + k])) >= p.threshold;
-                const unsigned long long mask = __ballot(out);
-                if (out) mylist[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)k;
-                cnt += __popcll(mask);
+    const bool thr_on = p.threshold > 0.f;
+    // wave reductions: DPP inside 16-lane rows, two ds_bpermute steps across rows; one barrier per block reduction
+    // (alternating scratch slots, so a slot is rewritten only after two later barriers)
+    auto blk_reduce = [&](float v, int slot, bool is_max) -> float {
+        if (is_max) {
+            v = MI355_DPP_MAX(v, 0xB1);
+            v = MI355_DPP_MAX(v, 0x4E);
+            v = MI355_DPP_MAX(v, 0x141);
+            v = MI355_DPP_MAX(v, 0x140);
+            v = fmaxf(v, __shfl_xor(v, 16, 64));
+            v = fmaxf(v, __shfl_xor(v, 32, 64));
+        } else {
+            v = group_sum(v, 64);
+        }
+        float* r = red + slot * 16;
+        if (lane == 0) r[wave] = v;
+        __syncthreads();
+        float t = r[0];
+        for (int w = 1; w < W; ++w) t = is_max ? fmaxf(t, r[w]) : t + r[w];
+        return t;
+    };
+    bool quantised = false;
+    // raw vectors -> f32
+    [[maybe_unused]] auto decode = [&](float (&xf)[NV][4]) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (x32) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xf[i][j] = __uint_as_float(xr[i][j]);
+            } else if (p.x_dtype == MI355_BF16) {
+                xf[i][0] = __uint_as_float(xr[i][0] << 16);
+                xf[i][1] = __uint_as_float(xr[i][0] & 0xffff0000u);
+                xf[i][2] = __uint_as_float(xr[i][1] << 16);
+                xf[i][3] = __uint_as_float(xr[i][1] & 0xffff0000u);
+            } else {
+                xf[i][0] = f16_to_f32((f16_t)(xr[i][0] & 0xffffu));
+                xf[i][1] = f16_to_f32((f16_t)(xr[i][0] >> 16));
+                xf[i][2] = f16_to_f32((f16_t)(xr[i][1] & 0xffffu));
+                xf[i][3] = f16_to_f32((f16_t)(xr[i][1] >> 16));
             }
         }
-        if (lane == 0) ocnt[wave] = cnt;
-    }
-    // quantise: CA[m,k] = rint(x * (127 / SCA[m])), whole outlier columns zeroed
-    for (int k = tid; k < Kp; k += blockDim.x) {
-        bool out = false;
-        if (p.threshold > 0.f)
-            for (int m = 0; m < p.M; ++m) out |= fabsf(f16_to_f32(xh[(size_t)m * Kp + k])) >= p.threshold;
+    };
+    [[maybe_unused]] auto sum_sq = [&](const float (&xf)[NV][4]) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ss += xf[i][j] * xf[i][j];
+        return ss;
+    };
+    // f16 copy of one chunk -> LDS, outlier bits, sub-threshold absmax; hf / outm keep the chunk in registers
+    [[maybe_unused]] auto emit = [&](int m, int c, const float (&xf)[NV][4], float rinv, float& amax,
+                                     float (&hf)[NV][4], unsigned& outm) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = (c * NV + i) * nthr + tid;
+            if (v < nvecp) {
+                uint32_t hb[4];
+                unsigned ob = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float val = xf[i][j];  // zero beyond K (buffer load)
+                    if (p.norm_scale != nullptr) {
+                        const uint32_t w2 = nr[i][j >> 1];
+                        const float sc = __uint_as_float((j & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+                        val = sc * (val * rinv);
+                    }
+                    const f16_t h = f32_to_f16(val);
+                    hb[j] = (uint32_t)h;
+                    const float hv = f16_to_f32(h);
+                    hf[i][j] = hv;
+                    const float a = fabsf(hv);
+                    if (thr_on && a >= p.threshold)
+                        ob |= 1u << j;
+                    else
+                        amax = fmaxf(amax, a);
+                }
+                u32x2 o2;
+                o2[0] = hb[0] | (hb[1] << 16);
+                o2[1] = hb[2] | (hb[3] << 16);
+                *(u32x2*)(xh + (size_t)m * Kp + 4 * (size_t)v) = o2;
+                if (ob != 0u) atomicOr(&obits[v >> 3], ob << ((v & 7) * 4));
+                outm |= ob << (4 * i);
+            }
+        }
+    };
+    if constexpr (VEC) {
+        const int nchunk = (nvecp + NV * nthr - 1) / (NV * nthr);  // 1 whenever a norm scale is fused (host check)
+        if (p.M == 1 && nchunk == 1) {
+            // decode: straight-line code on the vectors requested before the ring (a loop around the loads would
+            // make the compiler wait for the whole ring prefill first), quantised straight from registers
+            float xf[NV][4], hf[NV][4];
+            decode(xf);
+            float rinv = 1.f;
+            if (p.norm_scale != nullptr) rinv = rsqrtf(blk_reduce(sum_sq(xf), 0, false) / (float)p.K + p.eps);
+            float amax = 0.f;
+            unsigned outm = 0u;
+            emit(0, 0, xf, rinv, amax, hf, outm);
+            amax = blk_reduce(amax, 1, true);
+            const float inv = amax > 0.f ? __fdiv_rn(127.0f, amax) : 0.f;  // IEEE division: parity with the oracle
+            if (tid == 0) {
+                sca[0] = amax;
+                sinv[0] = inv;
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int v = i * nthr + tid;
+                if (v < nvecp) {
+                    uint32_t q4 = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float q = ((outm >> (4 * i + j)) & 1u) ? 0.f : rintf(hf[i][j] * inv);
+                        q4 |= ((uint32_t)(int)q & 0xffu) << (j * 8);
+                    }
+                    *(uint32_t*)(xq + 4 * (size_t)v) = q4;
+                }
+            }
+            quantised = true;
+        } else {
+            for (int m = 0; m < p.M; ++m) {
+                float amax = 0.f;
+                for (int c = 0; c < nchunk; ++c) {
+                    if ((m | c) != 0) load_chunk(m, c);
+                    float xf[NV][4], hf[NV][4];
+                    unsigned outm = 0u;
+                    decode(xf);
+                    float rinv = 1.f;
+                    if (p.norm_scale != nullptr)
+                        rinv = rsqrtf(blk_reduce(sum_sq(xf), (2 * m) & 3, false) / (float)p.K + p.eps);
+                    emit(m, c, xf, rinv, amax, hf, outm);
+                }
+                amax = blk_reduce(amax, (2 * m + 1) & 3, true);
+                if (tid == 0) {
+                    sca[m] = amax;
+                    sinv[m] = amax > 0.f ? __fdiv_rn(127.0f, amax) : 0.f;
+                }
+            }
+        }
+    } else {
         for (int m = 0; m < p.M; ++m) {
-            const float s = sca[m];
-            const float inv = s > 0.f ? __fdiv_rn(127.0f, s) : 0.f;  // IEEE division: bit parity with the oracle
-            const float q = out ? 0.f : rintf(f16_to_f32(xh[(size_t)m * Kp + k]) * inv);
-            ((int8_t*)(xq + (size_t)m * p.xq_stride))[k] = (int8_t)q;
+            const int64_t base = (int64_t)m * p.ldx;
+            float rinv = 1.f;
+            if (p.norm_scale != nullptr) {
+                float ss = 0.f;
+                for (int k = tid; k < p.K; k += blockDim.x) {
+                    const float v = ld_as_f32(p.x, base + k, p.x_dtype);
+                    ss += v * v;
+                }
+                ss = blk_reduce(ss, (2 * m) & 3, false);
+                rinv = rsqrtf(ss / (float)p.K + p.eps);
+            }
+            float amax = 0.f;
+            for (int k = tid; k < Kp; k += blockDim.x) {
+                f16_t h = 0;
+                if (k < p.K) {
+                    float v = ld_as_f32(p.x, base + k, p.x_dtype);
+                    if (p.norm_scale != nullptr) v = ld_as_f32(p.norm_scale, k, p.norm_dtype) * (v * rinv);
+                    h = f32_to_f16(v);
+                }
+                xh[(size_t)m * Kp + k] = h;
+                const float a = fabsf(f16_to_f32(h));
+                if (thr_on && a >= p.threshold)
+                    atomicOr(&obits[k >> 5], 1u << (k & 31));
+                else
+                    amax = fmaxf(amax, a);
+            }
+            amax = blk_reduce(amax, (2 * m + 1) & 3, true);
+            if (tid == 0) {
+                sca[m] = amax;
+                sinv[m] = amax > 0.f ? __fdiv_rn(127.0f, amax) : 0.f;
+            }
+        }
+    }
+    MI355_STAMP(2);
+    // every atomic OR precedes its thread's last blk_reduce barrier: the bit set is complete here.
+    // Wave 0 writes the ascending outlier list while the other waves quantise.
+    if (wave == 0 && thr_on) {
+        int oc = 0;
+        for (int w0 = 0; w0 < (Kp >> 5); w0 += 64) {
+            const unsigned word = (w0 + lane < (Kp >> 5)) ? obits[w0 + lane] : 0u;
+            unsigned long long live = __ballot(word != 0u);
+            while (live != 0ull) {
+                const int src = __builtin_ctzll(live);
+                live &= live - 1ull;
+                unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)word, src);
+                while (bits != 0u) {
+                    const int b = __builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    if (lane == 0) olist[oc] = (uint16_t)(((w0 + src) << 5) + b);
+                    ++oc;
+                }
+            }
+        }
+        if (lane == 0) ototal[0] = oc;
+    }
+    if (!quantised) {
+        // general case (several rows / long rows): 8 columns per thread step from the f16 copy in LDS;
+        // CA[m,k] = rint(x * (127 / SCA[m])), whole outlier columns zeroed
+        __syncthreads();  // sinv of the last row
+        for (int v8 = tid; v8 < (Kp >> 3); v8 += blockDim.x) {
+            const unsigned outm = thr_on ? ((obits[v8 >> 2] >> ((v8 & 3) * 8)) & 0xffu) : 0u;
+            for (int m = 0; m < p.M; ++m) {
+                const u32x4 hh = *(const u32x4*)(xh + (size_t)m * Kp + 8 * (size_t)v8);
+                const float inv = sinv[m];
+                u32x2 q2 = u32x2{0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f16_t h = (f16_t)((hh[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+                    const float q = ((outm >> j) & 1u) ? 0.f : rintf(f16_to_f32(h) * inv);
+                    q2[j >> 2] |= ((uint32_t)(int)q & 0xffu) << ((j & 3) * 8);
+                }
+                *(u32x2*)(xq + (size_t)m * p.xq_stride + 8 * (size_t)v8) = q2;
+            }
         }
     }
     __syncthreads();
+    const int n_out = ototal[0];
+    MI355_STAMP(3);
 
     const int e_row = (tid >> 4) & 15, e_col = tid & 15;
     const bool e_owner = tid < 256 && e_col < p.M;
 
     // epilogue operands of the NEXT tile are fetched one tile ahead and kept as raw bits (see gemv.hip)
-    uint32_t eo_scb[R], eo_bias[R], eo_old[R];
+    uint32_t eo_scb[R], eo_bias[R], eo_old[R], eo_out[R][kFastOut];
 #pragma unroll
-    for (int r = 0; r < R; ++r) eo_scb[r] = eo_bias[r] = eo_old[r] = 0u;
+    for (int r = 0; r < R; ++r) {
+        eo_scb[r] = eo_bias[r] = eo_old[r] = 0u;
+#pragma unroll
+        for (int i = 0; i < kFastOut; ++i) eo_out[r][i] = 0u;
+    }
+    // byte offset of CB[n = row e_row of (tile, r), k] in the weight stream
+    auto w_off = [&](int tile, int r, int k) -> int64_t {
+        const int u = k >> 7, e = (k >> 6) & 1, g = (k >> 4) & 3, j = k & 15;
+        return ((((int64_t)tile * units + u) * R + r) * 2 + e) * 1024 + (g * 16 + e_row) * 16 + j;
+    };
     auto load_epi = [&](int tile) {
         if (e_owner && tile < p.n_tiles) {
             const bool sw = p.epi == MI355_EPI_SWIGLU;
@@ -160,6 +385,9 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
             for (int r = 0; r < R; ++r) {
                 const int n = sw ? tile * 16 + e_row : (tile * R + r) * 16 + e_row;
                 if (n < p.N) {
+#pragma unroll
+                    for (int i = 0; i < kFastOut; ++i)
+                        if (i < n_out) eo_out[r][i] = (uint32_t)p.w[w_off(tile, r, olist[i])];
                     eo_scb[r] = ((const uint32_t*)((sw && r == 1) ? p.scb2 : p.scb))[n];
                     if (!sw) {
                         if (p.bias != nullptr)
@@ -200,21 +428,20 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
             d = f16r(d);
             // mixed-precision decomposition: outlier columns in f16, ascending k
             float o = 0.f;
-            bool any = false;
-            for (int w = 0; w < W; ++w) {
-                const int wu0 = (units * w) / W;
-                const uint16_t* lst = olist + wu0 * kUnitK;
-                const int c = ocnt[w];
-                for (int i = 0; i < c; ++i) {
-                    const int k = lst[i];
-                    const int u = k >> 7, e = (k >> 6) & 1, g = (k >> 4) & 3, j = k & 15;
-                    const int64_t off =
-                        ((((int64_t)tile * units + u) * R + r) * 2 + e) * 1024 + (g * 16 + e_row) * 16 + j;
-                    const float cb = (float)(int8_t)p.w[off];
+            const bool any = n_out > 0;
+#pragma unroll
+            for (int i = 0; i < kFastOut; ++i) {
+                if (i < n_out) {
+                    const float cb = (float)(int8_t)eo_out[r][i];
                     const float sub = f16r(__fdiv_rn(cb * scb, 127.0f));
-                    o += f16_to_f32(xh[(size_t)e_col * Kp + k]) * sub;
-                    any = true;
+                    o += f16_to_f32(xh[(size_t)e_col * Kp + olist[i]]) * sub;
                 }
+            }
+            for (int i = kFastOut; i < n_out; ++i) {  // rare: more outlier columns than prefetch registers
+                const int k = olist[i];
+                const float cb = (float)(int8_t)p.w[w_off(tile, r, k)];
+                const float sub = f16r(__fdiv_rn(cb * scb, 127.0f));
+                o += f16_to_f32(xh[(size_t)e_col * Kp + k]) * sub;
             }
             if (any) d = f16r(d + f16r(o));
             v[r] = d;
@@ -281,8 +508,10 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
                         pp[r * 64] = acc[r];
                         acc[r] = i32x4{0, 0, 0, 0};
                     }
+                    if (tile == bid) MI355_STAMP(4);
                     __syncthreads();
                     if (e_owner) epilogue(tile, buf);
+                    if (tile == bid) MI355_STAMP(5);
                     tile += nb;
                     buf ^= 1;
                     load_epi(tile);
@@ -291,7 +520,9 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
             MI355_ISSUE(j);
         }
     }
+    MI355_STAMP(6);
 #undef MI355_ISSUE
+#undef MI355_STAMP
 }
 
 // bnb.functional.double_quant(W) rows: SCB[n] = max_k |f16(W[n,k])|, CB = rint(w * (127 / SCB))
@@ -310,21 +541,26 @@ __global__ void int8_quant_rows_kernel(const void* w, int dtype, int K, int8_t* 
     }
 }
 
-template <int R, int P>
-int launch_i8(const I8Params& p, int grid, int waves, size_t lds, hipStream_t stream) {
+template <int R, int P, bool VEC>
+int launch_i8v(const I8Params& p, int grid, int waves, size_t lds, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)int8_gemv_kernel<R, P>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kMaxLds);
+        attr_err = hipFuncSetAttribute((const void*)int8_gemv_kernel<R, P, VEC>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     });
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    hipLaunchKernelGGL((int8_gemv_kernel<R, P>), dim3(grid), dim3(waves * 64), lds, stream, p);
+    hipLaunchKernelGGL((int8_gemv_kernel<R, P, VEC>), dim3(grid), dim3(waves * 64), lds, stream, p);
     MI355_LAUNCH_CHECK();
     return 0;
+}
+
+template <int R, int P>
+int launch_i8(const I8Params& p, int grid, int waves, size_t lds, hipStream_t stream) {
+    return p.vec ? launch_i8v<R, P, true>(p, grid, waves, lds, stream) : launch_i8v<R, P, false>(p, grid, waves, lds, stream);
 }
 
 }  // namespace
@@ -373,6 +609,7 @@ extern "C" int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream
     p.xq_stride = Kp + 16;
     p.eps = a->eps;
     p.threshold = a->threshold;
+    p.dbg = a->debug_stamps;
     {
         const size_t wb = mi355_packed_bytes(MI355_W_I8, a->N, a->K, a->R, swiglu ? 1 : 0);
         MI355_CHECK_ARG(wb > 0 && wb < 0xFFFFFFF0ull, MI355_E_SHAPE, "linear_int8: weight stream of %zu B exceeds 4 GiB", wb);
@@ -382,15 +619,26 @@ extern "C" int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream
     int waves = a->waves > 0 ? a->waves : 8;
     if (waves > 8) waves = 8;
     if (waves < 4) waves = 4;
+    {
+        // vector staging: 4 columns per load (16 B of f32 / 8 B of bf16, f16), rows aligned accordingly; with a
+        // fused norm the whole row must sit in one register chunk (kStageVec vectors per thread) and the scale be bf16
+        const int esz = a->x_dtype == MI355_F32 ? 4 : 2;
+        const uintptr_t al = esz == 4 ? 16 : 8;
+        bool ok = a->K % 4 == 0 && (uintptr_t)a->x % al == 0 && (a->M == 1 || (a->ldx * esz) % al == 0);
+        if (a->norm_scale != nullptr)
+            ok = ok && a->norm_dtype == MI355_BF16 && (uintptr_t)a->norm_scale % 8 == 0 && Kp / 4 <= kStageVec * waves * 64;
+        p.vec = ok ? 1 : 0;
+    }
     const size_t lds = kHdr + (size_t)2 * waves * a->R * 1024 + (size_t)a->M * p.xq_stride + (size_t)a->M * Kp * 2 +
-                       (size_t)Kp * 2 + 16;
+                       (size_t)Kp * 2 + (size_t)Kp / 8 + 16;
     MI355_CHECK_ARG(lds <= (size_t)kMaxLds, MI355_E_SHAPE,
                     "linear_int8: M=%d x K=%d activations do not fit LDS (%zu B); chunk M", a->M, a->K, lds);
     int grid = a->grid;
     if (grid <= 0) grid = (mi355_num_cus() > 0 ? mi355_num_cus() : 256) * 2;
     if (grid > p.n_tiles) grid = p.n_tiles;
     hipStream_t s = (hipStream_t)stream;
-    const bool deep = a->prefetch >= 4;
+    // ring depth: 4 units in flight per wave measured best for single matrices, 2 for the c_fc1/c_fc2 pair
+    const bool deep = a->prefetch > 0 ? a->prefetch >= 4 : a->R == 1;
     if (a->R == 1) return deep ? launch_i8<1, 4>(p, grid, waves, lds, s) : launch_i8<1, 2>(p, grid, waves, lds, s);
     return deep ? launch_i8<2, 4>(p, grid, waves, lds, s) : launch_i8<2, 2>(p, grid, waves, lds, s);
 }

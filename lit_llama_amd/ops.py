@@ -22,7 +22,7 @@ def fast_linear_max_m(K: int, R: int, fmt: int = W_Q4, waves: int = 8) -> int:
     """Largest M whose staged activations fit the 160 KiB LDS of one workgroup (see gemv.hip)."""
     kp = (K + 127) // 128 * 128
     if fmt == W_I8:
-        fixed = 512 + 2 * waves * R * 1024 + kp * 2 + 16
+        fixed = 512 + 2 * waves * R * 1024 + kp * 2 + kp // 8 + 16
         per_m = (kp + 16) + kp * 2
     else:
         fixed = 1024 + 2 * max(waves, 8) * (R + 1) * 1024
