@@ -241,8 +241,11 @@ def main():
             traffic = json.loads(pmc.read_text()).get("fc_swiglu_bytes_per_launch")
         except Exception:
             traffic = None
+    default_cfg = args.model == "7B" and args.quantize == "gptq.int4"
+    cfg_idx = {"none": 1, "gptq.int4": 2, "llm.int8": 3}[args.quantize] if args.model == "7B" else None
+    wname = {"gptq.int4": "int4", "llm.int8": "int8", "none": "bf16"}[args.quantize]
     out = {
-        "metric": METRIC,
+        "metric": METRIC if default_cfg else f"decode tokens/sec/GPU LLaMA-{args.model} {args.quantize} bs=1; % HBM roofline",
         "value": round(tok_s_gpu * world, 2),
         "unit": "tokens/s",
         "n_gpus": world,
@@ -255,7 +258,9 @@ def main():
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": f"LLaMA-{args.model} {args.quantize} bs=1 greedy decode (configs[2]), random-init weights, "
+            "workload": f"LLaMA-{args.model} {args.quantize} bs=1 greedy decode "
+                        + (f"(configs[{cfg_idx}]), " if cfg_idx is not None else "(single GPU, not a BASELINE config), ")
+                        + "random-init weights, "
                         f"prompt {T} tokens, positions {T + W}..{T + W + K - 1}",
             "prompt_len": T,
             "max_seq_length": S,
@@ -265,12 +270,13 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "gemv_kernel<Q4,R=2,SwiGLU> (c_fc1/c_fc2 pair)" if args.quantize == "gptq.int4" else "fc pair",
+            "kernel": {"gptq.int4": "gemv_kernel<Q4,R=2,SwiGLU>", "none": "gemv_kernel<BF16,R=2,SwiGLU>",
+                       "llm.int8": "int8_gemv_kernel<R=2>"}[args.quantize] + " (c_fc1/c_fc2 pair)",
             "achieved": round(algo / avg_s / 1e9, 1),
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
             "frac": round(algo / avg_s / HBM_PEAK, 4),
-            "traffic": traffic,
+            "traffic": traffic if default_cfg else None,
             "algorithmic_bytes_per_launch": algo,
             "avg_launch_us": round(avg_s * 1e6, 2),
             "median_launch_us": round(med_s * 1e6, 2),
@@ -279,7 +285,7 @@ def main():
             "bytes_per_token_weights": bpt["weights"],
             "bytes_per_token_total": bpt["total"] + int(bpt["kv_per_pos"] * (mean_pos + 2)),
             "tokens_per_s_at_100pct": round(HBM_PEAK / bpt["weights"], 1),
-            "frac_of_int4_weight_roofline": round(tok_s_gpu * bpt["weights"] / HBM_PEAK, 4),
+            f"frac_of_{wname}_weight_roofline": round(tok_s_gpu * bpt["weights"] / HBM_PEAK, 4),
         },
         "prefill_s": round(t_prefill, 4),
     }

@@ -165,35 +165,53 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     const int li = lane % LPR, lr = lane / LPR;
     const int stride = nw * rpw;
 
-    // ---- first batch of K/V rows: in flight while q is prepared
-    u32x4 kr[U], vr[U];
-    if (vec_ok) {
-        const int s0 = s_begin + wave * rpw + lr;
+    // ---- K/V rows stream through two register batches (A, B) of U row groups per wave: while one batch is
+    // reduced the other one (and the refill of the first) is in flight, so a long context keeps ~2 x 16 KiB per
+    // wave outstanding instead of paying the full HBM latency once per batch.  Loads go through buffer
+    // descriptors bounded at this split's last row: rows past the end return zeros without a branch (a guarded
+    // load is its own basic block and makes the compiler drain vmcnt at the join).  Both batches are requested
+    // before q is prepared.
+    u32x4 krA[U], vrA[U], krB[U], vrB[U];
+    const __amdgpu_buffer_rsrc_t rk =
+        __builtin_amdgcn_make_buffer_rsrc((void*)kc, 0, vec_ok ? s_end * row_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv =
+        __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, vec_ok ? s_end * row_bytes : 0, 0x00020000);
+    auto issue = [&](u32x4 (&kr)[U], u32x4 (&vr)[U], int base) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int s = s0 + u * stride;
-            if (s < s_end) {
-                kr[u] = *(const u32x4*)((const char*)kc + (int64_t)s * row_bytes + li * 16);
-                vr[u] = *(const u32x4*)((const char*)vc + (int64_t)s * row_bytes + li * 16);
-            }
+            const int s = base + wave * rpw + lr + u * stride;
+            const unsigned off = s < s_end ? (unsigned)s * (unsigned)row_bytes + (unsigned)li * 16u : 0xFFFFFFF0u;
+            kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+            vr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
         }
-    }
+    };
+    // A split whose rows fit one batch (every decode step of a short context) takes a straight-line path with
+    // half the load instructions; the choice is made once, around the whole staging + reduction code, so that the
+    // compiler's vmcnt bookkeeping in the long loop never has to cover "batch B was not requested".
+    const int bstep = stride * U;
+    const bool one_batch = s_begin + bstep >= s_end;
 
-    MI355_STAMP(1);
     // ---- q (and, fused, the new k / v row) through RoPE into LDS
     const int rrow = p.rope_gathered ? t : pos;
-    if (p.qkv_dtype == MI355_F32 && half <= (int)blockDim.x && hs <= (int)blockDim.x) {
-        // engine path: every load of the prologue is issued before the first use (the generic path below waits
-        // after each dtype-switched element load: ~6 dependent L2-miss round trips, 4 us of a 9 us launch)
-        const float* qrow = (const float*)p.qkv + row;
-        float2 qv = {0.f, 0.f}, kv = {0.f, 0.f}, cs = {0.f, 0.f};
-        float vv = 0.f;
-        if (tid < half) {
-            qv = *(const float2*)(qrow + h * hs + 2 * tid);
-            cs = *(const float2*)(p.rope + ((int64_t)rrow * half + tid) * 2);
-            if (own_cur) kv = *(const float2*)(qrow + C + h * hs + 2 * tid);
+    // engine path (f32 qkv): the few q / rope / new-k / new-v loads are requested FIRST, unconditionally (clamped
+    // indices, no branch -> no wait at a join), then the K/V batches; VMEM returns in order, so q is staged while
+    // the rows are still in flight instead of queueing behind them
+    const bool fastq = p.qkv_dtype == MI355_F32 && half <= (int)blockDim.x && hs <= (int)blockDim.x;
+    float2 qv = {0.f, 0.f}, kv = {0.f, 0.f}, cs = {0.f, 0.f};
+    float vv = 0.f;
+    auto q_load = [&]() {
+        if (fastq) {
+            const float* qrow = (const float*)p.qkv + row;
+            const int pt = tid < half ? tid : 0, dt = tid < hs ? tid : 0;
+            qv = *(const float2*)(qrow + h * hs + 2 * pt);
+            cs = *(const float2*)(p.rope + ((int64_t)rrow * half + pt) * 2);
+            kv = *(const float2*)(qrow + (own_cur ? C : 0) + h * hs + 2 * pt);
+            vv = qrow[(own_cur ? 2 * C : 0) + h * hs + dt];
         }
-        if (own_cur && tid < hs) vv = qrow[2 * C + h * hs + tid];
+    };
+    auto stage_q = [&]() {
+    MI355_STAMP(1);
+    if (fastq) {
         if (tid < half) {
             qs[2 * tid] = qv.x * cs.x - qv.y * cs.y;
             qs[2 * tid + 1] = qv.y * cs.x + qv.x * cs.y;
@@ -241,20 +259,22 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     }
     __syncthreads();
     MI355_STAMP(2);
+    };  // stage_q
 
     if (vec_ok) {
-        float qf[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) qf[j] = qs[li * VEC + j];
-        float m_run = kNegBig, l_run = 0.f, of[VEC];
+        float qf[VEC], m_run = kNegBig, l_run = 0.f, of[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) of[j] = 0.f;
-        // wave-uniform trip count: the shuffles below need every lane of a row group in the loop
-        for (int base = s_begin; base < s_end; base += stride * U) {
+        auto load_q = [&]() {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) qf[j] = qs[li * VEC + j];
+        };
+        // one batch: all U partial dot products first, then the U lane-group reductions (independent ->
+        // interleaved), then the sequential online-softmax updates.  Steps whose rows are all past the end are
+        // skipped with a wave-uniform test (a 150-row context over 4 splits uses 3 of the 8 steps); the
+        // shuffles need every lane of a row group, so every test here is wave-uniform.
+        auto process = [&](const u32x4 (&kr)[U], const u32x4 (&vr)[U], int base) {
             const int s0 = base + wave * rpw + lr;
-            // all U partial dot products first, then the U lane-group reductions (independent -> interleaved),
-            // then the sequential online-softmax updates.  Steps whose rows are all past the end are skipped
-            // with a wave-uniform test (a 150-row context over 4 splits uses 3 of the 8 steps).
             const int sw0 = base + wave * rpw;  // first row of this wave's step 0
             float dots[U];
 #pragma unroll
@@ -293,15 +313,24 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
                 for (int j = 0; j < VEC; ++j) of[j] = of[j] * corr + pr * vf[j];
                 m_run = m_new;
             }
-            // next batch (only long contexts get here)
-            const int n0 = s0 + stride * U;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int s = n0 + u * stride;
-                if (s < s_end) {
-                    kr[u] = *(const u32x4*)((const char*)kc + (int64_t)s * row_bytes + li * 16);
-                    vr[u] = *(const u32x4*)((const char*)vc + (int64_t)s * row_bytes + li * 16);
-                }
+        };
+        if (one_batch) {
+            q_load();
+            issue(krA, vrA, s_begin);
+            stage_q();
+            load_q();
+            process(krA, vrA, s_begin);
+        } else {
+            q_load();
+            issue(krA, vrA, s_begin);
+            issue(krB, vrB, s_begin + bstep);
+            stage_q();
+            load_q();
+            for (int base = s_begin; base < s_end; base += 2 * bstep) {
+                process(krA, vrA, base);
+                issue(krA, vrA, base + 2 * bstep);
+                if (base + bstep < s_end) process(krB, vrB, base + bstep);
+                issue(krB, vrB, base + 3 * bstep);
             }
         }
         // merge the rpw row groups of the wave (lanes with equal li)
@@ -323,6 +352,8 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
             }
         }
     } else {
+        q_load();
+        stage_q();
         // odd head sizes (tiny test models): one row per wave step, lanes stride the head dimension
         float m_run = kNegBig, l_run = 0.f;
         float oacc[4] = {0.f, 0.f, 0.f, 0.f};  // d = lane + 64 j, hs <= 256

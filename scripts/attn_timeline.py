@@ -11,9 +11,16 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from lit_llama_amd import _native as nat  # noqa: E402
 from oracle import oracle  # noqa: E402
 
+import argparse  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--S", type=int, default=401)
+ap.add_argument("--pos", default="150,399")
+ap.add_argument("--splits", default="1,2,4,8")
+cli = ap.parse_args()
 NAMES = ["entry", "kv issued", "q staged", "rows done", "exit"]
 dev = torch.device("cuda:0")
-n_head, hs, S = 32, 128, 401
+n_head, hs, S = 32, 128, cli.S
 C_ = n_head * hs
 gen = torch.Generator(device=dev).manual_seed(0)
 rope = oracle.build_rope_cache(2048, hs, dtype=torch.int64).to(dev)
@@ -22,9 +29,9 @@ ks = [torch.randn((1, n_head, S, hs), generator=gen, device=dev).to(torch.bfloat
 vs = [torch.randn((1, n_head, S, hs), generator=gen, device=dev).to(torch.bfloat16) for _ in range(L)]
 qkv = torch.randn((1, 1, 3 * C_), generator=gen, device=dev)
 y = torch.zeros((1, 1, C_), dtype=torch.bfloat16, device=dev)
-for pos_v in (150, 399):
+for pos_v in [int(v) for v in cli.pos.split(",")]:
     pos = torch.tensor([pos_v], dtype=torch.int32, device=dev)
-    for ns in (1, 2, 4, 8):
+    for ns in [int(v) for v in cli.splits.split(",")]:
         parts = torch.zeros((1, n_head, ns, hs + 4), dtype=torch.float32, device=dev)
         nblk = n_head * ns
         stamps = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)

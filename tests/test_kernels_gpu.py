@@ -384,7 +384,8 @@ def test_int8_weight_quantisation_is_bit_exact(dev):
 
 
 @pytest.mark.parametrize("N,K,M,R,outliers", [(64, 128, 1, 1, 0), (96, 512, 3, 2, 2), (4096, 4096, 1, 1, 5),
-                                              (4096, 11008, 2, 1, 7), (40, 200, 2, 1, 1)])
+                                              (4096, 11008, 2, 1, 7), (40, 200, 2, 1, 1),
+                                              (256, 4096, 1, 1, 12), (128, 11008, 1, 2, 3)])
 def test_int8_linear_matches_oracle(dev, N, K, M, R, outliers):
     gen = torch.Generator().manual_seed(N + K)
     w = torch.randn((N, K), generator=gen) * K**-0.5

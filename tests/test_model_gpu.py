@@ -186,6 +186,27 @@ def test_engine_graph_equals_eager_and_module_path(dev, golden):
         assert int(fast_c[T + j]) == int(slow_logits[j]) or g["margin"][j] <= 0.1 * std
 
 
+def test_engine_attention_split_variants_agree(dev, golden):
+    """1 / 4 (fused into the c_proj prologue) / 8 (stand-alone combine: the path wide single-GPU shards take)
+    K/V splits per head compute the same attention; logits agree to the bf16-path tolerance."""
+    from lit_llama_amd.engine import DecodeEngine
+
+    g = golden("cfg1_int4")
+    T, S = int(g["prompt_len"]), int(g["max_seq_length"])
+    toks = _t(g["tokens"]).to(dev)
+    model, _, _ = build(CFG1, "gptq.int4", torch.bfloat16, dev)
+    std = float(g["std"].mean())
+    ref = None
+    for splits in (4, 1, 8):
+        model._engine = DecodeEngine(model, tune={"attn_splits": splits})
+        lg = teacher_forced(model, toks, T, S, dev)
+        if ref is None:
+            ref = lg
+        else:
+            assert (lg - ref).abs().max().item() <= 0.02 * std, f"attn_splits={splits}"
+    model._engine = None
+
+
 def test_generate_api_sampling_and_eos(dev):
     model, _, cfg = build(CFG1, "gptq.int4", torch.bfloat16, dev)
     prompt = synth.make_prompt(6).to(dev)
