@@ -146,7 +146,13 @@ class DecodeEngine:
             # multiple of the CU count keep every CU equally busy (7B: c_attn 768 tiles = 3 per CU, c_proj /
             # mlp.c_proj 256 = 1 per CU, lm_head 2000 = 7.8); the c_fc1/c_fc2 pair is 688 tiles (2.7 per CU).
             cus = nat.num_cus() or 256
-            dflt = lambda key: {"grid": cus, **self.tune.get(key, {})}  # noqa: E731
+            # Measured (scripts/sweep_gemv.py, 7B shapes): one workgroup per CU is best for c_proj / the fc pair /
+            # mlp.c_proj; the single-matrix STORE launches with several tiles per CU (c_attn 9.6 -> 9.2 us, lm_head
+            # 18.8 -> 16.4 us) prefer two.
+            # The LLM.int8 launches (heavier quantising prologue) stay at one per CU: 449 vs 423 tok/s.
+            i8 = _kind(first.attn.c_attn) == "i8"
+            grids = {} if i8 else {"attn": 2 * cus, "lm_head": 2 * cus}
+            dflt = lambda key: {"grid": grids.get(key, cus), **self.tune.get(key, {})}  # noqa: E731
             for i, blk in enumerate(model.transformer.h):
                 attn = pack_linear(blk.attn.c_attn, 1, tune=dflt("attn"))
                 proj = pack_linear(blk.attn.c_proj, 1, tune=dflt("proj"))

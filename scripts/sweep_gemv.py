@@ -23,6 +23,8 @@ SHAPES_7B = {
     "fc": (11008, 4096, 2, nat.EPI_SWIGLU),
     "mproj": (4096, 11008, 1, nat.EPI_ACCUM),
     "lm_head": (32000, 4096, 2, nat.EPI_STORE),
+    "attn1": (12288, 4096, 1, nat.EPI_STORE),
+    "lm_head1": (32000, 4096, 1, nat.EPI_STORE),
 }
 
 
