@@ -266,7 +266,7 @@ def main():
             "max_seq_length": S,
             "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (bs=1 path does not shard)",
             "hipgraph": bool(eng.use_graph and eng._graphs),
-            "launches_per_token": cfg.n_layer * 5 + 3,
+            "launches_per_token": cfg.n_layer * 5 + 2,
         },
         "roofline": {
             "bound": "hbm",
