@@ -423,11 +423,9 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
         }                                                                                                       \
     } while (0)
 
-#pragma unroll
-    for (int j = 0; j < P; ++j) MI355_ISSUE(j);
-    MI355_STAMP(1);
-
-    // ---- per-tile epilogue operands, fetched one tile ahead (threads < 256 own output (row, col))
+    // ---- per-tile epilogue operands, fetched one tile ahead (threads < 256 own output (row, col)).  The first
+    // tile's are requested BEFORE the ring: they sit in a divergent branch, so hipcc cannot count them, and a wait
+    // for the activation loads then also waits for as many of the OLDEST later loads — which must not be weights.
     const int e_row = (threadIdx.x >> 4) & 15, e_col = threadIdx.x & 15;
     const bool e_owner = threadIdx.x < 256 && e_col < p.M;
     EpiOps<R> eo;
@@ -435,9 +433,15 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
     for (int r = 0; r < R; ++r) eo.s[r] = eo.z[r] = eo.bias[r] = eo.old[r] = 0u;
     load_epi<FMT, R, EPI>(p, bid, e_row, e_col, e_owner, eo);
 
-    // ---- stage the activation rows; per-wave partial sums of squares ride along (no extra barrier)
-    for (int m = p.stage_first ? 1 : 0; m < p.M; ++m) {
-        if (m > 0) stager.load(p, m);
+#pragma unroll
+    for (int j = 0; j < P; ++j) MI355_ISSUE(j);
+    MI355_STAMP(1);
+
+    // ---- stage the activation rows; per-wave partial sums of squares ride along (no extra barrier).
+    // Row 0 (the only row of a decode step) is staged by straight-line code: inside the loop over rows the loads
+    // of row m + 1 make hipcc wait with vmcnt(0), i.e. for the whole ring prefill (measured: "x staged" moved
+    // from 2.0 to 3.4 us after ring issue and grew with the ring depth).
+    auto stage_row = [&](int m) {
         float ss = stager.store(p, m, xs);
         for (int k = p.K + (int)threadIdx.x; k < p.units * kUnitK; k += blockDim.x)
             ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;  // stream padding
@@ -445,6 +449,11 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
             ss = wave_sum(ss);
             if (lane == 0) wss[wave * 16 + m] = ss;
         }
+    };
+    if (!p.stage_first) stage_row(0);
+    for (int m = 1; m < p.M; ++m) {
+        stager.load(p, m);
+        stage_row(m);
     }
     __syncthreads();
     MI355_STAMP(2);
