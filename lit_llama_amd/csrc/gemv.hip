@@ -101,7 +101,8 @@ __device__ __forceinline__ u32x4 ldw(const uint8_t* p) {
 //     of HBM weight traffic per wave would only be usable when that traffic has landed.
 // Vectorised modes (p.vec_mode, chosen on the host; all need K % 8 == 0 and 16-B aligned rows):
 //   1: x f32 with a bf16 norm scale, <= 2 x 8 elements per thread      (decode: c_attn, c_fc1/c_fc2, lm_head)
-//   2: x bf16, no norm, <= 4 x 8 elements per thread                   (decode: mlp.c_proj; attn.c_proj unsplit)
+//   4: the same with <= 4 x 8 elements per thread                      (n_embd 5120 .. 8192: 13B .. 65B)
+//   2: x bf16, no norm, <= 6 x 8 elements per thread                   (decode: mlp.c_proj; attn.c_proj unsplit)
 //   3: x = combine of split-attention partial records, <= 8 elements per thread, <= 4 splits   (attn.c_proj)
 //   0: any dtype / shape, element loop.
 template <int VMODE>
@@ -128,15 +129,15 @@ struct Stager<0> {  // element loop, any dtype
     }
 };
 
-template <>
-struct Stager<1> {  // f32 row, bf16 norm scale, <= 2 x 8 elements per thread
-    f32x4 xa[2], xb[2];
-    u32x4 ns[2];
+template <int NC>
+struct StagerF32Norm {  // f32 row, bf16 norm scale, <= NC x 8 elements per thread
+    f32x4 xa[NC], xb[NC];
+    u32x4 ns[NC];
     __device__ __forceinline__ void load(const GemvParams& p, int m) {
         const int tid = threadIdx.x, nt = blockDim.x, nvec = p.K >> 3;
         const float* xrow = (const float*)p.x + (int64_t)m * p.ldx;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int v = tid + c * nt;
             if (v < nvec) {
                 xa[c] = *(const f32x4*)(xrow + v * 8);
@@ -150,7 +151,7 @@ struct Stager<1> {  // f32 row, bf16 norm scale, <= 2 x 8 elements per thread
         char* row = xs + (size_t)m * p.xs_stride;
         float ss = 0.f;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int v = tid + c * nt;
             if (v < nvec) {
                 u32x4 o;
@@ -169,15 +170,19 @@ struct Stager<1> {  // f32 row, bf16 norm scale, <= 2 x 8 elements per thread
         return ss;
     }
 };
+template <>
+struct Stager<1> : StagerF32Norm<2> {};  // n_embd <= 4096 at 512 threads (7B)
+template <>
+struct Stager<4> : StagerF32Norm<4> {};  // n_embd <= 8192 (13B .. 65B)
 
 template <>
-struct Stager<2> {  // bf16 row, no norm, <= 4 x 8 elements per thread
-    u32x4 r[4];
+struct Stager<2> {  // bf16 row, no norm, <= 6 x 8 elements per thread (65B mlp.c_proj: K = 22016)
+    u32x4 r[6];
     __device__ __forceinline__ void load(const GemvParams& p, int m) {
         const int tid = threadIdx.x, nt = blockDim.x, nvec = p.K >> 3;
         const bf16_t* xrow = (const bf16_t*)p.x + (int64_t)m * p.ldx;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 6; ++c) {
             const int v = tid + c * nt;
             if (v < nvec) r[c] = *(const u32x4*)(xrow + v * 8);
         }
@@ -186,7 +191,7 @@ struct Stager<2> {  // bf16 row, no norm, <= 4 x 8 elements per thread
         const int tid = threadIdx.x, nt = blockDim.x, nvec = p.K >> 3;
         char* row = xs + (size_t)m * p.xs_stride;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 6; ++c) {
             const int v = tid + c * nt;
             if (v < nvec) *(u32x4*)(row + v * 16) = r[c];
         }
@@ -392,7 +397,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
         // keeps the staging off the critical path (the ring then has the whole staging/barrier time to land).
         float ss = stager.store(p, 0, xs);
         for (int k = p.K + (int)threadIdx.x; k < p.units * kUnitK; k += blockDim.x) ((bf16_t*)xs)[k] = 0;
-        if constexpr (VMODE == 0 || VMODE == 1) {
+        if constexpr (VMODE == 0 || VMODE == 1 || VMODE == 4) {
             ss = wave_sum(ss);
             if (lane == 0) wss[wave * 16] = ss;
         }
@@ -445,7 +450,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
         float ss = stager.store(p, m, xs);
         for (int k = p.K + (int)threadIdx.x; k < p.units * kUnitK; k += blockDim.x)
             ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;  // stream padding
-        if constexpr (VMODE == 0 || VMODE == 1) {
+        if constexpr (VMODE == 0 || VMODE == 1 || VMODE == 4) {
             ss = wave_sum(ss);
             if (lane == 0) wss[wave * 16 + m] = ss;
         }
@@ -706,6 +711,9 @@ int launch_gemv_epi(const GemvParams& p, int grid, int waves, size_t lds, hipStr
         case 1:
             if constexpr (EPI != MI355_EPI_ACCUM) return launch_gemv_v<FMT, R, P, EPI, 1>(p, grid, waves, lds, stream);
             break;
+        case 4:
+            if constexpr (EPI != MI355_EPI_ACCUM) return launch_gemv_v<FMT, R, P, EPI, 4>(p, grid, waves, lds, stream);
+            break;
         case 2:
             if constexpr (EPI != MI355_EPI_SWIGLU) return launch_gemv_v<FMT, R, P, EPI, 2>(p, grid, waves, lds, stream);
             break;
@@ -734,13 +742,12 @@ int launch_gemv(const GemvParams& p, int grid, int waves, size_t lds, hipStream_
 }
 
 template <int FMT, int R>
-int dispatch_p(const GemvParams& p, int prefetch, int grid, int waves, size_t lds, hipStream_t s) {
+int dispatch_p(const GemvParams& p, int /*prefetch*/, int grid, int waves, size_t lds, hipStream_t s) {
+    // One ring depth per format: 4 units (Q4) / 2 units (bf16) in flight per wave.  Rings twice as deep were
+    // slower on every 7B shape (the CU's memory pipeline accepts requests in order, so a longer prefill only
+    // delays the activation loads; scripts/sweep_gemv.py) and doubled the code size; `prefetch` is accepted and
+    // ignored.
     constexpr int PA = FMT == MI355_W_Q4 ? 4 : 2;
-    constexpr int PB = FMT == MI355_W_Q4 ? 8 : 4;
-    if (prefetch >= PB) {
-        // BF16 R=2 at 4 units x 8 pieces would need 128 VGPRs of ring alone; cap at the shallow ring
-        if constexpr (!(FMT == MI355_W_BF16 && R == 2)) return launch_gemv<FMT, R, PB>(p, grid, waves, lds, s);
-    }
     return launch_gemv<FMT, R, PA>(p, grid, waves, lds, s);
 }
 
@@ -886,9 +893,9 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
         p.vec_mode = 0;
         const int nvec = a->K / 8, nthr = waves * 64;
         if (aligned && a->norm_scale != nullptr && a->x_dtype == MI355_F32 && a->norm_dtype == MI355_BF16 &&
-            (uintptr_t)a->norm_scale % 16 == 0 && nvec <= 2 * nthr)
-            p.vec_mode = 1;
-        else if (aligned && a->norm_scale == nullptr && a->x_dtype == MI355_BF16 && nvec <= 4 * nthr)
+            (uintptr_t)a->norm_scale % 16 == 0 && nvec <= 4 * nthr)
+            p.vec_mode = nvec <= 2 * nthr ? 1 : 4;
+        else if (aligned && a->norm_scale == nullptr && a->x_dtype == MI355_BF16 && nvec <= 6 * nthr)
             p.vec_mode = 2;
         if (a->attn_partials != nullptr) {
             MI355_CHECK_ARG(a->attn_splits <= 4 && nvec <= nthr && ((uintptr_t)a->attn_partials % 16) == 0,

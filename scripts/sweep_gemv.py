@@ -53,9 +53,9 @@ def main():
         out = torch.zeros((1, N), device=dev, dtype=torch.float32 if epi != nat.EPI_SWIGLU else torch.bfloat16)
         n_tiles = (N + (16 if pair else 16 * R) - 1) // (16 if pair else 16 * R)
         grids = sorted({g for g in (n_tiles, cus, 2 * cus, 3 * cus, 4 * cus, 8 * cus) if g <= n_tiles})
-        waves_l, pf_l, nt_l = (8, 16), (4, 8), (0,)
+        waves_l, pf_l, nt_l = (8, 16), (4,), (0,)
         if args.quick:
-            grids, waves_l, pf_l, nt_l = [g for g in grids if g in (cus, 2 * cus)] or grids[-1:], (8, 16), (4, 8), (0,)
+            grids, waves_l, pf_l, nt_l = [g for g in grids if g in (cus, 2 * cus)] or grids[-1:], (8,), (4,), (0,)
         best = None
         import ctypes as C
 

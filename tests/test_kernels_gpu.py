@@ -88,6 +88,8 @@ Q4_SHAPES = [
     (4096, 11008, 5, 1, 8, 200, 8),
     (32000, 4096, 1, 2, 0, 0, 0),   # lm_head
     (8192, 2752, 1, 1, 0, 0, 0),    # 65B TP=8 mlp.c_proj shard: K = 21.5 units
+    (256, 22016, 1, 1, 0, 0, 0),    # 65B mlp.c_proj width on one GPU: six 16-B vectors per thread
+    (256, 13824, 2, 1, 0, 0, 0),    # 13B mlp.c_proj width
 ]
 
 
@@ -130,8 +132,9 @@ def test_q4_linear_f32_scales_and_determinism(dev):
     assert (y0 - y3).abs().max().item() <= 1e-4 * _rms(ref64)
 
 
-def test_q4_linear_fused_rmsnorm_accumulate_and_bias(dev):
-    N, K, M = 256, 512, 3
+@pytest.mark.parametrize("N,K,M", [(256, 512, 3), (128, 8192, 1), (64, 5120, 2), (64, 16384, 1)])
+def test_q4_linear_fused_rmsnorm_accumulate_and_bias(dev, N, K, M):
+    # K = 5120 / 8192: the four-vector staging mode of the 13B .. 65B widths; 16384: past it (element loop)
     p = _q4_problem(N, K, M, seed=3, dev=dev, x_scale=3.0)
     gen = torch.Generator().manual_seed(8)
     nscale = (1 + 0.1 * torch.randn(K, generator=gen)).to(torch.bfloat16)
