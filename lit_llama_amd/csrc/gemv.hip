@@ -431,6 +431,8 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
     // ---- per-tile epilogue operands, fetched one tile ahead (threads < 256 own output (row, col)).  The first
     // tile's are requested BEFORE the ring: they sit in a divergent branch, so hipcc cannot count them, and a wait
     // for the activation loads then also waits for as many of the OLDEST later loads — which must not be weights.
+    // (The owners are always waves 0-3: the CU's memory pipeline serves the waves in issue order, so these get
+    // their weights first and have slack; taking turns with waves 4-7 was measured 4 % slower end to end.)
     const int e_row = (threadIdx.x >> 4) & 15, e_col = threadIdx.x & 15;
     const bool e_owner = threadIdx.x < 256 && e_col < p.M;
     EpiOps<R> eo;
