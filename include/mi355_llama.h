@@ -128,6 +128,10 @@ typedef struct mi355_linear_args {
 
 int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stream);
 /* `count` launches back to back from one host call (tuning / measurement loops that must not be host bound) */
+/* Rows (M) one launch of mi355_linear_fast / mi355_linear_int8 can stage in the 160 KiB LDS of a workgroup for
+ * this format, input width, R and wave count (<= 16); callers chunk larger M. */
+int mi355_linear_max_rows(int fmt, int K, int R, int waves);
+
 int mi355_linear_fast_batch(const mi355_linear_args* a, int count, mi355_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -71,9 +71,33 @@ __global__ void add_f32_kernel(float* x, const float* p, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] += p[i];
 }
 
+int run_linear_rows(const mi355_model* m, const mi355_weight& w, const void* x, int x_dtype, int M, int64_t ldx,
+                    const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy, hipStream_t s,
+                    const float* attn_partials);
+
+// One linear over M <= max_T rows.  The rows of one launch must fit the workgroup's LDS next to the combine
+// buffers (7B: 13 rows at K = 4096, 5 at K = 11008), so wide inputs are fed in equal sub-chunks of rows: the
+// prompt chunk size is set by the NARROW linears and only mlp.c_proj pays extra launches.
 int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x_dtype, int M, int64_t ldx,
                const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy, hipStream_t s,
                const float* attn_partials = nullptr) {
+    const int cap = mi355_linear_max_rows(w.fmt, w.K, w.R, w.waves);
+    MI355_CHECK_ARG(cap >= 1, MI355_E_SHAPE, "forward: a row of K=%d does not fit LDS", w.K);
+    if (M <= cap) return run_linear_rows(m, w, x, x_dtype, M, ldx, norm_scale, epi, y, y_dtype, ldy, s, attn_partials);
+    const int n_sub = (M + cap - 1) / cap, step = (M + n_sub - 1) / n_sub;
+    const size_t xe = x_dtype == MI355_F32 ? 4 : 2, ye = y_dtype == MI355_F32 ? 4 : 2;
+    for (int m0 = 0; m0 < M; m0 += step) {
+        const int rows = M - m0 < step ? M - m0 : step;
+        if (int rc = run_linear_rows(m, w, (const char*)x + (size_t)m0 * ldx * xe, x_dtype, rows, ldx, norm_scale, epi,
+                                     (char*)y + (size_t)m0 * ldy * ye, y_dtype, ldy, s, nullptr))
+            return rc;
+    }
+    return 0;
+}
+
+int run_linear_rows(const mi355_model* m, const mi355_weight& w, const void* x, int x_dtype, int M, int64_t ldx,
+                    const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy, hipStream_t s,
+                    const float* attn_partials) {
     if (w.fmt == MI355_W_I8) {
         return mi355_linear_int8_from_weight(&w, m, x, x_dtype, M, ldx, norm_scale, epi, y, y_dtype, ldy, s);
     }

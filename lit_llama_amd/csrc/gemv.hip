@@ -938,6 +938,28 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
                      : dispatch_p<MI355_W_BF16, 2>(p, a->prefetch, grid, waves, lds, s);
 }
 
+extern "C" int mi355_linear_max_rows(int fmt, int K, int R, int waves) {
+    if (K <= 0 || R < 1 || R > 2) return 0;
+    int w = waves > 0 ? waves : 8;
+    if (w > 16) w = 16;
+    if (w < 4) w = 4;
+    const int64_t kp = (int64_t)((K + kUnitK - 1) / kUnitK) * kUnitK;
+    int64_t fixed, per_row;
+    if (fmt == MI355_W_I8) {
+        if (w > 8) w = 8;
+        fixed = 512 + (int64_t)2 * w * R * 1024 + kp * 2 + kp / 8 + 16;  // int8.hip
+        per_row = (kp + 16) + kp * 2;
+    } else if (fmt == MI355_W_Q4 || fmt == MI355_W_BF16) {
+        const int RS = R + (fmt == MI355_W_Q4 ? 1 : 0);
+        fixed = kLdsHeader + (int64_t)2 * w * RS * 1024;
+        per_row = kp * 2 + 16;
+    } else {
+        return 0;
+    }
+    const int64_t rows = (kMaxLds - fixed) / per_row;
+    return rows < 0 ? 0 : (rows > kMaxM ? kMaxM : (int)rows);
+}
+
 extern "C" int mi355_linear_fast_batch(const mi355_linear_args* a, int count, mi355_stream_t stream) {
     MI355_CHECK_ARG(a != nullptr && count >= 0, MI355_E_ARG, "linear_fast_batch: bad argument");
     for (int i = 0; i < count; ++i)

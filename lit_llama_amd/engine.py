@@ -169,7 +169,11 @@ class DecodeEngine:
             # LDS bound on the rows one launch can stage (see ops.fast_linear_max_m)
             fmts = {p.desc.fmt for p in self.packed}
             worst_fmt = W_I8 if W_I8 in fmts else W_Q4
-            max_T = min(16, ops.fast_linear_max_m(self.n_hidden, 1, worst_fmt), ops.fast_linear_max_m(C_, 2, worst_fmt))
+            # the prompt chunk is what the n_embd-wide linears can stage; the wider mlp.c_proj input is fed in
+            # sub-chunks of rows by the native side (engine.hip run_linear)
+            max_T = min(16, ops.fast_linear_max_m(C_, 2, worst_fmt))
+            if ops.fast_linear_max_m(self.n_hidden, 1, worst_fmt) < 1:
+                max_T = 0
             if max_T < 1:
                 raise EngineUnavailable("hidden size does not fit LDS")
             self.max_T = max_T

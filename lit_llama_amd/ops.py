@@ -15,19 +15,12 @@ from ._native import (BF16, EPI_ACCUM, EPI_STORE, EPI_SWIGLU, F32, W_BF16, W_I8,
                       check, dtype_code, lib, ptr, require_gpu, stream_ptr)
 
 MAX_M = 16
-_LDS_BUDGET = 160 * 1024
 
 
 def fast_linear_max_m(K: int, R: int, fmt: int = W_Q4, waves: int = 8) -> int:
-    """Largest M whose staged activations fit the 160 KiB LDS of one workgroup (see gemv.hip)."""
-    kp = (K + 127) // 128 * 128
-    if fmt == W_I8:
-        fixed = 512 + 2 * waves * R * 1024 + kp * 2 + kp // 8 + 16
-        per_m = (kp + 16) + kp * 2
-    else:
-        fixed = 1024 + 2 * max(waves, 8) * (R + 1) * 1024
-        per_m = kp * 2 + 16
-    return max(0, min(MAX_M, (_LDS_BUDGET - fixed) // per_m))
+    """Largest M whose staged activations fit the 160 KiB LDS of one workgroup (mi355_linear_max_rows: the same
+    arithmetic as the launchers in gemv.hip / int8.hip)."""
+    return max(0, min(MAX_M, int(lib().mi355_linear_max_rows(fmt, K, R, waves))))
 
 
 # ------------------------------------------------------------------------------------------ repack
