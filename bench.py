@@ -105,13 +105,22 @@ def measure_dominant_kernel(eng, reps: int = 3):
     n_layer = eng.cfg.n_layer
     s = eng.stream.cuda_stream
     evs = []
+    # Q4 / bf16: the launcher hands the events to hipExtLaunchKernel, so they carry the dispatch's own begin / end
+    # timestamps (what rocprofv3 --kernel-trace reports).  int8 (no hook): events recorded around the launch.
+    hook = eng.m.layers[0].fc.fmt != 2
     with torch.cuda.stream(eng.stream):
         for _ in range(reps):
             for l in range(n_layer):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+                if hook:
+                    e0.record()  # creates the underlying hipEvent_t objects (lazily allocated by torch)
+                    e1.record()
+                    check(lib().mi355_debug_time_next_launch(C.c_void_p(e0.cuda_event), C.c_void_p(e1.cuda_event)), "hook")
+                else:
+                    e0.record()
                 check(lib().mi355_forward_segment(C.byref(eng.m), 1, l, 2, 3, s), "forward_segment")
-                e1.record()
+                if not hook:
+                    e1.record()
                 evs.append((e0, e1))
     eng.stream.synchronize()
     times = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs[n_layer:])  # first pass = warm-up

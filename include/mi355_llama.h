@@ -128,6 +128,11 @@ typedef struct mi355_linear_args {
 
 int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stream);
 /* `count` launches back to back from one host call (tuning / measurement loops that must not be host bound) */
+/* Measurement hook: the NEXT mi355_linear_fast launch of the calling thread records its dispatch begin / end
+ * timestamps into the two hipEvent_t (hipExtLaunchKernel start / stop events): hipEventElapsedTime(start, stop) is
+ * then the launch duration as rocprofv3's kernel trace reports it.  NULL, NULL disarms. */
+int mi355_debug_time_next_launch(void* start_event, void* stop_event);
+
 /* Rows (M) one launch of mi355_linear_fast / mi355_linear_int8 can stage in the 160 KiB LDS of a workgroup for
  * this format, input width, R and wave count (<= 16); callers chunk larger M. */
 int mi355_linear_max_rows(int fmt, int K, int R, int waves);

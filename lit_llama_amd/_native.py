@@ -139,6 +139,7 @@ PROTOTYPES = {
     "mi355_graph_destroy": (c_int, [c_void_p]),
     "mi355_sizeof": (c_int, [c_int]),
     "mi355_linear_max_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "mi355_debug_time_next_launch": (c_int, [c_void_p, c_void_p]),
 }
 
 ABI_STRUCTS = [LinearArgs, AttnArgs, Int8Args, Weight, Layer, Model]

@@ -23,6 +23,8 @@
 //    SwiGLU of an interleaved c_fc1/c_fc2 pair) writes the 16*R outputs of the tile.
 #include <mutex>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace {
@@ -689,6 +691,8 @@ __global__ void i8_repack_kernel(const int8_t* c0, const int8_t* c1, int N, int 
     }
 }
 
+thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
+
 template <int FMT, int R, int P, int EPI, int VMODE>
 int launch_gemv_v(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     static std::once_flag once;
@@ -702,7 +706,16 @@ int launch_gemv_v(const GemvParams& p, int grid, int waves, size_t lds, hipStrea
         return (int)attr_err;
     }
     if (waves * 64 > kMaxThreads<FMT, P>) waves = kMaxThreads<FMT, P> / 64;
-    hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE>), dim3(grid), dim3(waves * 64), lds, stream, p);
+    if (t_time_start != nullptr) {
+        // measurement hook (mi355_debug_time_next_launch): the events receive the dispatch's own begin / end
+        // timestamps, i.e. the duration rocprofv3 reports for this launch
+        hipEvent_t e0 = t_time_start, e1 = t_time_stop;
+        t_time_start = t_time_stop = nullptr;
+        hipExtLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE>), dim3(grid), dim3(waves * 64), (uint32_t)lds, stream,
+                              e0, e1, 0, p);
+    } else {
+        hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE>), dim3(grid), dim3(waves * 64), lds, stream, p);
+    }
     MI355_LAUNCH_CHECK();
     return 0;
 }
@@ -936,6 +949,14 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     }
     return a->R == 1 ? dispatch_p<MI355_W_BF16, 1>(p, a->prefetch, grid, waves, lds, s)
                      : dispatch_p<MI355_W_BF16, 2>(p, a->prefetch, grid, waves, lds, s);
+}
+
+extern "C" int mi355_debug_time_next_launch(void* start_event, void* stop_event) {
+    MI355_CHECK_ARG((start_event == nullptr) == (stop_event == nullptr), MI355_E_ARG,
+                    "debug_time_next_launch: pass both events or neither");
+    t_time_start = (hipEvent_t)start_event;
+    t_time_stop = (hipEvent_t)stop_event;
+    return 0;
 }
 
 extern "C" int mi355_linear_max_rows(int fmt, int K, int R, int waves) {

@@ -41,20 +41,24 @@ def main():
     print(f"{'kernel':80s} {'calls':>7s} {'total_ms':>9s} {'avg_us':>8s} {'share':>6s}")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
         print(f"{k:80s} {c:7d} {t / 1e6:9.3f} {t / c / 1e3:8.2f} {100 * t / total:5.1f}%")
-    # steady-state decode: the last complete token (from one embedding_kernel to the next)
-    idx = [i for i, r in enumerate(rows) if "embedding_kernel" in r[0]]
-    if len(idx) >= 3:
-        a, b = idx[-3], idx[-2]
-        tok = rows[a:b]
-        span = tok[-1][2] - tok[0][1]
-        busy = sum(e - s for _, s, e in tok)
-        print(f"\nlast full decode step: {len(tok)} launches, span {span / 1e3:.1f} us, sum of kernel durations {busy / 1e3:.1f} us")
+    # steady-state decode: chained greedy steps, each ending with argmax_advance_kernel.  Averages over the last
+    # (up to) 32 complete steps, M = 1 launches only (the per-kernel table above also contains the prompt chunks).
+    ends = [i for i, r in enumerate(rows) if "argmax_advance_kernel" in r[0]]
+    if len(ends) >= 3:
+        ends = ends[-33:]
+        steps = [rows[ends[i] + 1:ends[i + 1] + 1] for i in range(len(ends) - 1)]
+        n = len(steps)
+        span = sum(st[-1][2] - st[0][1] for st in steps) / n
+        busy = sum(sum(e - s_ for _, s_, e in st) for st in steps) / n
+        print(f"\nsteady-state decode, mean of the last {n} chained steps: {len(steps[-1])} launches per step, "
+              f"span {span / 1e3:.1f} us, sum of kernel durations {busy / 1e3:.1f} us")
         per = defaultdict(lambda: [0, 0])
-        for n, s, e in tok:
-            per[short(n)][0] += 1
-            per[short(n)][1] += e - s
+        for st in steps:
+            for nme, s_, e in st:
+                per[short(nme)][0] += 1
+                per[short(nme)][1] += e - s_
         for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
-            print(f"  {k:78s} {c:4d} x {t / c / 1e3:7.2f} us = {t / 1e3:8.1f} us")
+            print(f"  {k:78s} {c / n:6.1f} x {t / c / 1e3:7.2f} us = {t / n / 1e3:8.1f} us per step")
 
 
 if __name__ == "__main__":
