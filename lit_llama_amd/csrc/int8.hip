@@ -47,7 +47,7 @@ constexpr int kStageVec = 8;  // 4-column activation vectors a thread keeps in r
 
 // LDS map: [hdr: red[64] | sca[16] | sinv[16] | ototal] [part 2*W*R KiB] [xq M*xq_stride] [xh M*Kp f16]
 //          [olist Kp u16: outlier columns, ascending] [obits Kp/8 B: outlier bit set]
-template <int R, int P, bool VEC>
+template <int R, int P, int VNV>  // VNV: 0 element loop, else 4-column vectors per thread kept in registers
 __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
     } while (0)
     // Vector staging: this thread's first activation vectors (and their norm scales) are requested BEFORE the
     // weight ring, because VMEM returns in order and the prologue must not queue behind ~32 KiB of weights.
-    constexpr int NV = kStageVec;
+    constexpr bool VEC = VNV > 0;
+    constexpr int NV = VEC ? VNV : 1;
     const int nthr = blockDim.x;
     const int nvecp = Kp >> 2;
     const bool x32 = p.x_dtype == MI355_F32;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
     // Outlier columns {k : |x[m,k]| >= threshold for some row m} are a bit set in LDS (atomic OR by whichever
     // thread stages the column; there are only a handful), from which wave 0 later writes the ascending list.
     for (int i = tid; i < (Kp >> 5); i += nthr) obits[i] = 0u;
+    if (tid < 64) red[tid] = 0.f;
     if (tid == 0) ototal[0] = 0;
     __syncthreads();
     const bool thr_on = p.threshold > 0.f;
@@ -160,9 +162,11 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
         float* r = red + slot * 16;
         if (lane == 0) r[wave] = v;
         __syncthreads();
-        float t = r[0];
-        for (int w = 1; w < W; ++w) t = is_max ? fmaxf(t, r[w]) : t + r[w];
-        return t;
+        // W <= 8; unused slots hold 0 (identity of both reductions: sums of squares and absolute maxima), so the
+        // eight reads are unconditional and overlap
+        const f32x4 a = *(const f32x4*)r, b = *(const f32x4*)(r + 4);
+        if (is_max) return fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+        return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
     };
     bool quantised = false;
     // raw vectors -> f32
@@ -541,26 +545,31 @@ __global__ void int8_quant_rows_kernel(const void* w, int dtype, int K, int8_t* 
     }
 }
 
-template <int R, int P, bool VEC>
+template <int R, int P, int VNV>
 int launch_i8v(const I8Params& p, int grid, int waves, size_t lds, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)int8_gemv_kernel<R, P, VEC>,
+        attr_err = hipFuncSetAttribute((const void*)int8_gemv_kernel<R, P, VNV>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     });
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    hipLaunchKernelGGL((int8_gemv_kernel<R, P, VEC>), dim3(grid), dim3(waves * 64), lds, stream, p);
+    hipLaunchKernelGGL((int8_gemv_kernel<R, P, VNV>), dim3(grid), dim3(waves * 64), lds, stream, p);
     MI355_LAUNCH_CHECK();
     return 0;
 }
 
 template <int R, int P>
 int launch_i8(const I8Params& p, int grid, int waves, size_t lds, hipStream_t stream) {
-    return p.vec ? launch_i8v<R, P, true>(p, grid, waves, lds, stream) : launch_i8v<R, P, false>(p, grid, waves, lds, stream);
+    // register staging sized to the row: 2 vectors per thread cover K <= 4096 at 512 threads (every n_embd-wide
+    // input of the 7B model) with ~100 VGPRs; the 8-vector variant (K <= 16384) needs ~200 and its workgroups
+    // take visibly longer to dispatch
+    if (p.vec == 0) return launch_i8v<R, P, 0>(p, grid, waves, lds, stream);
+    if (p.units * kUnitK / 4 <= 2 * waves * 64) return launch_i8v<R, P, 2>(p, grid, waves, lds, stream);
+    return launch_i8v<R, P, kStageVec>(p, grid, waves, lds, stream);
 }
 
 }  // namespace
