@@ -269,6 +269,10 @@ typedef struct mi355_int8_args {
     uint64_t* debug_stamps; /* optional: uint64 [workgroups][8] wall-clock stamps (100 MHz): 0 entry, 1 ring issued,
                                2 rows staged (f16 + scales), 3 quantised + outlier list, 4 first tile streamed,
                                5 first tile stored, 6 exit */
+    /* optional: the activation row is the combine of split-attention partial records (mi355_attn_args.partials),
+     * rounded to bf16 like the attention kernel's own output.  M = 1, no norm, <= 4 splits, K <= 4096. */
+    const float* attn_partials;
+    int32_t attn_splits, attn_heads, attn_hs, reserved0;
 } mi355_int8_args;
 
 int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream);

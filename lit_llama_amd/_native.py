@@ -62,6 +62,8 @@ class Int8Args(C.Structure):
         ("epi", c_int32), ("scb2", c_void_p), ("y", c_void_p), ("y_dtype", c_int32),
         ("waves", c_int32), ("ldy", c_int64), ("grid", c_int32), ("prefetch", c_int32),
         ("debug_stamps", c_void_p),
+        ("attn_partials", c_void_p), ("attn_splits", c_int32), ("attn_heads", c_int32), ("attn_hs", c_int32),
+        ("reserved0", c_int32),
     ]
 
 

@@ -13,7 +13,7 @@
 // implemented in int8.hip: the LLM.int8 linear driven from a mi355_weight descriptor
 int mi355_linear_int8_from_weight(const mi355_weight* w, const mi355_model* m, const void* x, int x_dtype, int M,
                                   int64_t ldx, const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy,
-                                  hipStream_t stream);
+                                  hipStream_t stream, const float* attn_partials);
 
 namespace {
 
@@ -99,7 +99,7 @@ int run_linear_rows(const mi355_model* m, const mi355_weight& w, const void* x, 
                     const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy, hipStream_t s,
                     const float* attn_partials) {
     if (w.fmt == MI355_W_I8) {
-        return mi355_linear_int8_from_weight(&w, m, x, x_dtype, M, ldx, norm_scale, epi, y, y_dtype, ldy, s);
+        return mi355_linear_int8_from_weight(&w, m, x, x_dtype, M, ldx, norm_scale, epi, y, y_dtype, ldy, s, attn_partials);
     }
     mi355_linear_args a;
     memset(&a, 0, sizeof(a));
@@ -195,7 +195,7 @@ extern "C" int mi355_forward_segment(const mi355_model* m, int T, int layer, int
     const int Cl = m->n_head * m->hs;  // local attention width (== C unless tensor parallel)
     const bool tp = m->tp_world > 1;
     // decode steps spread each head's K/V over attn_splits workgroups; the c_proj prologue combines the partials
-    const bool split = T == 1 && m->attn_splits > 1 && m->attn_part != nullptr && L.proj.fmt != MI355_W_I8;
+    const bool split = T == 1 && m->attn_splits > 1 && m->attn_part != nullptr;
     for (int seg = seg_begin; seg < seg_end; ++seg) {
         switch (seg) {
             case 0: {

@@ -37,6 +37,8 @@ struct I8Params {
     unsigned w_bytes;  // size of the weight stream (buffer descriptor bound)
     float eps, threshold;
     uint64_t* dbg;
+    const float* attn_part;  // split-attention partial records feeding the row (M = 1), or nullptr
+    int attn_splits, attn_heads, attn_hs;
     int vec;  // 1: 16-B / 8-B vector staging of x (aligned rows, bf16 norm scale), see mi355_linear_int8
 };
 
@@ -126,8 +128,33 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
             }
         }
     };
+    // split-attention input (attn.c_proj of a decode step): per vector the <= 4 partial records of its head
+    constexpr bool PARTS = VNV == 2;  // only the short-row variant carries the 48 extra registers
+    [[maybe_unused]] f32x4 po[PARTS ? NV : 1][4];
+    [[maybe_unused]] float pm[PARTS ? NV : 1][4], pl[PARTS ? NV : 1][4];
+    const bool from_parts = PARTS && p.attn_part != nullptr;
     if constexpr (VEC) {
-        load_chunk(0, 0);
+        if (from_parts) {
+            if constexpr (PARTS) {
+                const int rs = p.attn_hs + 4, last = (p.K >> 2) - 1;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    int v = i * nthr + tid;
+                    v = v < last ? v : last;  // clamped, not branched: rows past the end are zeroed in decode()
+                    const int k0 = v * 4, h = k0 / p.attn_hs, d0 = k0 - h * p.attn_hs;
+                    const float* rec = p.attn_part + (size_t)h * p.attn_splits * rs;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float* q = rec + (j < p.attn_splits ? j : p.attn_splits - 1) * rs;
+                        pm[i][j] = q[0];
+                        pl[i][j] = q[1];
+                        po[i][j] = *(const f32x4*)(q + 4 + d0);
+                    }
+                }
+            }
+        } else {
+            load_chunk(0, 0);
+        }
         const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.norm_scale != nullptr ? p.norm_scale : p.x), 0, p.norm_scale != nullptr ? p.K * 2 : 0, 0x00020000);
 #pragma unroll
@@ -171,6 +198,31 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
     bool quantised = false;
     // raw vectors -> f32
     [[maybe_unused]] auto decode = [&](float (&xf)[NV][4]) {
+        if (from_parts) {
+            if constexpr (PARTS) {
+                // x[h*hs + d] = sum_j e^{m_j - M} o_j[d] / sum_j e^{m_j - M} l_j (flash-decoding combine), rounded
+                // to bf16 like the attention kernel's own output
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    float M_ = -1.0e30f, L = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < p.attn_splits) {
+                            const float Mn = fmaxf(M_, pm[i][j]);
+                            const float c_old = expf(M_ - Mn), c_new = expf(pm[i][j] - Mn);
+                            L = L * c_old + pl[i][j] * c_new;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[e] = acc[e] * c_old + po[i][j][e] * c_new;
+                            M_ = Mn;
+                        }
+                    const float inv = 1.0f / L;
+                    const bool live = i * nthr + tid < (p.K >> 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xf[i][e] = live ? bf16_to_f32(f32_to_bf16(acc[e] * inv)) : 0.f;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             if (x32) {
@@ -619,6 +671,10 @@ extern "C" int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream
     p.eps = a->eps;
     p.threshold = a->threshold;
     p.dbg = a->debug_stamps;
+    p.attn_part = a->attn_partials;
+    p.attn_splits = a->attn_splits;
+    p.attn_heads = a->attn_heads;
+    p.attn_hs = a->attn_hs;
     {
         const size_t wb = mi355_packed_bytes(MI355_W_I8, a->N, a->K, a->R, swiglu ? 1 : 0);
         MI355_CHECK_ARG(wb > 0 && wb < 0xFFFFFFF0ull, MI355_E_SHAPE, "linear_int8: weight stream of %zu B exceeds 4 GiB", wb);
@@ -638,6 +694,14 @@ extern "C" int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream
             ok = ok && a->norm_dtype == MI355_BF16 && (uintptr_t)a->norm_scale % 8 == 0 && Kp / 4 <= kStageVec * waves * 64;
         p.vec = ok ? 1 : 0;
     }
+    if (a->attn_partials != nullptr) {
+        MI355_CHECK_ARG(a->M == 1 && a->norm_scale == nullptr && a->attn_splits >= 1 && a->attn_splits <= 4 &&
+                            a->attn_hs >= 4 && a->attn_hs % 4 == 0 && a->attn_heads * a->attn_hs == a->K &&
+                            a->K % 4 == 0 && Kp / 4 <= 2 * waves * 64 && (uintptr_t)a->attn_partials % 16 == 0,
+                        MI355_E_SHAPE, "linear_int8: split-attention input needs M = 1, no norm, <= 4 splits, K <= %d",
+                        8 * waves * 64);
+        p.vec = 1;  // the partial records replace the row loads
+    }
     const size_t lds = kHdr + (size_t)2 * waves * a->R * 1024 + (size_t)a->M * p.xq_stride + (size_t)a->M * Kp * 2 +
                        (size_t)Kp * 2 + (size_t)Kp / 8 + 16;
     MI355_CHECK_ARG(lds <= (size_t)kMaxLds, MI355_E_SHAPE,
@@ -654,7 +718,7 @@ extern "C" int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream
 
 int mi355_linear_int8_from_weight(const mi355_weight* w, const mi355_model* m, const void* x, int x_dtype, int M,
                                   int64_t ldx, const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, const float* attn_partials) {
     mi355_int8_args a;
     memset(&a, 0, sizeof(a));
     a.w = (const int8_t*)w->w;
@@ -679,5 +743,11 @@ int mi355_linear_int8_from_weight(const mi355_weight* w, const mi355_model* m, c
     a.waves = w->waves;
     a.grid = w->grid;
     a.prefetch = w->prefetch;
+    if (attn_partials != nullptr) {
+        a.attn_partials = attn_partials;
+        a.attn_splits = m->attn_splits;
+        a.attn_heads = m->n_head;
+        a.attn_hs = m->hs;
+    }
     return mi355_linear_int8(&a, stream);
 }

@@ -155,6 +155,7 @@ def linear_int8(
     waves: int = 0,
     grid: int = 0,
     prefetch: int = 0,
+    attn_partials: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     require_gpu(x2d, "linear_int8")
     assert x2d.dim() == 2 and x2d.shape[1] == K and x2d.stride(1) == 1
@@ -177,6 +178,11 @@ def linear_int8(
     a.y_dtype = dtype_code(out.dtype)
     a.ldy = out.stride(0)
     a.waves, a.grid, a.prefetch = waves, grid, prefetch
+    if attn_partials is not None:
+        # [1, n_head, n_split, hs + 4] f32 records of ops.attention(..., return_partials=True); x2d is only a shape
+        assert attn_partials.dtype == torch.float32 and attn_partials.dim() == 4 and M == 1
+        a.attn_partials = ptr(attn_partials)
+        a.attn_heads, a.attn_splits, a.attn_hs = attn_partials.shape[1], attn_partials.shape[2], attn_partials.shape[3] - 4
     step = fast_linear_max_m(K, R, W_I8, waves or 8)
     if step < 1:
         raise nat.NativeError(f"linear_int8: K={K} does not fit LDS even for M=1")

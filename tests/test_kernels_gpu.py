@@ -326,6 +326,14 @@ def test_split_attention_equals_single_workgroup_and_feeds_the_projection(dev, n
         return  # the fused c_proj prologue takes at most 4 splits
     # projection fed by the partial records
     parts = ops.attention(qkv, rope, n_head, pos=p_t, kv_cache=(k2, v2), n_split=n_split, return_partials=True)
+    # ... the LLM.int8 linear: same rows (bf16-rounded combine), so the same int8 levels up to that rounding
+    gen_c = torch.Generator().manual_seed(17)
+    cb, scb = ops.int8_quant_rows((torch.randn((256, C), generator=gen_c) * C**-0.5).to(dev))
+    s8 = ops.repack_i8(cb, None, 1)
+    ref8 = ops.linear_int8(y2.to(torch.bfloat16).view(1, C), s8, scb, 1, 256, C, out_dtype=torch.float32)
+    got8 = ops.linear_int8(y2.to(torch.bfloat16).view(1, C), s8, scb, 1, 256, C, out_dtype=torch.float32,
+                           attn_partials=parts)
+    assert (got8 - ref8).abs().max().item() <= 2e-2 * _rms(ref8)
     p = _q4_problem(4096, C, 1, seed=5, dev=dev)
     stream = ops.repack_q4(p["packed"], None, 4096, C, 1)
     sc, ze = p["scale"].to(torch.bfloat16).to(dev), p["zero"].to(torch.bfloat16).to(dev)
