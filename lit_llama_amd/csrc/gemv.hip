@@ -295,14 +295,14 @@ __device__ __forceinline__ void load_epi(const GemvParams& p, int tile, int e_ro
 
 // Combine the W partial 16x16 tiles of `buf` in wave order and write the tile's outputs (stores only).
 // RS = partial tiles per wave: R weight tiles (+ the all-ones tile carrying sum_k x_k for Q4).
-template <int FMT, int R, int EPI>
+template <int FMT, int R, int EPI, bool MULTI>
 __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* part, int buf, int W, int tile,
                                               int e_row, int e_col, const EpiOps<R>& o, float rinv) {
     constexpr int RS = R + (FMT == MI355_W_Q4 ? 1 : 0);
     // D layout of mfma_f32_16x16x32: lane (row >> 2) * 16 + col holds D[row][col] in register (row & 3)
     float sx = 0.f;
     float v[R];
-    if (p.M == 1) {
+    if (!MULTI) {
         // decode: the 16 lanes of a row's group each fetch ONE wave's partial and the group is summed with DPP
         // (fixed butterfly order -> reproducible); a serial loop over W x (R + 1) LDS reads per owner cost ~0.6 us
         // per tile on the critical path.  Here e_col doubles as the wave index.
@@ -362,8 +362,11 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
 template <int FMT, int P>
 constexpr int kMaxThreads = (FMT == MI355_W_Q4 && P <= 4) ? 1024 : 512;
 
-template <int FMT, int R, int P, int EPI, int VMODE>
+// MULTI = false is the decode step (M == 1): no row loop, no per-row branches — the loop around the row-staging
+// loads alone cost 0.4-1 us per launch through hipcc's conservative vmcnt waits (12.9 -> 11.9 us for the fc pair).
+template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
 __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvParams p) {
+    const int M = MULTI ? p.M : 1;
     constexpr bool NT = true;  // weights are read once: non-temporal
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* wss = (float*)smem;  // [W][16] per-wave partial sums of x^2 (RMSNorm)
@@ -436,7 +439,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
     // (The owners are always waves 0-3: the CU's memory pipeline serves the waves in issue order, so these get
     // their weights first and have slack; taking turns with waves 4-7 was measured 4 % slower end to end.)
     const int e_row = (threadIdx.x >> 4) & 15, e_col = threadIdx.x & 15;
-    const bool e_owner = threadIdx.x < 256 && e_col < p.M;
+    const bool e_owner = threadIdx.x < 256 && e_col < M;
     EpiOps<R> eo;
 #pragma unroll
     for (int r = 0; r < R; ++r) eo.s[r] = eo.z[r] = eo.bias[r] = eo.old[r] = 0u;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
         }
     };
     if (!p.stage_first) stage_row(0);
-    for (int m = 1; m < p.M; ++m) {
+    for (int m = 1; m < M; ++m) {
         stager.load(p, m);
         stage_row(m);
     }
@@ -487,7 +490,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
 #pragma unroll
             for (int r = 0; r < RS; ++r) pp[r * 64] = acc1;  // zeros
             __syncthreads();
-            if (e_owner || (p.M == 1 && threadIdx.x < 256)) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
+            if (e_owner || (!MULTI && threadIdx.x < 256)) tile_epilogue<FMT, R, EPI, MULTI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
             tile += nb;
             buf ^= 1;
             load_epi<FMT, R, EPI>(p, tile, e_row, e_col, e_owner, eo);
@@ -497,7 +500,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
 
     // ---- main loop
     const int g = lane >> 4, c = lane & 15;
-    const int xrow = c < p.M ? c : p.M - 1;
+    const int xrow = c < M ? c : M - 1;
     const char* xl = xs + (size_t)xrow * p.xs_stride + g * 64;
     const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // 8 x bf16 1.0
     int uu = 0;
@@ -554,7 +557,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
                     }
                     if (tile == bid) MI355_STAMP(3);
                     __syncthreads();
-                    if (e_owner || (p.M == 1 && threadIdx.x < 256)) tile_epilogue<FMT, R, EPI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
+                    if (e_owner || (!MULTI && threadIdx.x < 256)) tile_epilogue<FMT, R, EPI, MULTI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
                     if (tile == bid) MI355_STAMP(4);
                     tile += nb;
                     buf ^= 1;
@@ -693,12 +696,12 @@ __global__ void i8_repack_kernel(const int8_t* c0, const int8_t* c1, int N, int 
 
 thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
 
-template <int FMT, int R, int P, int EPI, int VMODE>
-int launch_gemv_v(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
+template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
+int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, EPI, VMODE>,
+        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     });
     if (attr_err != hipSuccess) {
@@ -711,13 +714,23 @@ int launch_gemv_v(const GemvParams& p, int grid, int waves, size_t lds, hipStrea
         // timestamps, i.e. the duration rocprofv3 reports for this launch
         hipEvent_t e0 = t_time_start, e1 = t_time_stop;
         t_time_start = t_time_stop = nullptr;
-        hipExtLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE>), dim3(grid), dim3(waves * 64), (uint32_t)lds, stream,
-                              e0, e1, 0, p);
+        hipExtLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>), dim3(grid), dim3(waves * 64), (uint32_t)lds,
+                              stream, e0, e1, 0, p);
     } else {
-        hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE>), dim3(grid), dim3(waves * 64), lds, stream, p);
+        hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>), dim3(grid), dim3(waves * 64), lds, stream, p);
     }
     MI355_LAUNCH_CHECK();
     return 0;
+}
+
+template <int FMT, int R, int P, int EPI, int VMODE>
+int launch_gemv_v(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
+    if constexpr (VMODE == 3) {  // split-attention input exists for M = 1 only (host check)
+        return launch_gemv_m<FMT, R, P, EPI, VMODE, false>(p, grid, waves, lds, stream);
+    } else {
+        return p.M > 1 ? launch_gemv_m<FMT, R, P, EPI, VMODE, true>(p, grid, waves, lds, stream)
+                       : launch_gemv_m<FMT, R, P, EPI, VMODE, false>(p, grid, waves, lds, stream);
+    }
 }
 
 template <int FMT, int R, int P, int EPI>
@@ -852,7 +865,7 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     MI355_CHECK_ARG(a->R == 1 || a->R == 2, MI355_E_ARG, "linear_fast: R must be 1 or 2");
     MI355_CHECK_ARG(a->w && (a->x || a->attn_partials) && a->y, MI355_E_ARG, "linear_fast: null w/x/y");
     if (a->attn_partials != nullptr) {
-        MI355_CHECK_ARG(a->attn_splits >= 1 && a->attn_heads >= 1 && a->attn_hs % 8 == 0 && a->norm_scale == nullptr &&
+        MI355_CHECK_ARG(a->M == 1 && a->attn_splits >= 1 && a->attn_heads >= 1 && a->attn_hs % 8 == 0 && a->norm_scale == nullptr &&
                             a->K == a->attn_heads * a->attn_hs && a->epi != MI355_EPI_SWIGLU,
                         MI355_E_ARG, "linear_fast: bad split-attention activation spec");
     }
