@@ -259,35 +259,65 @@ struct Stager<3> {  // split-attention partial records, <= 8 elements per thread
 // for it on the spot.
 template <int R>
 struct EpiOps {
-    uint32_t s[R], z[R];   // Q4 scale / zero of the output row (sz_dtype bits)
-    uint32_t bias[R];      // sz_dtype bits
-    uint32_t old[R];       // y_dtype bits of the value to accumulate into
+    uint32_t s[R], z[R];   // dword holding the Q4 scale / zero of the output row
+    uint32_t bias[R];
+    uint32_t old[R];       // dword holding the value to accumulate into
+    uint32_t sh_sz[R], sh_y[R];  // bit offset of a 16-bit element inside its dword (0 for f32)
 };
 
-__device__ __forceinline__ uint32_t ld2_raw(const void* p, int64_t i, int dtype) {
-    return dtype == MI355_F32 ? ((const uint32_t*)p)[i] : (uint32_t)((const uint16_t*)p)[i];
+// Buffer descriptors of the epilogue operands.  Every operand load is ONE unconditional buffer_load_dword: rows
+// past N, non-owner threads and absent operands (descriptor of 0 bytes) fall out of range, which returns zero
+// without a memory request and — unlike a guarded load — keeps hipcc's vmcnt bookkeeping exact, so that waiting
+// for these operands at a tile's end does not also drain the weight ring.  A 16-bit element is fetched as the
+// aligned dword that contains it.
+struct EpiRsrc {
+    __amdgpu_buffer_rsrc_t s0, z0, s1, z1, bias, y;
+    int sz_shift, y_shift;  // log2(element bytes)
+};
+__device__ __forceinline__ EpiRsrc make_epi_rsrc(const GemvParams& p, int M) {
+    EpiRsrc r;
+    r.sz_shift = p.sz_dtype == MI355_F32 ? 2 : 1;
+    r.y_shift = p.y_dtype == MI355_F32 ? 2 : 1;
+    const int nb = ((p.N << r.sz_shift) + 3) & ~3;
+    auto mk = [](const void* ptr, int bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, ptr != nullptr ? bytes : 0, 0x00020000);
+    };
+    r.s0 = mk(p.scales, nb);
+    r.z0 = mk(p.zeros, nb);
+    r.s1 = mk(p.scales2, nb);
+    r.z1 = mk(p.zeros2, nb);
+    r.bias = mk(p.bias, nb);
+    r.y = mk(p.y, (int)(((((int64_t)(M - 1) * p.ldy + p.N) << r.y_shift) + 3) & ~(int64_t)3));
+    return r;
+}
+__device__ __forceinline__ uint32_t ld_epi_dword(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, bool ok) {
+    return __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (byte_off & ~3u) : 0xFFFFFFF0u, 0, 0);
 }
 __device__ __forceinline__ float cvt2(uint32_t raw, int dtype) {
     return dtype == MI355_F32 ? __uint_as_float(raw) : __uint_as_float(raw << 16);
 }
 
 template <int FMT, int R, int EPI>
-__device__ __forceinline__ void load_epi(const GemvParams& p, int tile, int e_row, int e_col, bool e_owner,
-                                         EpiOps<R>& o) {
-    if (e_owner && tile < p.n_tiles) {
-        constexpr bool sw = EPI == MI355_EPI_SWIGLU;
+__device__ __forceinline__ void load_epi(const GemvParams& p, const EpiRsrc& er, int tile, int e_row, int e_col,
+                                         bool e_owner, EpiOps<R>& o) {
+    constexpr bool sw = EPI == MI355_EPI_SWIGLU;
+    const bool live = e_owner && tile < p.n_tiles;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int n = sw ? tile * 16 + e_row : (tile * R + r) * 16 + e_row;
-            if (n < p.N) {
-                if constexpr (FMT == MI355_W_Q4) {
-                    o.s[r] = ld2_raw((sw && r == 1) ? p.scales2 : p.scales, n, p.sz_dtype);
-                    o.z[r] = ld2_raw((sw && r == 1) ? p.zeros2 : p.zeros, n, p.sz_dtype);
-                }
-                if (!sw) {
-                    if (p.bias != nullptr) o.bias[r] = ld2_raw(p.bias, n, p.sz_dtype);
-                    if (EPI == MI355_EPI_ACCUM) o.old[r] = ld2_raw(p.y, (int64_t)e_col * p.ldy + n, p.y_dtype);
-                }
+    for (int r = 0; r < R; ++r) {
+        const int n = sw ? tile * 16 + e_row : (tile * R + r) * 16 + e_row;
+        const bool ok = live && n < p.N;
+        const unsigned off = (unsigned)n << er.sz_shift;
+        o.sh_sz[r] = er.sz_shift == 2 ? 0u : (off & 2u) * 8u;
+        if constexpr (FMT == MI355_W_Q4) {
+            o.s[r] = ld_epi_dword((sw && r == 1) ? er.s1 : er.s0, off, ok);
+            o.z[r] = ld_epi_dword((sw && r == 1) ? er.z1 : er.z0, off, ok);
+        }
+        if constexpr (!sw) {
+            o.bias[r] = ld_epi_dword(er.bias, off, ok);
+            if constexpr (EPI == MI355_EPI_ACCUM) {
+                const unsigned yo = (unsigned)(((int64_t)e_col * p.ldy + n) << er.y_shift);
+                o.sh_y[r] = er.y_shift == 2 ? 0u : (yo & 2u) * 8u;
+                o.old[r] = ld_epi_dword(er.y, yo, ok);
             }
         }
     }
@@ -333,7 +363,8 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float s = v[r];
-        if constexpr (FMT == MI355_W_Q4) s = cvt2(o.s[r], p.sz_dtype) * (s - (128.f + cvt2(o.z[r], p.sz_dtype)) * sx);
+        if constexpr (FMT == MI355_W_Q4)
+            s = cvt2(o.s[r] >> o.sh_sz[r], p.sz_dtype) * (s - (128.f + cvt2(o.z[r] >> o.sh_sz[r], p.sz_dtype)) * sx);
         v[r] = s * rinv;
     }
     if constexpr (EPI == MI355_EPI_SWIGLU) {
@@ -347,8 +378,8 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
             const int n = (tile * R + r) * 16 + e_row;
             if (n < p.N) {
                 float out = v[r];
-                if (p.bias != nullptr) out += cvt2(o.bias[r], p.sz_dtype);
-                if (EPI == MI355_EPI_ACCUM) out += cvt2(o.old[r], p.y_dtype);
+                if (p.bias != nullptr) out += cvt2(o.bias[r] >> o.sh_sz[r], p.sz_dtype);
+                if (EPI == MI355_EPI_ACCUM) out += cvt2(o.old[r] >> o.sh_y[r], p.y_dtype);
                 st2(p.y, (int64_t)e_col * p.ldy + n, p.y_dtype, out);
             }
         }
@@ -442,8 +473,9 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
     const bool e_owner = threadIdx.x < 256 && e_col < M;
     EpiOps<R> eo;
 #pragma unroll
-    for (int r = 0; r < R; ++r) eo.s[r] = eo.z[r] = eo.bias[r] = eo.old[r] = 0u;
-    load_epi<FMT, R, EPI>(p, bid, e_row, e_col, e_owner, eo);
+    for (int r = 0; r < R; ++r) eo.s[r] = eo.z[r] = eo.bias[r] = eo.old[r] = eo.sh_sz[r] = eo.sh_y[r] = 0u;
+    const EpiRsrc er = make_epi_rsrc(p, M);
+    load_epi<FMT, R, EPI>(p, er, bid, e_row, e_col, e_owner, eo);
 
 #pragma unroll
     for (int j = 0; j < P; ++j) MI355_ISSUE(j);
@@ -493,7 +525,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
             if (e_owner || (!MULTI && threadIdx.x < 256)) tile_epilogue<FMT, R, EPI, MULTI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
             tile += nb;
             buf ^= 1;
-            load_epi<FMT, R, EPI>(p, tile, e_row, e_col, e_owner, eo);
+            load_epi<FMT, R, EPI>(p, er, tile, e_row, e_col, e_owner, eo);
         }
         return;
     }
@@ -561,7 +593,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
                     if (tile == bid) MI355_STAMP(4);
                     tile += nb;
                     buf ^= 1;
-                    load_epi<FMT, R, EPI>(p, tile, e_row, e_col, e_owner, eo);
+                    load_epi<FMT, R, EPI>(p, er, tile, e_row, e_col, e_owner, eo);
                 }
             }
             MI355_ISSUE(j);  // refill the slot just consumed (offset out of range once the work is exhausted)
