@@ -395,7 +395,7 @@ constexpr int kMaxThreads = (FMT == MI355_W_Q4 && P <= 4) ? 1024 : 512;
 
 // MULTI = false is the decode step (M == 1): no row loop, no per-row branches — the loop around the row-staging
 // loads alone cost 0.4-1 us per launch through hipcc's conservative vmcnt waits (12.9 -> 11.9 us for the fc pair).
-template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
+template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI, bool ALIGNED>
 __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvParams p) {
     const int M = MULTI ? p.M : 1;
     constexpr bool NT = true;  // weights are read once: non-temporal
@@ -537,66 +537,93 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
     const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // 8 x bf16 1.0
     int uu = 0;
 
-    for (int t = 0; t < total; t += P) {
+    // one k-unit: operands from LDS, int4 -> bf16, MFMAs
+    auto consume = [&](int j) {
+        const char* xb = xl + (u0 + uu) * (kUnitK * 2);
+        bf16x8 b[4];
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-            if (t + j < total) {
-                const char* xb = xl + (u0 + uu) * (kUnitK * 2);
-                bf16x8 b[4];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) b[d] = *(const bf16x8*)(xb + 16 * d);
+        for (int d = 0; d < 4; ++d) b[d] = *(const bf16x8*)(xb + 16 * d);
 
-                if constexpr (FMT == MI355_W_Q4) {
-                    // sum_k x_k of the rounded operands, from the otherwise idle matrix pipe
+        if constexpr (FMT == MI355_W_Q4) {
+            // sum_k x_k of the rounded operands, from the otherwise idle matrix pipe
 #pragma unroll
-                    for (int d = 0; d < 4; ++d)
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ones), b[d], acc1, 0, 0, 0);
+            for (int d = 0; d < 4; ++d)
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ones), b[d], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if constexpr (FMT == MI355_W_Q4) {
+                const u32x4 q = ring[j][r];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t v = q[d];
+                    u32x4 a;
+                    a[0] = (v & 0x000F000Fu) | 0x43004300u;
+                    a[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
+                    a[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
+                    a[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), b[d], acc[r], 0, 0, 0);
                 }
+            } else {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if constexpr (FMT == MI355_W_Q4) {
-                        const u32x4 q = ring[j][r];
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            const uint32_t v = q[d];
-                            u32x4 a;
-                            a[0] = (v & 0x000F000Fu) | 0x43004300u;
-                            a[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
-                            a[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
-                            a[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
-                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), b[d], acc[r], 0, 0, 0);
-                        }
-                    } else {
-#pragma unroll
-                        for (int d = 0; d < 4; ++d)
-                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ring[j][r * kPieces + d]), b[d],
-                                                                             acc[r], 0, 0, 0);
-                    }
-                }
-
-                if (++uu == nu) {
-                    // tile done for this wave: publish the partial 16x16 tiles, combine, epilogue
-                    uu = 0;
-                    f32x4* pp = (f32x4*)(part + (size_t)((buf * W + wave) * RS) * 1024) + lane;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        pp[r * 64] = acc[r];
-                        acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    if constexpr (FMT == MI355_W_Q4) {
-                        pp[R * 64] = acc1;
-                        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    if (tile == bid) MI355_STAMP(3);
-                    __syncthreads();
-                    if (e_owner || (!MULTI && threadIdx.x < 256)) tile_epilogue<FMT, R, EPI, MULTI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
-                    if (tile == bid) MI355_STAMP(4);
-                    tile += nb;
-                    buf ^= 1;
-                    load_epi<FMT, R, EPI>(p, er, tile, e_row, e_col, e_owner, eo);
-                }
+                for (int d = 0; d < 4; ++d)
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ring[j][r * kPieces + d]), b[d], acc[r], 0,
+                                                                     0, 0);
             }
-            MI355_ISSUE(j);  // refill the slot just consumed (offset out of range once the work is exhausted)
+        }
+    };
+    // tile done for this wave: publish the partial 16x16 tiles, combine, epilogue
+    auto flush = [&]() {
+        f32x4* pp = (f32x4*)(part + (size_t)((buf * W + wave) * RS) * 1024) + lane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            pp[r * 64] = acc[r];
+            acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (FMT == MI355_W_Q4) {
+            pp[R * 64] = acc1;
+            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (tile == bid) MI355_STAMP(3);
+        __syncthreads();
+        if (e_owner || (!MULTI && threadIdx.x < 256))
+            tile_epilogue<FMT, R, EPI, MULTI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
+        if (tile == bid) MI355_STAMP(4);
+        tile += nb;
+        buf ^= 1;
+        load_epi<FMT, R, EPI>(p, er, tile, e_row, e_col, e_owner, eo);
+    };
+
+    if constexpr (ALIGNED) {
+        // every wave's share of a tile is a whole number of ring turns (K = 4096: 32 units = 8 waves x 4): the tile
+        // can only end after slot P - 1, so there is ONE copy of the flush code instead of P, and the wait for
+        // the epilogue operands leaves the whole ring in flight (in the general loop hipcc must assume the
+        // previous tile ended one unit ago and waits for all but one slot).
+        for (int t = 0; t < total; t += P) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                consume(j);
+                ++uu;
+                MI355_ISSUE(j);
+            }
+            if (uu == nu) {
+                uu = 0;
+                flush();
+            }
+        }
+    } else {
+        for (int t = 0; t < total; t += P) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                if (t + j < total) {
+                    consume(j);
+                    if (++uu == nu) {
+                        uu = 0;
+                        flush();
+                    }
+                }
+                MI355_ISSUE(j);  // refill the slot just consumed (offset out of range once the work is exhausted)
+            }
         }
     }
     MI355_STAMP(5);
@@ -728,12 +755,12 @@ __global__ void i8_repack_kernel(const int8_t* c0, const int8_t* c1, int N, int 
 
 thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
 
-template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
-int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
+template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI, bool ALIGNED>
+int launch_gemv_a(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>,
+        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, EPI, VMODE, MULTI, ALIGNED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     });
     if (attr_err != hipSuccess) {
@@ -746,13 +773,23 @@ int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStrea
         // timestamps, i.e. the duration rocprofv3 reports for this launch
         hipEvent_t e0 = t_time_start, e1 = t_time_stop;
         t_time_start = t_time_stop = nullptr;
-        hipExtLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>), dim3(grid), dim3(waves * 64), (uint32_t)lds,
+        hipExtLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI, ALIGNED>), dim3(grid), dim3(waves * 64), (uint32_t)lds,
                               stream, e0, e1, 0, p);
     } else {
-        hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>), dim3(grid), dim3(waves * 64), lds, stream, p);
+        hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI, ALIGNED>), dim3(grid), dim3(waves * 64), lds, stream, p);
     }
     MI355_LAUNCH_CHECK();
     return 0;
+}
+
+template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
+int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
+    if constexpr (!MULTI) {
+        int w = waves;
+        if (w * 64 > kMaxThreads<FMT, P>) w = kMaxThreads<FMT, P> / 64;
+        if (p.units % (w * P) == 0) return launch_gemv_a<FMT, R, P, EPI, VMODE, false, true>(p, grid, waves, lds, stream);
+    }
+    return launch_gemv_a<FMT, R, P, EPI, VMODE, MULTI, false>(p, grid, waves, lds, stream);
 }
 
 template <int FMT, int R, int P, int EPI, int VMODE>
