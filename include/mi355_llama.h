@@ -113,7 +113,7 @@ typedef struct mi355_linear_args {
     int32_t waves;      /* waves per workgroup (split of K) */
     int32_t grid;       /* workgroups (persistent loop over tiles) */
     int32_t prefetch;   /* accepted, ignored: one ring depth per format (4 units Q4, 2 units bf16) */
-    int32_t flags;      /* bit0: stage activation row 0 before issuing the weight ring (tuning knob) */
+    int32_t flags;      /* reserved, pass 0 (a retired tuning knob) */
     /* activations given as split-attention partial records instead of x (x may be NULL): the prologue combines
      * them (K = attn_heads * attn_hs); layout as written by mi355_attention with n_split = attn_splits.  M = 1 */
     const float* attn_partials;

@@ -46,6 +46,8 @@ struct GemvParams {
     void* y;
     int64_t ldx, ldy;
     int N, K, M, n_tiles, units;
+    int u_q, u_r;  // units / waves, units % waves: wave w takes u_q (+1 if w < u_r) consecutive units of every tile
+    int t_q, t_r;  // n_tiles / grid, n_tiles % grid: workgroup b takes t_q (+1 if b < t_r) tiles, b, b + grid, ...
     int x_dtype, norm_dtype, sz_dtype, y_dtype, epi;
     int xs_stride;  // bytes per LDS activation row
     int vec_mode;   // 0 scalar staging, 1 f32 + bf16-scale RMSNorm vectorised, 2 bf16 copy vectorised
@@ -53,7 +55,6 @@ struct GemvParams {
     const float* attn_part;  // vec_mode 3: activations = combine of split-attention partial records
     int attn_splits, attn_heads, attn_hs;
     unsigned long long* dbg;  // optional wall-clock stamps [grid][8]
-    int stage_first;  // stage activation row 0 (waits for its loads) BEFORE issuing the weight ring
     float eps;
 };
 
@@ -418,27 +419,17 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
     MI355_STAMP(0);
 
     const int units = p.units;
-    const int u0 = (units * wave) / W, u1 = (units * (wave + 1)) / W;
-    const int nu = u1 - u0;
+    // K split over the waves / tiles over the workgroups, from host-computed quotients (integer divisions by
+    // runtime values cost ~60 instructions of every launch's prologue)
+    const int nu = p.u_q + (wave < p.u_r ? 1 : 0);
+    const int u0 = wave * p.u_q + (wave < p.u_r ? wave : p.u_r), u1 = u0 + nu;
     const int bid = blockIdx.x, nb = gridDim.x;
-    const int my_tiles = (p.n_tiles > bid) ? (p.n_tiles - bid + nb - 1) / nb : 0;
+    const int my_tiles = p.t_q + (bid < p.t_r ? 1 : 0);
     const int total = my_tiles * nu;
 
     // ---- row 0 of the activations: loads first (in-order VMEM return, see Stager)
     Stager<VMODE> stager;
     stager.load(p, 0);
-    if (p.stage_first) {
-        // With two workgroups per CU the activation loads of one queue behind the other's weight prefetch in the
-        // CU's memory pipeline and arrive 2-3 us late; consuming them before this workgroup's own ring is issued
-        // keeps the staging off the critical path (the ring then has the whole staging/barrier time to land).
-        float ss = stager.store(p, 0, xs);
-        for (int k = p.K + (int)threadIdx.x; k < p.units * kUnitK; k += blockDim.x) ((bf16_t*)xs)[k] = 0;
-        if constexpr (VMODE == 0 || VMODE == 1 || VMODE == 4) {
-            ss = wave_sum(ss);
-            if (lane == 0) wss[wave * 16] = ss;
-        }
-    }
-
     // ---- weight prefetch ring: P units in flight per wave.
     // Every refill is an UNCONDITIONAL load: a conditional refill makes the ring registers phi nodes, and hipcc
     // then drains the whole ring with s_waitcnt vmcnt(0) at the loop back-edge to copy them.  Past the end of the
@@ -494,7 +485,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
             if (lane == 0) wss[wave * 16 + m] = ss;
         }
     };
-    if (!p.stage_first) stage_row(0);
+    stage_row(0);
     for (int m = 1; m < M; ++m) {
         stager.load(p, m);
         stage_row(m);
@@ -767,7 +758,10 @@ int launch_gemv_a(const GemvParams& p, int grid, int waves, size_t lds, hipStrea
         mi355_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    if (waves * 64 > kMaxThreads<FMT, P>) waves = kMaxThreads<FMT, P> / 64;
+    if (waves * 64 > kMaxThreads<FMT, P>) {  // the host split (u_q / u_r) was computed for `waves`
+        mi355_set_error("internal: %d waves exceed the variant's workgroup size", waves);
+        return MI355_E_ARG;
+    }
     if (t_time_start != nullptr) {
         // measurement hook (mi355_debug_time_next_launch): the events receive the dispatch's own begin / end
         // timestamps, i.e. the duration rocprofv3 reports for this launch
@@ -785,9 +779,7 @@ int launch_gemv_a(const GemvParams& p, int grid, int waves, size_t lds, hipStrea
 template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
 int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     if constexpr (!MULTI) {
-        int w = waves;
-        if (w * 64 > kMaxThreads<FMT, P>) w = kMaxThreads<FMT, P> / 64;
-        if (p.units % (w * P) == 0) return launch_gemv_a<FMT, R, P, EPI, VMODE, false, true>(p, grid, waves, lds, stream);
+        if (p.units % (waves * P) == 0) return launch_gemv_a<FMT, R, P, EPI, VMODE, false, true>(p, grid, waves, lds, stream);
     }
     return launch_gemv_a<FMT, R, P, EPI, VMODE, MULTI, false>(p, grid, waves, lds, stream);
 }
@@ -1005,7 +997,6 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
         p.attn_heads = a->attn_heads;
         p.attn_hs = a->attn_hs;
         p.dbg = (unsigned long long*)a->debug_stamps;
-        p.stage_first = (a->flags & 1) ? 1 : 0;
     }
     {
         const size_t wb = mi355_packed_bytes(a->fmt, a->N, a->K, a->R, swiglu ? 1 : 0);
@@ -1024,6 +1015,10 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
         grid = cus * 2;
     }
     if (grid > p.n_tiles) grid = p.n_tiles;
+    p.u_q = p.units / waves;
+    p.u_r = p.units % waves;
+    p.t_q = p.n_tiles / grid;
+    p.t_r = p.n_tiles % grid;
     hipStream_t s = (hipStream_t)stream;
     if (a->fmt == MI355_W_Q4) {
         return a->R == 1 ? dispatch_p<MI355_W_Q4, 1>(p, a->prefetch, grid, waves, lds, s)

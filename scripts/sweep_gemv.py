@@ -88,7 +88,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (reps * n_buf)
             gbs = nbytes / us / 1e3
-            rec = dict(shape=name, waves=waves, grid=grid, prefetch=pf, stage_first=flags, us=round(us, 2), GBps=round(gbs, 1))
+            rec = dict(shape=name, waves=waves, grid=grid, prefetch=pf, us=round(us, 2), GBps=round(gbs, 1))
             print(json.dumps(rec), flush=True)
             if best is None or us < best["us"]:
                 best = rec
