@@ -28,7 +28,9 @@ struct AttnParams {
     int B, T, n_head, hs, S;
     int fused;  // 1: this kernel writes the (single) new K/V row itself
     int rope_gathered;  // rope row of token t is t (rows pre-selected by the caller), not pos[t]
-    int n_split;        // workgroups per head (flash-decoding); > 1 writes partial records to `part`
+    int n_split;        // workgroups per head (flash-decoding, a power of two); > 1 writes partial records to `part`
+    int ns_shift;       // log2(n_split)
+    int lpr_shift;      // log2(lanes per cache row) when a row is 16 B x a power of two <= 64 lanes, else -1
     float* part;
     unsigned long long* dbg;
     float scale;
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     constexpr int U = 8;
     const int h = blockIdx.x, t = blockIdx.y;
     const int ns = p.n_split;
-    const int b = blockIdx.z / ns, sj = blockIdx.z % ns;
+    const int b = blockIdx.z >> p.ns_shift, sj = blockIdx.z & (ns - 1);  // host-computed shifts: runtime integer
+                                                                          // divisions cost ~25 instructions each
     const int hs = p.hs, half = hs >> 1, C = p.n_head * hs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
 
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     const int slot = pos < p.S - 1 ? pos : p.S - 1;
     const int len = slot + 1;
     const int n_glob = p.fused ? slot : len;  // rows read from the cache in global memory
-    const int chunk = (n_glob + ns - 1) / ns;
+    const int chunk = (n_glob + ns - 1) >> p.ns_shift;
     const int s_begin = sj * chunk;
     const int s_end = (s_begin + chunk < n_glob) ? s_begin + chunk : n_glob;
     const bool own_cur = p.fused && sj == ns - 1;  // the split that folds in the new token
@@ -158,11 +161,10 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     const CT* vc = (const CT*)p.vcache + ((int64_t)b * p.n_head + h) * p.S * hs;
 
     const int row_bytes = hs * (int)sizeof(CT);
-    const int n16 = row_bytes / 16;
-    const bool vec_ok = (row_bytes % 16 == 0) && (n16 <= 64) && ((n16 & (n16 - 1)) == 0);
-    const int LPR = vec_ok ? n16 : 64;  // lanes per row
-    const int rpw = 64 / LPR;           // rows per wave instruction
-    const int li = lane % LPR, lr = lane / LPR;
+    const bool vec_ok = p.lpr_shift >= 0;
+    const int LPR = vec_ok ? (1 << p.lpr_shift) : 64;  // lanes per row
+    const int rpw = vec_ok ? (64 >> p.lpr_shift) : 1;  // rows per wave instruction
+    const int li = vec_ok ? (lane & (LPR - 1)) : lane, lr = vec_ok ? (lane >> p.lpr_shift) : 0;
     const int stride = nw * rpw;
 
     // ---- K/V rows stream through two register batches (A, B) of U row groups per wave: while one batch is
@@ -512,7 +514,14 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
     int ns = a->n_split > 1 ? a->n_split : 1;
     MI355_CHECK_ARG(ns == 1 || a->partials != nullptr, MI355_E_ARG, "attention: n_split > 1 needs a partials buffer");
     MI355_CHECK_ARG(ns <= 64 && (int64_t)a->B * ns <= 65535, MI355_E_SHAPE, "attention: n_split too large");
+    MI355_CHECK_ARG((ns & (ns - 1)) == 0, MI355_E_ARG, "attention: n_split must be a power of two (got %d)", ns);
     p.n_split = ns;
+    p.ns_shift = __builtin_ctz((unsigned)ns);
+    {
+        const int row_bytes = a->hs * esz, n16 = row_bytes / 16;
+        const bool vec_ok = (row_bytes % 16 == 0) && n16 >= 1 && n16 <= 64 && (n16 & (n16 - 1)) == 0;
+        p.lpr_shift = vec_ok ? __builtin_ctz((unsigned)n16) : -1;
+    }
     p.part = (float*)a->partials;
     p.dbg = (unsigned long long*)a->debug_stamps;
     const int threads = ns > 1 ? 256 : 512, nw = threads / 64;

@@ -32,6 +32,7 @@ struct I8Params {
     void* y;
     int64_t ldx, ldy;
     int N, K, M, n_tiles, units;
+    int u_q, u_r, t_q, t_r;  // units / waves, units % waves, n_tiles / grid, n_tiles % grid
     int x_dtype, norm_dtype, bias_dtype, y_dtype, epi;
     int xq_stride;  // bytes per int8 activation row in LDS
     unsigned w_bytes;  // size of the weight stream (buffer descriptor bound)
@@ -72,10 +73,11 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
     uint16_t* olist = (uint16_t*)(xh + (size_t)p.M * Kp);
     unsigned* obits = (unsigned*)(olist + Kp);
 
-    const int u0 = (units * wave) / W, u1 = (units * (wave + 1)) / W;
-    const int nu = u1 - u0;
+    // K split over the waves / tiles over the workgroups from host-computed quotients (see gemv.hip)
+    const int nu = p.u_q + (wave < p.u_r ? 1 : 0);
+    const int u0 = wave * p.u_q + (wave < p.u_r ? wave : p.u_r), u1 = u0 + nu;
     const int bid = blockIdx.x, nb = gridDim.x;
-    const int my_tiles = (p.n_tiles > bid) ? (p.n_tiles - bid + nb - 1) / nb : 0;
+    const int my_tiles = p.t_q + (bid < p.t_r ? 1 : 0);
     const int total = my_tiles * nu;
 
     constexpr int kSlot = R * 2;
@@ -709,6 +711,10 @@ extern "C" int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream
     int grid = a->grid;
     if (grid <= 0) grid = (mi355_num_cus() > 0 ? mi355_num_cus() : 256) * 2;
     if (grid > p.n_tiles) grid = p.n_tiles;
+    p.u_q = p.units / waves;
+    p.u_r = p.units % waves;
+    p.t_q = p.n_tiles / grid;
+    p.t_r = p.n_tiles % grid;
     hipStream_t s = (hipStream_t)stream;
     // ring depth: 4 units in flight per wave measured best for single matrices, 2 for the c_fc1/c_fc2 pair
     const bool deep = a->prefetch > 0 ? a->prefetch >= 4 : a->R == 1;
