@@ -146,12 +146,11 @@ class DecodeEngine:
             # multiple of the CU count keep every CU equally busy (7B: c_attn 768 tiles = 3 per CU, c_proj /
             # mlp.c_proj 256 = 1 per CU, lm_head 2000 = 7.8); the c_fc1/c_fc2 pair is 688 tiles (2.7 per CU).
             cus = nat.num_cus() or 256
-            # Measured (scripts/sweep_gemv.py, 7B shapes): one workgroup per CU is best for c_proj / the fc pair /
-            # mlp.c_proj; the single-matrix STORE launches with several tiles per CU (c_attn 9.6 -> 9.2 us, lm_head
-            # 18.8 -> 16.4 us) prefer two.
-            # The LLM.int8 launches (heavier quantising prologue) stay at one per CU: 449 vs 423 tok/s.
+            # Measured (scripts/sweep_gemv.py, 7B shapes): one workgroup per CU is best for every per-layer linear
+            # (c_attn 7.9 vs 8.1 us with two); only lm_head (7.8 tiles per CU) prefers two (15.5 vs 16.6 us).
+            # The LLM.int8 launches (heavier quantising prologue) stay at one per CU throughout.
             i8 = _kind(first.attn.c_attn) == "i8"
-            grids = {} if i8 else {"attn": 2 * cus, "lm_head": 2 * cus}
+            grids = {} if i8 else {"lm_head": 2 * cus}
             dflt = lambda key: {"grid": grids.get(key, cus), **self.tune.get(key, {})}  # noqa: E731
             for i, blk in enumerate(model.transformer.h):
                 attn = pack_linear(blk.attn.c_attn, 1, tune=dflt("attn"))
