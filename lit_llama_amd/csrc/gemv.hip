@@ -481,7 +481,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
         for (int k = p.K + (int)threadIdx.x; k < p.units * kUnitK; k += blockDim.x)
             ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;  // stream padding
         if constexpr (VMODE == 0 || VMODE == 1 || VMODE == 4) {
-            ss = wave_sum(ss);
+            ss = group_sum(ss, 64);  // 4 DPP steps + 2 ds_bpermute (wave_sum: 6 ds_bpermute, ~0.2 us more)
             if (lane == 0) wss[wave * 16 + m] = ss;
         }
     };
