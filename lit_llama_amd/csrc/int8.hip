@@ -50,8 +50,12 @@ constexpr int kStageVec = 8;  // 4-column activation vectors a thread keeps in r
 
 // LDS map: [hdr: red[64] | sca[16] | sinv[16] | ototal] [part 2*W*R KiB] [xq M*xq_stride] [xh M*Kp f16]
 //          [olist Kp u16: outlier columns, ascending] [obits Kp/8 B: outlier bit set]
-template <int R, int P, int VNV>  // VNV: 0 element loop, else 4-column vectors per thread kept in registers
+// VNV: 0 element loop, else 4-column vectors per thread kept in registers.  FAST: the decode step (one row that
+// fits the registers) as its own kernel, without the row / chunk loops of the prompt path (cold instruction cache:
+// every instruction of a launch's prologue is paid at memory latency).
+template <int R, int P, int VNV, bool FAST>
 __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
+    const int M = FAST ? 1 : p.M;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
     float* sca = (float*)(smem + 256);
@@ -69,8 +73,8 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
     MI355_STAMP(0);
     const int units = p.units, Kp = units * kUnitK;
     char* xq = part + 2 * W * R * 1024;
-    f16_t* xh = (f16_t*)(xq + (size_t)p.M * p.xq_stride);
-    uint16_t* olist = (uint16_t*)(xh + (size_t)p.M * Kp);
+    f16_t* xh = (f16_t*)(xq + (size_t)M * p.xq_stride);
+    uint16_t* olist = (uint16_t*)(xh + (size_t)M * Kp);
     unsigned* obits = (unsigned*)(olist + Kp);
 
     // K split over the waves / tiles over the workgroups from host-computed quotients (see gemv.hip)
@@ -288,8 +292,8 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
         }
     };
     if constexpr (VEC) {
-        const int nchunk = (nvecp + NV * nthr - 1) / (NV * nthr);  // 1 whenever a norm scale is fused (host check)
-        if (p.M == 1 && nchunk == 1) {
+        [[maybe_unused]] const int nchunk = FAST ? 1 : (nvecp + NV * nthr - 1) / (NV * nthr);  // 1 with a fused norm
+        if constexpr (FAST) {
             // decode: straight-line code on the vectors requested before the ring (a loop around the loads would
             // make the compiler wait for the whole ring prefill first), quantised straight from registers
             float xf[NV][4], hf[NV][4];
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
             }
             quantised = true;
         } else {
-            for (int m = 0; m < p.M; ++m) {
+            for (int m = 0; m < M; ++m) {
                 float amax = 0.f;
                 for (int c = 0; c < nchunk; ++c) {
                     if ((m | c) != 0) load_chunk(m, c);
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
             }
         }
     } else {
-        for (int m = 0; m < p.M; ++m) {
+        for (int m = 0; m < M; ++m) {
             const int64_t base = (int64_t)m * p.ldx;
             float rinv = 1.f;
             if (p.norm_scale != nullptr) {
@@ -396,13 +400,14 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
         }
         if (lane == 0) ototal[0] = oc;
     }
-    if (!quantised) {
+    if constexpr (!FAST) {
+      if (!quantised) {
         // general case (several rows / long rows): 8 columns per thread step from the f16 copy in LDS;
         // CA[m,k] = rint(x * (127 / SCA[m])), whole outlier columns zeroed
         __syncthreads();  // sinv of the last row
         for (int v8 = tid; v8 < (Kp >> 3); v8 += blockDim.x) {
             const unsigned outm = thr_on ? ((obits[v8 >> 2] >> ((v8 & 3) * 8)) & 0xffu) : 0u;
-            for (int m = 0; m < p.M; ++m) {
+            for (int m = 0; m < M; ++m) {
                 const u32x4 hh = *(const u32x4*)(xh + (size_t)m * Kp + 8 * (size_t)v8);
                 const float inv = sinv[m];
                 u32x2 q2 = u32x2{0u, 0u};
@@ -415,13 +420,14 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
                 *(u32x2*)(xq + (size_t)m * p.xq_stride + 8 * (size_t)v8) = q2;
             }
         }
+      }
     }
     __syncthreads();
     const int n_out = ototal[0];
     MI355_STAMP(3);
 
     const int e_row = (tid >> 4) & 15, e_col = tid & 15;
-    const bool e_owner = tid < 256 && e_col < p.M;
+    const bool e_owner = tid < 256 && e_col < M;
 
     // epilogue operands of the NEXT tile are fetched one tile ahead and kept as raw bits (see gemv.hip)
     uint32_t eo_scb[R], eo_bias[R], eo_old[R], eo_out[R][kFastOut];
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
     }
 
     const int g = lane >> 4, c = lane & 15;
-    const int xrow = c < p.M ? c : p.M - 1;
+    const int xrow = c < M ? c : M - 1;
     const char* xl = xq + (size_t)xrow * p.xq_stride + g * 16;
     int uu = 0;
     for (int t = 0; t < total; t += P) {
@@ -599,19 +605,19 @@ __global__ void int8_quant_rows_kernel(const void* w, int dtype, int K, int8_t* 
     }
 }
 
-template <int R, int P, int VNV>
+template <int R, int P, int VNV, bool FAST>
 int launch_i8v(const I8Params& p, int grid, int waves, size_t lds, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)int8_gemv_kernel<R, P, VNV>,
+        attr_err = hipFuncSetAttribute((const void*)int8_gemv_kernel<R, P, VNV, FAST>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     });
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    hipLaunchKernelGGL((int8_gemv_kernel<R, P, VNV>), dim3(grid), dim3(waves * 64), lds, stream, p);
+    hipLaunchKernelGGL((int8_gemv_kernel<R, P, VNV, FAST>), dim3(grid), dim3(waves * 64), lds, stream, p);
     MI355_LAUNCH_CHECK();
     return 0;
 }
@@ -621,9 +627,14 @@ int launch_i8(const I8Params& p, int grid, int waves, size_t lds, hipStream_t st
     // register staging sized to the row: 2 vectors per thread cover K <= 4096 at 512 threads (every n_embd-wide
     // input of the 7B model) with ~100 VGPRs; the 8-vector variant (K <= 16384) needs ~200 and its workgroups
     // take visibly longer to dispatch
-    if (p.vec == 0) return launch_i8v<R, P, 0>(p, grid, waves, lds, stream);
-    if (p.units * kUnitK / 4 <= 2 * waves * 64) return launch_i8v<R, P, 2>(p, grid, waves, lds, stream);
-    return launch_i8v<R, P, kStageVec>(p, grid, waves, lds, stream);
+    if (p.vec == 0) return launch_i8v<R, P, 0, false>(p, grid, waves, lds, stream);
+    const int nvecp = p.units * kUnitK / 4, nthr = waves * 64;
+    if (nvecp <= 2 * nthr) {
+        return p.M == 1 ? launch_i8v<R, P, 2, true>(p, grid, waves, lds, stream)
+                        : launch_i8v<R, P, 2, false>(p, grid, waves, lds, stream);
+    }
+    return (p.M == 1 && nvecp <= kStageVec * nthr) ? launch_i8v<R, P, kStageVec, true>(p, grid, waves, lds, stream)
+                                                   : launch_i8v<R, P, kStageVec, false>(p, grid, waves, lds, stream);
 }
 
 }  // namespace
