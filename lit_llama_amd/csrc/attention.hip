@@ -120,7 +120,9 @@ __global__ void rope_kv_write_kernel(const AttnParams p) {
 //   n_split == 1: the workgroup normalises and writes y.
 //   n_split  > 1: it writes its un-normalised partial (m, l, o[hs]) to `part`; the consumer combines them
 //                 (mi355_attn_combine, or the prologue of the following c_proj linear — see gemv.hip).
-template <typename CT>
+// LEAN: the engine's decode shape (f32 qkv row, cache rows of 16 B x a power of two lanes) with the generic
+// fall-backs compiled out — a launch starts with a cold instruction cache, so dead code between the live paths costs.
+template <typename CT, bool LEAN>
 __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int VEC = Vec16<CT>::kN;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     const CT* vc = (const CT*)p.vcache + ((int64_t)b * p.n_head + h) * p.S * hs;
 
     const int row_bytes = hs * (int)sizeof(CT);
-    const bool vec_ok = p.lpr_shift >= 0;
+    const bool vec_ok = LEAN || p.lpr_shift >= 0;
     const int LPR = vec_ok ? (1 << p.lpr_shift) : 64;  // lanes per row
     const int rpw = vec_ok ? (64 >> p.lpr_shift) : 1;  // rows per wave instruction
     const int li = vec_ok ? (lane & (LPR - 1)) : lane, lr = vec_ok ? (lane >> p.lpr_shift) : 0;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     // engine path (f32 qkv): the few q / rope / new-k / new-v loads are requested FIRST, unconditionally (clamped
     // indices, no branch -> no wait at a join), then the K/V batches; VMEM returns in order, so q is staged while
     // the rows are still in flight instead of queueing behind them
-    const bool fastq = p.qkv_dtype == MI355_F32 && half <= (int)blockDim.x && hs <= (int)blockDim.x;
+    const bool fastq = LEAN || (p.qkv_dtype == MI355_F32 && half <= (int)blockDim.x && hs <= (int)blockDim.x);
     float2 qv = {0.f, 0.f}, kv = {0.f, 0.f}, cs = {0.f, 0.f};
     float vv = 0.f;
     auto q_load = [&]() {
@@ -530,17 +532,22 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
     MI355_CHECK_ARG(lds <= 160 * 1024, MI355_E_SHAPE, "attention: hs=%d needs %zu B of LDS", a->hs, lds);
     static bool attr_done = false;
     if (!attr_done) {
-        MI355_HIP(hipFuncSetAttribute((const void*)attn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        MI355_HIP(hipFuncSetAttribute((const void*)attn_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024));
-        MI355_HIP(hipFuncSetAttribute((const void*)attn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        MI355_HIP(hipFuncSetAttribute((const void*)attn_kernel<bf16_t, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MI355_HIP(hipFuncSetAttribute((const void*)attn_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024));
         attr_done = true;
     }
     const dim3 agrid(a->n_head, a->T, a->B * ns);
+    const bool lean = esz == 2 && p.lpr_shift >= 0 && a->qkv_dtype == MI355_F32 && a->hs <= threads;
     if (esz == 4)
-        hipLaunchKernelGGL(attn_kernel<float>, agrid, dim3(threads), lds, s, p);
+        hipLaunchKernelGGL((attn_kernel<float, false>), agrid, dim3(threads), lds, s, p);
+    else if (lean)
+        hipLaunchKernelGGL((attn_kernel<bf16_t, true>), agrid, dim3(threads), lds, s, p);
     else
-        hipLaunchKernelGGL(attn_kernel<bf16_t>, agrid, dim3(threads), lds, s, p);
+        hipLaunchKernelGGL((attn_kernel<bf16_t, false>), agrid, dim3(threads), lds, s, p);
     MI355_LAUNCH_CHECK();
     return 0;
 }
