@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         for (int o = LPR; o < 64; o <<= 1) {
             const float m_o = __shfl_xor(m_run, o, 64), l_o = __shfl_xor(l_run, o, 64);
             const float m_new = fmaxf(m_run, m_o);
-            const float ca = expf(m_run - m_new), cb = expf(m_o - m_new);
+            const float ca = __expf(m_run - m_new), cb = __expf(m_o - m_new);
             l_run = l_run * ca + l_o * cb;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) of[j] = of[j] * ca + __shfl_xor(of[j], o, 64) * cb;
@@ -388,29 +388,42 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     if (own_cur && wave == nw - 1) {
         float dot = 0.f;
         for (int d = lane; d < hs; d += 64) dot += qs[d] * kcur[d];
-        dot = wave_sum(dot);
+        dot = group_sum(dot, 64);
         if (lane == 0) scur[0] = dot * p.scale;
     }
     MI355_STAMP(3);
     __syncthreads();
 
     // ---- combine the waves (fixed order) and, fused, the current position from its LDS copy
+    // nw <= 8: fixed-trip loops, so the LDS reads of a loop overlap and each wave's weight e^{m_w - M} is
+    // computed once (v_exp_f32) instead of once per output element
     float m_all = kNegBig;
-    for (int w = 0; w < nw; ++w) m_all = fmaxf(m_all, wm[w]);
+    float wmv[8], wgt[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        wmv[w] = w < nw ? wm[w] : kNegBig;
+        m_all = fmaxf(m_all, wmv[w]);
+    }
     float s_cur = kNegBig;
     if (own_cur) {
         s_cur = scur[0];
         m_all = fmaxf(m_all, s_cur);
     }
     float l_all = 0.f;
-    for (int w = 0; w < nw; ++w) l_all += wl[w] * expf(wm[w] - m_all);
-    const float p_cur = own_cur ? expf(s_cur - m_all) : 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        wgt[w] = w < nw ? __expf(wmv[w] - m_all) : 0.f;
+        l_all += (w < nw ? wl[w] : 0.f) * wgt[w];
+    }
+    const float p_cur = own_cur ? __expf(s_cur - m_all) : 0.f;
     l_all += p_cur;
     if (ns == 1) {
         const float inv = 1.0f / l_all;
         for (int d = tid; d < hs; d += blockDim.x) {
             float o = 0.f;
-            for (int w = 0; w < nw; ++w) o += opart[w * hs + d] * expf(wm[w] - m_all);
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+                if (w < nw) o += opart[w * hs + d] * wgt[w];
             if (own_cur) o += p_cur * vcur[d];
             st_from_f32(p.y, ((int64_t)b * p.T + t) * p.ldy + h * hs + d, p.y_dtype, o * inv);
         }
@@ -425,7 +438,9 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
         }
         for (int d = tid; d < hs; d += blockDim.x) {
             float o = 0.f;
-            for (int w = 0; w < nw; ++w) o += opart[w * hs + d] * expf(wm[w] - m_all);
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+                if (w < nw) o += opart[w * hs + d] * wgt[w];
             if (own_cur) o += p_cur * vcur[d];
             rec[4 + d] = o;
         }
