@@ -133,6 +133,25 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // this kernel's time.  Only groups wider than a 16-lane row use ds_bpermute for the last step(s).
 #define MI355_DPP_ADD(v, ctrl) \
     ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, false)))
+// xor-16 / xor-32 lane exchanges on the VALU: gfx950's v_permlane16_swap / v_permlane32_swap swap the odd 16-lane
+// rows (upper 32 lanes) of one register with the even rows (lower 32 lanes) of another; fed the same value twice,
+// one of the two results holds the partner lane's value (semantics checked by scripts/micro/permlane.hip).
+// ds_bpermute (what __shfl_xor lowers to) is an LDS round trip of ~100 cycles.
+__device__ __forceinline__ float lane_xor16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(((threadIdx.x >> 4) & 1) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+// value of lane (lane ^ o), o a wave-uniform power of two
+__device__ __forceinline__ float lane_xor(float v, int o) {
+    if (o == 16) return lane_xor16(v);
+    if (o == 32) return lane_xor32(v);
+    return __shfl_xor(v, o, 64);
+}
+
 #define MI355_DPP_MAX(v, ctrl) \
     fmaxf((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, false)))
 __device__ __forceinline__ float group_sum(float v, int lpr) {
@@ -140,7 +159,8 @@ __device__ __forceinline__ float group_sum(float v, int lpr) {
     if (lpr >= 4) v = MI355_DPP_ADD(v, 0x4E);
     if (lpr >= 8) v = MI355_DPP_ADD(v, 0x141);
     if (lpr >= 16) v = MI355_DPP_ADD(v, 0x140);
-    for (int o = 16; o < lpr; o <<= 1) v += __shfl_xor(v, o, 64);
+    if (lpr >= 32) v += lane_xor16(v);
+    if (lpr >= 64) v += lane_xor32(v);
     return v;
 }
 

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(512) void int8_gemv_kernel(const I8Params p) {
             v = MI355_DPP_MAX(v, 0x4E);
             v = MI355_DPP_MAX(v, 0x141);
             v = MI355_DPP_MAX(v, 0x140);
-            v = fmaxf(v, __shfl_xor(v, 16, 64));
-            v = fmaxf(v, __shfl_xor(v, 32, 64));
+            v = fmaxf(v, lane_xor16(v));
+            v = fmaxf(v, lane_xor32(v));
         } else {
             v = group_sum(v, 64);
         }
