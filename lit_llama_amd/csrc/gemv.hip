@@ -974,7 +974,7 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     p.eps = a->eps;
     int waves = a->waves > 0 ? a->waves : 8;
     if (waves > 16) waves = 16;
-    if (!(a->fmt == MI355_W_Q4 && a->prefetch < 8) && waves > 8) waves = 8;  // see kMaxThreads
+    if (a->fmt != MI355_W_Q4 && waves > 8) waves = 8;  // see kMaxThreads
     if (waves < 4) waves = 4;  // the combine step needs 256 owner threads
     {
         const int esz = a->x_dtype == MI355_F32 ? 4 : 2;
