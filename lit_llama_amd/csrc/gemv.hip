@@ -47,6 +47,8 @@ struct GemvParams {
     int64_t ldx, ldy;
     int N, K, M, n_tiles, units;
     int u_q, u_r;  // units / waves, units % waves: wave w takes u_q (+1 if w < u_r) consecutive units of every tile
+    int nu_pad;    // ring turns are whole: every wave steps through nu_pad = ceil(max units per wave / P) * P units per
+                   // tile; the steps past its own units load nothing (out-of-range offsets) and multiply zeros
     int t_q, t_r;  // n_tiles / grid, n_tiles % grid: workgroup b takes t_q (+1 if b < t_r) tiles, b, b + grid, ...
     int x_dtype, norm_dtype, sz_dtype, y_dtype, epi;
     int xs_stride;  // bytes per LDS activation row
@@ -396,7 +398,7 @@ constexpr int kMaxThreads = (FMT == MI355_W_Q4 && P <= 4) ? 1024 : 512;
 
 // MULTI = false is the decode step (M == 1): no row loop, no per-row branches — the loop around the row-staging
 // loads alone cost 0.4-1 us per launch through hipcc's conservative vmcnt waits (12.9 -> 11.9 us for the fc pair).
-template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI, bool ALIGNED>
+template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
 __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvParams p) {
     const int M = MULTI ? p.M : 1;
     constexpr bool NT = true;  // weights are read once: non-temporal
@@ -422,10 +424,11 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
     // K split over the waves / tiles over the workgroups, from host-computed quotients (integer divisions by
     // runtime values cost ~60 instructions of every launch's prologue)
     const int nu = p.u_q + (wave < p.u_r ? 1 : 0);
-    const int u0 = wave * p.u_q + (wave < p.u_r ? wave : p.u_r), u1 = u0 + nu;
+    const int u0 = wave * p.u_q + (wave < p.u_r ? wave : p.u_r);
     const int bid = blockIdx.x, nb = gridDim.x;
     const int my_tiles = p.t_q + (bid < p.t_r ? 1 : 0);
-    const int total = my_tiles * nu;
+    const int nu_pad = p.nu_pad;
+    const int total = my_tiles * nu_pad;
 
     // ---- row 0 of the activations: loads first (in-order VMEM return, see Stager)
     Stager<VMODE> stager;
@@ -437,20 +440,21 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
     // issues NO memory request.  (Re-reading a fixed dummy address instead funnels every wave of the chip into
     // one L2 channel: measured ~8 us of a 16 us launch.)
     u32x4 ring[P][kSlot];
-    int pf_tile = bid, pf_u = u0, pf_n = 0;
+    int pf_tile = bid, pf_u = 0, pf_n = 0;  // pf_u: step inside the tile, 0 .. nu_pad - 1 (real units: pf_u < nu)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
     const unsigned lane_off = lane * 16;
     const unsigned unit_bytes32 = (unsigned)kSlot * 1024u;
 #define MI355_ISSUE(slot)                                                                                       \
     do {                                                                                                        \
-        const bool ok__ = pf_n < total;                                                                         \
-        const unsigned off__ = ok__ ? ((unsigned)pf_tile * (unsigned)units + (unsigned)pf_u) * unit_bytes32 + lane_off \
-                                    : 0xFFFFF000u;                                                              \
+        const bool ok__ = pf_n < total && pf_u < nu;                                                            \
+        const unsigned off__ =                                                                                  \
+            ok__ ? ((unsigned)pf_tile * (unsigned)units + (unsigned)(u0 + pf_u)) * unit_bytes32 + lane_off      \
+                 : 0xFFFFF000u;                                                                                 \
         _Pragma("unroll") for (int s__ = 0; s__ < kSlot; ++s__) ring[slot][s__] = __builtin_bit_cast(           \
             u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off__ + s__ * 1024, 0, NT ? 2 : 0));             \
         ++pf_n;                                                                                                 \
-        if (ok__ && ++pf_u == u1) {                                                                             \
-            pf_u = u0;                                                                                          \
+        if (++pf_u == nu_pad) {                                                                                 \
+            pf_u = 0;                                                                                           \
             pf_tile += nb;                                                                                      \
         }                                                                                                       \
     } while (0)
@@ -478,8 +482,8 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
     // from 2.0 to 3.4 us after ring issue and grew with the ring depth).
     auto stage_row = [&](int m) {
         float ss = stager.store(p, m, xs);
-        for (int k = p.K + (int)threadIdx.x; k < p.units * kUnitK; k += blockDim.x)
-            ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;  // stream padding
+        for (int k = p.K + (int)threadIdx.x; k < (p.units + 1) * kUnitK; k += blockDim.x)
+            ((bf16_t*)(xs + (size_t)m * p.xs_stride))[k] = 0;  // stream padding + the all-zero unit of the idle steps
         if constexpr (VMODE == 0 || VMODE == 1 || VMODE == 4) {
             ss = group_sum(ss, 64);  // 4 DPP steps + 2 ds_bpermute (wave_sum: 6 ds_bpermute, ~0.2 us more)
             if (lane == 0) wss[wave * 16 + m] = ss;
@@ -506,21 +510,6 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
 
     int tile = bid, buf = 0;
 
-    if (nu == 0) {
-        // more waves than units: this wave only takes part in the combine
-        for (int i = 0; i < my_tiles; ++i) {
-            f32x4* pp = (f32x4*)(part + (size_t)((buf * W + wave) * RS) * 1024) + lane;
-#pragma unroll
-            for (int r = 0; r < RS; ++r) pp[r * 64] = acc1;  // zeros
-            __syncthreads();
-            if (e_owner || (!MULTI && threadIdx.x < 256)) tile_epilogue<FMT, R, EPI, MULTI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
-            tile += nb;
-            buf ^= 1;
-            load_epi<FMT, R, EPI>(p, er, tile, e_row, e_col, e_owner, eo);
-        }
-        return;
-    }
-
     // ---- main loop
     const int g = lane >> 4, c = lane & 15;
     const int xrow = c < M ? c : M - 1;
@@ -530,7 +519,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
 
     // one k-unit: operands from LDS, int4 -> bf16, MFMAs
     auto consume = [&](int j) {
-        const char* xb = xl + (u0 + uu) * (kUnitK * 2);
+        const char* xb = xl + (uu < nu ? u0 + uu : units) * (kUnitK * 2);  // idle step: the all-zero unit
         bf16x8 b[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) b[d] = *(const bf16x8*)(xb + 16 * d);
@@ -585,36 +574,21 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
         load_epi<FMT, R, EPI>(p, er, tile, e_row, e_col, e_owner, eo);
     };
 
-    if constexpr (ALIGNED) {
-        // every wave's share of a tile is a whole number of ring turns (K = 4096: 32 units = 8 waves x 4): the tile
-        // can only end after slot P - 1, so there is ONE copy of the flush code instead of P, and the wait for
-        // the epilogue operands leaves the whole ring in flight (in the general loop hipcc must assume the
-        // previous tile ended one unit ago and waits for all but one slot).
-        for (int t = 0; t < total; t += P) {
+    // Every wave steps through nu_pad (a multiple of P) units per tile, so a tile can only end after slot P - 1:
+    // ONE copy of the tile-end code instead of P, and the wait for the epilogue operands leaves the whole ring in
+    // flight (with a tile end possible after any slot hipcc must assume the previous one was a single unit ago and
+    // waits for all but one slot).  K = 4096 over 8 waves is exactly one ring turn per tile; where the split is
+    // uneven (K = 11008: 10 or 11 units per wave, nu_pad = 12) the idle steps cost a few MFMAs on zeros.
+    for (int t = 0; t < total; t += P) {
 #pragma unroll
-            for (int j = 0; j < P; ++j) {
-                consume(j);
-                ++uu;
-                MI355_ISSUE(j);
-            }
-            if (uu == nu) {
-                uu = 0;
-                flush();
-            }
+        for (int j = 0; j < P; ++j) {
+            consume(j);
+            ++uu;
+            MI355_ISSUE(j);
         }
-    } else {
-        for (int t = 0; t < total; t += P) {
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                if (t + j < total) {
-                    consume(j);
-                    if (++uu == nu) {
-                        uu = 0;
-                        flush();
-                    }
-                }
-                MI355_ISSUE(j);  // refill the slot just consumed (offset out of range once the work is exhausted)
-            }
+        if (uu == nu_pad) {
+            uu = 0;
+            flush();
         }
     }
     MI355_STAMP(5);
@@ -746,12 +720,12 @@ __global__ void i8_repack_kernel(const int8_t* c0, const int8_t* c1, int N, int 
 
 thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
 
-template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI, bool ALIGNED>
-int launch_gemv_a(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
+template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
+int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, EPI, VMODE, MULTI, ALIGNED>,
+        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     });
     if (attr_err != hipSuccess) {
@@ -767,21 +741,13 @@ int launch_gemv_a(const GemvParams& p, int grid, int waves, size_t lds, hipStrea
         // timestamps, i.e. the duration rocprofv3 reports for this launch
         hipEvent_t e0 = t_time_start, e1 = t_time_stop;
         t_time_start = t_time_stop = nullptr;
-        hipExtLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI, ALIGNED>), dim3(grid), dim3(waves * 64), (uint32_t)lds,
+        hipExtLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>), dim3(grid), dim3(waves * 64), (uint32_t)lds,
                               stream, e0, e1, 0, p);
     } else {
-        hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI, ALIGNED>), dim3(grid), dim3(waves * 64), lds, stream, p);
+        hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>), dim3(grid), dim3(waves * 64), lds, stream, p);
     }
     MI355_LAUNCH_CHECK();
     return 0;
-}
-
-template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
-int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
-    if constexpr (!MULTI) {
-        if (p.units % (waves * P) == 0) return launch_gemv_a<FMT, R, P, EPI, VMODE, false, true>(p, grid, waves, lds, stream);
-    }
-    return launch_gemv_a<FMT, R, P, EPI, VMODE, MULTI, false>(p, grid, waves, lds, stream);
 }
 
 template <int FMT, int R, int P, int EPI, int VMODE>
@@ -970,7 +936,7 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     p.sz_dtype = a->sz_dtype;
     p.y_dtype = a->y_dtype;
     p.epi = a->epi;
-    p.xs_stride = p.units * kUnitK * 2 + 16;
+    p.xs_stride = (p.units + 1) * kUnitK * 2 + 16;  // + one all-zero unit (idle ring steps read it)
     p.eps = a->eps;
     int waves = a->waves > 0 ? a->waves : 8;
     if (waves > 16) waves = 16;
@@ -1017,6 +983,10 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     if (grid > p.n_tiles) grid = p.n_tiles;
     p.u_q = p.units / waves;
     p.u_r = p.units % waves;
+    {
+        const int P = a->fmt == MI355_W_Q4 ? 4 : 2, nu_max = p.u_q + (p.u_r ? 1 : 0);
+        p.nu_pad = (nu_max + P - 1) / P * P;
+    }
     p.t_q = p.n_tiles / grid;
     p.t_r = p.n_tiles % grid;
     hipStream_t s = (hipStream_t)stream;
@@ -1050,7 +1020,7 @@ extern "C" int mi355_linear_max_rows(int fmt, int K, int R, int waves) {
     } else if (fmt == MI355_W_Q4 || fmt == MI355_W_BF16) {
         const int RS = R + (fmt == MI355_W_Q4 ? 1 : 0);
         fixed = kLdsHeader + (int64_t)2 * w * RS * 1024;
-        per_row = kp * 2 + 16;
+        per_row = (kp + kUnitK) * 2 + 16;  // + the all-zero unit
     } else {
         return 0;
     }
