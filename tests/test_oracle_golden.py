@@ -1,6 +1,7 @@
 """The oracle (CPU restatement) against the golden vectors produced by the real reference
 (oracle/gen_golden.py).  This is the pin that makes the oracle trustworthy as a checker."""
 import numpy as np
+import pytest
 import torch
 
 from lit_llama_amd import synth
@@ -102,3 +103,23 @@ def test_llm_int8_restatement_is_close_to_fp_and_handles_outliers():
     # the outlier columns must not saturate the int8 scale: error stays at the no-outlier level
     y3 = oracle.llm_int8_linear(x, cb, scb, threshold=0.0)
     assert (y3 - x @ w.t()).abs().max() > (y2 - x @ w.t()).abs().max()
+
+
+@pytest.mark.parametrize("name", ["gptq_actorder", "gptq_plain"])
+def test_gptq_restatement_matches_reference(golden, name):
+    """oracle/gptq.py against the reference GPTQQuantizer's own results (quantization.py:426-616), bit for bit:
+    Hessian accumulation, row parameters, the quantised weights handed to pack_weight, the error and the bytes."""
+    from oracle import gptq as ogptq
+
+    g = golden(name)
+    W = torch.from_numpy(g["weight"])
+    hs = ogptq.Hessian(W.shape[1])
+    for b in torch.from_numpy(g["batches"]):
+        hs.add(b)
+    Q, sc, ze, err = ogptq.gptq_quantize(W, hs.H, bits=int(g["bits"]), groupsize=int(g["groupsize"]),
+                                         actorder=bool(g["actorder"]))
+    assert torch.equal(sc, torch.from_numpy(g["scales"])) and torch.equal(ze, torch.from_numpy(g["zeros"]))
+    assert torch.equal(Q, torch.from_numpy(g["Q"]))
+    assert err == float(g["error"])
+    packed = oracle.colblock_pack(Q, sc, ze, 4, W.shape[1])
+    assert torch.equal(packed.contiguous(), torch.from_numpy(g["quant_weight"]))
