@@ -278,6 +278,27 @@ typedef struct mi355_int8_args {
 int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GPTQ weight quantisation (offline producer of the int4 checkpoint format).
+ * One block (<= 128 columns) of GPTQQuantizer.quantize's inner loop, lit_llama/quantization.py:573-592,
+ * all rows in parallel, the columns in sequence:
+ *     q = scale * (clamp(rint(w / scale) + zero, 0, maxq) - zero);   e = (w - q) / Hinv1[i, i];
+ *     w_j -= e * Hinv1[i, j]  (j >= i);   loss = (w - q)^2 / Hinv1[i, i]^2
+ * in f32 without fused multiply-adds (bit-identical to the reference's CPU arithmetic).
+ * W1 [N, count] is read only (row stride ldw; the updated copy is not needed afterwards, :596);
+ * Hinv1 [count, count] is the block of the upper Cholesky factor of H^-1; scale / zero are addressed as
+ * [row * sz_row_stride + col * sz_col_stride] (per-row parameters: strides 1, 0);
+ * Q1 (dequantised levels), Err1 and Loss1 are [N, count] outputs with row stride ldo.
+ * ---------------------------------------------------------------------------------------- */
+/* Row parameters of W[:, 0:cols] (find_params_weight, lit_llama/quantization.py:472-513, perchannel): scale[n] =
+ * (max(row, 0) - min(row, 0)) / maxq, zero[n] = rint(-min / scale) (sym != 0: the symmetric variant). */
+int mi355_gptq_row_params(const float* W, int64_t ldw, int N, int cols, int maxq, int sym, float* scale, float* zero,
+                          mi355_stream_t stream);
+
+int mi355_gptq_block(const float* W1, int64_t ldw, int N, int count, const float* Hinv1, int64_t ldh,
+                     const float* scale, const float* zero, int64_t sz_row_stride, int64_t sz_col_stride,
+                     int maxq, float* Q1, float* Err1, float* Loss1, int64_t ldo, mi355_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Whole-forward entry: LLaMA.forward (lit_llama/model.py:76-122) for B = 1, T <= 16 tokens with
  * KV cache, entered once per call; the T = 1 step can be captured in a hipGraph and replayed
  * (positions / token ids live in device memory so the graph is static).

@@ -142,6 +142,9 @@ PROTOTYPES = {
     "mi355_sizeof": (c_int, [c_int]),
     "mi355_linear_max_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "mi355_debug_time_next_launch": (c_int, [c_void_p, c_void_p]),
+    "mi355_gptq_row_params": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "mi355_gptq_block": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                 c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 ABI_STRUCTS = [LinearArgs, AttnArgs, Int8Args, Weight, Layer, Model]

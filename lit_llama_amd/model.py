@@ -98,7 +98,14 @@ def _linear(mod: nn.Module, x: torch.Tensor) -> torch.Tensor:
         y = torch.nn.functional.linear(x2d, w, mod.bias)
     else:
         y = ops.linear_dense(x2d, w.detach().to(x.dtype), mod.bias)
-    return y.view(*x.shape[:-1], w.shape[0])
+    y = y.view(*x.shape[:-1], w.shape[0])
+    # this path bypasses nn.Module.__call__; forward hooks (GPTQ calibration statistics, lit_llama_amd/gptq.py)
+    # still see (module, inputs, output)
+    for hook in list(mod._forward_hooks.values()):
+        r = hook(mod, (x,), y)
+        if r is not None:
+            y = r
+    return y
 
 
 class RMSNorm(nn.Module):

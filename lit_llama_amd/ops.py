@@ -381,3 +381,38 @@ def kv_roll(k: torch.Tensor, v: torch.Tensor) -> None:
     require_gpu(k, "kv_roll")
     B, nh, S, hs = k.shape
     check(lib().mi355_kv_roll(ptr(k), ptr(v), dtype_code(k.dtype), B, nh, S, hs, stream_ptr()), "mi355_kv_roll")
+
+
+# ------------------------------------------------------------------------------------------ GPTQ (offline)
+def gptq_row_params(W: torch.Tensor, maxq: int, sym: bool = False):
+    """(scale [N], zero [N]) of the rows of W [N, cols] f32 (column slices are fine): mi355_gptq_row_params."""
+    require_gpu(W, "gptq_row_params")
+    assert W.dtype == torch.float32 and W.dim() == 2 and W.stride(1) == 1
+    N, cols = W.shape
+    scale = torch.empty((N,), dtype=torch.float32, device=W.device)
+    zero = torch.empty_like(scale)
+    check(lib().mi355_gptq_row_params(ptr(W), W.stride(0), N, cols, int(maxq), 1 if sym else 0, ptr(scale), ptr(zero),
+                                      stream_ptr()), "mi355_gptq_row_params")
+    return scale, zero
+
+
+def gptq_block(W1: torch.Tensor, Hinv1: torch.Tensor, scale: torch.Tensor, zero: torch.Tensor, maxq: int):
+    """One block of GPTQ's inner loop (mi355_gptq_block): W1 [N, count] f32 (a column slice of W is fine),
+    Hinv1 [count, count] f32, scale / zero [N] (per row) or [N, count] (per column).  Returns (Q1, Err1, Loss1)."""
+    require_gpu(W1, "gptq_block")
+    assert W1.dtype == torch.float32 and Hinv1.dtype == torch.float32 and W1.dim() == 2 and W1.stride(1) == 1
+    N, count = W1.shape
+    assert Hinv1.shape == (count, count)
+    if Hinv1.stride(1) != 1:  # torch.linalg.cholesky(upper=True) returns a transposed view
+        Hinv1 = Hinv1.contiguous()
+    scale = scale.reshape(N, -1).float().contiguous()
+    zero = zero.reshape(N, -1).float().contiguous()
+    assert scale.shape == zero.shape and scale.shape[1] in (1, count)
+    per_col = scale.shape[1] == count and count > 1
+    Q1 = torch.empty((N, count), dtype=torch.float32, device=W1.device)
+    E1 = torch.empty_like(Q1)
+    L1 = torch.empty_like(Q1)
+    check(lib().mi355_gptq_block(ptr(W1), W1.stride(0), N, count, ptr(Hinv1), Hinv1.stride(0), ptr(scale), ptr(zero),
+                                 scale.stride(0), 1 if per_col else 0, int(maxq), ptr(Q1), ptr(E1), ptr(L1), count,
+                                 stream_ptr()), "mi355_gptq_block")
+    return Q1, E1, L1
