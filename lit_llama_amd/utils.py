@@ -3,7 +3,8 @@
 Mirrors /root/reference lit_llama/utils.py:29-41 (`llama_model_lookup`, `find_multiple`), :73-138
 (`EmptyInitOnDevice`) and :141-162 (`quantization`): while the context is active `torch.nn.Linear` is
 rebound to the quantised class, so `LLaMA.from_name(...)` builds every linear through the plug-in.
-Checkpoint streaming (`lazy_load`, `incremental_save`) is load-time tooling and out of scope.
+`lazy_load` (:332-344) is re-exported from checkpoint.py (a reader of the torch.save zip format itself);
+`incremental_save` is checkpoint-conversion tooling and out of scope.
 """
 from __future__ import annotations
 
@@ -12,6 +13,8 @@ from contextlib import contextmanager
 
 import torch
 import torch.utils._device
+
+from .checkpoint import lazy_load  # noqa: F401  (same name and use as lit_llama.utils.lazy_load)
 
 llama_model_sizes = {
     4096: "7B",  # 7B n_embd=4096

@@ -1,0 +1,114 @@
+"""lazy_load (lit_llama_amd/checkpoint.py): the streaming reader of torch.save checkpoints that replaces the
+reference's lazy_load / NotYetLoadedTensor (lit_llama/utils.py:166-344).  Host logic only: runs on CPU."""
+import warnings
+
+import pytest
+import torch
+
+from lit_llama_amd import synth, tp
+from lit_llama_amd.checkpoint import LazyTensor, lazy_load
+from lit_llama_amd.model import LLaMA, LLaMAConfig
+from lit_llama_amd.utils import lazy_load as lazy_load_from_utils
+
+warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
+
+
+def _sample_state():
+    gen = torch.Generator().manual_seed(0)
+    packed = torch.randint(0, 256, (24, 40), generator=gen, dtype=torch.uint8).t()  # [40, 24] stride (1, 40)
+    return {
+        "a.weight": torch.randn((48, 32), generator=gen),
+        "a.bf16": torch.randn((16, 8), generator=gen).to(torch.bfloat16),
+        "q.quant_weight": packed,
+        "q.scales": torch.rand((40, 1), generator=gen).to(torch.bfloat16),
+        "scalar": torch.tensor(3.5),
+        "ints": torch.arange(10, dtype=torch.int32),
+        "empty": torch.zeros((0, 4)),
+        "param": torch.nn.Parameter(torch.randn((5, 3), generator=gen)),
+        "view": torch.randn((10, 10), generator=gen)[2:7, 1:4],  # a non-trivial offset / stride into a bigger storage
+    }
+
+
+def test_lazy_load_reads_nothing_until_asked_and_matches_torch_load(tmp_path):
+    sd = _sample_state()
+    path = tmp_path / "ckpt.pth"
+    torch.save(sd, path)
+    ref = torch.load(path, weights_only=False)
+    with lazy_load(path) as ck:
+        reader = ck  # the dict
+        assert list(ck.keys()) == list(sd.keys())
+        assert all(isinstance(v, LazyTensor) for v in ck.values())
+        for k, v in ck.items():
+            assert v.shape == ref[k].shape and v.dtype == ref[k].dtype and v.dim() == ref[k].dim()
+        ll = [v for v in ck.values()][0]._storage.reader
+        assert ll.bytes_mapped == 0, "metadata access must not touch tensor bytes"
+        w = ck["a.weight"].materialize()
+        assert ll.bytes_mapped == 48 * 32 * 4
+        assert torch.equal(w, ref["a.weight"])
+        for k, v in ck.items():
+            t = v.materialize()
+            assert t.shape == ref[k].shape and t.stride() == ref[k].stride(), k
+            assert torch.equal(t, ref[k].data if isinstance(ref[k], torch.nn.Parameter) else ref[k]), k
+        assert isinstance(ck["param"].materialize(), torch.nn.Parameter)
+        assert ck["q.quant_weight"].stride() == (1, 40)
+    assert reader is ck
+
+
+def test_lazy_row_shards_read_only_their_byte_range(tmp_path):
+    w = torch.arange(64 * 16, dtype=torch.float32).view(64, 16)
+    path = tmp_path / "w.pth"
+    torch.save({"w": w}, path)
+    with lazy_load(path) as ck:
+        lt = ck["w"]
+        reader = lt._storage.reader
+        piece = lt[16:32]                       # stays lazy
+        assert isinstance(piece, LazyTensor) and piece.shape == (16, 16) and reader.bytes_mapped == 0
+        assert torch.equal(piece.materialize(), w[16:32])
+        assert reader.bytes_mapped == 16 * 16 * 4, "a row shard is a byte sub-range of the member"
+        assert torch.equal(lt.narrow(1, 4, 8).materialize(), w[:, 4:12])
+        with pytest.raises(IndexError):
+            lt.narrow(0, 60, 8)
+
+
+def test_module_load_state_dict_consumes_lazy_tensors(tmp_path):
+    cfg = LLaMAConfig(block_size=32, vocab_size=64, n_layer=2, n_head=4, n_embd=64)
+    sd = synth.make_state_dict(cfg, seed=3, mode=None)
+    path = tmp_path / "lit-llama.pth"
+    torch.save(sd, path)
+    model = LLaMA(cfg)
+    with lazy_load_from_utils(path) as ck:  # the name generate.py imports (lit_llama/utils.py)
+        missing = model.load_state_dict(ck, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
+def test_tp_shard_on_load_from_a_lazy_checkpoint(tmp_path):
+    """scripts/convert_checkpoint.py:57-65 shard map applied to lazy tensors: identical shards, and the column-parallel
+    fp weights of a rank are read as 1 / world of their bytes."""
+    cfg = LLaMAConfig(block_size=32, vocab_size=64, n_layer=1, n_head=4, n_embd=64)
+    sd = synth.make_state_dict(cfg, seed=5, mode=None)
+    path = tmp_path / "full.pth"
+    torch.save(sd, path)
+    want = tp.shard_state_dict(sd, cfg, 1, 2)
+    with lazy_load(path) as ck:
+        reader = next(iter(ck.values()))._storage.reader
+        got = tp.shard_state_dict(ck, cfg, 1, 2)
+        got = {k: (v.materialize() if isinstance(v, LazyTensor) else v) for k, v in got.items()}
+        total = sum(v.numel() * v.element_size() for v in sd.values())
+        assert reader.bytes_mapped < total, "sharding must not read the whole checkpoint"
+    assert got.keys() == want.keys()
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_rejects_non_checkpoint_pickles(tmp_path):
+    import pickle
+    import zipfile
+
+    path = tmp_path / "evil.pth"
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("archive/data.pkl", pickle.dumps({"f": print}))
+        z.writestr("archive/version", "3")
+    with pytest.raises(pickle.UnpicklingError):
+        lazy_load(path)
