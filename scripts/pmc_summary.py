@@ -38,7 +38,14 @@ def main():
         per = v / c
         print(f"{k[:70]:70s} {c:8d} {per:22.1f} {2 * per * 1024 / 1e6:16.2f}")
         res[k] = {"launches": c, "fetch_kib_per_launch": per, "corrected_bytes_per_launch": 2 * per * 1024}
-    fc = next((v for k, v in res.items() if k.startswith("gemv_kernel<0, 2,") and k.rstrip(">").split(",")[3].strip() == "2"), None)
+    # the c_fc1/c_fc2 + SwiGLU launch: gemv_kernel<FMT = 0 (Q4), R = 2, P, EPI = 2, VMODE, MULTI>; prefer the decode
+    # specialisation (MULTI = false) over the prompt-chunk one
+    def targs(k):
+        return [t.strip() for t in k[k.find("<") + 1:k.rfind(">")].split(",")]
+
+    cands = [(k, v) for k, v in res.items() if k.startswith("gemv_kernel<") and targs(k)[:2] == ["0", "2"] and targs(k)[3] == "2"]
+    cands.sort(key=lambda kv: (targs(kv[0])[5:6] != ["false"], -kv[1]["launches"]))
+    fc = cands[0][1] if cands else None
     if out_json and fc:
         json.dump({"fc_swiglu_bytes_per_launch": round(fc["corrected_bytes_per_launch"]),
                    "note": "rocprofv3 --pmc FETCH_SIZE, KiB x 1024 x 2 (gfx950 wide-read correction)",
