@@ -136,6 +136,15 @@ def test_product_path_refuses_cpu_tensors():
         lit_llama_amd.apply_rope(torch.zeros(1, 2, 2, 4), torch.zeros(2, 2, 2))
     with pytest.raises(nat.NativeError):
         lit_llama_amd.generate(model, torch.zeros(4, dtype=torch.int32), 2, top_k=1)
+    # the offline GPTQ quantiser is GPU-only as well: no silent CPU path next to the HIP kernels
+    from lit_llama_amd.gptq import GPTQQuantizer
+
+    with pytest.raises(ValueError, match="MI355X"):
+        GPTQQuantizer(torch.nn.Linear(32, 8, bias=False), bits=4)
+    with pytest.raises(nat.NativeError):
+        ops.gptq_block(torch.zeros(8, 16), torch.eye(16), torch.ones(8), torch.zeros(8), 15)
+    with pytest.raises(nat.NativeError):
+        ops.gptq_row_params(torch.zeros(8, 16), 15)
 
 
 def test_linear8bit_defers_quantisation_off_gpu():
