@@ -13,8 +13,10 @@ SURVEY.md §8e: "replicas only"), so scaling is "weak" and `value` is the sum ov
 
 Extra objects on the same line:
   roofline     — the dominant kernel (c_fc1/c_fc2 + SwiGLU int4 weight-streaming launch): algorithmic bytes per
-                 launch / average launch duration, measured with events on the launch stream over all 32 layers'
-                 weights (1.4 GB, larger than the 256 MiB Infinity Cache), vs the 8.0 TB/s HBM peak;
+                 launch / average launch duration — the dispatch's own begin / end timestamps, delivered into HIP
+                 events by hipExtLaunchKernel on the launch stream (mi355_debug_time_next_launch; the clock
+                 rocprofv3 reads) — over all 32 layers' weights (1.4 GB, larger than the 256 MiB Infinity Cache), vs
+                 the 8.0 TB/s HBM peak;
   cpu_baseline — oracle/oracle.py (a port of the reference's CPU path, which dequantises every weight on every
                  call) timed on the host cores over a bounded sample, extrapolated to 32 layers.
 """
