@@ -112,3 +112,33 @@ def test_rejects_non_checkpoint_pickles(tmp_path):
         z.writestr("archive/version", "3")
     with pytest.raises(pickle.UnpicklingError):
         lazy_load(path)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_lazy_load_random_views_and_dtypes(tmp_path, seed):
+    """Random tensors, transposes, slices and expanded views of shared storages: metadata and values as torch.load."""
+    gen = torch.Generator().manual_seed(seed)
+    dtypes = [torch.float32, torch.bfloat16, torch.float16, torch.uint8, torch.int8, torch.int64, torch.bool]
+    sd = {}
+    for i in range(8):
+        dt = dtypes[int(torch.randint(0, len(dtypes), (1,), generator=gen))]
+        shape = [int(v) for v in torch.randint(1, 9, (int(torch.randint(1, 4, (1,), generator=gen)),), generator=gen)]
+        if dt.is_floating_point:
+            base = (torch.randn(shape, generator=gen) * 8).to(dt)
+        else:
+            base = torch.randint(0, 2 if dt == torch.bool else 100, shape, generator=gen).to(dt)
+        sd[f"t{i}"] = base
+        if base.dim() >= 2:
+            sd[f"t{i}.T"] = base.transpose(0, 1)                 # shares the storage, other strides
+            sd[f"t{i}.rows"] = base[1:]                          # offset into the storage
+        sd[f"t{i}.x"] = base.reshape(-1)[:1].expand(3)           # stride 0
+    path = tmp_path / "r.pth"
+    torch.save(sd, path)
+    ref = torch.load(path, weights_only=True)
+    with lazy_load(path) as ck:
+        assert ck.keys() == ref.keys()
+        for k in ref:
+            lt = ck[k]
+            assert lt.shape == ref[k].shape and lt.dtype == ref[k].dtype and lt.stride() == ref[k].stride(), k
+            assert torch.equal(lt.materialize(), ref[k]), k
+            assert torch.equal(lt.to(torch.float32), ref[k].to(torch.float32)), k
