@@ -393,8 +393,58 @@ int mi355_graph_capture(const mi355_model* m, int argmax, mi355_stream_t stream,
 int mi355_graph_launch(mi355_graph* g, mi355_stream_t stream);
 int mi355_graph_destroy(mi355_graph* g);
 
+
+/* ------------------------------------------------------------------------------------------
+ * The whole T = 1 decode step (LLaMA.forward for one token + greedy sampling, lit_llama/model.py:76-122,
+ * generate.py:68-85) as ONE persistent launch: 7B-class gptq.int4 models on a 256-CU device
+ * (csrc/fused_step.hip; mi355_fused_step_supported tells).  Everything the launch touches is laid out in
+ * arenas so that a layer is addressed by a stride:
+ *   w        Q4 streams (mi355_q4_repack) of layer l at w + l * layer_stride: c_attn (R = 1) at off_attn, attn.c_proj
+ *            (R = 1) at off_proj, the interleaved c_fc1 / c_fc2 pair (R = 2) at off_fc, mlp.c_proj (R = 1) at off_mproj;
+ *            layer_bytes = bytes of one layer; w_head / head_bytes: the lm_head stream (R = 1)
+ *   sz       bf16 per-row scales / zeros, per layer (stride 10 C + 4 H elements):
+ *            s_attn[3C] z_attn[3C] s_proj[C] z_proj[C] s_fc1[H] z_fc1[H] s_fc2[H] z_fc2[H] s_mproj[C] z_mproj[C];
+ *            sz_head = s[V] z[V]
+ *   norms    bf16 [n_layer][2][C] (rms_1, rms_2), then ln_f[C]
+ *   kv       bf16 [n_layer][2][n_head][S][hs], rows < pos[0] valid; row pos[0] is written
+ *   tokens / pos   device int32: the step's token id and position (pos[0] < S)
+ *   workspace      mi355_fused_step_workspace_bytes(n_hidden) bytes, zeroed ONCE by the caller, then owned by the
+ *            library: word 0 = abort code (0 = fine; a non-zero value after the launch means a hand-off timed
+ *            out and the outputs are garbage), word 1 = step counter
+ *   mode     0: logits only; 1: + greedy arg-max into next_token[0] / out_tokens[pos + 1]; 3: + chaining
+ *            (tokens[0] = arg-max, pos[0] += 1), so a captured launch replays the loop of generate.py:63-91
+ *   logits   f32 [vocab]
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mi355_fused_step_args {
+    const void* w;
+    uint64_t layer_stride;
+    uint32_t off_attn, off_proj, off_fc, off_mproj;
+    uint32_t layer_bytes, head_bytes;
+    const void* w_head;
+    const void* sz;
+    const void* sz_head;
+    const void* norms;
+    const void* wte;
+    const float* rope;
+    void* kv;
+    int32_t* tokens;
+    int32_t* pos;
+    int32_t* next_token;
+    int32_t* out_tokens;
+    float* logits;
+    void* workspace;
+    uint64_t* debug_stamps; /* optional: uint64 [256][64] wall-clock stamps (100 MHz) */
+    int32_t n_layer, n_head, n_embd, hs, n_hidden, vocab, S, mode;
+    float eps;
+    int32_t reserved0;
+} mi355_fused_step_args;
+
+size_t mi355_fused_step_workspace_bytes(int n_hidden);
+int mi355_fused_step_supported(int n_embd, int n_head, int hs, int n_hidden, int vocab, int S);
+int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t stream);
+
 /* sizeof() of the ABI structs, for binding self-checks: 0 linear_args, 1 attn_args, 2 int8_args, 3 weight,
- * 4 layer, 5 model; -1 for an unknown index */
+ * 4 layer, 5 model, 6 fused_step_args; -1 for an unknown index */
 int mi355_sizeof(int which);
 
 #ifdef __cplusplus

@@ -100,6 +100,21 @@ class Model(C.Structure):
     ]
 
 
+class FusedStepArgs(C.Structure):
+    _fields_ = [
+        ("w", c_void_p), ("layer_stride", C.c_uint64),
+        ("off_attn", C.c_uint32), ("off_proj", C.c_uint32), ("off_fc", C.c_uint32), ("off_mproj", C.c_uint32),
+        ("layer_bytes", C.c_uint32), ("head_bytes", C.c_uint32),
+        ("w_head", c_void_p), ("sz", c_void_p), ("sz_head", c_void_p), ("norms", c_void_p), ("wte", c_void_p),
+        ("rope", c_void_p), ("kv", c_void_p),
+        ("tokens", c_void_p), ("pos", c_void_p), ("next_token", c_void_p), ("out_tokens", c_void_p),
+        ("logits", c_void_p), ("workspace", c_void_p), ("debug_stamps", c_void_p),
+        ("n_layer", c_int32), ("n_head", c_int32), ("n_embd", c_int32), ("hs", c_int32),
+        ("n_hidden", c_int32), ("vocab", c_int32), ("S", c_int32), ("mode", c_int32),
+        ("eps", c_float), ("reserved0", c_int32),
+    ]
+
+
 # name -> (restype, argtypes); must list every function declared in include/mi355_llama.h
 PROTOTYPES = {
     "mi355_version": (c_int, []),
@@ -139,6 +154,9 @@ PROTOTYPES = {
     "mi355_graph_capture": (c_int, [C.POINTER(Model), c_int, c_void_p, C.POINTER(c_void_p)]),
     "mi355_graph_launch": (c_int, [c_void_p, c_void_p]),
     "mi355_graph_destroy": (c_int, [c_void_p]),
+    "mi355_fused_step_workspace_bytes": (c_size_t, [c_int]),
+    "mi355_fused_step_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mi355_fused_step": (c_int, [C.POINTER(FusedStepArgs), c_void_p]),
     "mi355_sizeof": (c_int, [c_int]),
     "mi355_linear_max_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "mi355_debug_time_next_launch": (c_int, [c_void_p, c_void_p]),
@@ -147,7 +165,7 @@ PROTOTYPES = {
                                  c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
-ABI_STRUCTS = [LinearArgs, AttnArgs, Int8Args, Weight, Layer, Model]
+ABI_STRUCTS = [LinearArgs, AttnArgs, Int8Args, Weight, Layer, Model, FusedStepArgs]
 
 _lib: Optional[C.CDLL] = None
 

@@ -1,0 +1,902 @@
+// The whole T = 1 decode step of a 7B-class gptq.int4 LLaMA as ONE persistent launch on gfx950.
+//
+// Replaces, per generated token, the 161 operator calls of /root/reference lit_llama/model.py:76-122 (Block.forward
+// :165-168, CausalSelfAttention.forward :194-237, MLP.forward :251-254, RMSNorm :274-277, apply_rope :306-323) and the
+// greedy sampling of generate.py:68-85 — and this repository's own 162-launch step (engine.hip), whose launches are
+// latency-bound: ~4.2 us of dispatch + cold-cache prologue + drain each against 1.3-7 us of streaming.
+//
+// Structure (measured first as a protocol: scripts/micro/allgather.hip, profiles/r02_allgather_microbench.txt):
+//  * 256 workgroups, one per CU, all resident for the whole step.  A workgroup is 8 STREAMER waves that own every
+//    weight load (12-deep ring of 1-KiB non-temporal wave loads held in registers = 96 KiB per CU in flight, int4 ->
+//    bf16 by mask/or, MFMA 16x16x32 with the activation vector as the B operand — the body of gemv.hip) and
+//    2 GATHERER waves that own every other global access.
+//  * Activations move between the phases of a layer as 8-byte {tag, value} granules written with ONE sc1
+//    (write-through) store and swept with sc1 loads until every tag equals the phase's epoch: the data is the
+//    flag, there is no fence and no barrier between workgroups.  Tags are unique per (step, edge) — the step
+//    counter lives in device memory — so nothing needs zeroing between launches or graph replays.
+//  * The weights of phase k + 1 do not depend on activations: the streamers request its first ring turn right
+//    AFTER the gatherers have issued phase k's publish stores (a refill queued in front of the publish in the CU's
+//    in-order memory pipeline delays the whole chip: 6.2 -> 4.2 us per 96-KiB phase) and BEFORE the all-gather, so
+//    the HBM stream runs through the hand-off.
+//  * c_attn, RoPE, the KV-cache row write and the attention of a head are local to the 8 workgroups of that head
+//    (same XCD): they exchange q and the new k / v row (2 KiB) among themselves; each workgroup then computes the
+//    softmax over the whole context and its own 16 dimensions of the head's output.
+//  * The residual stream never leaves the chip: workgroup b owns rows 16 b .. 16 b + 15 in registers for the
+//    whole step; what travels is bf16(norm_scale * x) and the partial sums of x^2 (RMSNorm's 1/rms is applied in the
+//    consumer's epilogue, as in gemv.hip).
+// Every spin is bounded; a time-out raises the abort word, all other spins then give up at once and the host
+// reports MI355_E_STATE (mi355_fused_step_status).
+#include <math.h>
+
+#include <mutex>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int kG = 256;         // workgroups
+constexpr int kSW = 8;          // streamer waves
+constexpr int kGW = 2;          // gatherer waves
+constexpr int kThreads = 64 * (kSW + kGW);
+constexpr int kRing = 12;       // ring pieces (1 KiB each) per streamer wave
+constexpr int kC = 4096;        // n_embd
+constexpr int kHeads = 32;
+constexpr int kHs = 128;
+constexpr int kGs = kG / kHeads;  // workgroups per head
+constexpr int kUnitsC = kC / 128;
+constexpr int kMaxFcTiles = 3;    // c_fc1/c_fc2 pair tiles per workgroup (n_hidden <= 12288)
+constexpr int kMaxHeadTiles = 8;  // lm_head tiles per workgroup (vocab <= 32768)
+constexpr unsigned kSpinLimit = 400000u;
+
+// LDS map (bytes)
+constexpr int kOffMisc = 0;                       // [0] 1/rms, [1] softmax sum, [2] softmax max
+constexpr int kOffZero = 256;                     // one all-zero unit (idle ring steps read it)
+constexpr int kOffXs = 512;                       // activation vector, bf16, <= 96 units
+constexpr int kOffPart = kOffXs + 96 * 256;       // [2][8 waves][4][64 lanes][4] f32 partial tiles
+constexpr int kOffStage = kOffPart + 2 * kSW * 4 * 1024;  // 1 KiB epilogue staging
+constexpr int kOffQ = kOffStage + 1024;           // q[128] knew[128] vnew[128] f32
+constexpr int kOffOpart = kOffQ + 3 * 512;        // [8 waves][16] f32
+constexpr int kOffScores = kOffOpart + 512;       // [S] f32
+constexpr int kMaxS = 8192;
+constexpr int kLdsBytes = kOffScores + kMaxS * 4;
+static_assert(kLdsBytes <= 160 * 1024, "LDS map exceeds the CU");
+
+struct FusedParams {
+    const uint8_t* w;        // weight arena: layer l at w + l * layer_stride
+    u64 layer_stride;
+    unsigned off_attn, off_proj, off_fc, off_mproj, layer_bytes;
+    unsigned head_bytes;
+    const uint8_t* w_head;
+    const bf16_t* sz;        // per layer: s_attn[3C] z_attn[3C] s_proj[C] z_proj[C] s_fc1[H] z_fc1[H] s_fc2[H] z_fc2[H] s_mp[C] z_mp[C]
+    const bf16_t* sz_head;   // s[V] z[V]
+    const bf16_t* norms;     // [n_layer][2][C], then ln_f[C]
+    const bf16_t* wte;
+    const float* rope;       // [block_size][hs/2][2]
+    bf16_t* kv;              // [n_layer][2][n_head][S][hs]
+    int32_t* tokens;
+    int32_t* pos;
+    int32_t* next_token;
+    int32_t* out_tokens;
+    float* logits;
+    u64* gx;                 // [2][2048 + 256]   x-type edges (bf16 pairs + partial sums of squares)
+    u64* ga;                 // [2][2048]         attention output
+    u64* gh;                 // [2][H / 2]        MLP hidden
+    u64* gq;                 // [2][n_head][8][32] q / new k / new v of a head
+    u64* gm;                 // [512]             arg-max candidates
+    unsigned* state;         // [0] abort code, [1] step counter
+    u64* dbg;                // optional [kG][64] wall-clock stamps
+    unsigned sz_layer_stride;
+    int n_layer, H, V, S;
+    int units_h, fc_tiles, head_tiles, head_turns;
+    int mode;                // bit 0: greedy arg-max, bit 1: chained (advance tokens[0] / pos[0])
+    float eps, scale;
+};
+
+// ------------------------------------------------------------------------------------------------ granules
+__device__ __forceinline__ void gr_store(u64* p, unsigned tag, unsigned val) {
+    __hip_atomic_store(p, ((u64)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // one 8-B sc1 store
+}
+__device__ __forceinline__ bool aborted(const FusedParams& p) {
+    return __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+__device__ __forceinline__ void raise_abort(const FusedParams& p, unsigned code) {
+    __hip_atomic_store(p.state, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave sweeps 16-B loads (two granules each) number first + k * 64 + lane, k < NL, of the granule buffer behind
+// `rs` (load i covers bytes base + 16 i ..) until every tag equals `epoch`; loads at or past `end` are skipped.
+// Returns false after a time-out / abort (the values are then garbage, the caller keeps going so that the barrier
+// counts of the workgroup stay balanced).
+template <int NL>
+__device__ __forceinline__ bool sweep(const FusedParams& p, __amdgpu_buffer_rsrc_t rs, unsigned base, int first, int end,
+                                      unsigned epoch, u32x4 (&v)[NL], unsigned code) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = first + k * 64 + lane;
+            const unsigned off = i < end ? base + (unsigned)i * 16u : 0xFFFFFFF0u;
+            v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));  // sc1
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = first + k * 64 + lane;
+            ok &= i >= end || (v[k][1] == epoch && v[k][3] == epoch);
+        }
+        if (__all(ok)) return true;
+        if (spins > kSpinLimit || aborted(p)) {
+            if (lane == 0) raise_abort(p, code);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ streamers
+struct PhaseW {  // one phase as a streamer wave sees it (all wave-uniform)
+    unsigned base;  // byte offset of the stream inside the layer's descriptor
+    int tile0, tstride, ntiles, units, u0, nu;
+};
+
+// Scalar byte offset of the piece consumed at global step `gstep` of the phase, row group r; ok = false for an idle
+// piece (padding of the ring turn: the load then goes through a zero-sized descriptor = zeros, no memory request).
+// The offset travels in the load's SGPR operand and the lane's 16 B in ONE shared VGPR: per-piece address VGPRs are
+// loop-invariant over the layers, get hoisted and spill.
+template <int SPT, bool PAIR, bool QKV>
+__device__ __forceinline__ unsigned piece_off(const PhaseW& ph, int gstep, int r, bool& ok) {
+    const int ti = gstep / SPT, st = gstep - ti * SPT;
+    int tile;
+    if constexpr (QKV) {
+        tile = ph.tile0 + r * ph.tstride;  // the q, k and v tiles of this workgroup share the activation operand
+        ok = ti == 0 && st < ph.nu;
+    } else {
+        tile = ph.tile0 + ti * ph.tstride;
+        ok = ti < ph.ntiles && st < ph.nu;
+    }
+    return ph.base + (unsigned)((tile * ph.units + ph.u0 + st) * (PAIR ? 2 : 1) + (PAIR ? r : 0)) * 1024u;
+}
+__device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rs_null, bool ok,
+                                           unsigned lane_off, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rs : rs_null, lane_off, ok ? soff : 0u, 2));
+}
+
+#define FS_STAMP(i)                                                                   \
+    do {                                                                              \
+        if (p.dbg != nullptr && (threadIdx.x & 63) == 0) p.dbg[bid * 64 + (i)] = wall_clock64(); \
+    } while (0)
+
+}  // namespace
+
+__global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* misc = (float*)(smem + kOffMisc);
+    char* xs = smem + kOffXs;
+    char* part = smem + kOffPart;
+    float* stage = (float*)(smem + kOffStage);
+    float* qs = (float*)(smem + kOffQ);
+    float* knew = qs + kHs;
+    float* vnew = knew + kHs;
+    float* opart = (float*)(smem + kOffOpart);
+    float* scores = (float*)(smem + kOffScores);
+
+    // workgroup -> head group: the 8 workgroups of a head sit on one XCD (blocks are dealt round-robin to the 8 XCDs;
+    // a speed matter only — the protocol does not depend on placement)
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int head = xcd * (kHeads / 8) + slot / kGs;
+    const int hj = slot % kGs;  // which 16 dimensions of the head
+
+    const int pos = p.pos[0];
+    const int token = p.tokens[0];
+    const unsigned step_id = p.state[1];
+    const unsigned ebase = step_id * 1024u + 1u;
+    const int n_fc = (p.fc_tiles - bid + kG - 1) / kG;       // this workgroup's pair tiles (2 or 3 for 7B)
+    const int n_head_t = (p.head_tiles - bid + kG - 1) / kG;  // lm_head tiles (7 or 8)
+
+    // entered outside the cache (the host takes the cache-roll regime of model.py:214-218 elsewhere) or with a token id
+    // outside the embedding table: refuse before anything is written.  Uniform over the grid, so no hand-off hangs.
+    if (pos < 0 || pos >= p.S || token < 0 || token >= p.V) {
+        if (bid == 0 && threadIdx.x == 0) raise_abort(p, 0x10u);
+        return;
+    }
+    if (threadIdx.x < 64) ((unsigned*)(smem + kOffZero))[threadIdx.x] = 0u;
+    FS_STAMP(0);
+
+    if (wave < kSW) {
+        // =========================================================================================== streamers
+        unsigned lane_off = lane * 16;
+        const int g = lane >> 4;
+        u32x4 ring[kRing];
+        const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+        int buf = 0;
+
+        PhaseW ph_attn, ph_proj, ph_fc, ph_mp, ph_head;
+        ph_attn = {p.off_attn, head * 8 + hj, kC / 16, 1, kUnitsC, wave * 4, 4};
+        ph_proj = {p.off_proj, bid, kG, 1, kUnitsC, wave * 4, 4};
+        ph_fc = {p.off_fc, bid, kG, n_fc, kUnitsC, wave * 4, 4};
+        {
+            const int uq = p.units_h / kSW, ur = p.units_h % kSW;
+            ph_mp = {p.off_mproj, bid, kG, 1, p.units_h, wave * uq + (wave < ur ? wave : ur), uq + (wave < ur ? 1 : 0)};
+        }
+        ph_head = {0u, bid, kG, n_head_t, kUnitsC, wave * 4, 4};
+
+        __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.layer_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_h =
+            __builtin_amdgcn_make_buffer_rsrc((void*)p.w_head, 0, (int)p.head_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
+
+        // ---- first ring turn of a phase (12 pieces), requested right after the previous phase's publish
+#define FS_BURST(RS_, R_, SPT_, PAIR_, QKV_, PH_)                                                             \
+    do {                                                                                                     \
+        _Pragma("unroll") for (int pc__ = 0; pc__ < kRing; ++pc__) {                                         \
+            bool ok__;                                                                                       \
+            const unsigned so__ = piece_off<SPT_, PAIR_, QKV_>(PH_, pc__ / (R_), pc__ % (R_), ok__);          \
+            ring[pc__] = ring_load(RS_, rs_null, ok__, lane_off, so__);                                      \
+            __builtin_amdgcn_sched_barrier(0); /* issue order = consumption order (VMEM returns in order) */ \
+        }                                                                                                    \
+    } while (0)
+
+        // ---- one phase: BODIES x TURNS ring turns of 12 / R steps; a step = R pieces against one activation unit
+#define FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_)                                                     \
+    do {                                                                                                             \
+        constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
+        const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
+        f32x4 acc__[R__], acc1__ = f32x4{0.f, 0.f, 0.f, 0.f};                                                         \
+        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__] = f32x4{0.f, 0.f, 0.f, 0.f};                 \
+        __syncthreads(); /* B1: the activation vector is staged */                                                   \
+        for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
+            _Pragma("unroll") for (int t__ = 0; t__ < (TURNS_); ++t__) {                                              \
+                _Pragma("unroll") for (int s__ = 0; s__ < STEPS__; ++s__) {                                           \
+                    const int gstep__ = (body__ * (TURNS_) + t__) * STEPS__ + s__;                                    \
+                    const int ti__ = gstep__ / SPT__, st__ = gstep__ - ti__ * SPT__;                                  \
+                    const char* xb__ = (st__ < (PH_).nu ? xs + ((PH_).u0 + st__) * 256 : smem + kOffZero) + g * 64;   \
+                    bf16x8 b__[4];                                                                                    \
+                    _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) b__[d__] = *(const bf16x8*)(xb__ + 16 * d__); \
+                    _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) acc1__ = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
+                        __builtin_bit_cast(bf16x8, ones), b__[d__], acc1__, 0, 0, 0);                                 \
+                    _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                           \
+                        const u32x4 q__ = ring[s__ * R__ + r__];                                                      \
+                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                         \
+                            const uint32_t v__ = q__[d__];                                                            \
+                            u32x4 a__;                                                                                \
+                            a__[0] = (v__ & 0x000F000Fu) | 0x43004300u;                                               \
+                            a__[1] = ((v__ >> 4) & 0x000F000Fu) | 0x43004300u;                                        \
+                            a__[2] = ((v__ >> 8) & 0x000F000Fu) | 0x43004300u;                                        \
+                            a__[3] = ((v__ >> 12) & 0x000F000Fu) | 0x43004300u;                                       \
+                            acc__[r__] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a__),     \
+                                                                                b__[d__], acc__[r__], 0, 0, 0);       \
+                        }                                                                                             \
+                        /* refill with the same slot of the next turn of THIS phase (nothing past its end) */         \
+                        const int nstep__ = gstep__ + STEPS__;                                                        \
+                        bool ok__;                                                                                    \
+                        const unsigned so__ = piece_off<SPT__, PAIR_, QKV_>(PH_, nstep__, r__, ok__);                 \
+                        ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
+                    }                                                                                                 \
+                    if ((t__ * STEPS__ + s__ + 1) % SPT__ == 0) {                                           \
+                        /* tile done: publish this wave's partial 16x16 tiles */                                      \
+                        f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * 1024) + lane;                \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
+                            pp__[r__ * 64] = acc__[r__];                                                              \
+                            acc__[r__] = f32x4{0.f, 0.f, 0.f, 0.f};                                                   \
+                        }                                                                                             \
+                        pp__[3 * 64] = acc1__;                                                                        \
+                        acc1__ = f32x4{0.f, 0.f, 0.f, 0.f};                                                           \
+                        __syncthreads(); /* Bt */                                                                     \
+                        buf ^= 1;                                                                                     \
+                    }                                                                                                 \
+                    /* keep a step's conversions next to its MFMAs: hipcc otherwise hoists the shifts / masks of */   \
+                    /* all 12 pieces to the top of the turn and spills                                           */   \
+                    __builtin_amdgcn_sched_barrier(0);                                                                \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+        __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
+    } while (0)
+
+        FS_BURST(rs_l, 3, 4, false, true, ph_attn);
+        const bf16_t* kv_l = (const bf16_t*)p.kv;
+        for (int l = 0; l < p.n_layer; ++l) {
+            asm volatile("" : "+v"(lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
+            // ---------------- c_attn (q, k, v tiles of this workgroup's 16 dimensions of its head)
+            FS_RUN(rs_l, 3, 4, false, true, 1, ph_attn, 1);
+            // ---------------- attention: scores over the whole context, then this workgroup's 16 output dims
+            {
+                const bf16_t* kc = kv_l + (size_t)head * p.S * kHs;
+                const bf16_t* vc = kc + (size_t)kHeads * p.S * kHs;
+                const int li = (lane_off >> 4) & 15, lr = lane_off >> 8;
+                const int half = lane_off >> 9, rl = (lane_off >> 4) & 31;
+                const __amdgpu_buffer_rsrc_t rk =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)kc, 0, pos * (kHs * 2), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rv =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, pos * (kHs * 2), 0x00020000);
+                const int n_blocks = (pos + 255) >> 8;  // blocks of 256 cached rows
+                u32x4 kr[8], vr;
+                // rows of block 0: requested before q is known
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = u * 32 + wave * 4 + lr;
+                    kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                          rk, t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u, 0, 0));
+                }
+                {
+                    const int t = wave * 32 + rl;
+                    vr = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
+                }
+                __syncthreads();  // Ba1: q / new k / new v of the head are in LDS
+                float qf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[j] = qs[li * 8 + j];
+                for (int blk = 0; blk < n_blocks; ++blk) {
+                    if (blk > 0) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int t = blk * 256 + u * 32 + wave * 4 + lr;
+                            kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                  rk, t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u, 0, 0));
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        float dot = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            dot += qf[2 * i] * __uint_as_float(kr[u][i] << 16);
+                            dot += qf[2 * i + 1] * __uint_as_float(kr[u][i] & 0xffff0000u);
+                        }
+                        dot = group_sum(dot, 16);
+                        const int t = blk * 256 + u * 32 + wave * 4 + lr;
+                        if (li == 0 && t < pos) scores[t] = dot * p.scale;
+                    }
+                }
+                if (wave == 0) {  // the new token's own score, from the LDS copy of its key
+                    float dot = qs[lane] * knew[lane] + qs[lane + 64] * knew[lane + 64];
+                    dot = group_sum(dot, 64);
+                    if (lane == 0) scores[pos] = dot * p.scale;
+                }
+                __syncthreads();  // Ba2: scores[0 .. pos] complete
+                const int len = pos + 1;
+                float mx = -1.0e30f;
+                for (int t = lane; t < len; t += 64) mx = fmaxf(mx, scores[t]);
+                mx = fmaxf(mx, lane_xor32(mx));
+                mx = fmaxf(mx, lane_xor16(mx));
+                mx = MI355_DPP_MAX(mx, 0x140);
+                mx = MI355_DPP_MAX(mx, 0x141);
+                mx = MI355_DPP_MAX(mx, 0x4E);
+                mx = MI355_DPP_MAX(mx, 0xB1);
+                float sum = 0.f;
+                for (int t = lane; t < len; t += 64) sum += __expf(scores[t] - mx);
+                sum = group_sum(sum, 64);
+                float of[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) of[j] = 0.f;
+                for (int sb = 0; sb < n_blocks; ++sb) {  // 256 cached rows per pass: 32 per wave, 16 B per lane
+                    const int t = sb * 256 + wave * 32 + rl;
+                    u32x4 vv = vr;
+                    if (sb > 0)
+                        vv = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                           rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
+                    const float pr = t < pos ? __expf(scores[t] - mx) : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        of[2 * i] += pr * __uint_as_float(vv[i] << 16);
+                        of[2 * i + 1] += pr * __uint_as_float(vv[i] & 0xffff0000u);
+                    }
+                }
+                if (wave == 0 && rl == 0) {  // the new token's value row
+                    const float pr = __expf(scores[pos] - mx);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) of[j] += pr * vnew[hj * 16 + half * 8 + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) of[j] = group_sum(of[j], 32);
+                if (rl == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) opart[wave * 16 + half * 8 + j] = of[j];
+                }
+                if (threadIdx.x == 0) misc[1] = sum;
+                __syncthreads();  // Ba3: partial outputs of the 8 waves
+                __syncthreads();  // Ba4: the attention output is published
+            }
+            // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows)
+            FS_BURST(rs_l, 1, 12, false, false, ph_proj);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_proj, 1);
+            FS_BURST(rs_l, 2, 4, true, false, ph_fc);
+            FS_RUN(rs_l, 2, 4, true, false, 2, ph_fc, 1);
+            FS_BURST(rs_l, 1, 12, false, false, ph_mp);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_mp, 1);
+            // next layer (or the head)
+            kv_l += (size_t)2 * kHeads * p.S * kHs;
+            if (l + 1 < p.n_layer) {
+                rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (size_t)(l + 1) * p.layer_stride), 0,
+                                                         (int)p.layer_bytes, 0x00020000);
+                FS_BURST(rs_l, 3, 4, false, true, ph_attn);
+            } else {
+                FS_BURST(rs_h, 1, 4, false, false, ph_head);
+            }
+        }
+        FS_RUN(rs_h, 1, 4, false, false, 1, ph_head, p.head_turns);
+        if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
+#undef FS_RUN
+#undef FS_BURST
+    } else {
+        // =========================================================================================== gatherers
+        const int gw = wave - kSW;  // 0: combines / publishes, 1: helps with the sweeps
+        const int row = lane >> 2, qd = lane & 3;
+        const int psrc = ((row >> 2) << 4) * 4 + (row & 3);  // float index of D[row][0] inside a wave's partial tile
+        unsigned edge = 0;   // edges published so far in this step (the epoch of the next one is ebase + edge)
+        int xpar = 0, apar = 0, hpar = 0, qpar = 0;
+        int buf = 0;
+        const __amdgpu_buffer_rsrc_t rs_gx = __builtin_amdgcn_make_buffer_rsrc((void*)p.gx, 0, 2 * 2304 * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_ga = __builtin_amdgcn_make_buffer_rsrc((void*)p.ga, 0, 2 * 2048 * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_gh = __builtin_amdgcn_make_buffer_rsrc((void*)p.gh, 0, 2 * (p.H / 2) * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_gq =
+            __builtin_amdgcn_make_buffer_rsrc((void*)p.gq, 0, 2 * kHeads * 256 * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_gm = __builtin_amdgcn_make_buffer_rsrc((void*)p.gm, 0, 512 * 8, 0x00020000);
+
+        // partial tiles of wave w, row group r of the current tile
+        auto tile_sum = [&](int r) {
+            const float* b0 = (const float*)(part + (size_t)((buf * kSW + qd) * 4 + r) * 1024) + psrc;
+            const float* b1 = (const float*)(part + (size_t)((buf * kSW + qd + 4) * 4 + r) * 1024) + psrc;
+            float t = b0[0] + b1[0];
+            t = MI355_DPP_ADD(t, 0xB1);
+            t = MI355_DPP_ADD(t, 0x4E);
+            return t;
+        };
+        auto ldbf = [&](const bf16_t* q) { return bf16_to_f32(*q); };
+
+        // publish an x-type edge: bf16(norm_scale * x) pairs + the partial sum of squares of this workgroup's rows
+        auto publish_x = [&](float xv, float gsc) {
+            if (qd == 0) {
+                stage[row] = gsc * xv;
+                stage[16 + row] = xv * xv;
+            }
+            const unsigned ep = ebase + edge;
+            u64* dst = p.gx + (size_t)xpar * 2304;
+            if (lane < 8) {
+                const unsigned lo = f32_to_bf16(stage[2 * lane]), hi = f32_to_bf16(stage[2 * lane + 1]);
+                gr_store(dst + bid * 8 + lane, ep, lo | (hi << 16));
+            } else if (lane == 8) {
+                float ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ss += stage[16 + i];
+                gr_store(dst + 2048 + bid, ep, __float_as_uint(ss));
+            }
+        };
+        // gather an x-type edge into xs (bf16) and 1/rms into misc[0]
+        auto gather_x = [&]() {
+            const unsigned ep = ebase + edge;
+            const unsigned base = (unsigned)xpar * 2304u * 8u;
+            if (gw == 0) {
+                u32x4 v[8];
+                // loads 0 .. 383 of the pair region (6 per lane) and the 128 loads of the sums of squares (2 per lane)
+                const int lane_ = lane;
+                for (unsigned spins = 0;; ++spins) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned off = k < 6 ? base + (unsigned)(k * 64 + lane_) * 16u
+                                                   : base + 2048u * 8u + (unsigned)((k - 6) * 64 + lane_) * 16u;
+                        v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gx, off, 0, 16));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ok &= v[k][1] == ep && v[k][3] == ep;
+                    if (__all(ok)) break;
+                    if (spins > kSpinLimit || aborted(p)) {
+                        if (lane == 0) raise_abort(p, 0x100u + edge);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    *(u64*)(xs + (size_t)(k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                float ss = ((__uint_as_float(v[6][0]) + __uint_as_float(v[6][2])) + __uint_as_float(v[7][0])) +
+                           __uint_as_float(v[7][2]);
+                ss = group_sum(ss, 64);
+                if (lane == 0) misc[0] = rsqrtf(ss / (float)kC + p.eps);
+            } else {
+                u32x4 v[10];
+                sweep<10>(p, rs_gx, base, 384, 1024, ep, v, 0x200u + edge);
+#pragma unroll
+                for (int k = 0; k < 10; ++k)
+                    *(u64*)(xs + (size_t)(384 + k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+            }
+            xpar ^= 1;
+            ++edge;
+        };
+
+        // ---- the residual rows of this workgroup: embedding of the step's token (model.py:102)
+        float xres = ldbf(p.wte + (size_t)token * kC + bid * 16 + row);
+        const bf16_t* norms_l = p.norms;
+        const bf16_t* sz_l = p.sz;
+        bf16_t* kv_l = p.kv;
+        const float2 cs = *(const float2*)(p.rope + ((size_t)pos * (kHs / 2) + hj * 8 + (lane & 7)) * 2);
+        if (gw == 0) publish_x(xres, ldbf(norms_l + bid * 16 + row));
+        for (int l = 0; l < p.n_layer; ++l) {
+            // ================= c_attn
+            const int nq = (head * 8 + hj) * 16 + row;  // q row of this lane; k at + C, v at + 2 C
+            float sc[3], zr[3];
+            if (gw == 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    sc[r] = ldbf(sz_l + nq + r * kC);
+                    zr[r] = ldbf(sz_l + 3 * kC + nq + r * kC);
+                }
+            }
+            gather_x();
+            __syncthreads();  // B1
+            __syncthreads();  // Bt (one virtual tile)
+            if (gw == 0) {
+                const float rinv = misc[0];
+                const float sx = tile_sum(3);
+                float y[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) y[r] = sc[r] * (tile_sum(r) - (128.f + zr[r]) * sx) * rinv;
+                if (qd == 0) {
+                    stage[row] = y[0];
+                    stage[16 + row] = y[1];
+                    stage[32 + row] = y[2];
+                }
+                // RoPE (model.py:306-323) of the q / k pairs, publish to the head group, write the cache row
+                const unsigned ep = ebase + edge;
+                u64* dst = p.gq + ((size_t)qpar * kHeads + head) * 256 + hj * 32;
+                bf16_t* krow = kv_l + ((size_t)head * p.S + pos) * kHs + hj * 16;
+                bf16_t* vrow = krow + (size_t)kHeads * p.S * kHs;
+                if (lane < 8) {
+                    const float a = stage[2 * lane], b = stage[2 * lane + 1];
+                    gr_store(dst + 2 * lane, ep, __float_as_uint(a * cs.x - b * cs.y));
+                    gr_store(dst + 2 * lane + 1, ep, __float_as_uint(b * cs.x + a * cs.y));
+                } else if (lane < 16) {
+                    const int i = lane - 8;
+                    const float a = stage[16 + 2 * i], b = stage[16 + 2 * i + 1];
+                    const unsigned lo = f32_to_bf16(a * cs.x - b * cs.y), hi = f32_to_bf16(b * cs.x + a * cs.y);
+                    gr_store(dst + 16 + i, ep, lo | (hi << 16));
+                    ((unsigned*)krow)[i] = lo | (hi << 16);
+                } else if (lane < 24) {
+                    const int i = lane - 16;
+                    const unsigned lo = f32_to_bf16(stage[32 + 2 * i]), hi = f32_to_bf16(stage[32 + 2 * i + 1]);
+                    gr_store(dst + 24 + i, ep, lo | (hi << 16));
+                    ((unsigned*)vrow)[i] = lo | (hi << 16);
+                }
+            }
+            buf ^= 1;
+            __syncthreads();  // B3
+            // ================= attention
+            {
+                const unsigned ep = ebase + edge;
+                if (gw == 0) {
+                    u32x4 v[2];
+                    sweep<2>(p, rs_gq, (unsigned)((qpar * kHeads + head) * 256) * 8u, 0, 128, ep, v, 0x300u + edge);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const int gi = (k * 64 + lane) * 2 + e2;  // granule index inside the head's 256
+                            const int jj = gi >> 5, e = gi & 31;
+                            const unsigned val = v[k][2 * e2];
+                            if (e < 16) {
+                                qs[jj * 16 + e] = __uint_as_float(val);
+                            } else if (e < 24) {
+                                knew[jj * 16 + 2 * (e - 16)] = __uint_as_float(val << 16);
+                                knew[jj * 16 + 2 * (e - 16) + 1] = __uint_as_float(val & 0xffff0000u);
+                            } else {
+                                vnew[jj * 16 + 2 * (e - 24)] = __uint_as_float(val << 16);
+                                vnew[jj * 16 + 2 * (e - 24) + 1] = __uint_as_float(val & 0xffff0000u);
+                            }
+                        }
+                    }
+                }
+                qpar ^= 1;
+                ++edge;
+                __syncthreads();  // Ba1
+                __syncthreads();  // Ba2
+                __syncthreads();  // Ba3
+                if (gw == 0 && lane < 16) {
+                    float o = 0.f;
+#pragma unroll
+                    for (int w = 0; w < kSW; ++w) o += opart[w * 16 + lane];
+                    stage[lane] = o / misc[1];
+                }
+                if (gw == 0 && lane < 8) {
+                    const unsigned lo = f32_to_bf16(stage[2 * lane]), hi = f32_to_bf16(stage[2 * lane + 1]);
+                    // attention output element (head * 128 + hj * 16 + 2 lane) -> pair granule
+                    gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + lane, ebase + edge, lo | (hi << 16));
+                }
+                __syncthreads();  // Ba4
+            }
+            // ================= attn.c_proj (+ residual)
+            {
+                float s1 = 0.f, z1 = 0.f, gn = 0.f;
+                if (gw == 0) {
+                    s1 = ldbf(sz_l + 6 * kC + bid * 16 + row);
+                    z1 = ldbf(sz_l + 7 * kC + bid * 16 + row);
+                    gn = ldbf(norms_l + kC + bid * 16 + row);  // rms_2
+                }
+                const unsigned ep = ebase + edge;
+                u32x4 v[8];
+                sweep<8>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, ep, v, 0x400u + edge);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                apar ^= 1;
+                ++edge;
+                __syncthreads();  // B1
+                __syncthreads();  // Bt
+                if (gw == 0) {
+                    const float sx = tile_sum(3);
+                    xres += s1 * (tile_sum(0) - (128.f + z1) * sx);
+                    publish_x(xres, gn);
+                }
+                buf ^= 1;
+                __syncthreads();  // B3
+            }
+            // ================= c_fc1 / c_fc2 + SwiGLU
+            {
+                const bf16_t* s_fc = sz_l + 8 * kC;
+                float fs1[kMaxFcTiles], fz1[kMaxFcTiles], fs2[kMaxFcTiles], fz2[kMaxFcTiles];
+                if (gw == 0) {
+#pragma unroll
+                    for (int t = 0; t < kMaxFcTiles; ++t) {
+                        const int n = (bid + t * kG) * 16 + row;
+                        const bool ok = t < n_fc;
+                        fs1[t] = ok ? ldbf(s_fc + n) : 0.f;
+                        fz1[t] = ok ? ldbf(s_fc + p.H + n) : 0.f;
+                        fs2[t] = ok ? ldbf(s_fc + 2 * p.H + n) : 0.f;
+                        fz2[t] = ok ? ldbf(s_fc + 3 * p.H + n) : 0.f;
+                    }
+                }
+                gather_x();
+                __syncthreads();  // B1
+                const unsigned ep = ebase + edge;
+                u64* dst = p.gh + (size_t)hpar * (p.H / 2);
+                const float rinv = gw == 0 ? misc[0] : 0.f;
+#pragma unroll
+                for (int t = 0; t < kMaxFcTiles; ++t) {
+                    __syncthreads();  // Bt
+                    if (gw == 0 && t < n_fc) {
+                        const float sx = tile_sum(3);
+                        const float a = fs1[t] * (tile_sum(0) - (128.f + fz1[t]) * sx) * rinv;
+                        const float b = fs2[t] * (tile_sum(1) - (128.f + fz2[t]) * sx) * rinv;
+                        if (qd == 0) stage[(t & 1) * 16 + row] = swiglu_f32(a, b);
+                        if (lane < 8) {
+                            const unsigned lo = f32_to_bf16(stage[(t & 1) * 16 + 2 * lane]),
+                                           hi = f32_to_bf16(stage[(t & 1) * 16 + 2 * lane + 1]);
+                            gr_store(dst + (bid + t * kG) * 8 + lane, ep, lo | (hi << 16));
+                        }
+                    }
+                    buf ^= 1;
+                }
+                __syncthreads();  // B3
+            }
+            // ================= mlp.c_proj (+ residual) -> next layer's x edge
+            {
+                float s1 = 0.f, z1 = 0.f, gn = 0.f;
+                const bf16_t* s_mp = sz_l + 8 * kC + 4 * p.H;
+                if (gw == 0) {
+                    s1 = ldbf(s_mp + bid * 16 + row);
+                    z1 = ldbf(s_mp + kC + bid * 16 + row);
+                    gn = ldbf(norms_l + 2 * kC + bid * 16 + row);  // rms_1 of the next layer, or ln_f after the last
+                }
+                const unsigned ep = ebase + edge;
+                const int n_loads = p.H / 4, half_l = (n_loads + 1) / 2;
+                const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
+                for (int c0 = first; c0 < end; c0 += 8 * 64) {
+                    u32x4 v[8];
+                    sweep<8>(p, rs_gh, (unsigned)hpar * (unsigned)(p.H / 2) * 8u, c0, end, ep, v, 0x500u + edge);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int i = c0 + k * 64 + lane;
+                        if (i < end) *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                    }
+                }
+                hpar ^= 1;
+                ++edge;
+                __syncthreads();  // B1
+                __syncthreads();  // Bt
+                if (gw == 0) {
+                    const float sx = tile_sum(3);
+                    xres += s1 * (tile_sum(0) - (128.f + z1) * sx);
+                    publish_x(xres, gn);
+                }
+                buf ^= 1;
+                __syncthreads();  // B3
+            }
+            norms_l += 2 * kC;
+            sz_l += p.sz_layer_stride;
+            kv_l += (size_t)2 * kHeads * p.S * kHs;
+        }
+        // ================= ln_f + lm_head (+ greedy arg-max, generate.py:68-85 with top_k = 1)
+        {
+            // scale / zero of a tile's row are requested one tile ahead
+            auto head_sz = [&](int t, float& sc_, float& z_) {
+                const int n = (bid + t * kG) * 16 + row;
+                const bool ok = t < n_head_t && n < p.V;
+                sc_ = ok ? ldbf(p.sz_head + n) : 0.f;
+                z_ = ok ? ldbf(p.sz_head + p.V + n) : 0.f;
+            };
+            float sct = 0.f, zt = 0.f;
+            if (gw == 0) head_sz(0, sct, zt);
+            gather_x();
+            __syncthreads();  // B1
+            const float rinv = gw == 0 ? misc[0] : 0.f;
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+            const int tiles_pad = p.head_turns * 3;
+            for (int t = 0; t < tiles_pad; ++t) {
+                float scn = 0.f, zn = 0.f;
+                if (gw == 0) head_sz(t + 1, scn, zn);
+                __syncthreads();  // Bt
+                if (gw == 0 && t < n_head_t) {
+                    const int n = (bid + t * kG) * 16 + row;
+                    const float sx = tile_sum(3);
+                    const float y = sct * (tile_sum(0) - (128.f + zt) * sx) * rinv;
+                    if (qd == 0 && n < p.V) {
+                        p.logits[n] = y;
+                        if (y > best || (y == best && n < bi)) {
+                            best = y;
+                            bi = n;
+                        }
+                    }
+                }
+                sct = scn;
+                zt = zn;
+                buf ^= 1;
+            }
+            __syncthreads();  // B3
+            if (p.mode & 1) {
+                if (gw == 0) {
+                    // best of this workgroup's rows (lanes 0, 4, .., 60), lowest index on ties
+#pragma unroll
+                    for (int o = 4; o < 64; o <<= 1) {
+                        const float ov = __shfl_xor(best, o, 64);
+                        const int oi = __shfl_xor(bi, o, 64);
+                        if (ov > best || (ov == best && oi < bi)) {
+                            best = ov;
+                            bi = oi;
+                        }
+                    }
+                    const unsigned ep = ebase + edge;
+                    if (lane == 0) {
+                        gr_store(p.gm + 2 * bid, ep, __float_as_uint(best));
+                        gr_store(p.gm + 2 * bid + 1, ep, (unsigned)bi);
+                    }
+                    if (bid == 0) {
+                        u32x4 v[4];
+                        const bool ok = sweep<4>(p, rs_gm, 0u, 0, 256, ep, v, 0x600u + edge);
+                        float bv = -INFINITY;
+                        int bx = 0x7fffffff;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float cv = __uint_as_float(v[k][0]);
+                            const int ci = (int)v[k][2];
+                            if (cv > bv || (cv == bv && ci < bx)) {
+                                bv = cv;
+                                bx = ci;
+                            }
+                        }
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const float ov = __shfl_xor(bv, o, 64);
+                            const int oi = __shfl_xor(bx, o, 64);
+                            if (ov > bv || (ov == bv && oi < bx)) {
+                                bv = ov;
+                                bx = oi;
+                            }
+                        }
+                        if (bx == 0x7fffffff) bx = 0;
+                        if (lane == 0 && ok && !aborted(p)) {
+                            p.next_token[0] = bx;
+                            if (p.out_tokens != nullptr) p.out_tokens[pos + 1] = bx;
+                            if (p.mode & 2) {
+                                p.tokens[0] = bx;
+                                p.pos[0] = pos + 1;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (bid == 0 && gw == 0 && lane == 0) p.state[1] = step_id + 1u;
+        }
+    }
+    FS_STAMP(1);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+namespace {
+constexpr size_t kWsState = 0, kWsGx = 256, kWsGa = kWsGx + 2 * 2304 * 8, kWsGq = kWsGa + 2 * 2048 * 8,
+                 kWsGm = kWsGq + 2 * kHeads * 256 * 8, kWsGh = kWsGm + 512 * 8;
+}
+
+extern "C" size_t mi355_fused_step_workspace_bytes(int n_hidden) {
+    if (n_hidden <= 0) return 0;
+    return kWsGh + (size_t)2 * (n_hidden / 2) * 8;
+}
+
+extern "C" int mi355_fused_step_supported(int n_embd, int n_head, int hs, int n_hidden, int vocab, int S) {
+    if (mi355_num_cus() != kG) return 0;  // one resident workgroup per CU, head groups of 8
+    if (n_embd != kC || n_head != kHeads || hs != kHs) return 0;
+    if (n_hidden <= 0 || n_hidden % 128 != 0 || n_hidden / 16 > kMaxFcTiles * kG || n_hidden / 128 > 96) return 0;
+    if (vocab <= 0 || (vocab + 15) / 16 > kMaxHeadTiles * kG) return 0;
+    if (S < 1 || S > kMaxS) return 0;
+    return 1;
+}
+
+extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t stream) {
+    MI355_CHECK_ARG(a != nullptr, MI355_E_ARG, "fused_step: null args");
+    MI355_CHECK_ARG(mi355_fused_step_supported(a->n_embd, a->n_head, a->hs, a->n_hidden, a->vocab, a->S), MI355_E_SHAPE,
+                    "fused_step: needs %d CUs, n_embd %d, %d heads of %d, n_hidden %% 128 == 0 and <= %d, vocab <= %d, "
+                    "S <= %d (got %d CUs, C=%d, heads=%d x %d, H=%d, V=%d, S=%d)",
+                    kG, kC, kHeads, kHs, kMaxFcTiles * kG * 16, kMaxHeadTiles * kG * 16, kMaxS, mi355_num_cus(), a->n_embd,
+                    a->n_head, a->hs, a->n_hidden, a->vocab, a->S);
+    MI355_CHECK_ARG(a->w && a->w_head && a->sz && a->sz_head && a->norms && a->wte && a->rope && a->kv && a->tokens &&
+                        a->pos && a->logits && a->workspace,
+                    MI355_E_ARG, "fused_step: null pointer");
+    MI355_CHECK_ARG(a->n_layer >= 1 && a->n_layer * 5 + 8 < 1024, MI355_E_SHAPE, "fused_step: n_layer %d", a->n_layer);
+    MI355_CHECK_ARG(!(a->mode & 1) || a->next_token != nullptr, MI355_E_ARG, "fused_step: arg-max without next_token");
+    MI355_CHECK_ARG(a->mode >= 0 && a->mode <= 3 && a->mode != 2, MI355_E_ARG, "fused_step: mode must be 0, 1 or 3");
+    MI355_CHECK_ARG(((uintptr_t)a->w | (uintptr_t)a->w_head | (uintptr_t)a->workspace | a->layer_stride | a->off_attn |
+                     a->off_proj | a->off_fc | a->off_mproj) % 16 == 0,
+                    MI355_E_ARG, "fused_step: streams and workspace must be 16-B aligned");
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)fused_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    });
+    MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "fused_step: hipFuncSetAttribute failed: %s",
+                    hipGetErrorString(attr_err));
+    FusedParams p;
+    memset(&p, 0, sizeof(p));
+    p.w = (const uint8_t*)a->w;
+    p.layer_stride = a->layer_stride;
+    p.off_attn = a->off_attn;
+    p.off_proj = a->off_proj;
+    p.off_fc = a->off_fc;
+    p.off_mproj = a->off_mproj;
+    p.layer_bytes = a->layer_bytes;
+    p.head_bytes = a->head_bytes;
+    p.w_head = (const uint8_t*)a->w_head;
+    p.sz = (const bf16_t*)a->sz;
+    p.sz_head = (const bf16_t*)a->sz_head;
+    p.norms = (const bf16_t*)a->norms;
+    p.wte = (const bf16_t*)a->wte;
+    p.rope = a->rope;
+    p.kv = (bf16_t*)a->kv;
+    p.tokens = a->tokens;
+    p.pos = a->pos;
+    p.next_token = a->next_token;
+    p.out_tokens = a->out_tokens;
+    p.logits = a->logits;
+    char* ws = (char*)a->workspace;
+    p.state = (unsigned*)(ws + kWsState);
+    p.gx = (u64*)(ws + kWsGx);
+    p.ga = (u64*)(ws + kWsGa);
+    p.gq = (u64*)(ws + kWsGq);
+    p.gm = (u64*)(ws + kWsGm);
+    p.gh = (u64*)(ws + kWsGh);
+    p.dbg = (u64*)a->debug_stamps;
+    p.sz_layer_stride = (unsigned)(10 * kC + 4 * a->n_hidden);
+    p.n_layer = a->n_layer;
+    p.H = a->n_hidden;
+    p.V = a->vocab;
+    p.S = a->S;
+    p.units_h = a->n_hidden / 128;
+    p.fc_tiles = a->n_hidden / 16;
+    p.head_tiles = (a->vocab + 15) / 16;
+    {
+        const int per_wg = (p.head_tiles + kG - 1) / kG;  // tiles of the busiest workgroup, 4 steps each
+        p.head_turns = (per_wg * 4 + kRing - 1) / kRing;
+    }
+    p.mode = a->mode;
+    p.eps = a->eps;
+    p.scale = 1.0f / sqrtf((float)kHs);
+    hipLaunchKernelGGL(fused_step_kernel, dim3(kG), dim3(kThreads), kLdsBytes, (hipStream_t)stream, p);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}

@@ -28,6 +28,7 @@ extern "C" int mi355_sizeof(int which) {
         case 3: return (int)sizeof(mi355_weight);
         case 4: return (int)sizeof(mi355_layer);
         case 5: return (int)sizeof(mi355_model);
+        case 6: return (int)sizeof(mi355_fused_step_args);
         default: return -1;
     }
 }

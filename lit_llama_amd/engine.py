@@ -52,8 +52,10 @@ def _kind(mod: nn.Module) -> str:
     raise EngineUnavailable(f"unsupported linear type {type(mod).__name__}")
 
 
-def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: Optional[dict] = None) -> _PackedWeight:
-    """Repack one linear (or the c_fc1 / c_fc2 pair) into the weight stream of its format."""
+def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: Optional[dict] = None,
+                out: Optional[torch.Tensor] = None) -> _PackedWeight:
+    """Repack one linear (or the c_fc1 / c_fc2 pair) into the weight stream of its format (`out`: the slice of a
+    weight arena the Q4 stream is written to)."""
     from .quantization import ColBlockQuantizedLinear, Linear8bitLt
 
     kind = _kind(mod)
@@ -73,7 +75,7 @@ def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: 
         if mod.bias is not None:
             raise EngineUnavailable("bias on a quantised linear")
         N, K = mod.out_features, mod.in_features
-        stream = ops.repack_q4(mod.quant_weight, pair.quant_weight if pair is not None else None, N, K, d.R)
+        stream = ops.repack_q4(mod.quant_weight, pair.quant_weight if pair is not None else None, N, K, d.R, out=out)
         s0, z0 = mod.scales.reshape(-1).contiguous(), mod.zeros.reshape(-1).contiguous()
         d.fmt, d.w, d.N, d.K = W_Q4, ptr(stream), N, K
         d.scales, d.zeros, d.sz_dtype = ptr(s0), ptr(z0), dtype_code(s0.dtype)
@@ -115,8 +117,43 @@ def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: 
     return pw
 
 
+def model_fingerprint(model: "nn.Module") -> tuple:
+    """(data_ptr, version, dtype) of every parameter and buffer the engine packed or points at.  The engine holds
+    repacked copies and raw device pointers: `load_state_dict`, `.to()`, `.bfloat16()`, re-quantisation or an
+    in-place edit make them stale, and `LLaMA.engine()` rebuilds the engine when this changes."""
+    out = []
+    for t in list(model.parameters()) + list(model.buffers()):
+        out.append((t.data_ptr(), t._version, t.dtype, t.device))
+    for mod in model.modules():
+        w = getattr(mod, "weight", None)
+        cb = getattr(w, "CB", None) if w is not None else None
+        if cb is not None:  # Linear8bitLt keeps its int8 rows as attributes of the parameter
+            out.append((cb.data_ptr(), cb._version, cb.dtype, cb.device))
+    return tuple(out)
+
+
+def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
+    """Byte layout of the weight arena of the fused decode step (csrc/fused_step.hip), or None when the model is
+    not one the persistent launch handles (then every linear keeps its own stream tensor)."""
+    if _env_int("MI355_FUSED", 1) == 0 or kinds != {"q4"}:
+        return None
+    if not lib().mi355_fused_step_supported(C_, nh, hs, H, V, 1):
+        return None
+    first = model.transformer.h[0]
+    for mod in (first.attn.c_attn, first.attn.c_proj, first.mlp.c_fc1, first.mlp.c_fc2, first.mlp.c_proj, model.lm_head):
+        if not mod.fast_eligible(torch.bfloat16) or mod.scales.dtype != torch.bfloat16:
+            return None
+    sizes = [ops.packed_bytes(W_Q4, 3 * C_, C_, 1, False), ops.packed_bytes(W_Q4, C_, C_, 1, False),
+             ops.packed_bytes(W_Q4, H, C_, 2, True), ops.packed_bytes(W_Q4, C_, H, 1, False)]
+    offs = [0, sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2]]
+    layer_bytes = sum(sizes)
+    if layer_bytes >= 1 << 32 or any(o % 16 for o in offs) or layer_bytes % 16:
+        return None
+    return {"sizes": sizes, "offs": offs, "layer_bytes": layer_bytes}
+
+
 class DecodeEngine:
-    """Owns everything `mi355_forward` needs for one `LLaMA` instance."""
+    """Owns everything `mi355_forward` / `mi355_fused_step` need for one `LLaMA` instance."""
 
     def __init__(self, model: "nn.Module", *, tp_rank: int = 0, tp_world: int = 1, tune: Optional[dict] = None):
         cfg = model.config
@@ -126,9 +163,15 @@ class DecodeEngine:
         if wte.dtype != torch.bfloat16:
             raise EngineUnavailable(f"model dtype {wte.dtype}: the engine computes with bf16 MFMA operands; "
                                     "f32 models run op by op through the exact f32 kernels")
+        for name, sc in [("ln_f", model.transformer.ln_f.scale)] + [
+                (f"h.{i}.rms_{j}", getattr(blk, f"rms_{j}").scale) for i, blk in enumerate(model.transformer.h) for j in (1, 2)]:
+            if sc.dtype != wte.dtype or sc.device != wte.device:
+                raise EngineUnavailable(f"{name}.scale is {sc.dtype} on {sc.device}, wte is {wte.dtype} on {wte.device}: "
+                                        "the engine reads every norm scale in the embedding's dtype")
         self.model = model
         self.device = wte.device
         self.cfg = cfg
+        self.fingerprint = model_fingerprint(model)
         self.tp_world = tp_world
         self.tune = tune or {}
         self.stream = torch.cuda.Stream(device=self.device)  # capturable (the legacy default stream is not)
@@ -152,11 +195,29 @@ class DecodeEngine:
             i8 = _kind(first.attn.c_attn) == "i8"
             grids = {} if i8 else {"lm_head": 2 * cus}
             dflt = lambda key: {"grid": grids.get(key, cus), **self.tune.get(key, {})}  # noqa: E731
+            kinds = {_kind(m_) for blk in model.transformer.h
+                     for m_ in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj)}
+            kinds.add(_kind(model.lm_head))
+            # the fused decode step addresses a layer by a stride: all Q4 streams of the model live in ONE arena
+            plan = None
+            if tp_world == 1 and wte.dtype == torch.bfloat16:
+                plan = _fused_plan(model, kinds, C_, nh, hs, self.n_hidden, model.lm_head.out_features)
+            self.fused_plan = plan
+            self.w_arena = None
+            if plan is not None:
+                self.w_arena = torch.empty(cfg.n_layer * plan["layer_bytes"], dtype=torch.uint8, device=self.device)
+
+            def slot(i, j):
+                if plan is None:
+                    return None
+                o = i * plan["layer_bytes"] + plan["offs"][j]
+                return self.w_arena[o:o + plan["sizes"][j]]
+
             for i, blk in enumerate(model.transformer.h):
-                attn = pack_linear(blk.attn.c_attn, 1, tune=dflt("attn"))
-                proj = pack_linear(blk.attn.c_proj, 1, tune=dflt("proj"))
-                fc = pack_linear(blk.mlp.c_fc1, 2, pair=blk.mlp.c_fc2, tune=dflt("fc"))
-                mproj = pack_linear(blk.mlp.c_proj, 1, tune=dflt("mproj"))
+                attn = pack_linear(blk.attn.c_attn, 1, tune=dflt("attn"), out=slot(i, 0))
+                proj = pack_linear(blk.attn.c_proj, 1, tune=dflt("proj"), out=slot(i, 1))
+                fc = pack_linear(blk.mlp.c_fc1, 2, pair=blk.mlp.c_fc2, tune=dflt("fc"), out=slot(i, 2))
+                mproj = pack_linear(blk.mlp.c_proj, 1, tune=dflt("mproj"), out=slot(i, 3))
                 self.packed += [attn, proj, fc, mproj]
                 L = layers[i]
                 L.rms1, L.rms2 = ptr(blk.rms_1.scale.detach()), ptr(blk.rms_2.scale.detach())
@@ -221,6 +282,59 @@ class DecodeEngine:
         self.m = m
         self.S = 0
         self._cache_pool = {}  # S -> list of (k, v): kept across reset_cache() so captured graphs stay valid
+        self.fused = None
+        self.fused_enabled = True  # tests / measurements switch between the persistent launch and the 162-launch step
+        if self.fused_plan is not None:
+            self._build_fused(model, head)
+
+    # ---- fused decode step (csrc/fused_step.hip) -------------------------------------------------------
+    def _build_fused(self, model, head) -> None:
+        """Side arenas of the persistent decode launch: scales / zeros, norm scales, hand-off workspace."""
+        cfg, plan, dev = self.cfg, self.fused_plan, self.device
+        C_, H, V = cfg.n_embd, self.n_hidden, model.lm_head.out_features
+        with torch.cuda.device(dev):
+            sz = torch.empty((cfg.n_layer, 10 * C_ + 4 * H), dtype=torch.bfloat16, device=dev)
+            norms = torch.empty((2 * cfg.n_layer + 1, C_), dtype=torch.bfloat16, device=dev)
+            for i, blk in enumerate(model.transformer.h):
+                parts = []
+                for mod in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj):
+                    parts += [mod.scales.reshape(-1), mod.zeros.reshape(-1)]
+                sz[i].copy_(torch.cat(parts))
+                norms[2 * i].copy_(blk.rms_1.scale.detach())
+                norms[2 * i + 1].copy_(blk.rms_2.scale.detach())
+            norms[2 * cfg.n_layer].copy_(model.transformer.ln_f.scale.detach())
+            sz_head = torch.cat([model.lm_head.scales.reshape(-1), model.lm_head.zeros.reshape(-1)]).contiguous()
+            ws = torch.zeros(int(lib().mi355_fused_step_workspace_bytes(H)), dtype=torch.uint8, device=dev)
+        a = nat.FusedStepArgs()
+        a.w, a.layer_stride = ptr(self.w_arena), plan["layer_bytes"]
+        a.off_attn, a.off_proj, a.off_fc, a.off_mproj = plan["offs"]
+        a.layer_bytes, a.head_bytes = plan["layer_bytes"], head.stream_bytes
+        a.w_head = head.desc.w
+        a.sz, a.sz_head, a.norms = ptr(sz), ptr(sz_head), ptr(norms)
+        a.wte, a.rope = self.m.wte, self.m.rope
+        a.tokens, a.pos, a.next_token, a.out_tokens = self.m.tokens, self.m.pos, self.m.next_token, self.m.out_tokens
+        a.logits, a.workspace = self.m.logits, ptr(ws)
+        a.n_layer, a.n_head, a.n_embd, a.hs = cfg.n_layer, self.local_heads, C_, C_ // cfg.n_head
+        a.n_hidden, a.vocab, a.eps = H, V, self.m.eps
+        self.fused = a
+        self._fused_keep = [sz, sz_head, norms, ws]
+        self._fused_ws = ws
+        self._fused_warm = False
+
+    def fused_ready(self) -> bool:
+        return (self.fused is not None and self.fused_enabled and self.fused.kv is not None and self.fused.S == self.S
+                and self.S > 0)
+
+    def check_status(self) -> None:
+        """Raise if a hand-off of the fused step timed out (abort word of the workspace); one device->host read, so
+        call it where the host synchronises anyway (end of generate, after a timed loop, in tests)."""
+        if self.fused is None:
+            return
+        code = int(self._fused_ws[:4].view(torch.int32).item())
+        if code != 0:
+            self._fused_ws[:4].zero_()
+            raise nat.NativeError(f"fused decode step aborted (code 0x{code:x}): a workgroup hand-off timed out or the "
+                                  "step was entered with pos >= S; the step's outputs are invalid")
 
     # ---- bookkeeping ---------------------------------------------------------------------------------
     def weight_stream_bytes(self) -> int:
@@ -252,10 +366,13 @@ class DecodeEngine:
         pool = self._cache_pool.get(S)
         if pool is None:
             self._destroy_graphs()  # captured kernels hold the old cache pointers / S by value
-            shape = (1, self.local_heads, S, hs)
-            pool = [(torch.zeros(shape, dtype=torch.bfloat16, device=self.device),
-                     torch.zeros(shape, dtype=torch.bfloat16, device=self.device)) for _ in range(cfg.n_layer)]
+            # one allocation [n_layer][2][1][n_head][S][hs]: the fused step addresses a layer's rows by a stride;
+            # kv_caches keeps the reference's per-layer (k, v) tensors of shape [1, n_head, S, hs] as views
+            self._cache_pool = {}
+            arena = torch.zeros((cfg.n_layer, 2, 1, self.local_heads, S, hs), dtype=torch.bfloat16, device=self.device)
+            pool = [(arena[i, 0], arena[i, 1]) for i in range(cfg.n_layer)]
             self._cache_pool = {S: pool}  # one cache geometry at a time
+            self._kv_arena = arena
         else:
             for k, v in pool:
                 k.zero_()
@@ -265,6 +382,11 @@ class DecodeEngine:
         self.model.kv_caches = list(pool)
         self.m.S = S
         self.S = S
+        if self.fused is not None:
+            ok = bool(lib().mi355_fused_step_supported(cfg.n_embd, self.local_heads, hs, self.n_hidden,
+                                                       self.fused.vocab, S))
+            self.fused.kv = ptr(self._kv_arena) if ok else None
+            self.fused.S = S if ok else 0
 
     # ---- execution -----------------------------------------------------------------------------------
     def _host_pos0(self, input_pos: torch.Tensor, T: int) -> Optional[int]:
@@ -303,6 +425,11 @@ class DecodeEngine:
         logits only, True/1 greedy argmax, 3 chained greedy step (needs `embed_step()` before the first one)."""
         s = self.stream.cuda_stream
         argmax = int(argmax)
+        if self.fused_ready():
+            # one persistent launch per token; launches are asynchronous, so the host runs ahead without a graph
+            self.fused.mode = argmax
+            check(lib().mi355_fused_step(C.byref(self.fused), s), "mi355_fused_step")
+            return
         if self.use_graph:
             try:
                 if argmax not in self._graphs:

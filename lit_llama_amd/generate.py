@@ -97,6 +97,7 @@ def _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id):
                 if eos_id in toks:
                     break
         out = eng.out_tokens[:T + done].to(dtype).clone()
+        eng.check_status()  # one read after the loop: a hand-off of the fused step timed out -> raise, never garbage
     cur.wait_stream(eng.stream)
     if eos_id is not None:
         gen = out[T:].tolist()

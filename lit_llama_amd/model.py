@@ -213,6 +213,7 @@ class LLaMA(nn.Module):
         self.kv_caches: List[KVCache] = []
         self._engine = None           # engine.DecodeEngine, built lazily
         self._engine_failed = None    # reason string once the engine turned out to be inapplicable
+        self._engine_failed_fp = None
         self.use_engine = True
 
     def _init_weights(self, module: nn.Module) -> None:
@@ -243,16 +244,42 @@ class LLaMA(nn.Module):
             self._engine.reset_cache()
 
     # ---- engine --------------------------------------------------------------------------------------
-    def engine(self):
-        """The native whole-forward engine for this model, or None (with the reason in `_engine_failed`)."""
-        if self._engine is None and self._engine_failed is None:
-            from .engine import DecodeEngine, EngineUnavailable
+    def engine(self, check: bool = True):
+        """The native whole-forward engine for this model, or None (with the reason in `_engine_failed`).
 
+        The engine holds repacked copies of the weights and raw device pointers.  `load_state_dict`, `.to()` /
+        `.bfloat16()` drop it (overrides below); with `check` the (data_ptr, version, dtype) fingerprint of every
+        parameter and buffer is compared as well, which also catches in-place edits and re-quantisation
+        (`LLaMA.forward` skips that walk on its per-token path; `generate`, tests and bench.py take it)."""
+        from .engine import DecodeEngine, EngineUnavailable, model_fingerprint
+
+        fp = None
+        if check and (self._engine is not None or self._engine_failed is not None):
+            fp = model_fingerprint(self)
+            if self._engine is not None and self._engine.fingerprint != fp:
+                self._drop_engine()
+            if self._engine_failed is not None and self._engine_failed_fp != fp:
+                self._engine_failed = None
+        if self._engine is None and self._engine_failed is None:
             try:
                 self._engine = DecodeEngine(self)
             except EngineUnavailable as e:
                 self._engine_failed = str(e)
+                self._engine_failed_fp = fp if fp is not None else model_fingerprint(self)
         return self._engine
+
+    def _drop_engine(self) -> None:
+        self._engine = None
+        self._engine_failed = None
+        self.kv_caches = []
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .bfloat16() / .float(): new storages
+        self._drop_engine()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._drop_engine()
+        return super().load_state_dict(*args, **kwargs)
 
     # ---- forward -------------------------------------------------------------------------------------
     def forward(
@@ -275,7 +302,7 @@ class LLaMA(nn.Module):
         if _tp(self.config) > 1:
             raise nat.NativeError("a rank-local tensor-parallel model is driven through tp.TPDecoder / tp.tp_forward")
         if input_pos is not None and B == 1 and self.use_engine:
-            eng = self.engine()
+            eng = self.engine(check=False)
             if eng is not None:
                 out = eng.forward(idx, max_seq_length, input_pos)
                 if out is not None:

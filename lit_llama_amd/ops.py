@@ -31,13 +31,18 @@ def packed_bytes(fmt: int, N: int, K: int, R: int, pair: bool) -> int:
     return n
 
 
-def repack_q4(q0: torch.Tensor, q1: Optional[torch.Tensor], N: int, K: int, R: int) -> torch.Tensor:
-    """quant_weight [N, K/2] uint8 (any strides) -> Q4 stream (uint8 1-D)."""
+def repack_q4(q0: torch.Tensor, q1: Optional[torch.Tensor], N: int, K: int, R: int,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """quant_weight [N, K/2] uint8 (any strides) -> Q4 stream (uint8 1-D; `out`: a slice of a caller's arena)."""
     require_gpu(q0, "repack_q4")
     assert q0.dtype == torch.uint8 and q0.shape == (N, K // 2)
     if q1 is not None:
         assert q1.dtype == torch.uint8 and q1.shape == q0.shape and q1.stride() == q0.stride()
-    out = torch.empty(packed_bytes(W_Q4, N, K, R, q1 is not None), dtype=torch.uint8, device=q0.device)
+    nbytes = packed_bytes(W_Q4, N, K, R, q1 is not None)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=q0.device)
+    elif out.dtype != torch.uint8 or out.numel() != nbytes or not out.is_contiguous() or out.device != q0.device:
+        raise nat.NativeError(f"repack_q4: `out` must be a contiguous uint8 tensor of {nbytes} bytes on {q0.device}")
     check(lib().mi355_q4_repack(ptr(q0), ptr(q1), q0.stride(0), q0.stride(1), N, K, R, ptr(out), stream_ptr()),
           "mi355_q4_repack")
     return out
