@@ -433,10 +433,15 @@ typedef struct mi355_fused_step_args {
     int32_t* out_tokens;
     float* logits;
     void* workspace;
-    uint64_t* debug_stamps; /* optional: uint64 [256][64] wall-clock stamps (100 MHz) */
+    uint64_t* debug_stamps; /* optional: uint64 [256][64] wall-clock stamps (100 MHz) of layer `reserved0`:
+                               0 entry, 1 exit; gatherer: 2 x gathered, 3 q/k/v published, 4 head's q gathered, 5 attention
+                               partials ready, 6 attention output published, 7 gathered, 8 c_proj published, 9 gathered,
+                               10 hidden published, 11 gathered, 12 mlp.c_proj published; streamer wave 0: 20/21 c_attn
+                               start / done, 23-25 attention (q staged, scores done, output done), 26/27 c_proj,
+                               28/29 fc, 30/31 mlp.c_proj */
     int32_t n_layer, n_head, n_embd, hs, n_hidden, vocab, S, mode;
     float eps;
-    int32_t reserved0;
+    int32_t reserved0;      /* layer to stamp when debug_stamps is given, else 0 */
 } mi355_fused_step_args;
 
 size_t mi355_fused_step_workspace_bytes(int n_hidden);

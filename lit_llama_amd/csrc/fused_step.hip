@@ -91,6 +91,7 @@ struct FusedParams {
     int n_layer, H, V, S;
     int units_h, fc_tiles, head_tiles, head_turns;
     int mode;                // bit 0: greedy arg-max, bit 1: chained (advance tokens[0] / pos[0])
+    int dbg_layer;           // layer whose phases are stamped into dbg
     float eps, scale;
 };
 
@@ -212,7 +213,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
         unsigned lane_off = lane * 16;
         const int g = lane >> 4;
         u32x4 ring[kRing];
-        const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
         int buf = 0;
 
         PhaseW ph_attn, ph_proj, ph_fc, ph_mp, ph_head;
@@ -238,54 +238,64 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             const unsigned so__ = piece_off<SPT_, PAIR_, QKV_>(PH_, pc__ / (R_), pc__ % (R_), ok__);          \
             ring[pc__] = ring_load(RS_, rs_null, ok__, lane_off, so__);                                      \
             __builtin_amdgcn_sched_barrier(0); /* issue order = consumption order (VMEM returns in order) */ \
+            /* at most 4 pieces per wave (32 KiB per CU, what a CU keeps in flight anyway) are queued at a  */ \
+            /* time: a deeper queue only stands in front of the gatherers' sweep in the CU's in-order       */ \
+            /* memory pipeline (the hand-offs into fc / mlp.c_proj took 5.5 / 5.0 us instead of ~3)         */ \
+            if (pc__ % 4 == 3 && pc__ + 1 < kRing) {                                                         \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                           \
+            }                                                                                                \
         }                                                                                                    \
     } while (0)
 
         // ---- one phase: BODIES x TURNS ring turns of 12 / R steps; a step = R pieces against one activation unit
-#define FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_)                                                     \
+#define FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_)                                             \
     do {                                                                                                             \
         constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
         const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
-        f32x4 acc__[R__], acc1__ = f32x4{0.f, 0.f, 0.f, 0.f};                                                         \
+        f32x4 acc__[R__];                                                                                             \
         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__] = f32x4{0.f, 0.f, 0.f, 0.f};                 \
         __syncthreads(); /* B1: the activation vector is staged */                                                   \
+        FS_SSTAMP(STAMP_);                                                                                            \
         for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
             _Pragma("unroll") for (int t__ = 0; t__ < (TURNS_); ++t__) {                                              \
                 _Pragma("unroll") for (int s__ = 0; s__ < STEPS__; ++s__) {                                           \
                     const int gstep__ = (body__ * (TURNS_) + t__) * STEPS__ + s__;                                    \
                     const int ti__ = gstep__ / SPT__, st__ = gstep__ - ti__ * SPT__;                                  \
-                    const char* xb__ = (st__ < (PH_).nu ? xs + ((PH_).u0 + st__) * 256 : smem + kOffZero) + g * 64;   \
-                    bf16x8 b__[4];                                                                                    \
-                    _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) b__[d__] = *(const bf16x8*)(xb__ + 16 * d__); \
-                    _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) acc1__ = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
-                        __builtin_bit_cast(bf16x8, ones), b__[d__], acc1__, 0, 0, 0);                                 \
-                    _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                           \
-                        const u32x4 q__ = ring[s__ * R__ + r__];                                                      \
-                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                         \
-                            const uint32_t v__ = q__[d__];                                                            \
-                            u32x4 a__;                                                                                \
-                            a__[0] = (v__ & 0x000F000Fu) | 0x43004300u;                                               \
-                            a__[1] = ((v__ >> 4) & 0x000F000Fu) | 0x43004300u;                                        \
-                            a__[2] = ((v__ >> 8) & 0x000F000Fu) | 0x43004300u;                                        \
-                            a__[3] = ((v__ >> 12) & 0x000F000Fu) | 0x43004300u;                                       \
-                            acc__[r__] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a__),     \
-                                                                                b__[d__], acc__[r__], 0, 0, 0);       \
+                    /* idle steps (padding of the ring turn) carry no data: skip their MFMAs (wave-uniform) */        \
+                    if (st__ < (PH_).nu && ((QKV_) || ti__ < (PH_).ntiles)) {                                         \
+                        const char* xb__ = xs + ((PH_).u0 + st__) * 256 + g * 64;                                     \
+                        bf16x8 b__[4];                                                                                \
+                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) b__[d__] = *(const bf16x8*)(xb__ + 16 * d__); \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
+                            const u32x4 q__ = ring[s__ * R__ + r__];                                                  \
+                            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                     \
+                                const uint32_t v__ = q__[d__];                                                        \
+                                u32x4 a__;                                                                            \
+                                a__[0] = (v__ & 0x000F000Fu) | 0x43004300u;                                           \
+                                a__[1] = ((v__ >> 4) & 0x000F000Fu) | 0x43004300u;                                    \
+                                a__[2] = ((v__ >> 8) & 0x000F000Fu) | 0x43004300u;                                    \
+                                a__[3] = ((v__ >> 12) & 0x000F000Fu) | 0x43004300u;                                   \
+                                acc__[r__] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a__), \
+                                                                                    b__[d__], acc__[r__], 0, 0, 0);   \
+                            }                                                                                         \
                         }                                                                                             \
-                        /* refill with the same slot of the next turn of THIS phase (nothing past its end) */         \
+                    }                                                                                                 \
+                    /* refill with the same slots of the next turn of THIS phase (nothing past its end) */            \
+                    _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                           \
                         const int nstep__ = gstep__ + STEPS__;                                                        \
                         bool ok__;                                                                                    \
                         const unsigned so__ = piece_off<SPT__, PAIR_, QKV_>(PH_, nstep__, r__, ok__);                 \
                         ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
                     }                                                                                                 \
-                    if ((t__ * STEPS__ + s__ + 1) % SPT__ == 0) {                                           \
+                    if ((t__ * STEPS__ + s__ + 1) % SPT__ == 0) {                                                     \
                         /* tile done: publish this wave's partial 16x16 tiles */                                      \
+                        if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
                         f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * 1024) + lane;                \
                         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
                             pp__[r__ * 64] = acc__[r__];                                                              \
                             acc__[r__] = f32x4{0.f, 0.f, 0.f, 0.f};                                                   \
                         }                                                                                             \
-                        pp__[3 * 64] = acc1__;                                                                        \
-                        acc1__ = f32x4{0.f, 0.f, 0.f, 0.f};                                                           \
                         __syncthreads(); /* Bt */                                                                     \
                         buf ^= 1;                                                                                     \
                     }                                                                                                 \
@@ -300,10 +310,16 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
 
         FS_BURST(rs_l, 3, 4, false, true, ph_attn);
         const bf16_t* kv_l = (const bf16_t*)p.kv;
+        bool dbg_on = false;
+#define FS_SSTAMP(i)                                                                      \
+    do {                                                                                  \
+        if (dbg_on && threadIdx.x == 0) p.dbg[bid * 64 + (i)] = wall_clock64();            \
+    } while (0)
         for (int l = 0; l < p.n_layer; ++l) {
+            dbg_on = p.dbg != nullptr && l == p.dbg_layer;
             asm volatile("" : "+v"(lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
             // ---------------- c_attn (q, k, v tiles of this workgroup's 16 dimensions of its head)
-            FS_RUN(rs_l, 3, 4, false, true, 1, ph_attn, 1);
+            FS_RUN(rs_l, 3, 4, false, true, 1, ph_attn, 1, 20);
             // ---------------- attention: scores over the whole context, then this workgroup's 16 output dims
             {
                 const bf16_t* kc = kv_l + (size_t)head * p.S * kHs;
@@ -329,6 +345,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                                                        rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
                 }
                 __syncthreads();  // Ba1: q / new k / new v of the head are in LDS
+                FS_SSTAMP(23);
                 float qf[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) qf[j] = qs[li * 8 + j];
@@ -360,6 +377,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                     if (lane == 0) scores[pos] = dot * p.scale;
                 }
                 __syncthreads();  // Ba2: scores[0 .. pos] complete
+                FS_SSTAMP(24);
                 const int len = pos + 1;
                 float mx = -1.0e30f;
                 for (int t = lane; t < len; t += 64) mx = fmaxf(mx, scores[t]);
@@ -400,16 +418,17 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                     for (int j = 0; j < 8; ++j) opart[wave * 16 + half * 8 + j] = of[j];
                 }
                 if (threadIdx.x == 0) misc[1] = sum;
+                FS_SSTAMP(25);
                 __syncthreads();  // Ba3: partial outputs of the 8 waves
                 __syncthreads();  // Ba4: the attention output is published
             }
             // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows)
             FS_BURST(rs_l, 1, 12, false, false, ph_proj);
-            FS_RUN(rs_l, 1, 12, false, false, 1, ph_proj, 1);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_proj, 1, 26);
             FS_BURST(rs_l, 2, 4, true, false, ph_fc);
-            FS_RUN(rs_l, 2, 4, true, false, 2, ph_fc, 1);
+            FS_RUN(rs_l, 2, 4, true, false, 2, ph_fc, 1, 28);
             FS_BURST(rs_l, 1, 12, false, false, ph_mp);
-            FS_RUN(rs_l, 1, 12, false, false, 1, ph_mp, 1);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_mp, 1, 30);
             // next layer (or the head)
             kv_l += (size_t)2 * kHeads * p.S * kHs;
             if (l + 1 < p.n_layer) {
@@ -420,15 +439,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 FS_BURST(rs_h, 1, 4, false, false, ph_head);
             }
         }
-        FS_RUN(rs_h, 1, 4, false, false, 1, ph_head, p.head_turns);
+        dbg_on = false;
+        FS_RUN(rs_h, 1, 4, false, false, 1, ph_head, p.head_turns, 32);
         if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
 #undef FS_RUN
 #undef FS_BURST
+#undef FS_SSTAMP
     } else {
         // =========================================================================================== gatherers
         const int gw = wave - kSW;  // 0: combines / publishes, 1: helps with the sweeps
-        const int row = lane >> 2, qd = lane & 3;
-        const int psrc = ((row >> 2) << 4) * 4 + (row & 3);  // float index of D[row][0] inside a wave's partial tile
         unsigned edge = 0;   // edges published so far in this step (the epoch of the next one is ebase + edge)
         int xpar = 0, apar = 0, hpar = 0, qpar = 0;
         int buf = 0;
@@ -439,49 +458,59 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             __builtin_amdgcn_make_buffer_rsrc((void*)p.gq, 0, 2 * kHeads * 256 * 8, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_gm = __builtin_amdgcn_make_buffer_rsrc((void*)p.gm, 0, 512 * 8, 0x00020000);
 
-        // partial tiles of wave w, row group r of the current tile
-        auto tile_sum = [&](int r) {
-            const float* b0 = (const float*)(part + (size_t)((buf * kSW + qd) * 4 + r) * 1024) + psrc;
-            const float* b1 = (const float*)(part + (size_t)((buf * kSW + qd + 4) * 4 + r) * 1024) + psrc;
-            float t = b0[0] + b1[0];
-            t = MI355_DPP_ADD(t, 0xB1);
-            t = MI355_DPP_ADD(t, 0x4E);
+        // ---- epilogue mapping of gatherer 0: lane = (pair pg = lane >> 3, streamer wave w8 = lane & 7).  A lane reads
+        // rows 2 pg, 2 pg + 1 of ONE wave's partial tile (8 B), the 8 lanes of a pair are summed with DPP (fixed
+        // order), and every lane then holds both outputs of its pair: RoPE pairs, bf16 pair granules and the residual
+        // rows stay in registers (the first version staged them through LDS: 0.6-1.1 us per phase on the chain).
+        int lane_v = lane;  // made opaque once per layer: per-lane pointers are otherwise hoisted out of the layer loop
+                            // (a few dozen 64-bit addresses) and spilled to scratch, i.e. to VMEM on the hand-off path
+        int pg = lane >> 3, w8 = lane & 7;
+        int psrc = ((pg >> 1) << 4) * 4 + ((2 * pg) & 3);  // float index of D[2 pg][0] in a wave's partial tile
+        auto tile_pair = [&](int r) {
+            float2 t = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * 1024) + psrc);
+            t.x = group_sum(t.x, 8);
+            t.y = group_sum(t.y, 8);
             return t;
         };
-        auto ldbf = [&](const bf16_t* q) { return bf16_to_f32(*q); };
+        auto ldpair = [&](const bf16_t* q) {  // two consecutive bf16 (4-byte aligned) as floats
+            const unsigned v = *(const unsigned*)q;
+            return float2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+        };
+        auto bfpair = [&](float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); };
+        // sum of the two bf16 halves of a staged dword (sum_k x_k undoes the +128 / zero-point offset of the int4
+        // operands: y = scale (acc - (128 + zero) sum_k x_k); every workgroup needs the same sum, so it is taken while
+        // the vector is staged instead of by an all-ones MFMA per k-step in every streamer wave)
+        auto pair_sum = [&](unsigned v) { return __uint_as_float(v << 16) + __uint_as_float(v & 0xffff0000u); };
+        bool dbg_on = false;
+#define FS_GSTAMP(i)                                                                              \
+    do {                                                                                          \
+        if (dbg_on && gw == 0 && lane == 0) p.dbg[bid * 64 + (i)] = wall_clock64();               \
+    } while (0)
 
         // publish an x-type edge: bf16(norm_scale * x) pairs + the partial sum of squares of this workgroup's rows
-        auto publish_x = [&](float xv, float gsc) {
-            if (qd == 0) {
-                stage[row] = gsc * xv;
-                stage[16 + row] = xv * xv;
-            }
+        auto publish_x = [&](float2 xv, float2 gsc) {
             const unsigned ep = ebase + edge;
             u64* dst = p.gx + (size_t)xpar * 2304;
-            if (lane < 8) {
-                const unsigned lo = f32_to_bf16(stage[2 * lane]), hi = f32_to_bf16(stage[2 * lane + 1]);
-                gr_store(dst + bid * 8 + lane, ep, lo | (hi << 16));
-            } else if (lane == 8) {
-                float ss = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) ss += stage[16 + i];
-                gr_store(dst + 2048 + bid, ep, __float_as_uint(ss));
-            }
+            if (w8 == 0) gr_store(dst + bid * 8 + pg, ep, bfpair(gsc.x * xv.x, gsc.y * xv.y));
+            float ss = xv.x * xv.x + xv.y * xv.y;  // the same in the 8 lanes of a pair: sum over the 8 pairs
+            ss = MI355_DPP_ADD(ss, 0x140);
+            ss += lane_xor16(ss);
+            ss += lane_xor32(ss);
+            if (lane == 0) gr_store(dst + 2048 + bid, ep, __float_as_uint(ss));
         };
-        // gather an x-type edge into xs (bf16) and 1/rms into misc[0]
+        // gather an x-type edge into xs (bf16), 1/rms into misc[0], the operand sum into misc[4] + misc[5]
         auto gather_x = [&]() {
             const unsigned ep = ebase + edge;
             const unsigned base = (unsigned)xpar * 2304u * 8u;
             if (gw == 0) {
                 u32x4 v[8];
                 // loads 0 .. 383 of the pair region (6 per lane) and the 128 loads of the sums of squares (2 per lane)
-                const int lane_ = lane;
                 for (unsigned spins = 0;; ++spins) {
                     bool ok = true;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const unsigned off = k < 6 ? base + (unsigned)(k * 64 + lane_) * 16u
-                                                   : base + 2048u * 8u + (unsigned)((k - 6) * 64 + lane_) * 16u;
+                        const unsigned off = k < 6 ? base + (unsigned)(k * 64 + lane) * 16u
+                                                   : base + 2048u * 8u + (unsigned)((k - 6) * 64 + lane) * 16u;
                         v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gx, off, 0, 16));
                     }
 #pragma unroll
@@ -493,78 +522,94 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                float sx = 0.f;
 #pragma unroll
-                for (int k = 0; k < 6; ++k)
+                for (int k = 0; k < 6; ++k) {
                     *(u64*)(xs + (size_t)(k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                    sx += pair_sum(v[k][0]) + pair_sum(v[k][2]);
+                }
                 float ss = ((__uint_as_float(v[6][0]) + __uint_as_float(v[6][2])) + __uint_as_float(v[7][0])) +
                            __uint_as_float(v[7][2]);
                 ss = group_sum(ss, 64);
-                if (lane == 0) misc[0] = rsqrtf(ss / (float)kC + p.eps);
+                sx = group_sum(sx, 64);
+                if (lane == 0) {
+                    misc[0] = rsqrtf(ss / (float)kC + p.eps);
+                    misc[4] = sx;
+                }
             } else {
                 u32x4 v[10];
                 sweep<10>(p, rs_gx, base, 384, 1024, ep, v, 0x200u + edge);
+                float sx = 0.f;
 #pragma unroll
-                for (int k = 0; k < 10; ++k)
+                for (int k = 0; k < 10; ++k) {
                     *(u64*)(xs + (size_t)(384 + k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                    sx += pair_sum(v[k][0]) + pair_sum(v[k][2]);
+                }
+                sx = group_sum(sx, 64);
+                if (lane == 0) misc[5] = sx;
             }
             xpar ^= 1;
             ++edge;
         };
+        auto deq = [&](float2 t, float2 sc_, float2 z_, float sx) {
+            return float2{sc_.x * (t.x - (128.f + z_.x) * sx), sc_.y * (t.y - (128.f + z_.y) * sx)};
+        };
 
         // ---- the residual rows of this workgroup: embedding of the step's token (model.py:102)
-        float xres = ldbf(p.wte + (size_t)token * kC + bid * 16 + row);
+        int r0 = bid * 16 + 2 * pg;  // first row of this lane's pair among the n_embd residual rows
+        float2 xres = ldpair(p.wte + (size_t)token * kC + r0);
         const bf16_t* norms_l = p.norms;
         const bf16_t* sz_l = p.sz;
         bf16_t* kv_l = p.kv;
-        const float2 cs = *(const float2*)(p.rope + ((size_t)pos * (kHs / 2) + hj * 8 + (lane & 7)) * 2);
-        if (gw == 0) publish_x(xres, ldbf(norms_l + bid * 16 + row));
+        const float2 cs = *(const float2*)(p.rope + ((size_t)pos * (kHs / 2) + hj * 8 + pg) * 2);
+        if (gw == 0) publish_x(xres, ldpair(norms_l + r0));
         for (int l = 0; l < p.n_layer; ++l) {
+            dbg_on = p.dbg != nullptr && l == p.dbg_layer;
+            asm volatile("" : "+v"(lane_v));
+            pg = lane_v >> 3;
+            w8 = lane_v & 7;
+            psrc = ((pg >> 1) << 4) * 4 + ((2 * pg) & 3);
+            r0 = bid * 16 + 2 * pg;
             // ================= c_attn
-            const int nq = (head * 8 + hj) * 16 + row;  // q row of this lane; k at + C, v at + 2 C
-            float sc[3], zr[3];
+            const int nq = (head * 8 + hj) * 16 + 2 * pg;  // q rows of this lane's pair; k at + C, v at + 2 C
+            float2 sc[3], zr[3];
             if (gw == 0) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    sc[r] = ldbf(sz_l + nq + r * kC);
-                    zr[r] = ldbf(sz_l + 3 * kC + nq + r * kC);
+                    sc[r] = ldpair(sz_l + nq + r * kC);
+                    zr[r] = ldpair(sz_l + 3 * kC + nq + r * kC);
                 }
             }
             gather_x();
+            FS_GSTAMP(2);
             __syncthreads();  // B1
             __syncthreads();  // Bt (one virtual tile)
             if (gw == 0) {
                 const float rinv = misc[0];
-                const float sx = tile_sum(3);
-                float y[3];
+                const float sx = misc[4] + misc[5];
+                float2 y[3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) y[r] = sc[r] * (tile_sum(r) - (128.f + zr[r]) * sx) * rinv;
-                if (qd == 0) {
-                    stage[row] = y[0];
-                    stage[16 + row] = y[1];
-                    stage[32 + row] = y[2];
+                for (int r = 0; r < 3; ++r) {
+                    y[r] = deq(tile_pair(r), sc[r], zr[r], sx);
+                    y[r].x *= rinv;
+                    y[r].y *= rinv;
                 }
-                // RoPE (model.py:306-323) of the q / k pairs, publish to the head group, write the cache row
+                // RoPE (model.py:306-323) of the q / k pair, publish to the head group, write the cache row
                 const unsigned ep = ebase + edge;
                 u64* dst = p.gq + ((size_t)qpar * kHeads + head) * 256 + hj * 32;
                 bf16_t* krow = kv_l + ((size_t)head * p.S + pos) * kHs + hj * 16;
                 bf16_t* vrow = krow + (size_t)kHeads * p.S * kHs;
-                if (lane < 8) {
-                    const float a = stage[2 * lane], b = stage[2 * lane + 1];
-                    gr_store(dst + 2 * lane, ep, __float_as_uint(a * cs.x - b * cs.y));
-                    gr_store(dst + 2 * lane + 1, ep, __float_as_uint(b * cs.x + a * cs.y));
-                } else if (lane < 16) {
-                    const int i = lane - 8;
-                    const float a = stage[16 + 2 * i], b = stage[16 + 2 * i + 1];
-                    const unsigned lo = f32_to_bf16(a * cs.x - b * cs.y), hi = f32_to_bf16(b * cs.x + a * cs.y);
-                    gr_store(dst + 16 + i, ep, lo | (hi << 16));
-                    ((unsigned*)krow)[i] = lo | (hi << 16);
-                } else if (lane < 24) {
-                    const int i = lane - 16;
-                    const unsigned lo = f32_to_bf16(stage[32 + 2 * i]), hi = f32_to_bf16(stage[32 + 2 * i + 1]);
-                    gr_store(dst + 24 + i, ep, lo | (hi << 16));
-                    ((unsigned*)vrow)[i] = lo | (hi << 16);
-                }
+                const float qa = y[0].x * cs.x - y[0].y * cs.y, qb = y[0].y * cs.x + y[0].x * cs.y;
+                const unsigned kp = bfpair(y[1].x * cs.x - y[1].y * cs.y, y[1].y * cs.x + y[1].x * cs.y);
+                const unsigned vp = bfpair(y[2].x, y[2].y);
+                if (w8 == 0) gr_store(dst + 2 * pg, ep, __float_as_uint(qa));
+                if (w8 == 1) gr_store(dst + 2 * pg + 1, ep, __float_as_uint(qb));
+                if (w8 == 2) gr_store(dst + 16 + pg, ep, kp);
+                if (w8 == 3) gr_store(dst + 24 + pg, ep, vp);
+                if (w8 == 4) ((unsigned*)krow)[pg] = kp;
+                if (w8 == 5) ((unsigned*)vrow)[pg] = vp;
             }
+            FS_GSTAMP(3);
             buf ^= 1;
             __syncthreads();  // B3
             // ================= attention
@@ -594,116 +639,132 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 }
                 qpar ^= 1;
                 ++edge;
+                FS_GSTAMP(4);
                 __syncthreads();  // Ba1
                 __syncthreads();  // Ba2
                 __syncthreads();  // Ba3
-                if (gw == 0 && lane < 16) {
-                    float o = 0.f;
-#pragma unroll
-                    for (int w = 0; w < kSW; ++w) o += opart[w * 16 + lane];
-                    stage[lane] = o / misc[1];
+                FS_GSTAMP(5);
+                if (gw == 0) {
+                    float2 o = *(const float2*)(opart + w8 * 16 + 2 * pg);
+                    o.x = group_sum(o.x, 8);
+                    o.y = group_sum(o.y, 8);
+                    const float inv = 1.0f / misc[1];
+                    // attention output elements head * 128 + hj * 16 + 2 pg, + 1 -> one pair granule
+                    if (w8 == 0)
+                        gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, bfpair(o.x * inv, o.y * inv));
                 }
-                if (gw == 0 && lane < 8) {
-                    const unsigned lo = f32_to_bf16(stage[2 * lane]), hi = f32_to_bf16(stage[2 * lane + 1]);
-                    // attention output element (head * 128 + hj * 16 + 2 lane) -> pair granule
-                    gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + lane, ebase + edge, lo | (hi << 16));
-                }
+                FS_GSTAMP(6);
                 __syncthreads();  // Ba4
             }
             // ================= attn.c_proj (+ residual)
             {
-                float s1 = 0.f, z1 = 0.f, gn = 0.f;
+                float2 s1 = {0.f, 0.f}, z1 = {0.f, 0.f}, gn = {0.f, 0.f};
                 if (gw == 0) {
-                    s1 = ldbf(sz_l + 6 * kC + bid * 16 + row);
-                    z1 = ldbf(sz_l + 7 * kC + bid * 16 + row);
-                    gn = ldbf(norms_l + kC + bid * 16 + row);  // rms_2
+                    s1 = ldpair(sz_l + 6 * kC + r0);
+                    z1 = ldpair(sz_l + 7 * kC + r0);
+                    gn = ldpair(norms_l + kC + r0);  // rms_2
                 }
                 const unsigned ep = ebase + edge;
                 u32x4 v[8];
                 sweep<8>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, ep, v, 0x400u + edge);
+                float sxp = 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
+                for (int k = 0; k < 8; ++k) {
                     *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                    sxp += pair_sum(v[k][0]) + pair_sum(v[k][2]);
+                }
+                sxp = group_sum(sxp, 64);
+                if (lane == 0) misc[4 + gw] = sxp;
                 apar ^= 1;
                 ++edge;
+                FS_GSTAMP(7);
                 __syncthreads();  // B1
                 __syncthreads();  // Bt
                 if (gw == 0) {
-                    const float sx = tile_sum(3);
-                    xres += s1 * (tile_sum(0) - (128.f + z1) * sx);
+                    const float2 d = deq(tile_pair(0), s1, z1, misc[4] + misc[5]);
+                    xres.x += d.x;
+                    xres.y += d.y;
                     publish_x(xres, gn);
                 }
+                FS_GSTAMP(8);
                 buf ^= 1;
                 __syncthreads();  // B3
             }
             // ================= c_fc1 / c_fc2 + SwiGLU
             {
                 const bf16_t* s_fc = sz_l + 8 * kC;
-                float fs1[kMaxFcTiles], fz1[kMaxFcTiles], fs2[kMaxFcTiles], fz2[kMaxFcTiles];
+                float2 fs1[kMaxFcTiles], fz1[kMaxFcTiles], fs2[kMaxFcTiles], fz2[kMaxFcTiles];
                 if (gw == 0) {
 #pragma unroll
                     for (int t = 0; t < kMaxFcTiles; ++t) {
-                        const int n = (bid + t * kG) * 16 + row;
-                        const bool ok = t < n_fc;
-                        fs1[t] = ok ? ldbf(s_fc + n) : 0.f;
-                        fz1[t] = ok ? ldbf(s_fc + p.H + n) : 0.f;
-                        fs2[t] = ok ? ldbf(s_fc + 2 * p.H + n) : 0.f;
-                        fz2[t] = ok ? ldbf(s_fc + 3 * p.H + n) : 0.f;
+                        const int n = (bid + (t < n_fc ? t : 0) * kG) * 16 + 2 * pg;
+                        fs1[t] = ldpair(s_fc + n);
+                        fz1[t] = ldpair(s_fc + p.H + n);
+                        fs2[t] = ldpair(s_fc + 2 * p.H + n);
+                        fz2[t] = ldpair(s_fc + 3 * p.H + n);
                     }
                 }
                 gather_x();
+                FS_GSTAMP(9);
                 __syncthreads();  // B1
                 const unsigned ep = ebase + edge;
                 u64* dst = p.gh + (size_t)hpar * (p.H / 2);
                 const float rinv = gw == 0 ? misc[0] : 0.f;
+                const float sx = gw == 0 ? misc[4] + misc[5] : 0.f;
 #pragma unroll
                 for (int t = 0; t < kMaxFcTiles; ++t) {
                     __syncthreads();  // Bt
                     if (gw == 0 && t < n_fc) {
-                        const float sx = tile_sum(3);
-                        const float a = fs1[t] * (tile_sum(0) - (128.f + fz1[t]) * sx) * rinv;
-                        const float b = fs2[t] * (tile_sum(1) - (128.f + fz2[t]) * sx) * rinv;
-                        if (qd == 0) stage[(t & 1) * 16 + row] = swiglu_f32(a, b);
-                        if (lane < 8) {
-                            const unsigned lo = f32_to_bf16(stage[(t & 1) * 16 + 2 * lane]),
-                                           hi = f32_to_bf16(stage[(t & 1) * 16 + 2 * lane + 1]);
-                            gr_store(dst + (bid + t * kG) * 8 + lane, ep, lo | (hi << 16));
-                        }
+                        const float2 a = deq(tile_pair(0), fs1[t], fz1[t], sx);
+                        const float2 b = deq(tile_pair(1), fs2[t], fz2[t], sx);
+                        if (w8 == 0)
+                            gr_store(dst + (bid + t * kG) * 8 + pg, ep,
+                                     bfpair(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv)));
                     }
                     buf ^= 1;
                 }
+                FS_GSTAMP(10);
                 __syncthreads();  // B3
             }
             // ================= mlp.c_proj (+ residual) -> next layer's x edge
             {
-                float s1 = 0.f, z1 = 0.f, gn = 0.f;
+                float2 s1 = {0.f, 0.f}, z1 = {0.f, 0.f}, gn = {0.f, 0.f};
                 const bf16_t* s_mp = sz_l + 8 * kC + 4 * p.H;
                 if (gw == 0) {
-                    s1 = ldbf(s_mp + bid * 16 + row);
-                    z1 = ldbf(s_mp + kC + bid * 16 + row);
-                    gn = ldbf(norms_l + 2 * kC + bid * 16 + row);  // rms_1 of the next layer, or ln_f after the last
+                    s1 = ldpair(s_mp + r0);
+                    z1 = ldpair(s_mp + kC + r0);
+                    gn = ldpair(norms_l + 2 * kC + r0);  // rms_1 of the next layer, or ln_f after the last
                 }
                 const unsigned ep = ebase + edge;
                 const int n_loads = p.H / 4, half_l = (n_loads + 1) / 2;
                 const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
+                float sxp = 0.f;
                 for (int c0 = first; c0 < end; c0 += 8 * 64) {
                     u32x4 v[8];
                     sweep<8>(p, rs_gh, (unsigned)hpar * (unsigned)(p.H / 2) * 8u, c0, end, ep, v, 0x500u + edge);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const int i = c0 + k * 64 + lane;
-                        if (i < end) *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                        if (i < end) {
+                            *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                            sxp += pair_sum(v[k][0]) + pair_sum(v[k][2]);
+                        }
                     }
                 }
+                sxp = group_sum(sxp, 64);
+                if (lane == 0) misc[4 + gw] = sxp;
                 hpar ^= 1;
                 ++edge;
+                FS_GSTAMP(11);
                 __syncthreads();  // B1
                 __syncthreads();  // Bt
                 if (gw == 0) {
-                    const float sx = tile_sum(3);
-                    xres += s1 * (tile_sum(0) - (128.f + z1) * sx);
+                    const float2 d = deq(tile_pair(0), s1, z1, misc[4] + misc[5]);
+                    xres.x += d.x;
+                    xres.y += d.y;
                     publish_x(xres, gn);
                 }
+                FS_GSTAMP(12);
                 buf ^= 1;
                 __syncthreads();  // B3
             }
@@ -711,36 +772,43 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             sz_l += p.sz_layer_stride;
             kv_l += (size_t)2 * kHeads * p.S * kHs;
         }
+        dbg_on = false;
         // ================= ln_f + lm_head (+ greedy arg-max, generate.py:68-85 with top_k = 1)
         {
-            // scale / zero of a tile's row are requested one tile ahead
-            auto head_sz = [&](int t, float& sc_, float& z_) {
-                const int n = (bid + t * kG) * 16 + row;
-                const bool ok = t < n_head_t && n < p.V;
-                sc_ = ok ? ldbf(p.sz_head + n) : 0.f;
-                z_ = ok ? ldbf(p.sz_head + p.V + n) : 0.f;
+            // scale / zero of a tile's rows are requested one tile ahead
+            auto head_sz = [&](int t, float2& sc_, float2& z_) {
+                const int n = (bid + t * kG) * 16 + 2 * pg;
+                const bool ok = t < n_head_t && n + 1 < p.V;
+                sc_ = ok ? ldpair(p.sz_head + n) : float2{0.f, 0.f};
+                z_ = ok ? ldpair(p.sz_head + p.V + n) : float2{0.f, 0.f};
             };
-            float sct = 0.f, zt = 0.f;
+            float2 sct = {0.f, 0.f}, zt = {0.f, 0.f};
             if (gw == 0) head_sz(0, sct, zt);
             gather_x();
             __syncthreads();  // B1
             const float rinv = gw == 0 ? misc[0] : 0.f;
+            const float sx = gw == 0 ? misc[4] + misc[5] : 0.f;
             float best = -INFINITY;
             int bi = 0x7fffffff;
             const int tiles_pad = p.head_turns * 3;
             for (int t = 0; t < tiles_pad; ++t) {
-                float scn = 0.f, zn = 0.f;
+                float2 scn = {0.f, 0.f}, zn = {0.f, 0.f};
                 if (gw == 0) head_sz(t + 1, scn, zn);
                 __syncthreads();  // Bt
                 if (gw == 0 && t < n_head_t) {
-                    const int n = (bid + t * kG) * 16 + row;
-                    const float sx = tile_sum(3);
-                    const float y = sct * (tile_sum(0) - (128.f + zt) * sx) * rinv;
-                    if (qd == 0 && n < p.V) {
-                        p.logits[n] = y;
-                        if (y > best || (y == best && n < bi)) {
-                            best = y;
+                    const int n = (bid + t * kG) * 16 + 2 * pg;
+                    float2 y = deq(tile_pair(0), sct, zt, sx);
+                    y.x *= rinv;
+                    y.y *= rinv;
+                    if (n + 1 < p.V) {  // vocab sizes are even (host check): a pair is inside or outside
+                        if (w8 == 0) *(float2*)(p.logits + n) = y;
+                        if (y.x > best || (y.x == best && n < bi)) {
+                            best = y.x;
                             bi = n;
+                        }
+                        if (y.y > best || (y.y == best && n + 1 < bi)) {
+                            best = y.y;
+                            bi = n + 1;
                         }
                     }
                 }
@@ -751,9 +819,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             __syncthreads();  // B3
             if (p.mode & 1) {
                 if (gw == 0) {
-                    // best of this workgroup's rows (lanes 0, 4, .., 60), lowest index on ties
+                    // best of this workgroup's rows (the 8 lanes of a pair agree), lowest index on ties
 #pragma unroll
-                    for (int o = 4; o < 64; o <<= 1) {
+                    for (int o = 8; o < 64; o <<= 1) {
                         const float ov = __shfl_xor(best, o, 64);
                         const int oi = __shfl_xor(bi, o, 64);
                         if (ov > best || (ov == best && oi < bi)) {
@@ -823,7 +891,7 @@ extern "C" int mi355_fused_step_supported(int n_embd, int n_head, int hs, int n_
     if (mi355_num_cus() != kG) return 0;  // one resident workgroup per CU, head groups of 8
     if (n_embd != kC || n_head != kHeads || hs != kHs) return 0;
     if (n_hidden <= 0 || n_hidden % 128 != 0 || n_hidden / 16 > kMaxFcTiles * kG || n_hidden / 128 > 96) return 0;
-    if (vocab <= 0 || (vocab + 15) / 16 > kMaxHeadTiles * kG) return 0;
+    if (vocab <= 0 || vocab % 2 != 0 || (vocab + 15) / 16 > kMaxHeadTiles * kG) return 0;
     if (S < 1 || S > kMaxS) return 0;
     return 1;
 }
@@ -881,6 +949,7 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     p.gm = (u64*)(ws + kWsGm);
     p.gh = (u64*)(ws + kWsGh);
     p.dbg = (u64*)a->debug_stamps;
+    p.dbg_layer = a->reserved0;  // with debug_stamps: the layer whose phases are stamped
     p.sz_layer_stride = (unsigned)(10 * kC + 4 * a->n_hidden);
     p.n_layer = a->n_layer;
     p.H = a->n_hidden;

@@ -1,0 +1,66 @@
+"""Phase timeline of one layer inside the fused decode step (in-kernel wall-clock stamps, 100 MHz).
+    python scripts/fused_timeline.py [--layer 10] [--prompt 128]
+"""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from lit_llama_amd import synth  # noqa: E402
+from lit_llama_amd.model import LLaMA, LLaMAConfig  # noqa: E402
+from lit_llama_amd.utils import EmptyInitOnDevice  # noqa: E402
+
+NAMES = {2: "G  x gathered (c_attn)", 3: "G  q/k/v published", 4: "G  head q gathered", 5: "G  attn partials ready",
+         6: "G  attn out published", 7: "G  attn out gathered", 8: "G  c_proj published", 9: "G  x gathered (fc)",
+         10: "G  hidden published", 11: "G  hidden gathered", 12: "G  mlp.c_proj published",
+         20: "S  c_attn B1", 21: "S  c_attn consumed", 23: "S  attn q staged", 24: "S  attn scores done",
+         25: "S  attn out done", 26: "S  c_proj B1", 27: "S  c_proj consumed", 28: "S  fc B1", 29: "S  fc consumed",
+         30: "S  mproj B1", 31: "S  mproj consumed"}
+ORDER = [2, 20, 21, 3, 4, 23, 24, 25, 5, 6, 7, 26, 27, 8, 9, 28, 29, 10, 11, 30, 31, 12]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layer", type=int, default=10)
+    ap.add_argument("--prompt", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=32)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    cfg = LLaMAConfig(n_layer=a.layers, n_head=32, n_embd=4096)
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
+        model = LLaMA(cfg)
+    synth.fill_model_random_int4(model, seed=0)
+    eng = model.engine()
+    assert eng is not None and eng.fused is not None, model._engine_failed
+    prompt = synth.make_prompt(a.prompt).to(dev)
+    stamps = torch.zeros((256, 64), dtype=torch.int64, device=dev)
+    with torch.cuda.stream(eng.stream):
+        eng._ensure_cache(a.prompt + 64)
+        eng.prefill(prompt, 0, all_logits=False, argmax=True)
+        eng.set_step(None, 1, a.prompt, from_next=True)
+        eng.embed_step()
+        for _ in range(8):
+            eng.run_step(3)
+        eng.fused.debug_stamps = stamps.data_ptr()
+        eng.fused.reserved0 = a.layer
+        eng.run_step(3)
+        eng.fused.debug_stamps = None
+        eng.fused.reserved0 = 0
+    eng.stream.synchronize()
+    eng.check_status()
+    st = stamps.cpu().numpy().astype(np.float64) / 100.0  # us
+    t0 = st[:, 2].min()
+    print(f"layer {a.layer}, position {a.prompt + 8}; whole step {st[:, 1].max() - st[:, 0].min():.1f} us; "
+          f"times in us after the first workgroup has gathered the layer's input")
+    prev = 0.0
+    for i in ORDER:
+        col = st[:, i] - t0
+        print(f"  {NAMES[i]:28s} min {col.min():7.2f}  med {np.median(col):7.2f}  max {col.max():7.2f}   (+{np.median(col) - prev:5.2f})")
+        prev = np.median(col)
+
+
+if __name__ == "__main__":
+    main()
