@@ -41,6 +41,10 @@ constexpr int kSW = 8;          // streamer waves
 constexpr int kGW = 2;          // gatherer waves
 constexpr int kThreads = 64 * (kSW + kGW);
 constexpr int kRing = 12;       // ring pieces (1 KiB each) per streamer wave
+#ifndef MI355_FUSED_WINDOW
+#define MI355_FUSED_WINDOW 4
+#endif
+constexpr int kWin = MI355_FUSED_WINDOW;  // pieces per wave in flight while a first ring turn is requested
 constexpr int kC = 4096;        // n_embd
 constexpr int kHeads = 32;
 constexpr int kHs = 128;
@@ -159,6 +163,12 @@ __device__ __forceinline__ unsigned piece_off(const PhaseW& ph, int gstep, int r
     }
     return ph.base + (unsigned)((tile * ph.units + ph.u0 + st) * (PAIR ? 2 : 1) + (PAIR ? r : 0)) * 1024u;
 }
+// (x & 0x000F000F) | 0x43004300 = the bf16 pair (128 + nibble 0, 128 + nibble 4) of x, as ONE VALU op: with literal
+// constants hipcc emits v_and + v_or (a gfx9 VOP3 cannot carry two literals), i.e. 11 instead of 7 ops per 8 weights —
+// and the conversion is what bounds a compute phase of the fused step.  With the mask in an SGPR and the exponent
+// pattern in a VGPR whose values the compiler cannot see, it selects v_and_or_b32 itself (and pads the VALU -> MFMA
+// hazard, which an inline-asm v_and_or_b32 does not get: that variant produced NaNs).
+__device__ __forceinline__ uint32_t nib2bf16(uint32_t x, uint32_t mask_s, uint32_t magic_v) { return (x & mask_s) | magic_v; }
 __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rs_null, bool ok,
                                            unsigned lane_off, unsigned soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rs : rs_null, lane_off, ok ? soff : 0u, 2));
@@ -212,6 +222,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
         // =========================================================================================== streamers
         unsigned lane_off = lane * 16;
         const int g = lane >> 4;
+        uint32_t magic = 0x43004300u;
+        uint32_t nmask = 0x000F000Fu;
+        asm volatile("" : "+v"(magic));  // opaque register values (see nib2bf16)
+        asm volatile("" : "+s"(nmask));
         u32x4 ring[kRing];
         int buf = 0;
 
@@ -238,11 +252,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             const unsigned so__ = piece_off<SPT_, PAIR_, QKV_>(PH_, pc__ / (R_), pc__ % (R_), ok__);          \
             ring[pc__] = ring_load(RS_, rs_null, ok__, lane_off, so__);                                      \
             __builtin_amdgcn_sched_barrier(0); /* issue order = consumption order (VMEM returns in order) */ \
-            /* at most 4 pieces per wave (32 KiB per CU, what a CU keeps in flight anyway) are queued at a  */ \
-            /* time: a deeper queue only stands in front of the gatherers' sweep in the CU's in-order       */ \
-            /* memory pipeline (the hand-offs into fc / mlp.c_proj took 5.5 / 5.0 us instead of ~3)         */ \
-            if (pc__ % 4 == 3 && pc__ + 1 < kRing) {                                                         \
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+            /* sliding window: at most kWin pieces per wave (8 kWin KiB per CU) are in flight; a deeper     */ \
+            /* queue only stands in front of the gatherers' sweep in the CU's in-order memory pipeline (the */ \
+            /* hand-offs into fc / mlp.c_proj took 5.5 / 5.0 us instead of ~3), and whole chunks separated  */ \
+            /* by vmcnt(0) serialise the memory latency (3 x 2 us for 96 KiB)                               */ \
+            if (pc__ + 1 >= kWin && pc__ + 1 < kRing) {                                                      \
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWin - 1) : "memory");                               \
                 __builtin_amdgcn_sched_barrier(0);                                                           \
             }                                                                                                \
         }                                                                                                    \
@@ -253,31 +268,42 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
     do {                                                                                                             \
         constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
         const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
-        f32x4 acc__[R__];                                                                                             \
-        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__] = f32x4{0.f, 0.f, 0.f, 0.f};                 \
+        /* two accumulators per row group (even / odd k-quarter): halves the dependent MFMA chain */                  \
+        f32x4 acc__[R__][2];                                                                                          \
+        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f}; \
         __syncthreads(); /* B1: the activation vector is staged */                                                   \
         FS_SSTAMP(STAMP_);                                                                                            \
+        /* B operands (activation unit of a step) are read one step ahead: a step otherwise starts with an LDS */     \
+        /* round trip (~150 cycles x 12 steps on the hand-off chain)                                           */     \
+        bf16x8 bn__[4];                                                                                               \
+        {                                                                                                             \
+            const char* xb0__ = xs + ((PH_).u0) * 256 + g * 64;                                                       \
+            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const bf16x8*)(xb0__ + 16 * d__);       \
+        }                                                                                                             \
         for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
             _Pragma("unroll") for (int t__ = 0; t__ < (TURNS_); ++t__) {                                              \
                 _Pragma("unroll") for (int s__ = 0; s__ < STEPS__; ++s__) {                                           \
                     const int gstep__ = (body__ * (TURNS_) + t__) * STEPS__ + s__;                                    \
                     const int ti__ = gstep__ / SPT__, st__ = gstep__ - ti__ * SPT__;                                  \
+                    bf16x8 b__[4];                                                                                    \
+                    _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) b__[d__] = bn__[d__];                         \
+                    {                                                                                                 \
+                        const int nst__ = (st__ + 1 == SPT__) ? 0 : st__ + 1;                                         \
+                        const char* xbn__ = xs + ((PH_).u0 + (nst__ < (PH_).nu ? nst__ : 0)) * 256 + g * 64;          \
+                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const bf16x8*)(xbn__ + 16 * d__); \
+                    }                                                                                                 \
                     /* idle steps (padding of the ring turn) carry no data: skip their MFMAs (wave-uniform) */        \
                     if (st__ < (PH_).nu && ((QKV_) || ti__ < (PH_).ntiles)) {                                         \
-                        const char* xb__ = xs + ((PH_).u0 + st__) * 256 + g * 64;                                     \
-                        bf16x8 b__[4];                                                                                \
-                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) b__[d__] = *(const bf16x8*)(xb__ + 16 * d__); \
-                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
-                            const u32x4 q__ = ring[s__ * R__ + r__];                                                  \
-                            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                     \
-                                const uint32_t v__ = q__[d__];                                                        \
+                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                         \
+                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                   \
+                                const uint32_t v__ = ring[s__ * R__ + r__][d__];                                      \
                                 u32x4 a__;                                                                            \
-                                a__[0] = (v__ & 0x000F000Fu) | 0x43004300u;                                           \
-                                a__[1] = ((v__ >> 4) & 0x000F000Fu) | 0x43004300u;                                    \
-                                a__[2] = ((v__ >> 8) & 0x000F000Fu) | 0x43004300u;                                    \
-                                a__[3] = ((v__ >> 12) & 0x000F000Fu) | 0x43004300u;                                   \
-                                acc__[r__] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a__), \
-                                                                                    b__[d__], acc__[r__], 0, 0, 0);   \
+                                a__[0] = nib2bf16(v__, nmask, magic);                                                        \
+                                a__[1] = nib2bf16(v__ >> 4, nmask, magic);                                                   \
+                                a__[2] = nib2bf16(v__ >> 8, nmask, magic);                                                   \
+                                a__[3] = nib2bf16(v__ >> 12, nmask, magic);                                                  \
+                                acc__[r__][d__ & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                        \
+                                    __builtin_bit_cast(bf16x8, a__), b__[d__], acc__[r__][d__ & 1], 0, 0, 0);         \
                             }                                                                                         \
                         }                                                                                             \
                     }                                                                                                 \
@@ -293,8 +319,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                         if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
                         f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * 1024) + lane;                \
                         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
-                            pp__[r__ * 64] = acc__[r__];                                                              \
-                            acc__[r__] = f32x4{0.f, 0.f, 0.f, 0.f};                                                   \
+                            pp__[r__ * 64] = acc__[r__][0] + acc__[r__][1];                                           \
+                            acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                                \
                         }                                                                                             \
                         __syncthreads(); /* Bt */                                                                     \
                         buf ^= 1;                                                                                     \
