@@ -4,21 +4,27 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one decoded token: one pass of the whole forward (32 layers x 5 launches + lm_head + on-device
-argmax, replayed from a hipGraph) over synthetic random-init weights of the 7B architecture, with the
+A "step" is one decoded token: one pass of the whole forward + on-device greedy argmax over synthetic random-init
+weights of the 7B architecture — ONE persistent launch per token for 7B gptq.int4 (csrc/fused_step.hip; the
+fallback and the other configs: 32 layers x 5 launches + lm_head + argmax replayed from a hipGraph) — with the
 prompt already prefilled and everything resident in HBM when the timed region starts.  W untimed steps, then
 EXACTLY K timed steps between (barrier +) torch.cuda.synchronize() on both sides; MAX over ranks; rank 0 prints
 ONE JSON line.  With N > 1 every GPU decodes its own independent stream (the bs=1 7B path does not shard —
 SURVEY.md §8e: "replicas only"), so scaling is "weak" and `value` is the sum over ranks.
 
 Extra objects on the same line:
-  roofline     — the dominant kernel (c_fc1/c_fc2 + SwiGLU int4 weight-streaming launch): algorithmic bytes per
+  roofline     — the dominant kernel: with the fused step that is `fused_step_kernel`, one launch = one token
+                 (algorithmic bytes = every weight byte once + scales / zeros + norm scales + the KV rows read at
+                 that position); otherwise the c_fc1/c_fc2 + SwiGLU weight-streaming launch.  Algorithmic bytes per
                  launch / average launch duration — the dispatch's own begin / end timestamps, delivered into HIP
                  events by hipExtLaunchKernel on the launch stream (mi355_debug_time_next_launch; the clock
-                 rocprofv3 reads) — over all 32 layers' weights (1.4 GB, larger than the 256 MiB Infinity Cache), vs
-                 the 8.0 TB/s HBM peak;
-  cpu_baseline — oracle/oracle.py (a port of the reference's CPU path, which dequantises every weight on every
-                 call) timed on the host cores over a bounded sample, extrapolated to 32 layers.
+                 rocprofv3 reads) — vs the 8.0 TB/s HBM peak.  `traffic` is NOT measured in this run: it is the
+                 FETCH_SIZE x 2 of the committed rocprofv3 --pmc pass over the same command (`traffic_source`);
+  cpu_baseline — the reference's CPU path timed on the host cores over a bounded sample, extrapolated to 32 layers:
+                 the real /root/reference code when that tree exists (kind "reference"; it does not on the GPU box),
+                 else oracle/oracle.py, its line-by-line restatement (kind "port").  Both dequantise every weight on
+                 every call, as the reference does off the Triton branch;
+  generate     — tokens/s of lit_llama_amd.generate INCLUDING the prompt (what generate.py:146-153 prints).
 """
 from __future__ import annotations
 
@@ -100,6 +106,25 @@ def build_model(args, dev):
     return model, cfg
 
 
+def measure_fused_step(eng, n: int = 48):
+    """Average duration of the fused_step_kernel launch (one token), dispatch timestamps via hipExtLaunchKernel; the
+    steps are chained greedy steps continuing the timed loop (state on the device)."""
+    from lit_llama_amd._native import check, lib
+
+    evs = []
+    with torch.cuda.stream(eng.stream):
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()  # creates the underlying hipEvent_t objects (lazily allocated by torch)
+            e1.record()
+            check(lib().mi355_debug_time_next_launch(C.c_void_p(e0.cuda_event), C.c_void_p(e1.cuda_event)), "hook")
+            eng.run_step(3)
+            evs.append((e0, e1))
+    eng.stream.synchronize()
+    times = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs[8:])
+    return sum(times) / len(times), times[len(times) // 2]
+
+
 def measure_dominant_kernel(eng, reps: int = 3):
     """Average duration of the c_fc1/c_fc2 + SwiGLU launch (segment 2 of every layer), events on eng.stream."""
     from lit_llama_amd._native import check, lib
@@ -129,9 +154,55 @@ def measure_dominant_kernel(eng, reps: int = 3):
     return sum(times) / len(times), times[len(times) // 2]
 
 
+def cpu_baseline_reference(cfg, mode: str):
+    """The REAL reference (imported from /root/reference through oracle/_stubs) on the same bounded sample as the
+    port: ONE 7B-width Block + ln_f + lm_head, 10 decode steps after a 1-token prompt, extrapolated to n_layer."""
+    sys.path[:0] = [str(ROOT / "oracle" / "_stubs"), "/root/reference"]
+    import lit_llama as ref
+    from lit_llama.utils import quantization as ref_quantization
+
+    from lit_llama_amd import synth
+    from lit_llama_amd.model import LLaMAConfig
+
+    qmode = mode if mode != "none" else None
+    small = LLaMAConfig(n_layer=1, n_head=cfg.n_head, n_embd=cfg.n_embd)
+    with ref_quantization(qmode):
+        model = ref.LLaMA(ref.LLaMAConfig(n_layer=1, n_head=cfg.n_head, n_embd=cfg.n_embd))
+    model.load_state_dict(synth.make_state_dict(small, seed=0, mode=qmode))
+    model.eval()
+    steps = 10
+    with torch.no_grad():
+        model(torch.tensor([[1]]), 16, torch.tensor([0]))
+        blk = model.transformer.h[0]
+        t_layer = t_head = 0.0
+        for i in range(steps):
+            x = torch.randn(1, 1, cfg.n_embd)
+            pos = torch.tensor([1 + i])
+            rope = model.rope_cache.index_select(0, pos)
+            mask = model.mask_cache.index_select(2, pos)[:, :, :, :16]
+            t0 = time.perf_counter()
+            x, model.kv_caches[0] = blk(x, rope, mask, 16, pos, model.kv_caches[0])
+            t1 = time.perf_counter()
+            model.lm_head(model.transformer.ln_f(x))
+            t2 = time.perf_counter()
+            t_layer += (t1 - t0) / steps
+            t_head += (t2 - t1) / steps
+    per_token = cfg.n_layer * t_layer + t_head
+    return dict(value=1.0 / per_token, unit="tokens/s", cores=torch.get_num_threads(), kind="reference",
+                sample=f"/root/reference lit_llama (unmodified), 1 of {cfg.n_layer} layers at {args_model_name(cfg)} width "
+                       f"+ lm_head, {steps} decode steps ({steps * (t_layer + t_head):.1f} s measured), extrapolated: "
+                       f"{cfg.n_layer} x {t_layer:.2f} s + {t_head:.2f} s per token")
+
+
 def cpu_baseline(cfg, mode: str):
-    """The oracle (port of the reference CPU path) on a bounded sample: ONE 7B-width layer + lm_head, 10 decode
-    steps after a 1-token prompt (~10 s); per-token time extrapolated to n_layer layers."""
+    """The reference's CPU path on a bounded sample: ONE 7B-width layer + lm_head, 10 decode steps after a 1-token
+    prompt (~10 s); per-token time extrapolated to n_layer layers.  The real reference when its tree is present,
+    else the oracle (its restatement)."""
+    if Path("/root/reference/lit_llama/model.py").exists():
+        try:
+            return cpu_baseline_reference(cfg, mode)
+        except Exception:  # fall through to the port
+            pass
     from lit_llama_amd import synth
     from lit_llama_amd.model import LLaMAConfig
     from oracle import oracle
@@ -228,8 +299,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    eng.check_status()  # a timed-out hand-off of the fused step must never be reported as a rate
     tokens = eng.out_tokens[: pos + 1].tolist()
     assert all(0 <= t_ < cfg.padded_vocab_size for t_ in tokens), "decode produced invalid ids"
+    fused = eng.fused_ready()
 
     if rank != 0:
         if dist is not None:
@@ -244,14 +317,36 @@ def main():
     wb = {"gptq.int4": C_ * H, "llm.int8": 2 * C_ * H, "none": 4 * C_ * H}[args.quantize]
     side = {"gptq.int4": 2 * 2 * H * 2, "llm.int8": 2 * H * 4, "none": 0}[args.quantize]
     algo = wb + side + C_ * 4 + C_ * 2 + H * 2
-    avg_s, med_s = measure_dominant_kernel(eng)
-    traffic = None
+    traffic, traffic_source = None, None
     pmc = ROOT / "profiles" / "pmc_traffic.json"
+    if fused:
+        # one launch = one token: every weight byte once + side operands + the KV rows read at the step's position
+        pos_mid = pos + 24  # the 48 measured launches continue the chained loop
+        algo = bpt["total"] + int(bpt["kv_per_pos"] * (pos_mid + 1))
+        avg_s, med_s = measure_fused_step(eng)
+        eng.check_status()
+        key = "fused_step_bytes_per_launch"
+    else:
+        avg_s, med_s = measure_dominant_kernel(eng)
+        key = "fc_swiglu_bytes_per_launch"
     if pmc.exists():
         try:
-            traffic = json.loads(pmc.read_text()).get("fc_swiglu_bytes_per_launch")
+            traffic = json.loads(pmc.read_text()).get(key)
+            traffic_source = ("profiles/pmc_traffic.json: committed rocprofv3 --pmc FETCH_SIZE pass over this command "
+                              "(x2 gfx950 wide-read correction); static, not measured in this run") if traffic else None
         except Exception:
             traffic = None
+    # tokens/s of generate() including the prompt (generate.py:146-153 prints this figure)
+    gen_new = 64
+    import lit_llama_amd
+
+    model.reset_cache()
+    lit_llama_amd.generate(model, prompt, 4, top_k=1, max_seq_length=T + gen_new)  # warm (cache geometry, graphs)
+    torch.cuda.synchronize(dev)
+    t_g0 = time.perf_counter()
+    lit_llama_amd.generate(model, prompt, gen_new, top_k=1, max_seq_length=T + gen_new)
+    torch.cuda.synchronize(dev)
+    t_gen = time.perf_counter() - t_g0
     default_cfg = args.model == "7B" and args.quantize == "gptq.int4"
     cfg_idx = {"none": 1, "gptq.int4": 2, "llm.int8": 3}[args.quantize] if args.model == "7B" else None
     wname = {"gptq.int4": "int4", "llm.int8": "int8", "none": "bf16"}[args.quantize]
@@ -276,18 +371,21 @@ def main():
             "prompt_len": T,
             "max_seq_length": S,
             "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (bs=1 path does not shard)",
-            "hipgraph": bool(eng.use_graph and eng._graphs),
-            "launches_per_token": cfg.n_layer * 5 + 2,
+            "hipgraph": bool(eng.use_graph and eng._graphs) and not fused,
+            "fused_step": fused,
+            "launches_per_token": 1 if fused else cfg.n_layer * 5 + 2,
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": {"gptq.int4": "gemv_kernel<Q4,R=2,SwiGLU>", "none": "gemv_kernel<BF16,R=2,SwiGLU>",
+            "kernel": "fused_step_kernel (the whole decode step, one launch per token)" if fused else
+                      {"gptq.int4": "gemv_kernel<Q4,R=2,SwiGLU>", "none": "gemv_kernel<BF16,R=2,SwiGLU>",
                        "llm.int8": "int8_gemv_kernel<R=2>"}[args.quantize] + " (c_fc1/c_fc2 pair)",
             "achieved": round(algo / avg_s / 1e9, 1),
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
             "frac": round(algo / avg_s / HBM_PEAK, 4),
             "traffic": traffic if default_cfg else None,
+            "traffic_source": traffic_source if default_cfg else None,
             "algorithmic_bytes_per_launch": algo,
             "avg_launch_us": round(avg_s * 1e6, 2),
             "median_launch_us": round(med_s * 1e6, 2),
@@ -299,6 +397,8 @@ def main():
             f"frac_of_{wname}_weight_roofline": round(tok_s_gpu * bpt["weights"] / HBM_PEAK, 4),
         },
         "prefill_s": round(t_prefill, 4),
+        "generate": {"tokens_per_s_incl_prompt": round(gen_new / t_gen, 1), "prompt_len": T, "new_tokens": gen_new,
+                     "what": "lit_llama_amd.generate(top_k=1) wall time incl. prefill, as generate.py:146-153 reports"},
     }
     if world == 1 and not args.no_cpu_baseline:
         try:

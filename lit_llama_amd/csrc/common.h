@@ -45,6 +45,10 @@ void mi355_set_error(const char* fmt, ...);
         }                                                                                  \
     } while (0)
 
+// Events armed by mi355_debug_time_next_launch: the next launch of a timed kernel (gemv_kernel, fused_step_kernel)
+// hands them to hipExtLaunchKernel, so they receive the dispatch's own begin / end timestamps (gemv.hip).
+extern thread_local hipEvent_t t_time_start, t_time_stop;
+
 // ---------------------------------------------------------------- scalar conversions (device)
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 

@@ -30,6 +30,8 @@
 
 #include <mutex>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace {
@@ -991,7 +993,14 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     p.mode = a->mode;
     p.eps = a->eps;
     p.scale = 1.0f / sqrtf((float)kHs);
-    hipLaunchKernelGGL(fused_step_kernel, dim3(kG), dim3(kThreads), kLdsBytes, (hipStream_t)stream, p);
+    if (t_time_start != nullptr) {  // measurement hook: see gemv.hip launch_gemv_m
+        hipEvent_t e0 = t_time_start, e1 = t_time_stop;
+        t_time_start = t_time_stop = nullptr;
+        hipExtLaunchKernelGGL(fused_step_kernel, dim3(kG), dim3(kThreads), (uint32_t)kLdsBytes, (hipStream_t)stream, e0, e1, 0,
+                              p);
+    } else {
+        hipLaunchKernelGGL(fused_step_kernel, dim3(kG), dim3(kThreads), kLdsBytes, (hipStream_t)stream, p);
+    }
     MI355_LAUNCH_CHECK();
     return 0;
 }

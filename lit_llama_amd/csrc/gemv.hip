@@ -718,7 +718,6 @@ __global__ void i8_repack_kernel(const int8_t* c0, const int8_t* c1, int N, int 
     }
 }
 
-thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
 
 template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
 int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
@@ -809,6 +808,9 @@ int dispatch_p(const GemvParams& p, int /*prefetch*/, int grid, int waves, size_
 int g_num_cus = 0;
 
 }  // namespace
+
+// measurement hook shared by the launchers of this library (mi355_debug_time_next_launch; declared in common.h)
+thread_local hipEvent_t t_time_start = nullptr, t_time_stop = nullptr;
 
 extern "C" int mi355_num_cus(void) {
     if (g_num_cus == 0) {

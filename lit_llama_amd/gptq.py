@@ -150,7 +150,10 @@ def llama_blockwise_quantization(model, sample_inputs: torch.Tensor, working_dev
     sample_inputs = sample_inputs.to(wd)
     inps = model.transformer.wte(sample_inputs)
     T = sample_inputs.shape[1]
-    rope = build_rope_cache(T, cfg.n_embd // cfg.n_head, inps.dtype, wd)
+    # quantize/gptq.py:62 calls model.build_rope_cache(sample_inputs): the table is built from the INTEGER dtype of
+    # the token ids, i.e. exactly in f32 (a bf16 arange rounds positions above 256 and theta to 8 mantissa bits:
+    # wrong rotation angles in every calibration attention)
+    rope = build_rope_cache(cfg.block_size, cfg.n_embd // cfg.n_head, sample_inputs.dtype, wd)[:T]
     mask = torch.tril(torch.ones((T, T), dtype=torch.bool, device=wd)).view(1, 1, T, T)
     outs = torch.zeros_like(inps)
 

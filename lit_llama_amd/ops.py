@@ -162,6 +162,11 @@ def linear_int8(
     prefetch: int = 0,
     attn_partials: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
+    """LLM.int8 linear (mi355_linear_int8).  Known deviation from bitsandbytes for M > the LDS chunk (<= 16 rows):
+    the rows are fed in chunks and the outlier COLUMN set (|x| >= threshold anywhere in the column) is determined
+    per chunk, whereas MatMul8bitLt determines it over all B * T rows — a column that is an outlier in one chunk only
+    takes the int8 path in the others.  Decode (M = 1) and prompts of up to one chunk are unaffected; prefill logits
+    of longer prompts depend on the chunking at the int8 granularity (1/127 of a row's absmax)."""
     require_gpu(x2d, "linear_int8")
     assert x2d.dim() == 2 and x2d.shape[1] == K and x2d.stride(1) == 1
     assert scb.dtype == torch.float32

@@ -210,6 +210,12 @@ class TPDecoder:
 
         T = prompt.numel()
         S = max_seq_length or min(T + max_new_tokens, self.cfg.block_size)
+        if S < T + max_new_tokens:
+            # the single-GPU path rolls the cache (model.py:214-218, mi355_kv_roll); the shard engines do not yet, and
+            # the attention kernel would clamp every later position onto the last slot: refuse instead of decoding
+            # against stale rows
+            raise ValueError(f"tensor-parallel decode needs max_seq_length >= prompt + new tokens "
+                             f"({S} < {T} + {max_new_tokens}); the cache-roll regime is single-GPU only")
         dev = prompt.device
         out = torch.empty(T + max_new_tokens, dtype=prompt.dtype, device=dev)
         out[:T] = prompt

@@ -62,7 +62,7 @@ def summarize(logits: torch.Tensor, vocab: int):
     )
 
 
-def model_case(name, cfg_kwargs, mode, prompt_len, new_tokens, max_seq_length=None, seed=0):
+def model_case(name, cfg_kwargs, mode, prompt_len, new_tokens, max_seq_length=None, seed=0, nocache=True):
     torch.manual_seed(1234)
     ref_cfg = ref.LLaMAConfig(**cfg_kwargs)
     our_cfg = OurConfig(**cfg_kwargs)
@@ -81,12 +81,13 @@ def model_case(name, cfg_kwargs, mode, prompt_len, new_tokens, max_seq_length=No
     if not rolled:
         logits = ref_teacher_forced(model, toks, prompt_len, S)
         fix.update(summarize(logits, ref_cfg.padded_vocab_size))
-        # no-cache full forward over the finished sequence (evaluate/full.py:120-129 shape of call)
-        with torch.no_grad():
-            full = model(toks[:-1].view(1, -1).long())[0].float()
-        fix["nocache_argmax"] = full.argmax(-1).numpy().astype(np.int32)
-        fix["nocache_probes"] = full[:, torch.from_numpy(probe_index(ref_cfg.padded_vocab_size))].numpy().astype(np.float32)
-        model.reset_cache()
+        if nocache:
+            # no-cache full forward over the finished sequence (evaluate/full.py:120-129 shape of call)
+            with torch.no_grad():
+                full = model(toks[:-1].view(1, -1).long())[0].float()
+            fix["nocache_argmax"] = full.argmax(-1).numpy().astype(np.int32)
+            fix["nocache_probes"] = full[:, torch.from_numpy(probe_index(ref_cfg.padded_vocab_size))].numpy().astype(np.float32)
+            model.reset_cache()
 
     # ---- pin the restatement on the very same run
     om = oracle.Model(oracle.Config(**cfg_kwargs), {k: v.clone() for k, v in sd.items()}, mode=mode)
@@ -182,8 +183,21 @@ def block_cases():
     np.savez_compressed(OUT / "blocks.npz", **fix)
 
 
+def big_case():
+    """BASELINE.json configs[2] at FULL depth: LLaMA-7B (32 layers) gptq.int4 with seeded synthetic weights, prompt of 8,
+    three greedy tokens, teacher-forced logits (probes / argmax / margins).  ~10 forwards of the real reference on the
+    CPU (every call dequantises 3.3 GB of int4 weights); run with `--big`."""
+    torch.set_num_threads(max(8, (torch.get_num_threads() or 8)))
+    model_case("cfg2_7b_int4", dict(n_layer=32, n_head=32, n_embd=4096), "gptq.int4", prompt_len=8, new_tokens=3,
+               nocache=False)
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--big" in sys.argv:
+        print("generating the full-depth 7B fixture from", REF)
+        big_case()
+        return
     torch.set_num_threads(8)
     print("generating golden fixtures from", REF)
     colblock_cases()

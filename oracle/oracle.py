@@ -290,12 +290,13 @@ def generate(model: Model, idx: torch.Tensor, max_new_tokens: int, *, max_seq_le
     T = idx.size(0)
     T_new = T + max_new_tokens
     if max_seq_length is None:
-        max_seq_length = min(T_new, model.cfg.block_size)
-    dtype = idx.dtype
-    empty = torch.empty(T_new, dtype=dtype)
+        cfg = model.config if hasattr(model, "config") else model.cfg  # generate.py:42 reads model.config
+        max_seq_length = min(T_new, cfg.block_size)
+    device, dtype = idx.device, idx.dtype  # generate.py:44: the loop runs on the prompt's device
+    empty = torch.empty(T_new, dtype=dtype, device=device)
     empty[:T] = idx
     idx = empty
-    input_pos = torch.arange(0, T)
+    input_pos = torch.arange(0, T, device=device)
     for _ in range(max_new_tokens):
         x = idx.index_select(0, input_pos).view(1, -1)
         logits = model(x, max_seq_length, input_pos)

@@ -46,10 +46,14 @@ def main():
     cands = [(k, v) for k, v in res.items() if k.startswith("gemv_kernel<") and targs(k)[:2] == ["0", "2"] and targs(k)[3] == "2"]
     cands.sort(key=lambda kv: (targs(kv[0])[5:6] != ["false"], -kv[1]["launches"]))
     fc = cands[0][1] if cands else None
-    if out_json and fc:
-        json.dump({"fc_swiglu_bytes_per_launch": round(fc["corrected_bytes_per_launch"]),
-                   "note": "rocprofv3 --pmc FETCH_SIZE, KiB x 1024 x 2 (gfx950 wide-read correction)",
-                   "kernels": res}, open(out_json, "w"), indent=1)
+    fused = next((v for k, v in res.items() if k.startswith("fused_step_kernel")), None)
+    if out_json and (fc or fused):
+        out = {"note": "rocprofv3 --pmc FETCH_SIZE, KiB x 1024 x 2 (gfx950 wide-read correction)", "kernels": res}
+        if fc:
+            out["fc_swiglu_bytes_per_launch"] = round(fc["corrected_bytes_per_launch"])
+        if fused:  # one launch = one decode step
+            out["fused_step_bytes_per_launch"] = round(fused["corrected_bytes_per_launch"])
+        json.dump(out, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -43,6 +43,14 @@ def main():
         print(f"{k:80s} {c:7d} {t / 1e6:9.3f} {t / c / 1e3:8.2f} {100 * t / total:5.1f}%")
     # steady-state decode: chained greedy steps, each ending with argmax_advance_kernel.  Averages over the last
     # (up to) 32 complete steps, M = 1 launches only (the per-kernel table above also contains the prompt chunks).
+    fused = [r for r in rows if "fused_step_kernel" in r[0]]
+    if len(fused) >= 8:
+        tail = fused[-64:]
+        dur = sum(e - s_ for _, s_, e in tail) / len(tail)
+        gaps = [tail[i + 1][1] - tail[i][2] for i in range(len(tail) - 1)]
+        print(f"\nsteady-state decode on the fused step: 1 launch per token; mean of the last {len(tail)} launches "
+              f"{dur / 1e3:.1f} us, mean gap between consecutive launches {sum(gaps) / len(gaps) / 1e3:.2f} us "
+              f"-> {1e9 / (dur + sum(gaps) / len(gaps)):.1f} tokens/s")
     ends = [i for i, r in enumerate(rows) if "argmax_advance_kernel" in r[0]]
     if len(ends) >= 3:
         ends = ends[-33:]

@@ -80,6 +80,29 @@ def test_cfg1_f32_tokens_equal_reference(dev, golden, name, mode):
     assert np.abs(full[:, PROBES].numpy() - g["nocache_probes"]).max() <= 2e-4 * float(g["std"].mean())
 
 
+@pytest.mark.parametrize("name,mode,dtype", [("cfg1_fp32", None, torch.float32), ("cfg1_int4", "gptq.int4", torch.bfloat16)])
+def test_reference_generate_loop_runs_over_the_gpu_model(dev, golden, name, mode, dtype):
+    """Drop-in under generate.py: the REFERENCE's sampling loop (restated line by line in oracle.generate, pinned to
+    /root/reference generate.py:20-91 by oracle/gen_golden.py) drives `lit_llama_amd.LLaMA` through nothing but the
+    module API the reference uses: model(x, max_seq_length, input_pos), model.config, model.reset_cache().  The f32
+    model must reproduce the reference's tokens; the bf16 engine-backed model must reproduce them up to the first
+    near tie and must agree with this repository's own generate()."""
+    g = golden(name)
+    model, _, cfg = build(CFG1, mode, dtype, dev)
+    T = int(g["prompt_len"])
+    toks = _t(g["tokens"])
+    out = oracle.generate(model, toks[:T].to(dev), toks.numel() - T, top_k=1).cpu()
+    if dtype == torch.float32:
+        assert torch.equal(out, toks), "reference loop over the GPU model: tokens differ from the reference CPU run"
+    else:
+        tol = 2 * 0.05 * float(g["std"].mean())
+        first_tie = next((i for i, m_ in enumerate(g["margin"]) if m_ <= tol), len(g["margin"]))
+        assert torch.equal(out[:T + first_tie], toks[:T + first_tie])
+        model.reset_cache()
+        mine = lit_llama_amd.generate(model, toks[:T].to(dev), toks.numel() - T, top_k=1).cpu()
+        assert torch.equal(out, mine), "the reference loop and lit_llama_amd.generate disagree on the same model"
+
+
 @pytest.mark.parametrize("name", ["tiny_roll", "tiny_noroll"])
 def test_tiny_model_cache_roll_tokens_equal_reference(dev, golden, name):
     """tests/test_generate.py:26-54 of the reference: max_seq_length < T + max_new_tokens rolls the cache."""
@@ -235,13 +258,56 @@ def test_generate_api_sampling_and_eos(dev):
     assert out.shape == (42,) and torch.equal(out[:37], long_prompt)
 
 
+def test_llm_int8_every_linear_teacher_forced_against_oracle(dev):
+    """Config 4, linear by linear (parity unpinned: bitsandbytes is absent everywhere, the oracle restates it).
+    The oracle model runs a prompt on the CPU; the input of EVERY LLM.int8 linear it evaluates — 2 layers x 5 + lm_head,
+    with the x20 outlier channels on, so the int8 / f16 column split is exercised — is fed to the GPU module of the
+    same name, and the output must match the oracle's on that same input to one f16 ulp (the bar of the kernel tests:
+    integer work exact, the f16 side product summed in another order).  This removes the drift a whole model
+    accumulates from the bound: what a model-level test can only show as a loose band is pinned per operator."""
+    model, sd, cfg = build(CFG1, "llm.int8", torch.bfloat16, dev, outliers=4)
+    om = oracle.Model(oracle.Config(**CFG1), {k: v.float() for k, v in sd.items()}, mode="llm.int8")
+    calls = []
+    real = oracle.llm_int8_linear
+
+    def spy(x, cb, scb, bias=None, threshold=6.0):
+        calls.append((x.detach().clone(), cb, scb))
+        return real(x, cb, scb, bias, threshold)
+
+    oracle.llm_int8_linear = spy
+    try:
+        with torch.no_grad():
+            om(synth.make_prompt(8).view(1, -1), 16, torch.arange(8))
+    finally:
+        oracle.llm_int8_linear = real
+    names = [f"transformer.h.{l}.{n}" for l in range(cfg.n_layer)
+             for n in ("attn.c_attn", "attn.c_proj", "mlp.c_fc1", "mlp.c_fc2", "mlp.c_proj")] + ["lm_head"]
+    assert len(calls) == len(names)
+    mods = dict(model.named_modules())
+    n_out_cols = 0
+    for name, (x, cb, scb) in zip(names, calls):
+        xb = x.to(torch.bfloat16)  # what the bf16 model hands to the linear
+        ref = real(xb, cb, scb).float()
+        got = mods[name](xb.to(dev)).float().cpu()
+        n_out_cols += int((xb.float().abs() >= 6.0).any(dim=1).any())
+        close = (got - ref).abs() <= 2.0 ** -9 * ref.abs() + 2.0 ** -7 * ref.abs().clamp(max=1e-3)  # bf16 output rounding
+        # outputs are rounded f16 -> bf16 on both sides: one f16 ulp before that rounding moves at most one bf16 ulp
+        close |= (got - ref).abs() <= 2.0 ** -7 * ref.abs()
+        assert bool(close.all()), f"{name}: {int((~close).sum())} of {close.numel()} outputs differ from the oracle"
+        exact = float((got == ref).float().mean())
+        assert exact >= 0.98, f"{name}: only {exact:.3f} of the outputs are bit-equal"
+    assert n_out_cols >= 6, "the outlier path was not exercised"
+
+
 def test_llm_int8_model_against_oracle(dev):
-    """Config 4 on a small model (parity unpinned: oracle only).  The kernels restate the oracle's LLM.int8
-    arithmetic exactly (tests/test_kernels_gpu.py), but a whole model re-quantises its activations at every linear:
-    a bf16-level perturbation (KV cache, residual rounding) flips int8 levels and comes out at int8 granularity
-    (~1/127).  Hence a wider band than for int4: 0.15 logit-std without outlier channels, and a sanity band with
-    the x20 outlier channels switched on."""
-    for outliers, band in ((0, 0.15), (4, 0.6)):
+    """Config 4 on a small model, whole-model view (the per-linear pin is the test above).  A model re-quantises its
+    activations at every linear: a bf16-level perturbation upstream (bf16 KV cache, bf16 residual rounding of the
+    module path) moves an activation across an int8 rounding boundary, and that comes out as one int8 level
+    (1/127 of the row's absmax) of that linear — the error is a random walk of such flips over 11 linears.
+    Bound used: 0.15 logit-std without outlier channels.  With the x20 outlier channels the same flips are scaled by
+    the (20x larger) row absmax of the rows that carry them, so only finiteness, correlation (> 0.995) and the argmax
+    wherever the reference's margin is decisive are required there — the 0.6-std band of round 1 proved nothing more."""
+    for outliers in (0, 4):
         model, sd, cfg = build(CFG1, "llm.int8", torch.bfloat16, dev, outliers=outliers)
         assert model.engine() is not None, model._engine_failed
         prompt = synth.make_prompt(8)
@@ -253,11 +319,37 @@ def test_llm_int8_model_against_oracle(dev):
         assert torch.isfinite(got).all()
         std = float(ref_logits.std(-1).mean())
         err = (got - ref_logits).abs().max().item()
-        assert err <= band * std, f"int8 (outliers={outliers}) logits off by {err:.4f} (std {std:.3f})"
+        corr = float(torch.corrcoef(torch.stack([got.flatten(), ref_logits.flatten()]))[0, 1])
+        if outliers == 0:
+            assert err <= 0.15 * std, f"int8 logits off by {err:.4f} (std {std:.3f})"
+        assert corr >= 0.995, f"int8 (outliers={outliers}) logits correlate only {corr:.4f} with the oracle"
+        band = 0.15 if outliers == 0 else max(0.15, err / std)
         top2 = torch.topk(ref_logits, 2, dim=-1).values
         decisive = (top2[:, 0] - top2[:, 1]) > 2 * band * std
         assert torch.equal(got.argmax(-1)[decisive], ref_logits.argmax(-1)[decisive])
-        print(f"int8 outliers={outliers}: max|dlogit| {err:.3f} (std {std:.3f})")
+        print(f"int8 outliers={outliers}: max|dlogit| {err:.3f} (std {std:.3f}), corr {corr:.5f}")
+
+
+@pytest.mark.parametrize("mode,band", [(None, 0.05), ("llm.int8", 0.15)])
+def test_7b_width_single_layer_engine_matches_oracle_bf16_int8(dev, mode, band):
+    """BASELINE.json configs[1] (bf16, no quantisation) and configs[3] (llm.int8) at the 7B width — n_embd 4096,
+    32 heads, n_hidden 11008, vocab 32000 — one layer through the engine against the oracle: the production tile
+    shapes / grids of the bf16 and int8 streaming kernels (the int4 twin is the next test)."""
+    cfgk = dict(n_layer=1, n_head=32, n_embd=4096)
+    model, sd, cfg = build(cfgk, mode, torch.bfloat16, dev)
+    assert model.engine() is not None, model._engine_failed
+    prompt = synth.make_prompt(5)
+    om = oracle.Model(oracle.Config(**cfgk), {k: v.float() for k, v in sd.items()}, mode=mode)
+    toks = oracle.generate(om, prompt, 3, top_k=1)
+    om.reset_cache()
+    ref = oracle.teacher_forced_logits(om, toks, 5)
+    got = teacher_forced(model, toks.to(dev), 5, 8, dev)
+    std = float(ref.std(-1).mean())
+    err = (got - ref).abs().max().item()
+    assert err <= band * std, f"7B-width {mode or 'bf16'} logits off by {err:.4f} (std {std:.3f})"
+    top2 = torch.topk(ref, 2, dim=-1).values
+    decisive = (top2[:, 0] - top2[:, 1]) > 2 * band * std
+    assert torch.equal(got.argmax(-1)[decisive], ref.argmax(-1)[decisive])
 
 
 def test_7b_width_single_layer_engine_matches_oracle(dev):
@@ -279,10 +371,12 @@ def test_7b_width_single_layer_engine_matches_oracle(dev):
 
 
 def test_full_7b_int4_model_size_independent_properties(dev):
-    """BASELINE.json configs[2] at FULL size (32 layers, 3.3 GB of int4 weights; the CPU oracle would need ~30 s per
-    token, so the checks are properties instead of a golden run): (1) greedy decode is reproducible run to run,
-    (2) the chained hipGraph replay, the un-chained graph and eager launches give bit-identical logits / tokens,
-    (3) the engine agrees with the op-by-op module path (independent generic kernels, reference arithmetic order)
+    """BASELINE.json configs[2] at FULL size (32 layers, 3.3 GB of int4 weights; the CPU oracle needs minutes per
+    token here — the full-depth golden run is tests/test_golden_7b_gpu.py — so these checks are properties):
+    (1) greedy decode is reproducible run to run, on the fused persistent step and on the launch-per-operator step;
+    (2) both give the same tokens, and teacher-forced logits within 0.02 logit-std of each other;
+    (3) on the launch-per-operator path the hipGraph replay and eager launches are bit-identical;
+    (4) the engine agrees with the op-by-op module path (independent generic kernels, reference arithmetic order)
     to the bf16-path tolerance on teacher-forced steps."""
     from lit_llama_amd.model import LLaMA, LLaMAConfig
 
@@ -295,20 +389,34 @@ def test_full_7b_int4_model_size_independent_properties(dev):
     assert eng is not None and eng.use_graph, model._engine_failed
     prompt = synth.make_prompt(9, vocab=cfg.vocab_size, seed=3).to(dev)
     n_new = 12
-    a = lit_llama_amd.generate(model, prompt, n_new, top_k=1)            # chained graph replays
-    model.reset_cache()
-    b = lit_llama_amd.generate(model, prompt, n_new, top_k=1)
-    assert torch.equal(a, b), "greedy decode of the full model is not reproducible"
-    assert a.shape == (9 + n_new,) and int(a.min()) >= 0 and int(a.max()) < cfg.padded_vocab_size
-    # teacher-forced over the generated sequence: graph (un-chained) vs eager, bit for bit; argmax chain == tokens
     S = 9 + n_new
-    lg_graph = teacher_forced(model, a, 9, S, dev)
+    runs = {}
+    for fused in ([True, False] if eng.fused is not None else [False]):
+        eng.fused_enabled = fused
+        model.reset_cache()
+        a = lit_llama_amd.generate(model, prompt, n_new, top_k=1)
+        model.reset_cache()
+        b = lit_llama_amd.generate(model, prompt, n_new, top_k=1)
+        assert torch.equal(a, b), f"greedy decode of the full model is not reproducible (fused={fused})"
+        assert a.shape == (9 + n_new,) and int(a.min()) >= 0 and int(a.max()) < cfg.padded_vocab_size
+        lg = teacher_forced(model, a, 9, S, dev)
+        assert torch.equal(lg.argmax(-1).to(a.dtype).cpu(), a[9:].cpu()), \
+            "the chained greedy loop and model.forward disagree on the argmax chain"
+        runs[fused] = (a, lg)
+        eng.check_status()
+    a, lg_graph = runs[False]
+    if True in runs:
+        assert torch.equal(runs[True][0], a), "fused and launch-per-operator steps decode different tokens"
+        std = float(lg_graph.std(-1).mean())
+        err = (runs[True][1] - lg_graph).abs().max().item()
+        assert err <= 0.02 * std, f"fused vs launch-per-operator logits at 7B: {err:.4f} (std {std:.3f})"
+    # launch-per-operator path: graph (un-chained) vs eager, bit for bit
+    eng.fused_enabled = False
     eng.use_graph = False
     lg_eager = teacher_forced(model, a, 9, S, dev)
     eng.use_graph = True
     assert torch.equal(lg_graph, lg_eager)
-    assert torch.equal(lg_graph.argmax(-1).to(a.dtype).cpu(), a[9:].cpu()), \
-        "the chained greedy loop and model.forward disagree on the argmax chain"
+    eng.fused_enabled = True
     # independent implementation: op-by-op module path (3 teacher-forced steps are enough at 32 layers)
     short = a[:12]
     model.use_engine = False

@@ -50,14 +50,18 @@ def test_shard_map_recombines_to_the_full_checkpoint():
     with pytest.raises(ValueError):
         tp.check_divisible(LLaMAConfig.from_name("30B"), 8)  # 52 heads
     tp.check_divisible(LLaMAConfig.from_name("65B"), 8)
-    with pytest.raises(Exception):
-        from lit_llama_amd import _native as nat
+    # rank-local module shapes (checked OUTSIDE any pytest.raises: an assertion failure must fail the test)
+    m = tp.build_local_model(cfg, 2, device="cpu", dtype=torch.float32)
+    assert m.transformer.h[0].attn.c_attn.out_features == 3 * C_ // 2
+    assert m.transformer.h[0].attn.c_proj.in_features == C_ // 2
+    assert m.transformer.h[0].mlp.c_fc1.out_features == cfg.n_hidden // 2
+    assert m.transformer.h[0].mlp.c_proj.in_features == cfg.n_hidden // 2
+    assert m.lm_head.out_features == cfg.padded_vocab_size // 2
+    from lit_llama_amd import _native as nat
 
-        m = tp.build_local_model(cfg, 2, device="cpu", dtype=torch.float32)
-        assert m.transformer.h[0].attn.c_attn.out_features == 3 * C_ // 2
-        assert m.transformer.h[0].mlp.c_proj.in_features == cfg.n_hidden // 2
-        assert m.lm_head.out_features == cfg.padded_vocab_size // 2
-        m(torch.zeros((1, 2), dtype=torch.int64), 4, torch.arange(2))  # rank-local models refuse plain forward
+    with pytest.raises(nat.NativeError):
+        # rank-local models refuse a plain forward (CPU tensors: the product path has no CPU fallback either way)
+        m(torch.zeros((1, 2), dtype=torch.int64), 4, torch.arange(2))
 
 
 class OracleShard:
@@ -189,22 +193,43 @@ def test_tp_loopback_two_engine_shards_match_single_engine(dev):
         shards.append(tp.EngineShard(m, world))
     dec = tp.TPDecoder(shards, tp.LoopbackComm(world), cfg)
     out = dec.generate(prompt, 8)
-    # identical kernels on half-size shards + f32 partial sums: same tokens unless a step is a near tie
-    same = (out == ref).cpu().numpy()
-    assert same[:7].all()
-    assert same.mean() >= 0.8, f"TP tokens {out.tolist()} vs {ref.tolist()}"
-    # logits of the prompt's last position agree to bf16-path tolerance
-    if all(s.eng.max_T >= 7 for s in shards):
-        run = shards[0].eng.stream
-        with torch.cuda.stream(run):
-            for s in shards:
-                s.eng.reset_cache()
-                s.eng._ensure_cache(15)
-                s.eng.set_step(prompt, 7, 0)
-            lg = tp.tp_forward(shards, tp.LoopbackComm(world), 7, cfg.n_layer)[0].float()
-        run.synchronize()
-        full.reset_cache()
-        pos = torch.arange(7, device=dev)
-        pos._mi355_pos0 = 0
-        lf = full(prompt.view(1, -1), 15, pos)[0, -1].float().cpu()
-        assert (lg.cpu()[0] - lf).abs().max().item() <= 0.05 * float(lf.std())
+    # teacher-forced on the single-engine tokens: the sharded logits must follow the single engine's at EVERY step
+    # (identical kernels on half-size shards + f32 partial sums in rank order), and free-running tokens may only
+    # part at a step where the single engine's own top-2 margin is inside that tolerance
+    eng0 = shards[0].eng
+    run = eng0.stream
+    S = 15
+    full.reset_cache()
+    for s_ in shards:
+        s_.eng.stream = run
+    per_step = []
+    with torch.cuda.stream(run):
+        for s_ in shards:
+            s_.eng.reset_cache()
+            s_.eng._ensure_cache(S)
+        pos = 0
+        feed = [ref[:7]] + [ref[7 + i: 8 + i] for i in range(7)]
+        for chunk in feed:
+            n = chunk.numel()
+            if any(s_.eng.max_T < n for s_ in shards):
+                pytest.skip("prompt chunk does not fit the shard engines")
+            for s_ in shards:
+                s_.eng.set_step(chunk, n, pos)
+            lg = tp.tp_forward(shards, tp.LoopbackComm(world), n, cfg.n_layer)[0].float()
+            ip = torch.arange(pos, pos + n, device=dev)
+            ip._mi355_pos0 = pos
+            lf = full(chunk.view(1, -1), S, ip)[0, -1].float()
+            per_step.append((lg[0].clone(), lf.clone()))
+            pos += n
+    run.synchronize()
+    first_tie = None
+    for i, (lg, lf) in enumerate(per_step):
+        std = float(lf.std())
+        err = (lg - lf).abs().max().item()
+        assert err <= 0.05 * std, f"step {i}: TP logits off by {err:.4f} (std {std:.3f})"
+        top2 = torch.topk(lf, 2).values
+        if first_tie is None and float(top2[0] - top2[1]) <= 0.1 * std:
+            first_tie = i
+    n_same = 7 + (len(per_step) if first_tie is None else first_tie)
+    same = (out[:n_same] == ref[:n_same]).cpu()
+    assert bool(same.all()), f"TP tokens {out.tolist()} vs {ref.tolist()} (first near tie at step {first_tie})"
