@@ -185,10 +185,10 @@ def block_cases():
 
 def big_case():
     """BASELINE.json configs[2] at FULL depth: LLaMA-7B (32 layers) gptq.int4 with seeded synthetic weights, prompt of 8,
-    three greedy tokens, teacher-forced logits (probes / argmax / margins).  ~10 forwards of the real reference on the
+    six greedy tokens, teacher-forced logits (probes / argmax / margins).  ~25 forwards of the real reference on the
     CPU (every call dequantises 3.3 GB of int4 weights); run with `--big`."""
     torch.set_num_threads(max(8, (torch.get_num_threads() or 8)))
-    model_case("cfg2_7b_int4", dict(n_layer=32, n_head=32, n_embd=4096), "gptq.int4", prompt_len=8, new_tokens=3,
+    model_case("cfg2_7b_int4", dict(n_layer=32, n_head=32, n_embd=4096), "gptq.int4", prompt_len=8, new_tokens=6,
                nocache=False)
 
 
