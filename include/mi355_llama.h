@@ -390,6 +390,9 @@ int mi355_forward_head(const mi355_model* m, int T, int logits_mode, int argmax,
 /* hipGraph of the T = 1 step (logits_mode 1).  capture/destroy synchronise the stream. */
 typedef struct mi355_graph mi355_graph;
 int mi355_graph_capture(const mi355_model* m, int argmax, mi355_stream_t stream, mi355_graph** out);
+/* capture any sequence of this library's launches enqueued on `stream` between the two calls */
+int mi355_graph_begin(mi355_stream_t stream);
+int mi355_graph_end(mi355_stream_t stream, mi355_graph** out);
 int mi355_graph_launch(mi355_graph* g, mi355_stream_t stream);
 int mi355_graph_destroy(mi355_graph* g);
 
@@ -448,8 +451,43 @@ size_t mi355_fused_step_workspace_bytes(int n_hidden);
 int mi355_fused_step_supported(int n_embd, int n_head, int hs, int n_hidden, int vocab, int S);
 int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Tensor-parallel all-reduce of the decode step (SURVEY.md 8b `tp_allreduce(buf, n, comm)`; the partition is
+ * scripts/convert_checkpoint.py:57-65): one-shot peer-write over xGMI (csrc/tp_comm.hip).  Every rank owns a
+ * receive buffer of mi355_tp_comm_bytes(world, slot_floats) bytes from mi355_tp_buffer_alloc (fine-grained
+ * device memory), exports it with mi355_ipc_export, and maps every peer's with mi355_ipc_open; `peer_buf[r]` is
+ * rank r's buffer as seen from this process (own rank: the local pointer).  `state` is 2 zeroed uint32 of local
+ * device memory: [0] step counter (mi355_tp_step_begin increments it once per forward, so tags never repeat and
+ * a captured step can be replayed), [1] abort code (non-zero after a launch = a peer did not deliver in time).
+ * mi355_tp_allreduce: x[i] (+)= sum over ranks, in rank order, of every rank's partial[i]; `call_index` numbers
+ * the all-reduces of one forward (0, 1, 2, ...; the same sequence on every rank; consecutive calls alternate
+ * buffer halves).  Returns at enqueue; the kernel completes when every peer's contribution has arrived.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mi355_tp_comm {
+    int32_t world, rank;
+    int32_t slot_floats; /* capacity of one rank's slot (>= the largest n) */
+    int32_t reserved0;
+    void* peer_buf[8];
+    uint32_t* state;
+} mi355_tp_comm;
+
+size_t mi355_tp_comm_bytes(int world, int slot_floats);
+int mi355_tp_buffer_alloc(size_t bytes, void** out);
+int mi355_tp_buffer_free(void* p);
+int mi355_ipc_export(void* dev_ptr, void* handle64);      /* hipIpcGetMemHandle: 64-byte handle */
+int mi355_ipc_open(const void* handle64, void** out);     /* hipIpcOpenMemHandle in ANOTHER process */
+int mi355_ipc_close(void* p);
+int mi355_tp_step_begin(const mi355_tp_comm* c, mi355_stream_t stream);
+int mi355_tp_allreduce(const mi355_tp_comm* c, const float* partial, float* x, int n, int call_index, int accumulate,
+                       mi355_stream_t stream);
+/* greedy sampling over vocabulary shards (lm_head split on dim 0): arg-max of the rank's [v_local] logits, exchange of
+ * the `world` (value, global index) pairs, same winner on every rank (lowest index on ties); writes next_token[0],
+ * out_tokens[pos[0] + 1] and, with `advance`, tokens[0] and pos[0] + 1 (the chained step of mi355_forward) */
+int mi355_tp_argmax(const mi355_tp_comm* c, const float* logits_local, int v_local, int call_index, int32_t* next_token,
+                    int32_t* out_tokens, int32_t* tokens, int32_t* pos, int advance, mi355_stream_t stream);
+
 /* sizeof() of the ABI structs, for binding self-checks: 0 linear_args, 1 attn_args, 2 int8_args, 3 weight,
- * 4 layer, 5 model, 6 fused_step_args; -1 for an unknown index */
+ * 4 layer, 5 model, 6 fused_step_args, 7 tp_comm; -1 for an unknown index */
 int mi355_sizeof(int which);
 
 #ifdef __cplusplus

@@ -115,6 +115,13 @@ class FusedStepArgs(C.Structure):
     ]
 
 
+class TpComm(C.Structure):
+    _fields_ = [
+        ("world", c_int32), ("rank", c_int32), ("slot_floats", c_int32), ("reserved0", c_int32),
+        ("peer_buf", c_void_p * 8), ("state", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); must list every function declared in include/mi355_llama.h
 PROTOTYPES = {
     "mi355_version": (c_int, []),
@@ -157,6 +164,18 @@ PROTOTYPES = {
     "mi355_fused_step_workspace_bytes": (c_size_t, [c_int]),
     "mi355_fused_step_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "mi355_fused_step": (c_int, [C.POINTER(FusedStepArgs), c_void_p]),
+    "mi355_tp_comm_bytes": (c_size_t, [c_int, c_int]),
+    "mi355_tp_buffer_alloc": (c_int, [c_size_t, C.POINTER(c_void_p)]),
+    "mi355_tp_buffer_free": (c_int, [c_void_p]),
+    "mi355_ipc_export": (c_int, [c_void_p, c_void_p]),
+    "mi355_ipc_open": (c_int, [c_void_p, C.POINTER(c_void_p)]),
+    "mi355_ipc_close": (c_int, [c_void_p]),
+    "mi355_tp_step_begin": (c_int, [C.POINTER(TpComm), c_void_p]),
+    "mi355_tp_allreduce": (c_int, [C.POINTER(TpComm), c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mi355_tp_argmax": (c_int, [C.POINTER(TpComm), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                c_void_p]),
+    "mi355_graph_begin": (c_int, [c_void_p]),
+    "mi355_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "mi355_sizeof": (c_int, [c_int]),
     "mi355_linear_max_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "mi355_debug_time_next_launch": (c_int, [c_void_p, c_void_p]),
@@ -165,7 +184,7 @@ PROTOTYPES = {
                                  c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
-ABI_STRUCTS = [LinearArgs, AttnArgs, Int8Args, Weight, Layer, Model, FusedStepArgs]
+ABI_STRUCTS = [LinearArgs, AttnArgs, Int8Args, Weight, Layer, Model, FusedStepArgs, TpComm]
 
 _lib: Optional[C.CDLL] = None
 

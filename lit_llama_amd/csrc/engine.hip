@@ -347,6 +347,38 @@ extern "C" int mi355_graph_capture(const mi355_model* m, int argmax, mi355_strea
     return 0;
 }
 
+// Capture of an arbitrary sequence of this library's launches (e.g. a tensor-parallel step: segments + peer-write
+// all-reduces + sharded arg-max, lit_llama_amd/tp.py): begin, enqueue on `stream`, end.
+extern "C" int mi355_graph_begin(mi355_stream_t stream) {
+    MI355_CHECK_ARG(stream != nullptr, MI355_E_ARG,
+                    "graph_begin: the legacy default stream cannot be captured; pass a created stream");
+    hipStream_t s = (hipStream_t)stream;
+    MI355_HIP(hipStreamSynchronize(s));
+    MI355_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+
+extern "C" int mi355_graph_end(mi355_stream_t stream, mi355_graph** out) {
+    MI355_CHECK_ARG(out != nullptr, MI355_E_ARG, "graph_end: null argument");
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
+    if (e != hipSuccess || graph == nullptr) {
+        mi355_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        return e != hipSuccess ? (int)e : MI355_E_STATE;
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e2 != hipSuccess) {
+        mi355_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+        return (int)e2;
+    }
+    mi355_graph* g = new mi355_graph;
+    g->exec = exec;
+    *out = g;
+    return 0;
+}
+
 extern "C" int mi355_graph_launch(mi355_graph* g, mi355_stream_t stream) {
     MI355_CHECK_ARG(g != nullptr && g->exec != nullptr, MI355_E_ARG, "graph_launch: null graph");
     MI355_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));

@@ -29,6 +29,7 @@ extern "C" int mi355_sizeof(int which) {
         case 4: return (int)sizeof(mi355_layer);
         case 5: return (int)sizeof(mi355_model);
         case 6: return (int)sizeof(mi355_fused_step_args);
+        case 7: return (int)sizeof(mi355_tp_comm);
         default: return -1;
     }
 }

@@ -138,22 +138,153 @@ class LoopbackComm:
         return [full.clone() for _ in tensors]
 
 
+class NativeComm:
+    """Peer-write all-reduce of libmi355llama (csrc/tp_comm.hip, `mi355_tp_allreduce`): one launch per all-reduce,
+    fused with the residual add, on the engine's stream — no host work between segments, capturable in a hipGraph.
+    One process per GPU; the 64-byte IPC handles of the receive buffers travel through `exchange`, a callable that
+    all-gathers a Python object across the ranks (default: torch.distributed.all_gather_object, which works over the
+    gloo / nccl group the launcher created).  Two processes on ONE GPU work the same way (how the 1-GPU box tests it:
+    RCCL refuses duplicate devices, HIP IPC does not)."""
+
+    def __init__(self, rank: int, world: int, n_embd: int, device, exchange=None):
+        from ._native import TpComm, check, lib
+
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        self.fused_residual = True
+        L = lib()
+        with torch.cuda.device(self.device):
+            nbytes = int(L.mi355_tp_comm_bytes(world, n_embd))
+            if nbytes <= 0:
+                raise ValueError(f"tp all-reduce handles 1..8 ranks (got {world})")
+            buf = C.c_void_p()
+            check(L.mi355_tp_buffer_alloc(nbytes, C.byref(buf)), "mi355_tp_buffer_alloc")
+            self._buf = buf
+            handle = (C.c_ubyte * 64)()
+            check(L.mi355_ipc_export(buf, handle), "mi355_ipc_export")
+            if exchange is None:
+                import torch.distributed as dist
+
+                def exchange(obj):
+                    out = [None] * world
+                    dist.all_gather_object(out, obj)
+                    return out
+            handles = exchange(bytes(handle))
+            self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
+            c = TpComm()
+            c.world, c.rank, c.slot_floats = world, rank, n_embd
+            self._opened = []
+            for r in range(world):
+                if r == rank:
+                    c.peer_buf[r] = buf.value
+                else:
+                    peer = C.c_void_p()
+                    hb = (C.c_ubyte * 64).from_buffer_copy(handles[r])
+                    check(L.mi355_ipc_open(hb, C.byref(peer)), f"mi355_ipc_open (rank {r})")
+                    c.peer_buf[r] = peer.value
+                    self._opened.append(peer)
+            c.state = self.state.data_ptr()
+            self.c = c
+            exchange("mapped")  # nobody frees / reuses before every peer has mapped every buffer
+        self._call = 0
+
+    def step_begin(self, stream) -> None:
+        from ._native import check, lib
+
+        check(lib().mi355_tp_step_begin(C.byref(self.c), stream.cuda_stream), "mi355_tp_step_begin")
+        self._call = 0
+
+    def reduce_add(self, shard, T: int) -> None:
+        """x[:T] += sum over ranks of partial[:T]  (all-reduce + residual add of model.py:166-167 in one launch)."""
+        from ._native import check, lib
+
+        eng = shard.eng
+        n = T * eng.cfg.n_embd
+        if n > self.c.slot_floats:  # prompt chunks: row by row (decode, the case that matters, is one row)
+            for t in range(T):
+                self._one(eng, t * eng.cfg.n_embd, eng.cfg.n_embd)
+            return
+        self._one(eng, 0, n)
+
+    def _one(self, eng, off: int, n: int) -> None:
+        from ._native import check, lib
+
+        check(lib().mi355_tp_allreduce(C.byref(self.c), eng.partial.data_ptr() + 4 * off, eng.x.data_ptr() + 4 * off, n,
+                                       self._call, 1, eng.stream.cuda_stream), "mi355_tp_allreduce")
+        self._call += 1
+
+    def argmax(self, shard, advance: bool, row: int = 0) -> None:
+        """Greedy sampling over the vocabulary shards, on the device (`mi355_tp_argmax`): next_token / out_tokens
+        (indexed by the position of token `row` of the step + 1) and, with `advance`, the token / position slots of
+        the next chained step."""
+        from ._native import check, lib
+
+        eng = shard.eng
+        assert not (advance and row)
+        check(lib().mi355_tp_argmax(C.byref(self.c), eng.logits.data_ptr(), int(eng.m.lm_head.N), self._call,
+                                    eng.next_token.data_ptr(), eng.out_tokens.data_ptr(), eng.tokens.data_ptr(),
+                                    eng.pos.data_ptr() + 4 * row, 1 if advance else 0, eng.stream.cuda_stream),
+              "mi355_tp_argmax")
+        self._call += 1
+
+    def check_status(self) -> None:
+        from ._native import NativeError
+
+        code = int(self.state[1].item())
+        if code:
+            self.state[1] = 0
+            raise NativeError(f"tensor-parallel all-reduce aborted (code 0x{code:x}): a peer did not deliver in time")
+
+    def all_gather_cols(self, tensors: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        import torch.distributed as dist  # one gather of [V / world] logits per token: not on the per-layer path
+
+        assert len(tensors) == 1
+        t = tensors[0].contiguous()
+        if dist.get_backend() == "gloo":  # test rigs (two processes on one GPU): gather on the host
+            parts = [torch.empty_like(t, device="cpu") for _ in range(self.world)]
+            dist.all_gather(parts, t.cpu())
+            return [torch.cat(parts, dim=-1).to(t.device)]
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t)
+        return [torch.cat(parts, dim=-1)]
+
+    def close(self) -> None:
+        from ._native import lib
+
+        for p_ in self._opened:
+            lib().mi355_ipc_close(p_)
+        self._opened = []
+        if self._buf is not None:
+            lib().mi355_tp_buffer_free(self._buf)
+            self._buf = None
+
+
 # ------------------------------------------------------------------------------------------------ protocol
 def tp_forward(shards: Sequence, comm, T: int, n_layer: int, want_logits: bool = True) -> Optional[List[torch.Tensor]]:
     """One forward over T tokens already placed in every shard.  Returns the full logits per shard
     ([rows, vocab], rows = whatever `head()` produced)."""
+    fused = getattr(comm, "fused_residual", False)  # NativeComm: all-reduce + residual add in ONE launch on the stream
+    if fused:
+        assert len(shards) == 1
+        comm.step_begin(shards[0].eng.stream)
     for s in shards:
         s.embed(T)
     for l in range(n_layer):
         for s in shards:
             s.attn_part(l, T)          # RMSNorm + c_attn shard + local heads + c_proj shard -> partial
-        comm.all_reduce_sum([s.partial_view(T) for s in shards])
+        if fused:
+            comm.reduce_add(shards[0], T)
+        else:
+            comm.all_reduce_sum([s.partial_view(T) for s in shards])
+            for s in shards:
+                s.residual_add(T)
         for s in shards:
-            s.residual_add(T)
             s.mlp_part(l, T)           # RMSNorm + fc shard + SwiGLU + mlp.c_proj shard -> partial
-        comm.all_reduce_sum([s.partial_view(T) for s in shards])
-        for s in shards:
-            s.residual_add(T)
+        if fused:
+            comm.reduce_add(shards[0], T)
+        else:
+            comm.all_reduce_sum([s.partial_view(T) for s in shards])
+            for s in shards:
+                s.residual_add(T)
     if not want_logits:
         return None
     return comm.all_gather_cols([s.head(T) for s in shards])
@@ -203,6 +334,76 @@ class TPDecoder:
 
     def _streams(self):
         return [s.eng.stream for s in self.shards]
+
+    @torch.no_grad()
+    def generate_chained(self, prompt: torch.Tensor, max_new_tokens: int, max_seq_length: Optional[int] = None,
+                         use_graph: bool = True) -> torch.Tensor:
+        """Greedy decode of one stream with `NativeComm`: the prompt goes through the segment protocol chunk by chunk;
+        every decode step is then ONE hipGraph replay per rank — embedding, 2 x n_layer [segments + peer-write
+        all-reduce fused with the residual add], lm_head shard, sharded arg-max that writes the next token and
+        position — with no host work, no RCCL call and no device->host read inside the loop."""
+        from ._native import check, lib
+
+        assert len(self.shards) == 1 and getattr(self.comm, "fused_residual", False)
+        shard, comm, cfg = self.shards[0], self.comm, self.cfg
+        eng = shard.eng
+        T = prompt.numel()
+        S = max_seq_length or min(T + max_new_tokens, cfg.block_size)
+        if S < T + max_new_tokens:
+            raise ValueError(f"tensor-parallel decode needs max_seq_length >= prompt + new tokens ({S} < {T} + {max_new_tokens})")
+        cur = torch.cuda.current_stream(prompt.device)
+        eng.stream.wait_stream(cur)
+        s = eng.stream.cuda_stream
+
+        def step(advance: bool):
+            comm.step_begin(eng.stream)
+            shard.embed(1)
+            for l in range(cfg.n_layer):
+                shard.attn_part(l, 1)
+                comm.reduce_add(shard, 1)
+                shard.mlp_part(l, 1)
+                comm.reduce_add(shard, 1)
+            shard.head(1)
+            comm.argmax(shard, advance)
+
+        with torch.cuda.stream(eng.stream):
+            eng._ensure_cache(S)
+            eng.out_tokens[:T].copy_(prompt.to(torch.int32))
+            pos = 0
+            while pos < T:
+                n = min(eng.max_T, T - pos)
+                eng.set_step(prompt[pos:pos + n], n, pos)
+                last = pos + n == T
+                tp_forward([shard], comm, n, cfg.n_layer, want_logits=False)
+                if last:
+                    shard.head(n)
+                    comm.argmax(shard, False, row=n - 1)  # out_tokens[T] = first generated token
+                pos += n
+            if max_new_tokens > 1:
+                eng.set_step(None, 1, T, from_next=True)
+                graph = None
+                if use_graph:
+                    step(False)  # eager warm-up (lazy kernel attributes); recomputes position T, state unchanged
+                    check(lib().mi355_graph_begin(s), "mi355_graph_begin")
+                    try:
+                        step(True)
+                    finally:
+                        h = C.c_void_p()
+                        rc = lib().mi355_graph_end(s, C.byref(h))
+                    check(rc, "mi355_graph_end")
+                    graph = h
+                for _ in range(max_new_tokens - 1):
+                    if graph is not None:
+                        check(lib().mi355_graph_launch(graph, s), "mi355_graph_launch")
+                    else:
+                        step(True)
+                if graph is not None:
+                    eng.stream.synchronize()
+                    lib().mi355_graph_destroy(graph)
+            out = eng.out_tokens[:T + max_new_tokens].to(prompt.dtype).clone()
+        cur.wait_stream(eng.stream)
+        comm.check_status()
+        return out
 
     @torch.no_grad()
     def generate(self, prompt: torch.Tensor, max_new_tokens: int, max_seq_length: Optional[int] = None) -> torch.Tensor:
