@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--quantize", default="gptq.int4", choices=["gptq.int4", "llm.int8", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-tp", action="store_true", help="skip the tensor-parallel leg (65B gptq.int4, TP = --gpus)")
+    ap.add_argument("--tp-model", default="65B")
+    ap.add_argument("--tp-steps", type=int, default=48)
+    ap.add_argument("--tp-comm", default="native", choices=["native", "rccl"])
     ap.add_argument("--tune", default=None, help="JSON dict of per-linear launch tuning (engine.DecodeEngine tune)")
     return ap.parse_args()
 
@@ -234,6 +238,92 @@ def cpu_baseline(cfg, mode: str):
                        f"extrapolated: {cfg.n_layer} x {t_layer:.2f} s + {t_head:.2f} s per token")
 
 
+def tp_leg(args, dev, rank, world, dist):
+    """BASELINE.json configs[4]: LLaMA-65B gptq.int4 decoded tensor-parallel over the `world` GPUs of this job (TP = 1
+    on a single GPU: the same code path at world 1).  Every rank holds its shard (scripts/convert_checkpoint.py:57-65),
+    a decode step is one hipGraph replay per rank: 2 x n_layer [segments + peer-write all-reduce] + lm_head shard +
+    sharded arg-max (lit_llama_amd/tp.py, csrc/tp_comm.hip); `--tp-comm rccl` runs the host-driven protocol over
+    torch.distributed instead (the comparison point)."""
+    from lit_llama_amd import synth, tp
+    from lit_llama_amd.model import LLaMAConfig
+
+    cfg = LLaMAConfig.from_name(args.tp_model)
+    tp.check_divisible(cfg, world)
+    model = tp.build_local_model(cfg, world, device=dev, mode="gptq.int4")
+    synth.fill_tp_shard_random_int4(model, seed=0, rank=rank)
+    shard = tp.EngineShard(model, world)
+    T, K = 32, args.tp_steps
+    prompt = synth.make_prompt(T, vocab=cfg.vocab_size, seed=99).to(dev)
+    if args.tp_comm == "native":
+        if world > 1:
+            exchange = None  # torch.distributed.all_gather_object over the job's process group
+        else:
+            exchange = lambda obj: [obj]  # noqa: E731
+        comm = tp.NativeComm(rank, world, cfg.n_embd, dev, exchange=exchange)
+    else:
+        comm = tp.DistComm() if world > 1 else tp.LoopbackComm(1)
+    dec = tp.TPDecoder([shard], comm, cfg)
+    run = (lambda n: dec.generate_chained(prompt, n, max_seq_length=T + K + 8)) if args.tp_comm == "native" else \
+          (lambda n: dec.generate(prompt, n, max_seq_length=T + K + 8))
+    run(8)  # warm: cache geometry, kernel attributes
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    # prompt + 8 tokens vs prompt + 8 + K tokens: the difference is K decode steps
+    t0 = time.perf_counter()
+    run(8)
+    torch.cuda.synchronize(dev)
+    t_short = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    toks = run(8 + K)
+    torch.cuda.synchronize(dev)
+    t_long = time.perf_counter() - t0
+    dt = torch.tensor([t_long - t_short], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    per_token = float(dt.item()) / K
+    # the collective alone: 2 x n_layer all-reduces of [n_embd] f32 per token
+    ar_us = None
+    if args.tp_comm == "native":
+        eng = shard.eng
+        with torch.cuda.stream(eng.stream):
+            comm.step_begin(eng.stream)
+            for _ in range(16):
+                comm.reduce_add(shard, 1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            comm.step_begin(eng.stream)
+            e0.record(eng.stream)
+            for _ in range(2 * cfg.n_layer):
+                comm.reduce_add(shard, 1)
+            e1.record(eng.stream)
+        e1.synchronize()
+        comm.check_status()
+        ar_us = e0.elapsed_time(e1) * 1e3 / (2 * cfg.n_layer)
+    bpt = bytes_per_token(cfg, "gptq.int4")
+    per_gpu = (bpt["weights"] - cfg.padded_vocab_size * cfg.n_embd // 2) // world + cfg.padded_vocab_size * cfg.n_embd // 2 // world
+    assert int(toks.min()) >= 0 and int(toks.max()) < cfg.padded_vocab_size
+    out = {
+        "workload": f"LLaMA-{args.tp_model} gptq.int4 bs=1 greedy decode, TP={world} (configs[4]"
+                    + ("" if world == 8 and args.tp_model == "65B" else f" at TP={world}") + "), random-init shards",
+        "tokens_per_s": round(1.0 / per_token, 2),
+        "ms_per_token": round(per_token * 1e3, 4),
+        "steps": K,
+        "comm": "peer-write all-reduce (mi355_tp_allreduce, HIP IPC over xGMI), hipGraph per step" if args.tp_comm == "native"
+                else "RCCL all-reduce via torch.distributed, host-driven segments",
+        "weight_bytes_per_gpu_per_token": int(per_gpu),
+        "frac_of_int4_weight_roofline_per_gpu": round(per_gpu / per_token / HBM_PEAK, 4),
+        "allreduce_us": None if ar_us is None else round(ar_us, 2),
+        "collective_us_per_token": None if ar_us is None else round(ar_us * 2 * cfg.n_layer, 1),
+        "note": "TP > 1 has not been run on hardware by the builder (1-GPU boxes only): the curve is whatever the driver's "
+                "multi-GPU run prints here",
+    }
+    if hasattr(comm, "close"):
+        comm.close()
+    return out
+
+
 def args_model_name(cfg):
     return {4096: "7B", 5120: "13B", 6656: "30B", 8192: "65B"}.get(cfg.n_embd, f"n_embd={cfg.n_embd}")
 
@@ -265,7 +355,7 @@ def main():
     if eng is None:
         raise SystemExit(f"native engine unavailable: {model._engine_failed}")
     T, W, K = args.prompt_len, args.warmup, args.steps
-    S = T + W + K + 1
+    S = T + W + K + 1 + 64  # + the launches the roofline measurement appends to the chained loop
     if S > cfg.block_size:
         raise SystemExit(f"prompt + warmup + steps + 1 = {S} exceeds block_size {cfg.block_size}")
     prompt = synth.make_prompt(T, vocab=cfg.vocab_size, seed=1234 + rank).to(dev)
@@ -303,50 +393,61 @@ def main():
     tokens = eng.out_tokens[: pos + 1].tolist()
     assert all(0 <= t_ < cfg.padded_vocab_size for t_ in tokens), "decode produced invalid ids"
     fused = eng.fused_ready()
+    hipgraph_used = bool(eng.use_graph and eng._graphs) and not fused
+    if rank == 0:
+        bpt = bytes_per_token(cfg, args.quantize)
+        tok_s_gpu = K / elapsed
+        mean_pos = T + W + K / 2
+        # ---- dominant kernel roofline (c_fc1/c_fc2 + SwiGLU)
+        C_, H = cfg.n_embd, cfg.n_hidden
+        wb = {"gptq.int4": C_ * H, "llm.int8": 2 * C_ * H, "none": 4 * C_ * H}[args.quantize]
+        side = {"gptq.int4": 2 * 2 * H * 2, "llm.int8": 2 * H * 4, "none": 0}[args.quantize]
+        algo = wb + side + C_ * 4 + C_ * 2 + H * 2
+        traffic, traffic_source = None, None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"
+        if fused:
+            # one launch = one token: every weight byte once + side operands + the KV rows read at the step's position
+            pos_mid = pos + 24  # the 48 measured launches continue the chained loop
+            algo = bpt["total"] + int(bpt["kv_per_pos"] * (pos_mid + 1))
+            avg_s, med_s = measure_fused_step(eng)
+            eng.check_status()
+            key = "fused_step_bytes_per_launch"
+        else:
+            avg_s, med_s = measure_dominant_kernel(eng)
+            key = "fc_swiglu_bytes_per_launch"
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get(key)
+                traffic_source = ("profiles/pmc_traffic.json: committed rocprofv3 --pmc FETCH_SIZE pass over this command "
+                                  "(x2 gfx950 wide-read correction); static, not measured in this run") if traffic else None
+            except Exception:
+                traffic = None
+        # tokens/s of generate() including the prompt (generate.py:146-153 prints this figure)
+        gen_new = 64
+        import lit_llama_amd
 
+        model.reset_cache()
+        lit_llama_amd.generate(model, prompt, 4, top_k=1, max_seq_length=T + gen_new)  # warm (cache geometry, graphs)
+        torch.cuda.synchronize(dev)
+        t_g0 = time.perf_counter()
+        lit_llama_amd.generate(model, prompt, gen_new, top_k=1, max_seq_length=T + gen_new)
+        torch.cuda.synchronize(dev)
+        t_gen = time.perf_counter() - t_g0
+    tp_res = None
+    if not args.no_tp and args.quantize == "gptq.int4":
+        # free the 7B replica first: the 65B shard of a small world is tens of GB
+        del eng
+        model._engine = None
+        del model
+        torch.cuda.empty_cache()
+        try:
+            tp_res = tp_leg(args, dev, rank, world, dist)
+        except Exception as e:  # the TP leg must never take the headline down with it
+            tp_res = {"error": repr(e)}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-
-    bpt = bytes_per_token(cfg, args.quantize)
-    tok_s_gpu = K / elapsed
-    mean_pos = T + W + K / 2
-    # ---- dominant kernel roofline (c_fc1/c_fc2 + SwiGLU)
-    C_, H = cfg.n_embd, cfg.n_hidden
-    wb = {"gptq.int4": C_ * H, "llm.int8": 2 * C_ * H, "none": 4 * C_ * H}[args.quantize]
-    side = {"gptq.int4": 2 * 2 * H * 2, "llm.int8": 2 * H * 4, "none": 0}[args.quantize]
-    algo = wb + side + C_ * 4 + C_ * 2 + H * 2
-    traffic, traffic_source = None, None
-    pmc = ROOT / "profiles" / "pmc_traffic.json"
-    if fused:
-        # one launch = one token: every weight byte once + side operands + the KV rows read at the step's position
-        pos_mid = pos + 24  # the 48 measured launches continue the chained loop
-        algo = bpt["total"] + int(bpt["kv_per_pos"] * (pos_mid + 1))
-        avg_s, med_s = measure_fused_step(eng)
-        eng.check_status()
-        key = "fused_step_bytes_per_launch"
-    else:
-        avg_s, med_s = measure_dominant_kernel(eng)
-        key = "fc_swiglu_bytes_per_launch"
-    if pmc.exists():
-        try:
-            traffic = json.loads(pmc.read_text()).get(key)
-            traffic_source = ("profiles/pmc_traffic.json: committed rocprofv3 --pmc FETCH_SIZE pass over this command "
-                              "(x2 gfx950 wide-read correction); static, not measured in this run") if traffic else None
-        except Exception:
-            traffic = None
-    # tokens/s of generate() including the prompt (generate.py:146-153 prints this figure)
-    gen_new = 64
-    import lit_llama_amd
-
-    model.reset_cache()
-    lit_llama_amd.generate(model, prompt, 4, top_k=1, max_seq_length=T + gen_new)  # warm (cache geometry, graphs)
-    torch.cuda.synchronize(dev)
-    t_g0 = time.perf_counter()
-    lit_llama_amd.generate(model, prompt, gen_new, top_k=1, max_seq_length=T + gen_new)
-    torch.cuda.synchronize(dev)
-    t_gen = time.perf_counter() - t_g0
     default_cfg = args.model == "7B" and args.quantize == "gptq.int4"
     cfg_idx = {"none": 1, "gptq.int4": 2, "llm.int8": 3}[args.quantize] if args.model == "7B" else None
     wname = {"gptq.int4": "int4", "llm.int8": "int8", "none": "bf16"}[args.quantize]
@@ -371,7 +472,7 @@ def main():
             "prompt_len": T,
             "max_seq_length": S,
             "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (bs=1 path does not shard)",
-            "hipgraph": bool(eng.use_graph and eng._graphs) and not fused,
+            "hipgraph": hipgraph_used,
             "fused_step": fused,
             "launches_per_token": 1 if fused else cfg.n_layer * 5 + 2,
         },
@@ -400,6 +501,8 @@ def main():
         "generate": {"tokens_per_s_incl_prompt": round(gen_new / t_gen, 1), "prompt_len": T, "new_tokens": gen_new,
                      "what": "lit_llama_amd.generate(top_k=1) wall time incl. prefill, as generate.py:146-153 reports"},
     }
+    if tp_res is not None:
+        out["tp"] = tp_res
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, args.quantize)

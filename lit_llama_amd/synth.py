@@ -142,3 +142,32 @@ def fill_model_random_int4(model, seed: int = 0) -> None:
                 mod.zeros.fill_(8.0)
             elif name.endswith(("rms_1", "rms_2", "ln_f")):
                 mod.scale.copy_((1.0 + 0.1 * _randn(tuple(mod.scale.shape), gen, dev)).to(mod.scale.dtype))
+
+
+def fill_tp_shard_random_int4(model, seed: int, rank: int) -> None:
+    """Bench-only: rank-local shard of a synthetic int4 model (tp.build_local_model) filled in place.  Replicated
+    tensors (embedding, norm scales, scale / zero of the row-parallel linears) come from a generator seeded the same
+    on every rank; sharded tensors from `seed + 1 + rank`."""
+    from .quantization import ColBlockQuantizedLinear
+
+    dev = model.transformer.wte.weight.device
+    shared = torch.Generator(device=dev)
+    shared.manual_seed(seed)
+    local = torch.Generator(device=dev)
+    local.manual_seed(seed + 1 + rank)
+    with torch.no_grad():
+        model.transformer.wte.weight.copy_(_randn(tuple(model.transformer.wte.weight.shape), shared, dev))
+        for name, mod in model.named_modules():
+            if name.endswith(("rms_1", "rms_2", "ln_f")):
+                mod.scale.copy_((1.0 + 0.1 * _randn(tuple(mod.scale.shape), shared, dev)).to(mod.scale.dtype))
+        for name, mod in model.named_modules():
+            if isinstance(mod, ColBlockQuantizedLinear):
+                N, Kb = mod.quant_weight.shape
+                raw = torch.randint(0, 256, (Kb, N), generator=local, device=dev, dtype=torch.uint8)
+                mod.quant_weight.copy_(raw.t())
+                row_parallel = name.endswith("c_proj")  # attn.c_proj / mlp.c_proj: per-row scale / zero replicated
+                K_full = mod.in_features * (getattr(model.config, "tp_world", 1) if row_parallel else 1)
+                g = shared if row_parallel else local
+                sc = (7.2 / 15.0) * K_full**-0.5 * (1.0 + 0.1 * torch.rand((N, 1), generator=g, device=dev))
+                mod.scales.copy_(sc.to(mod.scales.dtype))
+                mod.zeros.fill_(8.0)

@@ -21,11 +21,11 @@ for st in $STAGES; do
     bench)
       timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
       echo "bench exit $?" | tee -a $OUT/session.log; cat $OUT/bench.json; tail -5 $OUT/bench.err
-      timeout 600 python bench.py --no-graph --no-cpu-baseline --steps 64 > $OUT/bench_nograph.json 2>> $OUT/bench.err
+      timeout 600 python bench.py --no-graph --no-cpu-baseline --no-tp --steps 64 > $OUT/bench_nograph.json 2>> $OUT/bench.err
       cat $OUT/bench_nograph.json ;;
     prof)
       rm -rf $OUT/prof
-      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python bench.py --steps 64 --warmup 8 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
+      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-tp > $OUT/prof_bench.json 2> $OUT/prof.err
       echo "rocprof exit $?" | tee -a $OUT/session.log
       ls $OUT/prof | head
       f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv
@@ -34,7 +34,7 @@ for st in $STAGES; do
       find $OUT/prof -name '*kernel_trace.csv' -size +30M -delete ;;
     pmc)
       rm -rf $OUT/pmc
-      timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o fetch -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/pmc_bench.json 2> $OUT/pmc.err
+      timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o fetch -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-tp > $OUT/pmc_bench.json 2> $OUT/pmc.err
       echo "pmc exit $?" | tee -a $OUT/session.log
       f=$(find $OUT/pmc -name '*counter_collection.csv' | head -1)
       ls $OUT/pmc | head; [ -n "$f" ] && head -3 "$f"
