@@ -139,6 +139,14 @@ int mi355_linear_max_rows(int fmt, int K, int R, int waves);
 
 int mi355_linear_fast_batch(const mi355_linear_args* a, int count, mi355_stream_t stream);
 
+/* The same linear for WIDE inputs (prompt prefill, no-cache evaluation: lit_llama/quantization.py:284-333 at M >= 32,
+ * evaluate/full.py:120-129): LDS-tiled MFMA GEMM over the same Q4 stream (csrc/gemm.hip), any M >= 1.  Takes the
+ * mi355_linear_args of mi355_linear_fast (fmt Q4; R = 1 for STORE / ACCUM, the interleaved R = 2 stream for SWIGLU; no
+ * bias, no attention prologue; N and ldy multiples of 4) plus a scratch buffer of
+ * mi355_linear_gemm_workspace_bytes(M, K) bytes (16-B aligned) for the staged bf16 operands and row statistics. */
+size_t mi355_linear_gemm_workspace_bytes(int M, int K);
+int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Generic (any shape, any M, f32 / bf16 / f16 activations) operators.  They follow the
  * reference arithmetic step by step in f32 and are used for the f32 "plumbing" configuration,

@@ -1,0 +1,322 @@
+// Wide (M >= 32 tokens) int4-weight linear for gfx950: prompt prefill and no-cache evaluation.
+//
+// Replaces the reference's Triton `linear_kernel_4bit_weight` (/root/reference lit_llama/quantization.py:187-333,
+// reached from ColBlockQuantizedLinear.forward :413-421) at the shapes of evaluate/full.py:120-129 (T = 2048, no cache)
+// and of generate.py's prompt pass — where the skinny weight-streaming kernel (gemv.hip) re-reads the whole weight
+// stream once per 13 tokens.
+//
+// Design:
+//  * the weights stay in the decode path's stream layout [tile of 16 rows][unit of 128 k][r][lane][16 B]: a wave reads
+//    a (tile, unit) piece with ONE coalesced 1-KiB load straight into registers (no LDS for weights: a piece is
+//    private to its wave) and turns it into four MFMA A fragments with 7 VALU ops per 8 weights — amortised over the
+//    8 token tiles of the block, so the conversion that bounds the M = 1 path costs 1/8 MFMA slot here;
+//  * the activations of a block (128 tokens x 128 k, bf16) go through LDS, double buffered, 16-B chunks XOR-swizzled by
+//    (token & 7) so that the 16 lanes of a B fragment (16 tokens, same k) hit 8 different 16-B slots;
+//  * workgroup = 4 waves, block tile = 128 tokens x 8 row tiles (2 per wave; for the c_fc1 / c_fc2 pair stream the two
+//    tiles of a wave are the fc1 / fc2 halves of the same 16 rows, so SwiGLU stays in the epilogue): every B fragment
+//    read from LDS feeds two MFMAs, 64 x v_mfma_f32_16x16x32_bf16 per wave and unit against 32 LDS reads;
+//  * blockIdx.x runs over the row blocks, so workgroups that share a token block (the same 32 KiB of activations per
+//    unit) run at the same time and find it in L2;
+//  * operands are staged once per linear by stage_rows_kernel: bf16(norm_scale * x) with RMSNorm's 1/rms kept as a
+//    per-row factor for the epilogue, and the per-row operand sum that undoes the +128 / zero-point offset:
+//        y[m, n] = scale[n] * (acc[m, n] - (128 + zero[n]) * sum_k xb[m, k]) * rinv[m]      (same arithmetic as gemv.hip).
+#include "common.h"
+
+namespace {
+
+constexpr int kBM = 128;     // tokens per block
+constexpr int kSlots = 8;    // 16-row tile slots per block (2 per wave)
+constexpr int kThreads = 256;
+constexpr int kLds = 2 * kBM * 256;  // two buffers of 128 tokens x 128 k bf16
+
+struct GemmParams {
+    const uint8_t* w;
+    unsigned w_bytes;
+    const bf16_t* xb;      // [M, ldxb] staged operands
+    int64_t ldxb;
+    const float* rinv;     // [M]
+    const float* sx;       // [M]
+    const void* scales;
+    const void* zeros;
+    const void* scales2;
+    const void* zeros2;
+    void* y;
+    int64_t ldy;
+    int M, N, K, units, n_tiles;
+    int sz_dtype, y_dtype;
+};
+
+__device__ __forceinline__ float ldsz(const void* p, int i, int dtype) {
+    return dtype == MI355_F32 ? ((const float*)p)[i] : bf16_to_f32(((const bf16_t*)p)[i]);
+}
+
+// one row per workgroup: xb = bf16(norm_scale * x), rinv = rsqrt(mean(x^2) + eps) (1 without norm), sx = sum_k xb
+__global__ __launch_bounds__(256) void stage_rows_kernel(const void* x, int x_dtype, int64_t ldx, const void* norm_scale,
+                                                         int norm_dtype, float eps, int K, int Kp, bf16_t* xb, int64_t ldxb,
+                                                         float* rinv, float* sx) {
+    __shared__ float red[32];
+    const int m = blockIdx.x;
+    float ss = 0.f, sum = 0.f;
+    for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+        bf16_t o = 0;
+        if (k < K) {
+            float v = ld_as_f32(x, (int64_t)m * ldx + k, x_dtype);
+            if (norm_scale != nullptr) {
+                ss += v * v;
+                v *= ld_as_f32(norm_scale, k, norm_dtype);
+            }
+            o = f32_to_bf16(v);
+            sum += bf16_to_f32(o);
+        }
+        xb[(int64_t)m * ldxb + k] = o;
+    }
+    const float tot = block_sum(sum, red);
+    const float tss = block_sum(ss, red);
+    if (threadIdx.x == 0) {
+        sx[m] = tot;
+        rinv[m] = norm_scale != nullptr ? rsqrtf(tss / (float)K + eps) : 1.0f;
+    }
+}
+
+template <int EPI, bool PAIR>
+__global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int nb = blockIdx.x, m0 = blockIdx.y * kBM;
+
+    // this wave's two row tiles
+    int tile[2], rr[2];
+    if (PAIR) {
+        tile[0] = tile[1] = nb * 4 + wave;  // pair tile: 16 rows of c_fc1 (r = 0) and of c_fc2 (r = 1)
+        rr[0] = 0;
+        rr[1] = 1;
+    } else {
+        tile[0] = nb * kSlots + 2 * wave;
+        tile[1] = tile[0] + 1;
+        rr[0] = rr[1] = 0;
+    }
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
+    const unsigned xbytes = (unsigned)((int64_t)p.M * p.ldxb * 2);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.xb, 0, (int)xbytes, 0x00020000);
+    const unsigned lane_off = lane * 16;
+    auto wload = [&](int t, int u) {
+        const bool ok = tile[t] < p.n_tiles;
+        const unsigned off = (unsigned)((tile[t] * p.units + u) * (PAIR ? 2 : 1) + rr[t]) * 1024u;
+        return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rw : rw0, lane_off, ok ? off : 0u, 0));
+    };
+    // activation block of unit u: 2048 chunks of 16 B, 8 per thread; chunk = (token, 16-B column)
+    u32x4 stage[8];
+    auto xload = [&](int u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = i * kThreads + threadIdx.x;
+            const int tok = ch >> 4, col = ch & 15;
+            const unsigned off = (unsigned)(((int64_t)(m0 + tok) * p.ldxb) * 2) + (unsigned)u * 256u + (unsigned)col * 16u;
+            stage[i] = __builtin_bit_cast(
+                u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (m0 + tok) < p.M ? off : 0xFFFFFFF0u, 0, 0));
+        }
+    };
+    auto xstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = i * kThreads + threadIdx.x;
+            const int tok = ch >> 4, col = ch & 15;
+            *(u32x4*)(smem + buf * (kBM * 256) + tok * 256 + ((col ^ (tok & 7)) << 4)) = stage[i];
+        }
+    };
+
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) acc[t][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 wcur[2], wnext[2];
+    wcur[0] = wload(0, 0);
+    wcur[1] = wload(1, 0);
+    xload(0);
+    xstore(0);
+    __syncthreads();
+
+    for (int u = 0; u < p.units; ++u) {
+        const int buf = u & 1;
+        const bool more = u + 1 < p.units;
+        if (more) {
+            xload(u + 1);
+            wnext[0] = wload(0, u + 1);
+            wnext[1] = wload(1, u + 1);
+        }
+        // int4 -> bf16 MFMA A fragments: (w >> 4i) & 0x000F000F | 0x43004300 = (128 + q_2i, 128 + q_2i+1)
+        bf16x8 a[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t v = wcur[t][d];
+                u32x4 f;
+                f[0] = (v & 0x000F000Fu) | 0x43004300u;
+                f[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
+                f[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
+                f[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+                a[t][d] = __builtin_bit_cast(bf16x8, f);
+            }
+        const char* xs = smem + buf * (kBM * 256);
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            const int tok = tt * 16 + c;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const bf16x8 b = *(const bf16x8*)(xs + tok * 256 + (((4 * g + d) ^ (tok & 7)) << 4));
+                acc[0][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][d], b, acc[0][tt], 0, 0, 0);
+                acc[1][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][d], b, acc[1][tt], 0, 0, 0);
+            }
+        }
+        if (more) {
+            xstore(buf ^ 1);
+            wcur[0] = wnext[0];
+            wcur[1] = wnext[1];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (g, c) holds rows 4 g .. 4 g + 3 of its tiles for token tt * 16 + c
+    float sc[2][4], zp[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = tile[t] * 16 + 4 * g + r;
+            const bool ok = n < p.N;
+            const void* sp = (PAIR && t == 1) ? p.scales2 : p.scales;
+            const void* zq = (PAIR && t == 1) ? p.zeros2 : p.zeros;
+            sc[t][r] = ok ? ldsz(sp, n, p.sz_dtype) : 0.f;
+            zp[t][r] = ok ? 128.f + ldsz(zq, n, p.sz_dtype) : 0.f;
+        }
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+        const int m = m0 + tt * 16 + c;
+        if (m >= p.M) continue;
+        const float sxm = p.sx[m], ri = p.rinv[m];
+        float v[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[t][r] = sc[t][r] * (acc[t][tt][r] - zp[t][r] * sxm) * ri;
+        if constexpr (EPI == MI355_EPI_SWIGLU) {
+            const int n = tile[0] * 16 + 4 * g;
+            if (n < p.N) {  // N % 4 == 0 (host check)
+                bf16_t* dst = (bf16_t*)p.y + (int64_t)m * p.ldy + n;
+                u32x2 o;
+                o[0] = (uint32_t)f32_to_bf16(swiglu_f32(v[0][0], v[1][0])) | ((uint32_t)f32_to_bf16(swiglu_f32(v[0][1], v[1][1])) << 16);
+                o[1] = (uint32_t)f32_to_bf16(swiglu_f32(v[0][2], v[1][2])) | ((uint32_t)f32_to_bf16(swiglu_f32(v[0][3], v[1][3])) << 16);
+                *(u32x2*)dst = o;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int n = tile[t] * 16 + 4 * g;
+                if (n >= p.N) continue;
+                if (p.y_dtype == MI355_F32) {
+                    float* dst = (float*)p.y + (int64_t)m * p.ldy + n;
+                    f32x4 o = {v[t][0], v[t][1], v[t][2], v[t][3]};
+                    if constexpr (EPI == MI355_EPI_ACCUM) o += *(const f32x4*)dst;
+                    *(f32x4*)dst = o;
+                } else {
+                    bf16_t* dst = (bf16_t*)p.y + (int64_t)m * p.ldy + n;
+                    float o[4] = {v[t][0], v[t][1], v[t][2], v[t][3]};
+                    if constexpr (EPI == MI355_EPI_ACCUM) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] += bf16_to_f32(dst[r]);
+                    }
+                    u32x2 pk;
+                    pk[0] = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                    pk[1] = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    *(u32x2*)dst = pk;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, bool PAIR>
+int launch_gemm(const GemmParams& p, hipStream_t s) {
+    static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (attr_err != hipSuccess) {
+        mi355_set_error("hipFuncSetAttribute(gemm) failed: %s", hipGetErrorString(attr_err));
+        return (int)attr_err;
+    }
+    const int per_block = PAIR ? 4 : kSlots;
+    const dim3 grid((p.n_tiles + per_block - 1) / per_block, (p.M + kBM - 1) / kBM);
+    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR>), grid, dim3(kThreads), kLds, s, p);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t mi355_linear_gemm_workspace_bytes(int M, int K) {
+    if (M <= 0 || K <= 0) return 0;
+    const size_t kp = ((size_t)K + 127) / 128 * 128;
+    return (size_t)M * kp * 2 + (size_t)M * 8 + 256;
+}
+
+extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, size_t workspace_bytes,
+                                 mi355_stream_t stream) {
+    MI355_CHECK_ARG(a != nullptr && workspace != nullptr, MI355_E_ARG, "linear_gemm: null argument");
+    MI355_CHECK_ARG(a->fmt == MI355_W_Q4, MI355_E_ARG, "linear_gemm: the wide path handles the Q4 stream only (fmt %d)", a->fmt);
+    MI355_CHECK_ARG(a->w && a->x && a->y && a->scales && a->zeros, MI355_E_ARG, "linear_gemm: null w/x/y/scales/zeros");
+    MI355_CHECK_ARG(a->M >= 1 && a->N > 0 && a->K > 0, MI355_E_SHAPE, "linear_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+    MI355_CHECK_ARG(a->attn_partials == nullptr && a->bias == nullptr, MI355_E_ARG, "linear_gemm: no bias / attention prologue");
+    const bool swiglu = a->epi == MI355_EPI_SWIGLU;
+    MI355_CHECK_ARG(a->epi >= MI355_EPI_STORE && a->epi <= MI355_EPI_SWIGLU, MI355_E_ARG, "linear_gemm: bad epi");
+    MI355_CHECK_ARG(swiglu ? (a->R == 2 && a->scales2 && a->zeros2 && a->y_dtype == MI355_BF16) : a->R == 1, MI355_E_ARG,
+                    "linear_gemm: STORE / ACCUM take the R = 1 stream, SWIGLU the interleaved R = 2 stream with bf16 output");
+    MI355_CHECK_ARG(a->N % 4 == 0 && a->ldy % 4 == 0, MI355_E_SHAPE, "linear_gemm: N and ldy must be multiples of 4");
+    auto two = [](int d) { return d == MI355_F32 || d == MI355_BF16; };
+    MI355_CHECK_ARG(two(a->x_dtype) && two(a->y_dtype) && two(a->sz_dtype), MI355_E_DTYPE, "linear_gemm: dtypes must be f32 or bf16");
+    MI355_CHECK_ARG(a->norm_scale == nullptr || two(a->norm_dtype), MI355_E_DTYPE, "linear_gemm: norm scale dtype");
+    MI355_CHECK_ARG(workspace_bytes >= mi355_linear_gemm_workspace_bytes(a->M, a->K) && (uintptr_t)workspace % 16 == 0,
+                    MI355_E_SHAPE, "linear_gemm: workspace of %zu bytes is too small (need %zu)", workspace_bytes,
+                    mi355_linear_gemm_workspace_bytes(a->M, a->K));
+    hipStream_t s = (hipStream_t)stream;
+    const int units = (a->K + 127) / 128, kp = units * 128;
+    bf16_t* xb = (bf16_t*)workspace;
+    float* rinv = (float*)((char*)workspace + (size_t)a->M * kp * 2);
+    float* sx = rinv + a->M;
+    hipLaunchKernelGGL(stage_rows_kernel, dim3(a->M), dim3(256), 0, s, a->x, a->x_dtype, a->ldx, a->norm_scale, a->norm_dtype,
+                       a->eps, a->K, kp, xb, (int64_t)kp, rinv, sx);
+    MI355_LAUNCH_CHECK();
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.w = (const uint8_t*)a->w;
+    {
+        const size_t wb = mi355_packed_bytes(MI355_W_Q4, a->N, a->K, a->R, swiglu ? 1 : 0);
+        MI355_CHECK_ARG(wb > 0 && wb < 0xFFFFFFF0ull, MI355_E_SHAPE, "linear_gemm: weight stream of %zu B", wb);
+        p.w_bytes = (unsigned)wb;
+    }
+    MI355_CHECK_ARG((size_t)a->M * kp * 2 < 0xFFFFFFF0ull, MI355_E_SHAPE, "linear_gemm: M x K too large for one launch");
+    p.xb = xb;
+    p.ldxb = kp;
+    p.rinv = rinv;
+    p.sx = sx;
+    p.scales = a->scales;
+    p.zeros = a->zeros;
+    p.scales2 = a->scales2;
+    p.zeros2 = a->zeros2;
+    p.y = a->y;
+    p.ldy = a->ldy;
+    p.M = a->M;
+    p.N = a->N;
+    p.K = a->K;
+    p.units = units;
+    p.n_tiles = (a->N + 15) / 16;
+    p.sz_dtype = a->sz_dtype;
+    p.y_dtype = a->y_dtype;
+    if (swiglu) return launch_gemm<MI355_EPI_SWIGLU, true>(p, s);
+    if (a->epi == MI355_EPI_ACCUM) return launch_gemm<MI355_EPI_ACCUM, false>(p, s);
+    return launch_gemm<MI355_EPI_STORE, false>(p, s);
+}

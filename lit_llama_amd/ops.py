@@ -141,6 +141,41 @@ def linear_fast(
     return out
 
 
+_GEMM_WS = {}  # device -> scratch tensor of the wide linear (staged bf16 operands + row statistics)
+
+
+def linear_gemm(x2d: torch.Tensor, stream: torch.Tensor, R: int, N: int, K: int, *, scales: torch.Tensor,
+                zeros: torch.Tensor, scales2: Optional[torch.Tensor] = None, zeros2: Optional[torch.Tensor] = None,
+                norm_scale: Optional[torch.Tensor] = None, eps: float = 1e-5, epi: int = EPI_STORE,
+                out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """y[M, N] = epi(x2d[M, K] . W^T) for WIDE inputs through the LDS-tiled MFMA GEMM over the Q4 stream
+    (mi355_linear_gemm, csrc/gemm.hip): prompt prefill / no-cache evaluation (evaluate/full.py:120-129)."""
+    require_gpu(x2d, "linear_gemm")
+    assert x2d.dim() == 2 and x2d.shape[1] == K and x2d.stride(1) == 1
+    M = x2d.shape[0]
+    if out is None:
+        assert epi != EPI_ACCUM, "accumulate epilogue needs `out`"
+        out = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    need = int(lib().mi355_linear_gemm_workspace_bytes(M, K))
+    ws = _GEMM_WS.get(x2d.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 22), dtype=torch.uint8, device=x2d.device)
+        _GEMM_WS[x2d.device] = ws
+    a = LinearArgs()
+    a.fmt, a.R, a.w, a.N, a.K, a.M = W_Q4, R, ptr(stream), N, K, M
+    a.x, a.x_dtype, a.ldx = ptr(x2d), dtype_code(x2d.dtype), x2d.stride(0)
+    a.norm_scale = ptr(norm_scale)
+    a.norm_dtype = dtype_code(norm_scale.dtype) if norm_scale is not None else F32
+    a.eps = eps
+    a.scales, a.zeros, a.scales2, a.zeros2 = ptr(scales), ptr(zeros), ptr(scales2), ptr(zeros2)
+    a.sz_dtype = dtype_code(scales.dtype)
+    a.epi = epi
+    a.y, a.y_dtype, a.ldy = ptr(out), dtype_code(out.dtype), out.stride(0)
+    check(lib().mi355_linear_gemm(C.byref(a), ptr(ws), ws.numel(), stream_ptr()), "mi355_linear_gemm")
+    return out
+
+
 def linear_int8(
     x2d: torch.Tensor,
     stream: torch.Tensor,

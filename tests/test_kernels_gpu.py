@@ -418,3 +418,65 @@ def test_int8_linear_matches_oracle(dev, N, K, M, R, outliers):
     # sanity: the quantised product tracks the fp product
     fp = x.float() @ w.t()
     assert (y - fp).abs().max().item() <= 5e-2 * fp.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------- wide int4 GEMM (prefill)
+@pytest.mark.parametrize("M,N,K,epi", [(32, 64, 128, "store"), (128, 4096, 4096, "store"), (200, 4096, 4096, "accum"),
+                                        (257, 11008, 4096, "swiglu"), (96, 4096, 11008, "accum"), (40, 72, 200, "store"),
+                                        (512, 12288, 4096, "store")])
+def test_linear_gemm_matches_the_skinny_kernel_and_oracle(dev, M, N, K, epi):
+    """mi355_linear_gemm (LDS-tiled MFMA GEMM over the Q4 stream) against (a) the CPU oracle's dequantise-then-F.linear
+    (lit_llama/quantization.py:422-423) within the bf16-operand tolerance and (b) the skinny weight-streaming kernel,
+    which computes the same bf16 products with f32 accumulation in another order."""
+    gen = torch.Generator().manual_seed(M * 7 + N + K)
+    def qw():
+        q = torch.randint(0, 16, (N, K), generator=gen, dtype=torch.uint8)
+        scales = (torch.rand((N, 1), generator=gen) * 0.02 + 0.005).to(torch.bfloat16)
+        zeros = torch.randint(5, 11, (N, 1), generator=gen).to(torch.bfloat16)
+        return q, scales, zeros
+    q0, s0, z0 = qw()
+    x = (torch.randn((M, K), generator=gen)).to(torch.bfloat16)
+    pk = lambda q: synth.pack_colblock(q, 4).to(dev)  # noqa: E731
+    w0 = (q0.float() - z0.float()) * s0.float()
+    xd = x.to(dev)
+    if epi == "swiglu":
+        q1, s1, z1 = qw()
+        w1 = (q1.float() - z1.float()) * s1.float()
+        stream = ops.repack_q4(pk(q0), pk(q1), N, K, 2)
+        kw = dict(scales=s0.reshape(-1).to(dev), zeros=z0.reshape(-1).to(dev), scales2=s1.reshape(-1).to(dev),
+                  zeros2=z1.reshape(-1).to(dev), epi=nat.EPI_SWIGLU, out_dtype=torch.bfloat16)
+        got = ops.linear_gemm(xd, stream, 2, N, K, **kw).float().cpu()
+        ref = torch.nn.functional.silu(x.float() @ w0.t()) * (x.float() @ w1.t())
+        skinny = ops.linear_fast(xd, stream, nat.W_Q4, 2, N, K, **kw).float().cpu()
+    else:
+        stream = ops.repack_q4(pk(q0), None, N, K, 1)
+        kw = dict(scales=s0.reshape(-1).to(dev), zeros=z0.reshape(-1).to(dev))
+        base = torch.randn((M, N), generator=gen)
+        if epi == "accum":
+            o1, o2 = base.clone().to(dev), base.clone().to(dev)
+            got = ops.linear_gemm(xd, stream, 1, N, K, epi=nat.EPI_ACCUM, out=o1, **kw).float().cpu()
+            skinny = ops.linear_fast(xd, stream, nat.W_Q4, 1, N, K, epi=nat.EPI_ACCUM, out=o2, **kw).float().cpu()
+            ref = base + x.float() @ w0.t()
+        else:
+            got = ops.linear_gemm(xd, stream, 1, N, K, out_dtype=torch.float32, **kw).float().cpu()
+            skinny = ops.linear_fast(xd, stream, nat.W_Q4, 1, N, K, out_dtype=torch.float32, **kw).float().cpu()
+            ref = x.float() @ w0.t()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-2 * scale + 1e-3, f"vs oracle: {(got - ref).abs().max().item():.4e} (scale {scale:.3f})"
+    assert (got - skinny).abs().max().item() <= (8e-3 if epi == "swiglu" else 1e-4) * scale + 1e-5, \
+        f"vs skinny kernel: {(got - skinny).abs().max().item():.4e} (scale {scale:.3f})"
+
+
+def test_linear_gemm_with_fused_rmsnorm_matches_the_skinny_kernel(dev):
+    gen = torch.Generator().manual_seed(5)
+    M, N, K = 160, 512, 4096
+    q = torch.randint(0, 16, (N, K), generator=gen, dtype=torch.uint8)
+    scales = (torch.rand((N,), generator=gen) * 0.02 + 0.005).to(torch.bfloat16).to(dev)
+    zeros = torch.randint(5, 11, (N,), generator=gen).to(torch.bfloat16).to(dev)
+    x = (torch.randn((M, K), generator=gen) * 3).to(dev)  # f32 residual stream
+    g = (1 + 0.1 * torch.randn((K,), generator=gen)).to(torch.bfloat16).to(dev)
+    stream = ops.repack_q4(synth.pack_colblock(q, 4).to(dev), None, N, K, 1)
+    a = ops.linear_gemm(x, stream, 1, N, K, scales=scales, zeros=zeros, norm_scale=g, eps=1e-5, out_dtype=torch.float32)
+    b = ops.linear_fast(x, stream, nat.W_Q4, 1, N, K, scales=scales, zeros=zeros, norm_scale=g, eps=1e-5,
+                        out_dtype=torch.float32)
+    assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
