@@ -368,6 +368,9 @@ typedef struct mi355_model {
     float* attn_part;     /* [n_head][attn_splits][hs + 4] partial records of the split decode attention, or NULL */
     int32_t attn_splits;  /* > 1: T == 1 steps run the attention over attn_splits workgroups per head */
     int32_t reserved0;
+    void* gemm_ws;        /* scratch of mi355_linear_gemm_workspace_bytes(max_T, max K) bytes or NULL: with it, steps of
+                             >= 32 tokens of an int4 model take the wide GEMM instead of chunks through the skinny kernel */
+    uint64_t gemm_ws_bytes;
 } mi355_model;
 
 /* copy token ids / positions into the model's device slots (tiny kernel; arguments travel by value) */

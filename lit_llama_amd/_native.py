@@ -97,6 +97,7 @@ class Model(C.Structure):
         ("partial", c_void_p), ("logits", c_void_p),
         ("tokens", c_void_p), ("pos", c_void_p), ("next_token", c_void_p), ("out_tokens", c_void_p),
         ("attn_part", c_void_p), ("attn_splits", c_int32), ("reserved0", c_int32),
+        ("gemm_ws", c_void_p), ("gemm_ws_bytes", C.c_uint64),
     ]
 
 

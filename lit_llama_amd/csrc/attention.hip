@@ -14,6 +14,11 @@
 // global round trip) sits between the qkv projection and the attention output.
 #include "common.h"
 
+// flash_prefill.hip
+int mi355_flash_prefill(const void* qkv, int qkv_dtype, int64_t ld_qkv, const float* rope, int rope_gathered,
+                        const int32_t* pos, const void* kcache, const void* vcache, int T, int n_head, int S, void* y,
+                        int64_t ldy, float scale, hipStream_t s);
+
 namespace {
 
 struct AttnParams {
@@ -528,6 +533,13 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
             hipLaunchKernelGGL(rope_kv_write_kernel<bf16_t>, grid, dim3(thr), 0, s, p);
         MI355_LAUNCH_CHECK();
     }
+    // many query tokens against a bf16 cache at the LLaMA head size: flash-style MFMA kernel (flash_prefill.hip)
+    // (with a cache: rows [0, pos[t]]; without: the T tokens themselves, K / V in kv_tmp, token t at position t)
+    if (a->T >= 32 && a->B == 1 && esz == 2 && a->hs == 128 && (a->qkv_dtype == MI355_F32 || a->qkv_dtype == MI355_BF16) &&
+        a->y_dtype == MI355_BF16 && a->n_split <= 1 && a->ld_qkv % 8 == 0 && a->ldy % 4 == 0 &&
+        (int64_t)p.S * 256 < 0x7fffffffLL)
+        return mi355_flash_prefill(a->qkv, a->qkv_dtype, a->ld_qkv, a->rope, a->rope_gathered, p.pos, p.kcache, p.vcache,
+                                   a->T, a->n_head, p.S, a->y, a->ldy, p.scale, s);
     int ns = a->n_split > 1 ? a->n_split : 1;
     MI355_CHECK_ARG(ns == 1 || a->partials != nullptr, MI355_E_ARG, "attention: n_split > 1 needs a partials buffer");
     MI355_CHECK_ARG(ns <= 64 && (int64_t)a->B * ns <= 65535, MI355_E_SHAPE, "attention: n_split too large");

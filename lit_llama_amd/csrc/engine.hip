@@ -19,7 +19,7 @@ namespace {
 
 __global__ void set_step_kernel(int32_t* tokens, int32_t* pos, const void* idx, int idx_is_i64, int T, int pos0,
                                 const int32_t* next_token, int from_next) {
-    const int t = threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < T) {
         int32_t tok;
         if (from_next)
@@ -81,6 +81,33 @@ int run_linear_rows(const mi355_model* m, const mi355_weight& w, const void* x, 
 int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x_dtype, int M, int64_t ldx,
                const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy, hipStream_t s,
                const float* attn_partials = nullptr) {
+    // wide inputs (prompt chunks of >= 32 tokens) of an int4 model: the LDS-tiled MFMA GEMM over the same stream
+    if (w.fmt == MI355_W_Q4 && M >= 32 && m->gemm_ws != nullptr && attn_partials == nullptr && w.N % 4 == 0 && ldy % 4 == 0) {
+        mi355_linear_args a;
+        memset(&a, 0, sizeof(a));
+        a.fmt = w.fmt;
+        a.R = w.R;
+        a.w = w.w;
+        a.N = w.N;
+        a.K = w.K;
+        a.x = x;
+        a.x_dtype = x_dtype;
+        a.M = M;
+        a.ldx = ldx;
+        a.norm_scale = norm_scale;
+        a.norm_dtype = m->param_dtype;
+        a.eps = m->eps;
+        a.scales = w.scales;
+        a.zeros = w.zeros;
+        a.scales2 = w.scales2;
+        a.zeros2 = w.zeros2;
+        a.sz_dtype = w.sz_dtype;
+        a.epi = epi;
+        a.y = y;
+        a.y_dtype = y_dtype;
+        a.ldy = ldy;
+        return mi355_linear_gemm(&a, m->gemm_ws, (size_t)m->gemm_ws_bytes, s);
+    }
     const int cap = mi355_linear_max_rows(w.fmt, w.K, w.R, w.waves);
     MI355_CHECK_ARG(cap >= 1, MI355_E_SHAPE, "forward: a row of K=%d does not fit LDS", w.K);
     if (M <= cap) return run_linear_rows(m, w, x, x_dtype, M, ldx, norm_scale, epi, y, y_dtype, ldy, s, attn_partials);
@@ -143,13 +170,13 @@ int run_linear_rows(const mi355_model* m, const mi355_weight& w, const void* x, 
 extern "C" int mi355_set_step(const mi355_model* m, const void* idx, int idx_is_i64, int T, int pos0,
                               int from_next_token, mi355_stream_t stream) {
     MI355_CHECK_ARG(m != nullptr && m->tokens && m->pos, MI355_E_ARG, "set_step: null model/slots");
-    MI355_CHECK_ARG(T >= 1 && T <= m->max_T && T <= 64, MI355_E_SHAPE, "set_step: T=%d outside 1..%d", T, m->max_T);
+    MI355_CHECK_ARG(T >= 1 && T <= m->max_T, MI355_E_SHAPE, "set_step: T=%d outside 1..%d", T, m->max_T);
     MI355_CHECK_ARG(from_next_token ? (m->next_token != nullptr && T == 1) : (idx != nullptr), MI355_E_ARG,
                     "set_step: no token source");
     MI355_CHECK_ARG(pos0 >= 0 && pos0 + T <= m->block_size, MI355_E_SHAPE,
                     "set_step: positions %d..%d exceed block_size %d (RoPE table)", pos0, pos0 + T - 1, m->block_size);
-    hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, m->tokens, m->pos, idx, idx_is_i64,
-                       T, pos0, m->next_token, from_next_token);
+    hipLaunchKernelGGL(set_step_kernel, dim3((T + 63) / 64), dim3(64), 0, (hipStream_t)stream, m->tokens, m->pos, idx,
+                       idx_is_i64, T, pos0, m->next_token, from_next_token);
     MI355_LAUNCH_CHECK();
     return 0;
 }

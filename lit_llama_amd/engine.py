@@ -236,6 +236,13 @@ class DecodeEngine:
                 max_T = 0
             if max_T < 1:
                 raise EngineUnavailable("hidden size does not fit LDS")
+            # int4 models: prompt chunks of >= 32 tokens go through the wide MFMA GEMM + flash attention (csrc/gemm.hip,
+            # flash_prefill.hip), so the chunk is bounded by scratch memory only (65 MB of f32 logits rows at 512 x 32000)
+            self.gemm_ws = None
+            if kinds == {"q4"} and _env_int("MI355_PREFILL_GEMM", 1):
+                max_T = max(max_T, _env_int("MI355_PREFILL_T", 512))
+                need = int(lib().mi355_linear_gemm_workspace_bytes(max_T, max(C_, self.n_hidden)))
+                self.gemm_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             self.max_T = max_T
 
             local_heads = first.attn.c_attn.out_features // (3 * hs)
@@ -279,6 +286,8 @@ class DecodeEngine:
         m.tokens, m.pos, m.next_token = ptr(self.tokens), ptr(self.pos), ptr(self.next_token)
         m.out_tokens = ptr(self.out_tokens)
         m.attn_part, m.attn_splits = ptr(self.attn_part), self.attn_splits
+        if self.gemm_ws is not None:
+            m.gemm_ws, m.gemm_ws_bytes = ptr(self.gemm_ws), self.gemm_ws.numel()
         self.m = m
         self.S = 0
         self._cache_pool = {}  # S -> list of (k, v): kept across reset_cache() so captured graphs stay valid

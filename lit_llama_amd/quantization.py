@@ -107,7 +107,11 @@ class ColBlockQuantizedLinear(torch.nn.Module):
         x2d = inp.reshape(-1, inp.shape[-1])
         if x2d.stride(-1) != 1:
             x2d = x2d.contiguous()
-        if self.fast_eligible(inp.dtype):
+        if self.fast_eligible(inp.dtype) and x2d.shape[0] >= 32 and self.out_features % 4 == 0 and self.bias is None:
+            # wide input (prompt / no-cache evaluation, evaluate/full.py:120-129): LDS-tiled MFMA GEMM over the stream
+            y = ops.linear_gemm(x2d, self.weight_stream(1), 1, self.out_features, self.in_features,
+                                scales=self.scales.reshape(-1), zeros=self.zeros.reshape(-1), out_dtype=inp.dtype)
+        elif self.fast_eligible(inp.dtype):
             R = 2 if self.out_features % 32 == 0 and self.out_features >= 16384 else 1
             y = ops.linear_fast(
                 x2d, self.weight_stream(R), nat.W_Q4, R, self.out_features, self.in_features,
