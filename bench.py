@@ -433,6 +433,27 @@ def main():
         lit_llama_amd.generate(model, prompt, gen_new, top_k=1, max_seq_length=T + gen_new)
         torch.cuda.synchronize(dev)
         t_gen = time.perf_counter() - t_g0
+        # prompt prefill at the reference's evaluation length (evaluate/full.py:120-129: T = 2048): wide int4 GEMM +
+        # flash attention, MFMA-bound
+        prefill = None
+        if args.quantize == "gptq.int4" and cfg.block_size >= 2048:
+            T2 = 2048
+            long_prompt = synth.make_prompt(T2, vocab=cfg.vocab_size, seed=4321).to(dev)
+            with torch.cuda.stream(eng.stream):
+                eng._ensure_cache(T2 + 8)
+                eng.prefill(long_prompt, 0, all_logits=False, argmax=True)  # warm
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(eng.stream)
+                eng.prefill(long_prompt, 0, all_logits=False, argmax=True)
+                e1.record(eng.stream)
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            L = cfg.n_layer
+            flops = 2.0 * T2 * L * (4 * C_ * C_ + 3 * C_ * H) + 2.0 * 2.0 * L * C_ * T2 * (T2 + 1) / 2 + 2.0 * C_ * cfg.padded_vocab_size
+            prefill = {"tokens": T2, "ms": round(ms, 2), "tokens_per_s": round(T2 / ms * 1e3, 1),
+                       "tflops": round(flops / ms / 1e9, 1), "peak_tflops": 2500.0, "bound": "mfma",
+                       "frac": round(flops / ms / 1e9 / 2500.0, 4), "chunk": eng.max_T,
+                       "kernels": "gemm_q4_kernel (int4 stream -> bf16 MFMA 16x16x32) + flash_prefill_kernel"}
     tp_res = None
     if not args.no_tp and args.quantize == "gptq.int4":
         # free the 7B replica first: the 65B shard of a small world is tens of GB
@@ -498,6 +519,7 @@ def main():
             f"frac_of_{wname}_weight_roofline": round(tok_s_gpu * bpt["weights"] / HBM_PEAK, 4),
         },
         "prefill_s": round(t_prefill, 4),
+        "prefill": prefill,
         "generate": {"tokens_per_s_incl_prompt": round(gen_new / t_gen, 1), "prompt_len": T, "new_tokens": gen_new,
                      "what": "lit_llama_amd.generate(top_k=1) wall time incl. prefill, as generate.py:146-153 reports"},
     }

@@ -4,15 +4,19 @@
 // :230 for T >= 32 query tokens (evaluate/full.py:120-129 runs T = 2048): the one-workgroup-per-(head, query) kernel
 // of attention.hip re-reads a head's K / V once per query.
 //
-// One workgroup = 64 queries of one head (4 waves x 16), walking the keys 32 at a time up to the causal limit:
+// One workgroup = 128 queries of one head (8 waves x 16), walking the keys 32 at a time up to the causal limit:
 //   * S^T = K Q^T (keys x queries) rather than Q K^T: the MFMA result then has a QUERY per lane column and 4 + 4 keys
 //     per lane in registers, which is exactly the B-operand shape of the next product O^T = V^T P^T (32 keys x 16
 //     queries) — up to a fixed permutation of the 32 keys, which a sum over keys does not care about as long as V^T
 //     uses the same one.  So the probabilities never leave their registers (no LDS round trip, no transposition of
 //     P), and the online-softmax rescale is a per-lane scalar.  Row maxima / sums run over the 8 registers and two
 //     permlane swaps (lane ^ 16, lane ^ 32).
-//   * K tiles go to LDS as they are (XOR-swizzled 16-B chunks); V tiles are TRANSPOSED on the way in (d-major, keys in
-//     the permuted order, rows padded to 80 B: conflict-free 16-B fragment reads), both double buffered.
+//   * K tiles go to LDS as they are (16-B chunks XOR-swizzled by key & 15: conflict-free fragment reads); V tiles are TRANSPOSED on the way in (d-major, keys in
+//     the permuted order, rows padded to 96 B: conflict-free 16-B fragment reads), both double buffered.  The
+//     transposition happens in registers: a thread loads the same 8 dimensions of 4 consecutive keys and writes 8-byte
+//     groups of 4 keys (v_perm_b32), the row it writes rotated by its column so that the 16 columns of an instruction
+//     hit 16 different bank groups (2-byte stores were 8-way bank conflicted and bounded the kernel: 339 us per layer
+//     at T = 2048).
 //   * q is RoPE'd in registers while it is loaded (f32 qkv rows, rope row = the token's position); the new K / V rows
 //     were written to the cache by rope_kv_write_kernel before this launch.
 #include "common.h"
@@ -20,9 +24,10 @@
 namespace {
 
 constexpr int kHs = 128;
-constexpr int kBQ = 64;    // queries per workgroup
+constexpr int kBQ = 128;   // queries per workgroup (8 waves x 16)
+constexpr int kThreadsF = 512;
 constexpr int kBK = 32;    // keys per step
-constexpr int kVtRow = 80; // bytes per d-row of the transposed V tile (32 keys x 2 B, padded)
+constexpr int kVtRow = 96; // bytes per d-row of the transposed V tile (32 keys x 2 B, padded: conflict-free b128 reads)
 constexpr int kKTile = kBK * 256, kVTile = kHs * kVtRow;
 constexpr int kLds = 2 * (kKTile + kVTile);
 
@@ -34,13 +39,17 @@ struct FlashParams {
     const bf16_t* vcache;  // [n_head, S, 128]
     bf16_t* y;           // [T, ldy]
     int64_t ld_qkv, ldy;
-    int T, n_head, S, qkv_dtype, rope_gathered;
+    int T, n_head, S, qkv_dtype, rope_gathered, q_blocks;
     float scale;
 };
 
-__global__ __launch_bounds__(256) void flash_prefill_kernel(const FlashParams p) {
+__global__ __launch_bounds__(kThreadsF) void flash_prefill_kernel(const FlashParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int h = blockIdx.y, qb = blockIdx.x;
+    // XCD-aware order (workgroup b runs on XCD b % 8): all query blocks of a head on one XCD, whose L2 then holds that
+    // head's K / V once; the longest (last) query blocks first
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int h = xcd + 8 * (idx / p.q_blocks), qb = p.q_blocks - 1 - idx % p.q_blocks;
+    if (h >= p.n_head) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int q_idx = qb * kBQ + wave * 16 + c;  // this lane's query (column of every MFMA result below)
@@ -86,34 +95,49 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const FlashParams p)
     const bf16_t* vc = p.vcache + (int64_t)h * p.S * kHs;
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kc, 0, n_keys * 256, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, n_keys * 256, 0x00020000);
-    // tile staging: 512 chunks of 16 B per tile, 2 per thread: chunk = (key, 16-B column)
-    u32x4 ks[2], vs[2];
+    // tile staging.  K: 512 chunks of 16 B, one per thread: chunk = (key, 16-B column).  V: threads 0..127 take
+    // (group of 4 consecutive keys, 16-B column): 4 loads, transposed in registers.
+    u32x4 ks, vs[4];
+    const int vgrp = threadIdx.x >> 4, vcol = threadIdx.x & 15;  // key group 0..7 (threads < 128), column 0..15
     auto tload = [&](int kb) {
+        {
+            const int key = kb * kBK + (threadIdx.x >> 4);
+            const unsigned off = key < n_keys ? (unsigned)key * 256u + (unsigned)(threadIdx.x & 15) * 16u : 0xFFFFFFF0u;
+            ks = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+        }
+        if (threadIdx.x < 128) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ch = i * 256 + threadIdx.x;
-            const int key = kb * kBK + (ch >> 4);
-            const unsigned off = key < n_keys ? (unsigned)key * 256u + (unsigned)(ch & 15) * 16u : 0xFFFFFFF0u;
-            ks[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
-            vs[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb * kBK + vgrp * 4 + r;
+                const unsigned off = key < n_keys ? (unsigned)key * 256u + (unsigned)vcol * 16u : 0xFFFFFFF0u;
+                vs[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
+            }
         }
     };
     auto tstore = [&](int buf) {
         char* kt = smem + buf * (kKTile + kVTile);
         char* vt = kt + kKTile;
+        {
+            const int key = threadIdx.x >> 4, col = threadIdx.x & 15;
+            *(u32x4*)(kt + key * 256 + ((col ^ (key & 15)) << 4)) = ks;
+        }
+        if (threadIdx.x < 128) {
+            // keys 4 vg' .. + 3 of 16-key tile kt16 sit at positions 8 g' + (kt16 ? 4 : 0) + 0..3 of a d-row: 8 bytes
+            const int kt16 = vgrp >> 2, gq = vgrp & 3;
+            const int pbyte = (8 * gq + (kt16 ? 4 : 0)) * 2;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ch = i * 256 + threadIdx.x;
-            const int key = ch >> 4, col = ch & 15;
-            *(u32x4*)(kt + key * 256 + ((col ^ (key & 7)) << 4)) = ks[i];
-            // V transposed: d-major rows, the key at position 8 g' + j with key = (j < 4 ? 4 g' + j : 16 + 4 g' + j - 4)
-            const int kt16 = key >> 4, w16 = key & 15;
-            const int ppos = 8 * (w16 >> 2) + (kt16 ? 4 : 0) + (w16 & 3);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t v = vs[i][e];
-                *(bf16_t*)(vt + (col * 8 + 2 * e) * kVtRow + ppos * 2) = (bf16_t)(v & 0xffffu);
-                *(bf16_t*)(vt + (col * 8 + 2 * e + 1) * kVtRow + ppos * 2) = (bf16_t)(v >> 16);
+            for (int i = 0; i < 8; ++i) {
+                const int e = (i + vcol) & 7;  // rotate the row by the column: spreads an instruction over the banks
+                const int dw = e >> 1;
+                u32x2 o;
+                if (e & 1) {
+                    o[0] = __builtin_amdgcn_perm(vs[1][dw], vs[0][dw], 0x07060302u);
+                    o[1] = __builtin_amdgcn_perm(vs[3][dw], vs[2][dw], 0x07060302u);
+                } else {
+                    o[0] = __builtin_amdgcn_perm(vs[1][dw], vs[0][dw], 0x05040100u);
+                    o[1] = __builtin_amdgcn_perm(vs[3][dw], vs[2][dw], 0x05040100u);
+                }
+                *(u32x2*)(vt + (vcol * 8 + e) * kVtRow + pbyte) = o;
             }
         }
     };
@@ -128,21 +152,28 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const FlashParams p)
     __syncthreads();
     for (int kb = 0; kb < n_kb; ++kb) {
         const int buf = kb & 1;
-        const bool more = kb + 1 < n_kb;
-        if (more) tload(kb + 1);
+        tload(kb + 1);  // unconditional (past the last block: offsets beyond n_keys read zeros): no vmcnt drain at a join
         const char* kt = smem + buf * (kKTile + kVTile);
         const char* vt = kt + kKTile;
+        // every fragment of the block is requested up front: K (8 x 16 B) for the scores, V^T (8 x 16 B) lands while the
+        // softmax arithmetic runs
+        bf16x8 ka[2][4], va[8];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int key = t2 * 16 + c;  // A-operand row of this lane
+#pragma unroll
+            for (int dc = 0; dc < 4; ++dc) ka[t2][dc] = *(const bf16x8*)(kt + key * 256 + (((4 * dc + g) ^ (key & 15)) << 4));
+        }
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) va[dt] = *(const bf16x8*)(vt + (dt * 16 + c) * kVtRow + g * 16);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- S^T[key][q] for the two 16-key tiles
         f32x4 st[2];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             st[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int key = t2 * 16 + c;  // A-operand row of this lane
 #pragma unroll
-            for (int dc = 0; dc < 4; ++dc) {
-                const bf16x8 ka = *(const bf16x8*)(kt + key * 256 + (((4 * dc + g) ^ (key & 7)) << 4));
-                st[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bq[dc], st[t2], 0, 0, 0);
-            }
+            for (int dc = 0; dc < 4; ++dc) st[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[t2][dc], bq[dc], st[t2], 0, 0, 0);
         }
         // ---- causal mask, online softmax over this lane's query (8 keys here, the rest in lanes ^ 16, ^ 32)
         float sv[8];
@@ -176,15 +207,14 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const FlashParams p)
         const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb);
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
-            const bf16x8 va = *(const bf16x8*)(vt + (dt * 16 + c) * kVtRow + g * 16);
             f32x4 a = acc[dt];
             a[0] *= corr;
             a[1] *= corr;
             a[2] *= corr;
             a[3] *= corr;
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pfrag, a, 0, 0, 0);
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[dt], pfrag, a, 0, 0, 0);
         }
-        if (more) tstore(buf ^ 1);
+        tstore(buf ^ 1);
         __syncthreads();
     }
     float l = l_run + lane_xor16(l_run);
@@ -229,7 +259,8 @@ int mi355_flash_prefill(const void* qkv, int qkv_dtype, int64_t ld_qkv, const fl
     p.qkv_dtype = qkv_dtype;
     p.rope_gathered = rope_gathered;
     p.scale = scale;
-    hipLaunchKernelGGL(flash_prefill_kernel, dim3((T + kBQ - 1) / kBQ, n_head), dim3(256), kLds, s, p);
+    p.q_blocks = (T + kBQ - 1) / kBQ;
+    hipLaunchKernelGGL(flash_prefill_kernel, dim3(p.q_blocks * ((n_head + 7) / 8 * 8)), dim3(kThreadsF), kLds, s, p);
     MI355_LAUNCH_CHECK();
     return 0;
 }

@@ -10,13 +10,17 @@
 //    a (tile, unit) piece with ONE coalesced 1-KiB load straight into registers (no LDS for weights: a piece is
 //    private to its wave) and turns it into four MFMA A fragments with 7 VALU ops per 8 weights — amortised over the
 //    8 token tiles of the block, so the conversion that bounds the M = 1 path costs 1/8 MFMA slot here;
-//  * the activations of a block (128 tokens x 128 k, bf16) go through LDS, double buffered, 16-B chunks XOR-swizzled by
-//    (token & 7) so that the 16 lanes of a B fragment (16 tokens, same k) hit 8 different 16-B slots;
-//  * workgroup = 4 waves, block tile = 128 tokens x 8 row tiles (2 per wave; for the c_fc1 / c_fc2 pair stream the two
+//  * the activations of a block (128 tokens x 128 k, bf16) go through LDS, double buffered, the 16-B chunks of a row
+//    XOR-swizzled by swz(token & 15) — a GF(2)-linear map chosen by exhaustive search so that every ds_read_b128 lane
+//    group of a B-fragment read (the hardware serves {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... together) touches
+//    16 different 16-B slots: the obvious (token & 7) was 2-way conflicted and made the kernel LDS-bound;
+//  * workgroup = 8 waves, block tile = 128 tokens x 16 row tiles (2 per wave; for the c_fc1 / c_fc2 pair stream the two
 //    tiles of a wave are the fc1 / fc2 halves of the same 16 rows, so SwiGLU stays in the epilogue): every B fragment
-//    read from LDS feeds two MFMAs, 64 x v_mfma_f32_16x16x32_bf16 per wave and unit against 32 LDS reads;
-//  * blockIdx.x runs over the row blocks, so workgroups that share a token block (the same 32 KiB of activations per
-//    unit) run at the same time and find it in L2;
+//    read from LDS feeds two MFMAs, 64 x v_mfma_f32_16x16x32_bf16 per wave and unit (4 tiles per wave measured
+//    slower: 184 VGPRs halve the waves per SIMD);
+//  * XCD-aware block order: workgroup b runs on XCD b % 8 (each XCD has its own 4 MiB L2).  The (token block, row
+//    block) pairs are cut, token-block major, into 8 contiguous ranges, one per XCD: the workgroups an XCD runs side by
+//    side share one or two token blocks (1 MiB of activations each), fetched into that L2 once;
 //  * operands are staged once per linear by stage_rows_kernel: bf16(norm_scale * x) with RMSNorm's 1/rms kept as a
 //    per-row factor for the epilogue, and the per-row operand sum that undoes the +128 / zero-point offset:
 //        y[m, n] = scale[n] * (acc[m, n] - (128 + zero[n]) * sum_k xb[m, k]) * rinv[m]      (same arithmetic as gemv.hip).
@@ -25,8 +29,14 @@
 namespace {
 
 constexpr int kBM = 128;     // tokens per block
-constexpr int kSlots = 8;    // 16-row tile slots per block (2 per wave)
-constexpr int kThreads = 256;
+#ifndef MI355_GEMM_TPW
+#define MI355_GEMM_TPW 2
+#endif
+constexpr int kTPW = MI355_GEMM_TPW;  // 16-row tile slots per wave: one B fragment read from LDS feeds kTPW MFMAs
+constexpr int kWaves = 8;
+constexpr int kSlots = kWaves * kTPW;  // tile slots per block
+constexpr int kThreads = 64 * kWaves;
+constexpr int kXChunks = kBM * 16 / kThreads;  // 16-B activation chunks per thread and unit
 constexpr int kLds = 2 * kBM * 256;  // two buffers of 128 tokens x 128 k bf16
 
 struct GemmParams {
@@ -42,9 +52,16 @@ struct GemmParams {
     const void* zeros2;
     void* y;
     int64_t ldy;
-    int M, N, K, units, n_tiles;
+    int M, N, K, units, n_tiles, n_blocks, per_xcd, total_blocks;
     int sz_dtype, y_dtype;
 };
+
+// 16-B chunk swizzle of an activation row in LDS (see the header): bits 0, 1 of the token stay, bit 2 -> 8, bit 3 -> 12
+#ifdef MI355_NO_SWZ
+__device__ __forceinline__ int swz(int tok) { return tok & 7; }
+#else
+__device__ __forceinline__ int swz(int tok) { return (tok & 3) ^ (((tok >> 2) & 1) << 3) ^ (((tok >> 3) & 1) * 12); }
+#endif
 
 __device__ __forceinline__ float ldsz(const void* p, int i, int dtype) {
     return dtype == MI355_F32 ? ((const float*)p)[i] : bf16_to_f32(((const bf16_t*)p)[i]);
@@ -84,18 +101,26 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int nb = blockIdx.x, m0 = blockIdx.y * kBM;
+    // b -> (token block, row block): the (token block, row block) pairs, token block major, are cut into 8 contiguous
+    // ranges, one per XCD (b % 8): the workgroups an XCD runs side by side share one or two token blocks
+    const int n_blocks = p.n_blocks;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int L = xcd * p.per_xcd + j;
+    if (j >= p.per_xcd || L >= p.total_blocks) return;
+    const int mb = L / n_blocks, nb = L - mb * n_blocks;
+    const int m0 = mb * kBM;
 
-    // this wave's two row tiles
-    int tile[2], rr[2];
-    if (PAIR) {
-        tile[0] = tile[1] = nb * 4 + wave;  // pair tile: 16 rows of c_fc1 (r = 0) and of c_fc2 (r = 1)
-        rr[0] = 0;
-        rr[1] = 1;
-    } else {
-        tile[0] = nb * kSlots + 2 * wave;
-        tile[1] = tile[0] + 1;
-        rr[0] = rr[1] = 0;
+    // this wave's row tiles
+    int tile[kTPW], rr[kTPW];
+#pragma unroll
+    for (int t = 0; t < kTPW; ++t) {
+        if (PAIR) {
+            tile[t] = nb * (kSlots / 2) + (kTPW / 2) * wave + (t >> 1);  // pair tile: 16 rows of c_fc1 (r = 0) and c_fc2 (r = 1)
+            rr[t] = t & 1;
+        } else {
+            tile[t] = nb * kSlots + kTPW * wave + t;
+            rr[t] = 0;
+        }
     }
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
@@ -103,15 +128,17 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.xb, 0, (int)xbytes, 0x00020000);
     const unsigned lane_off = lane * 16;
     auto wload = [&](int t, int u) {
-        const bool ok = tile[t] < p.n_tiles;
+        // past the last unit / tile the load goes through a zero-sized descriptor: the scalar offset operand of a raw
+        // buffer load is NOT range-checked (an unconditional prefetch of unit `units` of the last tile faulted)
+        const bool ok = tile[t] < p.n_tiles && u < p.units;
         const unsigned off = (unsigned)((tile[t] * p.units + u) * (PAIR ? 2 : 1) + rr[t]) * 1024u;
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rw : rw0, lane_off, ok ? off : 0u, 0));
     };
-    // activation block of unit u: 2048 chunks of 16 B, 8 per thread; chunk = (token, 16-B column)
-    u32x4 stage[8];
+    // activation block of unit u: 2048 chunks of 16 B, kXChunks per thread; chunk = (token, 16-B column)
+    u32x4 stage[kXChunks];
     auto xload = [&](int u) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kXChunks; ++i) {
             const int ch = i * kThreads + threadIdx.x;
             const int tok = ch >> 4, col = ch & 15;
             const unsigned off = (unsigned)(((int64_t)(m0 + tok) * p.ldxb) * 2) + (unsigned)u * 256u + (unsigned)col * 16u;
@@ -121,77 +148,75 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
     };
     auto xstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kXChunks; ++i) {
             const int ch = i * kThreads + threadIdx.x;
             const int tok = ch >> 4, col = ch & 15;
-            *(u32x4*)(smem + buf * (kBM * 256) + tok * 256 + ((col ^ (tok & 7)) << 4)) = stage[i];
+            *(u32x4*)(smem + buf * (kBM * 256) + tok * 256 + ((col ^ swz(tok)) << 4)) = stage[i];
         }
     };
 
-    f32x4 acc[2][8];
+    f32x4 acc[kTPW][8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < kTPW; ++t)
 #pragma unroll
         for (int tt = 0; tt < 8; ++tt) acc[t][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 wcur[2], wnext[2];
-    wcur[0] = wload(0, 0);
-    wcur[1] = wload(1, 0);
+    u32x4 wcur[kTPW], wnext[kTPW];
+#pragma unroll
+    for (int t = 0; t < kTPW; ++t) wcur[t] = wload(t, 0);
     xload(0);
     xstore(0);
     __syncthreads();
 
     for (int u = 0; u < p.units; ++u) {
         const int buf = u & 1;
-        const bool more = u + 1 < p.units;
-        if (more) {
-            xload(u + 1);
-            wnext[0] = wload(0, u + 1);
-            wnext[1] = wload(1, u + 1);
-        }
-        // int4 -> bf16 MFMA A fragments: (w >> 4i) & 0x000F000F | 0x43004300 = (128 + q_2i, 128 + q_2i+1)
-        bf16x8 a[2][4];
+        // next unit's operands, requested UNCONDITIONALLY (a load inside `if (more)` makes hipcc drain vmcnt at the join,
+        // i.e. wait for these very loads before the first MFMA): past the last unit the offsets fall into the next row /
+        // tile or out of the descriptors (zeros) and the values are never used
+        xload(u + 1);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < kTPW; ++t) wnext[t] = wload(t, u + 1);
+        const char* xs = smem + buf * (kBM * 256);
+        // (explicitly software-pipelined B-fragment reads — 16 fragments in registers, pinned with sched_barrier —
+        // measured SLOWER, 600-670 vs 760-800 TFLOP/s: with 4 waves per SIMD the hardware hides the LDS latency itself)
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < 4; ++d) {
+            // int4 -> bf16 MFMA A fragments of k-quarter d: (w >> 4i) & 0x000F000F | 0x43004300 = (128 + q_2i, 128 + q_2i+1)
+            bf16x8 a[kTPW];
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) {
                 const uint32_t v = wcur[t][d];
                 u32x4 f;
                 f[0] = (v & 0x000F000Fu) | 0x43004300u;
                 f[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
                 f[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
                 f[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
-                a[t][d] = __builtin_bit_cast(bf16x8, f);
+                a[t] = __builtin_bit_cast(bf16x8, f);
             }
-        const char* xs = smem + buf * (kBM * 256);
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
-            const int tok = tt * 16 + c;
+            for (int tt = 0; tt < 8; ++tt) {
+                const int tok = tt * 16 + c;
+                const bf16x8 b = *(const bf16x8*)(xs + tok * 256 + (((4 * g + d) ^ swz(tok)) << 4));
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const bf16x8 b = *(const bf16x8*)(xs + tok * 256 + (((4 * g + d) ^ (tok & 7)) << 4));
-                acc[0][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][d], b, acc[0][tt], 0, 0, 0);
-                acc[1][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][d], b, acc[1][tt], 0, 0, 0);
+                for (int t = 0; t < kTPW; ++t) acc[t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[t][tt], 0, 0, 0);
             }
         }
-        if (more) {
-            xstore(buf ^ 1);
-            wcur[0] = wnext[0];
-            wcur[1] = wnext[1];
-        }
+        xstore(buf ^ 1);
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t) wcur[t] = wnext[t];
         __syncthreads();
     }
 
     // ---- epilogue: lane (g, c) holds rows 4 g .. 4 g + 3 of its tiles for token tt * 16 + c
-    float sc[2][4], zp[2][4];
+    float sc[kTPW][4], zp[kTPW][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < kTPW; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = tile[t] * 16 + 4 * g + r;
             const bool ok = n < p.N;
-            const void* sp = (PAIR && t == 1) ? p.scales2 : p.scales;
-            const void* zq = (PAIR && t == 1) ? p.zeros2 : p.zeros;
+            const void* sp = (PAIR && rr[t] == 1) ? p.scales2 : p.scales;
+            const void* zq = (PAIR && rr[t] == 1) ? p.zeros2 : p.zeros;
             sc[t][r] = ok ? ldsz(sp, n, p.sz_dtype) : 0.f;
             zp[t][r] = ok ? 128.f + ldsz(zq, n, p.sz_dtype) : 0.f;
         }
@@ -200,23 +225,28 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
         const int m = m0 + tt * 16 + c;
         if (m >= p.M) continue;
         const float sxm = p.sx[m], ri = p.rinv[m];
-        float v[2][4];
+        float v[kTPW][4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < kTPW; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[t][r] = sc[t][r] * (acc[t][tt][r] - zp[t][r] * sxm) * ri;
         if constexpr (EPI == MI355_EPI_SWIGLU) {
-            const int n = tile[0] * 16 + 4 * g;
-            if (n < p.N) {  // N % 4 == 0 (host check)
-                bf16_t* dst = (bf16_t*)p.y + (int64_t)m * p.ldy + n;
-                u32x2 o;
-                o[0] = (uint32_t)f32_to_bf16(swiglu_f32(v[0][0], v[1][0])) | ((uint32_t)f32_to_bf16(swiglu_f32(v[0][1], v[1][1])) << 16);
-                o[1] = (uint32_t)f32_to_bf16(swiglu_f32(v[0][2], v[1][2])) | ((uint32_t)f32_to_bf16(swiglu_f32(v[0][3], v[1][3])) << 16);
-                *(u32x2*)dst = o;
+#pragma unroll
+            for (int t = 0; t < kTPW; t += 2) {
+                const int n = tile[t] * 16 + 4 * g;
+                if (n < p.N) {  // N % 4 == 0 (host check)
+                    bf16_t* dst = (bf16_t*)p.y + (int64_t)m * p.ldy + n;
+                    u32x2 o;
+                    o[0] = (uint32_t)f32_to_bf16(swiglu_f32(v[t][0], v[t + 1][0])) |
+                           ((uint32_t)f32_to_bf16(swiglu_f32(v[t][1], v[t + 1][1])) << 16);
+                    o[1] = (uint32_t)f32_to_bf16(swiglu_f32(v[t][2], v[t + 1][2])) |
+                           ((uint32_t)f32_to_bf16(swiglu_f32(v[t][3], v[t + 1][3])) << 16);
+                    *(u32x2*)dst = o;
+                }
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < kTPW; ++t) {
                 const int n = tile[t] * 16 + 4 * g;
                 if (n >= p.N) continue;
                 if (p.y_dtype == MI355_F32) {
@@ -242,16 +272,19 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
 }
 
 template <int EPI, bool PAIR>
-int launch_gemm(const GemmParams& p, hipStream_t s) {
+int launch_gemm(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row tiles (pair tiles for the SwiGLU stream)
     static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute(gemm) failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    const int per_block = PAIR ? 4 : kSlots;
-    const dim3 grid((p.n_tiles + per_block - 1) / per_block, (p.M + kBM - 1) / kBM);
-    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR>), grid, dim3(kThreads), kLds, s, p);
+    const int per_block = PAIR ? kSlots / 2 : kSlots;
+    GemmParams q = p;
+    q.n_blocks = (p.n_tiles + per_block - 1) / per_block;
+    q.total_blocks = q.n_blocks * ((p.M + kBM - 1) / kBM);
+    q.per_xcd = (q.total_blocks + 7) / 8;
+    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR>), dim3(8 * q.per_xcd), dim3(kThreads), kLds, s, q);
     MI355_LAUNCH_CHECK();
     return 0;
 }

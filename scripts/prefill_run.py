@@ -1,0 +1,29 @@
+"""A 2048-token prompt through the 7B int4 engine (for rocprofv3 --kernel-trace --stats and for timing)."""
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from lit_llama_amd import synth  # noqa: E402
+from lit_llama_amd.model import LLaMA, LLaMAConfig  # noqa: E402
+from lit_llama_amd.utils import EmptyInitOnDevice  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = LLaMAConfig.from_name("7B")
+with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
+    model = LLaMA(cfg)
+synth.fill_model_random_int4(model, seed=0)
+eng = model.engine()
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+prompt = synth.make_prompt(T).to(dev)
+with torch.cuda.stream(eng.stream):
+    eng._ensure_cache(T + 8)
+    for i in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(eng.stream)
+        eng.prefill(prompt, 0, all_logits=False, argmax=True)
+        e1.record(eng.stream)
+        e1.synchronize()
+        print(f"prefill {T} tokens (chunk {eng.max_T}): {e0.elapsed_time(e1):.2f} ms")

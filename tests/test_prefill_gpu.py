@@ -44,12 +44,13 @@ def check(got, ref, what):
 
 
 @torch.no_grad()
-def test_chunked_prefill_through_the_engine_matches_oracle(dev):
+def test_chunked_prefill_through_the_engine_matches_oracle(dev, monkeypatch):
     """600 prompt tokens = one chunk of 512 + one of 88 starting at position 512 (flash attention over the cache rows
     of the first chunk), then one decode step on the fused path on top of that cache."""
+    monkeypatch.setenv("MI355_PREFILL_T", "512")
     model, om, cfg = build(dev)
     eng = model.engine()
-    assert eng is not None and eng.max_T >= 512, model._engine_failed
+    assert eng is not None and eng.max_T == 512, model._engine_failed
     T, S = 600, 640
     prompt = synth.make_prompt(T + 1)
     pos = torch.arange(T, device=dev)
