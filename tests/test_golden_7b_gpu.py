@@ -1,5 +1,5 @@
 """BASELINE.json configs[2] at FULL depth against the reference itself: LLaMA-7B (32 layers, n_embd 4096), gptq.int4,
-seeded synthetic weights (lit_llama_amd/synth.py), prompt of 8, three greedy tokens.  tests/golden/cfg2_7b_int4.npz
+seeded synthetic weights (lit_llama_amd/synth.py), prompt of 8, six greedy tokens.  tests/golden/cfg2_7b_int4.npz
 holds what the UNMODIFIED /root/reference produced on the CPU for exactly these weights (generate.py:63-91 with
 top_k = 1, then teacher-forced logits; oracle/gen_golden.py --big, which also pins oracle/oracle.py to it with
 max |dlogit| = 0).  Here the same checkpoint goes through the engine: prefill on the launch path, decode steps on
