@@ -433,6 +433,14 @@ def main():
         lit_llama_amd.generate(model, prompt, gen_new, top_k=1, max_seq_length=T + gen_new)
         torch.cuda.synchronize(dev)
         t_gen = time.perf_counter() - t_g0
+        # the same run with sampling (temperature 0.8, top_k 200: generate.py's defaults) on the device
+        model.reset_cache()
+        lit_llama_amd.generate(model, prompt, 4, temperature=0.8, top_k=200, max_seq_length=T + gen_new)
+        torch.cuda.synchronize(dev)
+        t_s0 = time.perf_counter()
+        lit_llama_amd.generate(model, prompt, gen_new, temperature=0.8, top_k=200, max_seq_length=T + gen_new)
+        torch.cuda.synchronize(dev)
+        t_samp = time.perf_counter() - t_s0
         # prompt prefill at the reference's evaluation length (evaluate/full.py:120-129: T = 2048): wide int4 GEMM +
         # flash attention, MFMA-bound
         prefill = None
@@ -520,7 +528,8 @@ def main():
         },
         "prefill_s": round(t_prefill, 4),
         "prefill": prefill,
-        "generate": {"tokens_per_s_incl_prompt": round(gen_new / t_gen, 1), "prompt_len": T, "new_tokens": gen_new,
+        "generate": {"tokens_per_s_incl_prompt": round(gen_new / t_gen, 1), "sampled_tokens_per_s_incl_prompt": round(gen_new / t_samp, 1),
+                     "prompt_len": T, "new_tokens": gen_new,
                      "what": "lit_llama_amd.generate(top_k=1) wall time incl. prefill, as generate.py:146-153 reports"},
     }
     if tp_res is not None:

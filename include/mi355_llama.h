@@ -373,6 +373,15 @@ typedef struct mi355_model {
     uint64_t gemm_ws_bytes;
 } mi355_model;
 
+/* The tail of generate.py:68-85 on the device: logits / temperature, exact top-k threshold (values below the k-th
+ * largest are dropped, ties kept; top_k <= 0 or >= V: none), softmax, and the inverse-CDF draw
+ *     token = min { i : sum_{j <= i} p_j > u },   u = uniforms[pos[0]]  in [0, 1)  (caller's generator)
+ * Writes next_token[0], out_tokens[pos[0] + 1] and, with `advance`, tokens[0] and pos[0] + 1 (so it can end a chained
+ * decode step); probs_out (optional, [V]) receives the probabilities. */
+int mi355_sample(const float* logits, int V, float temperature, int top_k, const float* uniforms, int32_t* next_token,
+                 int32_t* out_tokens, int32_t* tokens, int32_t* pos, int advance, float* probs_out,
+                 mi355_stream_t stream);
+
 /* copy token ids / positions into the model's device slots (tiny kernel; arguments travel by value) */
 int mi355_set_step(const mi355_model* m, const void* idx, int idx_is_i64, int T, int pos0, int from_next_token,
                    mi355_stream_t stream);

@@ -179,6 +179,8 @@ PROTOTYPES = {
                                 c_void_p]),
     "mi355_graph_begin": (c_int, [c_void_p]),
     "mi355_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),
+    "mi355_sample": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                             c_void_p, c_void_p]),
     "mi355_sizeof": (c_int, [c_int]),
     "mi355_linear_max_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "mi355_debug_time_next_launch": (c_int, [c_void_p, c_void_p]),

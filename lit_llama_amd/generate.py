@@ -34,6 +34,7 @@ def generate(
     temperature: float = 1.0,
     top_k: Optional[int] = None,
     eos_id: Optional[int] = None,
+    sample_on_device: bool = True,
 ) -> torch.Tensor:
     T = idx.size(0)
     T_new = T + max_new_tokens
@@ -44,6 +45,8 @@ def generate(
     eng = model.engine() if (getattr(model, "use_engine", False) and device.type == "cuda") else None
     if eng is not None and top_k == 1 and T_new <= max_seq_length and max_new_tokens > 0:
         return _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id)
+    if eng is not None and temperature > 0 and T_new <= max_seq_length and max_new_tokens > 0 and sample_on_device:
+        return _generate_sampled(model, eng, idx, max_new_tokens, max_seq_length, temperature, top_k, eos_id)
 
     # ---- reference loop (generate.py:45-91)
     empty = torch.empty(T_new, dtype=dtype, device=device)
@@ -68,6 +71,46 @@ def generate(
             # EOS position; kept as is so callers see the same length as with the reference
             return idx[:input_pos]
     return idx
+
+
+def _generate_sampled(model, eng, idx, max_new_tokens, max_seq_length, temperature, top_k, eos_id):
+    """generate.py:63-91 with sampling, entirely on the device: per token one decode step (logits) + one `mi355_sample`
+    launch (temperature, exact top-k threshold, softmax, inverse-CDF draw from a uniform of THIS call's torch generator
+    state), which also writes the next step's token / position.  No device->host read inside the loop.  The draws are
+    inverse-CDF, not torch.multinomial's: the same distribution, a different stream of samples for a given seed
+    (`sample_on_device=False` runs the reference's torch ops instead)."""
+    from . import ops
+
+    device, dtype = idx.device, idx.dtype
+    T = idx.size(0)
+    cur = torch.cuda.current_stream(device)
+    eng.stream.wait_stream(cur)
+    with torch.cuda.stream(eng.stream):
+        uniforms = torch.rand(max_seq_length + 1, device=device, dtype=torch.float32)  # indexed by position
+        eng._ensure_cache(max_seq_length)
+        eng.out_tokens[:T].copy_(idx.to(torch.int32))
+        eng.prefill(idx, 0, all_logits=False, argmax=False)  # logits of the last prompt token in row 0
+        eng.set_step(idx[-1:], 1, T - 1)                      # position slot = T - 1: the draw lands at out_tokens[T]
+        row = eng.logits[0, : eng.m.lm_head.N]
+        kw = dict(out_tokens=eng.out_tokens, tokens=eng.tokens, advance=True)
+        ops.sample(row, temperature, top_k, uniforms, eng.pos, eng.next_token, **kw)
+        done = 1
+        while done < max_new_tokens:
+            eng.run_step(0)
+            ops.sample(row, temperature, top_k, uniforms, eng.pos, eng.next_token, **kw)
+            done += 1
+            if eos_id is not None and (done % 16 == 0 or done == max_new_tokens):
+                toks = eng.out_tokens[T:T + done].tolist()
+                if eos_id in toks:
+                    break
+        out = eng.out_tokens[:T + done].to(dtype).clone()
+        eng.check_status()
+    cur.wait_stream(eng.stream)
+    if eos_id is not None:
+        gen = out[T:].tolist()
+        if eos_id in gen:
+            out = out[: T + gen.index(eos_id)]
+    return out
 
 
 def _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id):

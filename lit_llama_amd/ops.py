@@ -367,6 +367,19 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def sample(logits: torch.Tensor, temperature: float, top_k: Optional[int], uniforms: torch.Tensor,
+           pos: torch.Tensor, next_token: torch.Tensor, *, out_tokens: Optional[torch.Tensor] = None,
+           tokens: Optional[torch.Tensor] = None, advance: bool = False, probs_out: Optional[torch.Tensor] = None) -> None:
+    """Device-side tail of generate.py:68-85 (mi355_sample): temperature, exact top-k threshold, softmax and the
+    inverse-CDF draw `min {i : cumsum(p)[i] > uniforms[pos[0]]}`; see csrc/sample.hip."""
+    require_gpu(logits, "sample")
+    assert logits.dtype == torch.float32 and logits.dim() == 1 and logits.is_contiguous()
+    assert uniforms.dtype == torch.float32 and pos.dtype == torch.int32 and next_token.dtype == torch.int32
+    check(lib().mi355_sample(ptr(logits), logits.numel(), float(temperature), int(top_k or 0), ptr(uniforms),
+                             ptr(next_token), ptr(out_tokens), ptr(tokens), ptr(pos), 1 if advance else 0,
+                             ptr(probs_out), stream_ptr()), "mi355_sample")
+
+
 def attention(
     qkv: torch.Tensor,
     rope: torch.Tensor,

@@ -315,6 +315,21 @@ def generate(model: Model, idx: torch.Tensor, max_new_tokens: int, *, max_seq_le
     return idx
 
 
+def sample_from_uniform(logits: torch.Tensor, temperature: float, top_k: Optional[int], u: float):
+    """generate.py:68-76 with the multinomial draw replaced by the inverse CDF of a given uniform (torch.multinomial
+    consumes its own noise, so a sample cannot be compared bit for bit; kept set and probabilities can):
+    returns (token, probs).  token = min {i : cumsum(probs)[i] > u}."""
+    logits = logits.float() / temperature
+    if top_k is not None:
+        v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
+        logits = torch.where(logits < v[[-1]], -float("Inf"), logits)
+    probs = torch.nn.functional.softmax(logits, dim=-1)
+    cdf = torch.cumsum(probs.double(), dim=-1)
+    above = (cdf > u).nonzero()
+    token = int(above[0]) if above.numel() else int((probs > 0).nonzero()[-1])
+    return token, probs
+
+
 @torch.no_grad()
 def teacher_forced_logits(model: Model, tokens: torch.Tensor, prompt_len: int,
                           max_seq_length: Optional[int] = None) -> torch.Tensor:
