@@ -431,12 +431,12 @@ class DecodeEngine:
         if int(argmax) & 2:
             self.embed_step()  # the warm-up consumed the residual stream; restore the chained entry state
 
-    def run_step(self, argmax) -> None:
+    def run_step(self, argmax, allow_fused: bool = True) -> None:
         """One T = 1 forward on self.stream (tokens / positions already placed by set_step).  argmax: False/0
         logits only, True/1 greedy argmax, 3 chained greedy step (needs `embed_step()` before the first one)."""
         s = self.stream.cuda_stream
         argmax = int(argmax)
-        if self.fused_ready():
+        if allow_fused and self.fused_ready():
             # one persistent launch per token; launches are asynchronous, so the host runs ahead without a graph
             self.fused.mode = argmax
             check(lib().mi355_fused_step(C.byref(self.fused), s), "mi355_fused_step")
@@ -492,15 +492,23 @@ class DecodeEngine:
         pos0 = self._host_pos0(input_pos, T)
         if pos0 is None:
             return None
-        if pos0 + T > max_seq_length:
-            return None  # cache-roll regime (model.py:214-218): handled by the op-by-op path
+        roll = pos0 + T > max_seq_length
+        if roll and (T != 1 or pos0 >= self.cfg.block_size):
+            return None  # a multi-token call across the end of the cache: op-by-op path
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             self._ensure_cache(max_seq_length)
             if T == 1:
+                if roll:
+                    # cache-roll regime (model.py:214-218: input_pos[-1] >= max_seq_length): every layer's cache moves
+                    # up one row (mi355_kv_roll), the new row lands in the last slot (the attention kernel clamps the
+                    # slot to S - 1), RoPE keeps the true position.  Stays on the engine: n_layer roll launches + the
+                    # launch-per-operator step (the persistent step addresses the cache by position and refuses it).
+                    for k, v in self.model.kv_caches:
+                        ops.kv_roll(k, v)
                 self.set_step(idx.reshape(-1), 1, pos0)
-                self.run_step(False)  # hipGraph replay; logits land in row 0
+                self.run_step(False, allow_fused=not roll)  # logits land in row 0
                 logits = self.logits[:1].clone()
             else:
                 logits = self.prefill(idx, pos0, all_logits=True)

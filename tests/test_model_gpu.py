@@ -114,6 +114,45 @@ def test_tiny_model_cache_roll_tokens_equal_reference(dev, golden, name):
     assert torch.equal(out.cpu(), toks)
 
 
+def test_cache_roll_regime_stays_on_the_engine_and_matches_oracle(dev):
+    """model.py:214-218 on a bf16 int4 engine model: max_seq_length < prompt + new tokens, so the last steps roll the
+    cache.  The engine takes them (kv_roll per layer + the launch-per-operator step) instead of leaving to the
+    op-by-op path; logits follow the oracle's within the bf16-path tolerance, teacher-forced on the oracle's tokens."""
+    model, sd, cfg = build(CFG1, "gptq.int4", torch.bfloat16, dev)
+    eng = model.engine()
+    assert eng is not None, model._engine_failed
+    om = oracle.Model(oracle.Config(**CFG1), {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()},
+                      mode="gptq.int4")
+    prompt, S, new = synth.make_prompt(6), 10, 9  # positions 10..14 are past the cache
+    log = []
+    ref_toks = oracle.generate(om, prompt, new, top_k=1, max_seq_length=S, logits_log=log)
+    ref_logits = torch.stack(log)
+    # teacher-forced through LLaMA.forward with the reference's position protocol
+    model.reset_cache()
+    calls = {"n": 0}
+    real = eng.forward
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        calls["n"] += out is not None
+        return out
+
+    eng.forward = spy
+    rows = []
+    toks = ref_toks.to(dev)
+    input_pos = torch.arange(0, 6, device=dev)
+    for _ in range(new):
+        x = toks.index_select(0, input_pos).view(1, -1)
+        rows.append(model(x, S, input_pos)[0, -1].float().cpu())
+        input_pos = input_pos[-1:] + 1
+    eng.forward = real
+    assert calls["n"] == new, "some roll-regime steps left the engine"
+    got = torch.stack(rows)
+    std = float(ref_logits.std(-1).mean())
+    err = (got - ref_logits).abs().max().item()
+    assert err <= 0.05 * std, f"roll regime: logits off by {err:.4f} (std {std:.3f})"
+
+
 def test_module_level_forward_matches_reference_blocks(dev, golden):
     """Block / attention / cache semantics on the shapes of the reference's tests/test_model.py."""
     g = golden("blocks")
