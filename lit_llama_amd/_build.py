@@ -54,9 +54,23 @@ def build(force: bool = False, verbose: bool = True) -> Path:
                 print(r.stderr, file=sys.stderr)
         return obj
 
+    compiled = []
+
+    def compile_tracked(name: str):
+        obj = OBJ_DIR / (name + ".o")
+        before = obj.stat().st_mtime if obj.exists() else None
+        out = compile_one(name)
+        if before is None or out.stat().st_mtime != before:
+            compiled.append(name)
+        return out
+
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
+        objs = list(ex.map(compile_tracked, SOURCES))
+    relink = force or _stale(LIB, objs)
+    if verbose:  # say what this call did: an up-to-date tree compiles nothing, and the caller should see that
+        print(f"[build] {len(SOURCES)} sources for {ARCH}: compiled {sorted(compiled) if compiled else 'none (objects up to date)'}; "
+              f"{'linking' if relink else 'library up to date:'} {LIB}", file=sys.stderr)
+    if relink:
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -1,8 +1,11 @@
 """Boundary selector and small helpers of the hot path.
 
-Mirrors /root/reference lit_llama/utils.py:29-41 (`llama_model_lookup`, `find_multiple`), :73-138
-(`EmptyInitOnDevice`) and :141-162 (`quantization`): while the context is active `torch.nn.Linear` is
-rebound to the quantised class, so `LLaMA.from_name(...)` builds every linear through the plug-in.
+This is the ~50-line plug-in selector whose behaviour IS the drop-in contract, so about half of its lines are the same
+as /root/reference lit_llama/utils.py — `llama_model_sizes`, `llama_model_lookup`, `find_multiple` (:19-41) and the
+`__enter__` / `__exit__` / `__torch_function__` bodies of `EmptyInitOnDevice` (:73-138) and `quantization` (:141-162)
+are kept as they are there on purpose (host-side Python, off the hot path, nothing to re-design): while the context is
+active `torch.nn.Linear` is rebound to the quantised class, so `LLaMA.from_name(...)` builds every linear through the
+plug-in.  What differs: the quantised classes are this package's (HIP kernels, no bitsandbytes / Triton import).
 `lazy_load` (:332-344) is re-exported from checkpoint.py (a reader of the torch.save zip format itself);
 `incremental_save` is checkpoint-conversion tooling and out of scope.
 """
