@@ -165,12 +165,20 @@ __device__ __forceinline__ unsigned piece_off(const PhaseW& ph, int gstep, int r
     }
     return ph.base + (unsigned)((tile * ph.units + ph.u0 + st) * (PAIR ? 2 : 1) + (PAIR ? r : 0)) * 1024u;
 }
-// (x & 0x000F000F) | 0x43004300 = the bf16 pair (128 + nibble 0, 128 + nibble 4) of x, as ONE VALU op: with literal
-// constants hipcc emits v_and + v_or (a gfx9 VOP3 cannot carry two literals), i.e. 11 instead of 7 ops per 8 weights —
-// and the conversion is what bounds a compute phase of the fused step.  With the mask in an SGPR and the exponent
-// pattern in a VGPR whose values the compiler cannot see, it selects v_and_or_b32 itself (and pads the VALU -> MFMA
-// hazard, which an inline-asm v_and_or_b32 does not get: that variant produced NaNs).
-__device__ __forceinline__ uint32_t nib2bf16(uint32_t x, uint32_t mask_s, uint32_t magic_v) { return (x & mask_s) | magic_v; }
+// int4 -> MFMA operand, 5 VALU ops per 8 weights.  The conversion is what bounds a compute phase of the fused step, so
+// the operands are fp16, whose 10-bit mantissa holds TWO nibble positions under one exponent pattern:
+//   (x & 0x000F000F) | 0x64006400 = the fp16 pair (1024 + nibble 0, 1024 + nibble 4)
+//   (x & 0x00F000F0) | 0x64006400 = the fp16 pair (1024 + 16 nibble 1, 1024 + 16 nibble 5)
+// and the same two masks on x >> 8 give nibbles 2 / 6 and 16 x nibbles 3 / 7: one shift + four v_and_or_b32 (the bf16
+// form, 7-bit mantissa, needed a shift per nibble position: 7 ops).  The factor 16 is undone on the activation side:
+// the producers publish every ODD pair of the activation vector divided by 16 (exact in fp16), and the epilogue
+// subtracts 1024 (S_even + S_odd) + zero (S_even + 16 S_odd) with the two sums taken while the vector is staged.
+// With literal constants hipcc emits v_and + v_or (a gfx9 VOP3 cannot carry two literals); with the masks in SGPRs and
+// the exponent pattern in a VGPR whose values the compiler cannot see, it selects v_and_or_b32 itself (and pads the
+// VALU -> MFMA hazard, which an inline-asm v_and_or_b32 does not get: that variant produced NaNs).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+__device__ __forceinline__ uint32_t nib2f16(uint32_t x, uint32_t mask_s, uint32_t magic_v) { return (x & mask_s) | magic_v; }
 __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rs_null, bool ok,
                                            unsigned lane_off, unsigned soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rs : rs_null, lane_off, ok ? soff : 0u, 2));
@@ -224,10 +232,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
         // =========================================================================================== streamers
         unsigned lane_off = lane * 16;
         const int g = lane >> 4;
-        uint32_t magic = 0x43004300u;
-        uint32_t nmask = 0x000F000Fu;
-        asm volatile("" : "+v"(magic));  // opaque register values (see nib2bf16)
+        uint32_t magic = 0x64006400u;
+        uint32_t nmask = 0x000F000Fu, nmask16 = 0x00F000F0u;
+        asm volatile("" : "+v"(magic));  // opaque register values (see nib2f16)
         asm volatile("" : "+s"(nmask));
+        asm volatile("" : "+s"(nmask16));
         u32x4 ring[kRing];
         int buf = 0;
 
@@ -277,35 +286,36 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
         FS_SSTAMP(STAMP_);                                                                                            \
         /* B operands (activation unit of a step) are read one step ahead: a step otherwise starts with an LDS */     \
         /* round trip (~150 cycles x 12 steps on the hand-off chain)                                           */     \
-        bf16x8 bn__[4];                                                                                               \
+        f16x8 bn__[4];                                                                                                \
         {                                                                                                             \
             const char* xb0__ = xs + ((PH_).u0) * 256 + g * 64;                                                       \
-            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const bf16x8*)(xb0__ + 16 * d__);       \
+            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const f16x8*)(xb0__ + 16 * d__);       \
         }                                                                                                             \
         for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
             _Pragma("unroll") for (int t__ = 0; t__ < (TURNS_); ++t__) {                                              \
                 _Pragma("unroll") for (int s__ = 0; s__ < STEPS__; ++s__) {                                           \
                     const int gstep__ = (body__ * (TURNS_) + t__) * STEPS__ + s__;                                    \
                     const int ti__ = gstep__ / SPT__, st__ = gstep__ - ti__ * SPT__;                                  \
-                    bf16x8 b__[4];                                                                                    \
+                    f16x8 b__[4];                                                                                     \
                     _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) b__[d__] = bn__[d__];                         \
                     {                                                                                                 \
                         const int nst__ = (st__ + 1 == SPT__) ? 0 : st__ + 1;                                         \
                         const char* xbn__ = xs + ((PH_).u0 + (nst__ < (PH_).nu ? nst__ : 0)) * 256 + g * 64;          \
-                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const bf16x8*)(xbn__ + 16 * d__); \
+                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const f16x8*)(xbn__ + 16 * d__); \
                     }                                                                                                 \
                     /* idle steps (padding of the ring turn) carry no data: skip their MFMAs (wave-uniform) */        \
                     if (st__ < (PH_).nu && ((QKV_) || ti__ < (PH_).ntiles)) {                                         \
                         _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                         \
                             _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                   \
                                 const uint32_t v__ = ring[s__ * R__ + r__][d__];                                      \
+                                const uint32_t v8__ = v__ >> 8;                                                       \
                                 u32x4 a__;                                                                            \
-                                a__[0] = nib2bf16(v__, nmask, magic);                                                        \
-                                a__[1] = nib2bf16(v__ >> 4, nmask, magic);                                                   \
-                                a__[2] = nib2bf16(v__ >> 8, nmask, magic);                                                   \
-                                a__[3] = nib2bf16(v__ >> 12, nmask, magic);                                                  \
-                                acc__[r__][d__ & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                        \
-                                    __builtin_bit_cast(bf16x8, a__), b__[d__], acc__[r__][d__ & 1], 0, 0, 0);         \
+                                a__[0] = nib2f16(v__, nmask, magic);                                                  \
+                                a__[1] = nib2f16(v__, nmask16, magic);                                                \
+                                a__[2] = nib2f16(v8__, nmask, magic);                                                 \
+                                a__[3] = nib2f16(v8__, nmask16, magic);                                               \
+                                acc__[r__][d__ & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                         \
+                                    __builtin_bit_cast(f16x8, a__), b__[d__], acc__[r__][d__ & 1], 0, 0, 0);          \
                             }                                                                                         \
                         }                                                                                             \
                     }                                                                                                 \
@@ -505,10 +515,37 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             return float2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
         };
         auto bfpair = [&](float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); };
-        // sum of the two bf16 halves of a staged dword (sum_k x_k undoes the +128 / zero-point offset of the int4
-        // operands: y = scale (acc - (128 + zero) sum_k x_k); every workgroup needs the same sum, so it is taken while
-        // the vector is staged instead of by an all-ones MFMA per k-step in every streamer wave)
-        auto pair_sum = [&](unsigned v) { return __uint_as_float(v << 16) + __uint_as_float(v & 0xffff0000u); };
+        // activation pair granule: fp16 (a, b); ODD pairs of a vector carry a / 16, b / 16 (see nib2f16).  pg is the
+        // pair's index inside its 8-pair row, the rows start at even pair indices.
+        auto hpair = [&](float a, float b) {
+            const float k = (pg & 1) ? 0.0625f : 1.0f;
+            const f16x2 h = {(_Float16)(a * k), (_Float16)(b * k)};
+            return __builtin_bit_cast(unsigned, h);
+        };
+        // sums of the staged operands, even pairs in .x and odd pairs in .y (one v_dot2_f32_f16 per dword).  They undo
+        // the +1024 / zero-point offsets of the int4 operands:
+        //   y = scale (acc - 1024 (S_even + S_odd) - zero (S_even + 16 S_odd));
+        // every workgroup needs the same sums, so they are taken while the vector is staged instead of by all-ones
+        // MFMAs in every streamer wave.
+        const f16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
+        auto pair_sums = [&](float2& sx, unsigned even, unsigned odd) {
+            sx.x = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, even), ones2, sx.x, false);
+            sx.y = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, odd), ones2, sx.y, false);
+        };
+        // misc[4 + gw] / misc[6 + gw]: this gatherer wave's S_even / S_odd; the epilogue form {A, B}:
+        // y = scale (acc - A - zero B)
+        auto put_sums = [&](float2 sx) {
+            sx.x = group_sum(sx.x, 64);
+            sx.y = group_sum(sx.y, 64);
+            if (lane == 0) {
+                misc[4 + gw] = sx.x;
+                misc[6 + gw] = sx.y;
+            }
+        };
+        auto get_sums = [&]() {
+            const float se = misc[4] + misc[5], so = misc[6] + misc[7];
+            return float2{1024.f * (se + so), se + 16.f * so};
+        };
         bool dbg_on = false;
 #define FS_GSTAMP(i)                                                                              \
     do {                                                                                          \
@@ -519,14 +556,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
         auto publish_x = [&](float2 xv, float2 gsc) {
             const unsigned ep = ebase + edge;
             u64* dst = p.gx + (size_t)xpar * 2304;
-            if (w8 == 0) gr_store(dst + bid * 8 + pg, ep, bfpair(gsc.x * xv.x, gsc.y * xv.y));
+            if (w8 == 0) gr_store(dst + bid * 8 + pg, ep, hpair(gsc.x * xv.x, gsc.y * xv.y));
             float ss = xv.x * xv.x + xv.y * xv.y;  // the same in the 8 lanes of a pair: sum over the 8 pairs
             ss = MI355_DPP_ADD(ss, 0x140);
             ss += lane_xor16(ss);
             ss += lane_xor32(ss);
             if (lane == 0) gr_store(dst + 2048 + bid, ep, __float_as_uint(ss));
         };
-        // gather an x-type edge into xs (bf16), 1/rms into misc[0], the operand sum into misc[4] + misc[5]
+        // gather an x-type edge into xs (fp16), 1/rms into misc[0], the operand sums into misc[4 .. 7]
         auto gather_x = [&]() {
             const unsigned ep = ebase + edge;
             const unsigned base = (unsigned)xpar * 2304u * 8u;
@@ -550,37 +587,33 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                float sx = 0.f;
+                float2 sx = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     *(u64*)(xs + (size_t)(k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
-                    sx += pair_sum(v[k][0]) + pair_sum(v[k][2]);
+                    pair_sums(sx, v[k][0], v[k][2]);
                 }
                 float ss = ((__uint_as_float(v[6][0]) + __uint_as_float(v[6][2])) + __uint_as_float(v[7][0])) +
                            __uint_as_float(v[7][2]);
                 ss = group_sum(ss, 64);
-                sx = group_sum(sx, 64);
-                if (lane == 0) {
-                    misc[0] = rsqrtf(ss / (float)kC + p.eps);
-                    misc[4] = sx;
-                }
+                put_sums(sx);
+                if (lane == 0) misc[0] = rsqrtf(ss / (float)kC + p.eps);
             } else {
                 u32x4 v[10];
                 sweep<10>(p, rs_gx, base, 384, 1024, ep, v, 0x200u + edge);
-                float sx = 0.f;
+                float2 sx = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 10; ++k) {
                     *(u64*)(xs + (size_t)(384 + k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
-                    sx += pair_sum(v[k][0]) + pair_sum(v[k][2]);
+                    pair_sums(sx, v[k][0], v[k][2]);
                 }
-                sx = group_sum(sx, 64);
-                if (lane == 0) misc[5] = sx;
+                put_sums(sx);
             }
             xpar ^= 1;
             ++edge;
         };
-        auto deq = [&](float2 t, float2 sc_, float2 z_, float sx) {
-            return float2{sc_.x * (t.x - (128.f + z_.x) * sx), sc_.y * (t.y - (128.f + z_.y) * sx)};
+        auto deq = [&](float2 t, float2 sc_, float2 z_, float2 sx) {
+            return float2{sc_.x * (t.x - sx.x - z_.x * sx.y), sc_.y * (t.y - sx.x - z_.y * sx.y)};
         };
 
         // ---- the residual rows of this workgroup: embedding of the step's token (model.py:102)
@@ -614,7 +647,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             __syncthreads();  // Bt (one virtual tile)
             if (gw == 0) {
                 const float rinv = misc[0];
-                const float sx = misc[4] + misc[5];
+                const float2 sx = get_sums();
                 float2 y[3];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
@@ -650,7 +683,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                     for (int k = 0; k < 2; ++k) {
 #pragma unroll
                         for (int e2 = 0; e2 < 2; ++e2) {
-                            const int gi = (k * 64 + lane) * 2 + e2;  // granule index inside the head's 256
+                            const int gi = (k * 64 + lane_v) * 2 + e2;  // granule index inside the head's 256 (lane_v: not hoisted)
                             const int jj = gi >> 5, e = gi & 31;
                             const unsigned val = v[k][2 * e2];
                             if (e < 16) {
@@ -679,7 +712,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                     const float inv = 1.0f / misc[1];
                     // attention output elements head * 128 + hj * 16 + 2 pg, + 1 -> one pair granule
                     if (w8 == 0)
-                        gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, bfpair(o.x * inv, o.y * inv));
+                        gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair(o.x * inv, o.y * inv));
                 }
                 FS_GSTAMP(6);
                 __syncthreads();  // Ba4
@@ -695,21 +728,20 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 const unsigned ep = ebase + edge;
                 u32x4 v[8];
                 sweep<8>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, ep, v, 0x400u + edge);
-                float sxp = 0.f;
+                float2 sxp = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
-                    sxp += pair_sum(v[k][0]) + pair_sum(v[k][2]);
+                    pair_sums(sxp, v[k][0], v[k][2]);
                 }
-                sxp = group_sum(sxp, 64);
-                if (lane == 0) misc[4 + gw] = sxp;
+                put_sums(sxp);
                 apar ^= 1;
                 ++edge;
                 FS_GSTAMP(7);
                 __syncthreads();  // B1
                 __syncthreads();  // Bt
                 if (gw == 0) {
-                    const float2 d = deq(tile_pair(0), s1, z1, misc[4] + misc[5]);
+                    const float2 d = deq(tile_pair(0), s1, z1, get_sums());
                     xres.x += d.x;
                     xres.y += d.y;
                     publish_x(xres, gn);
@@ -738,7 +770,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 const unsigned ep = ebase + edge;
                 u64* dst = p.gh + (size_t)hpar * (p.H / 2);
                 const float rinv = gw == 0 ? misc[0] : 0.f;
-                const float sx = gw == 0 ? misc[4] + misc[5] : 0.f;
+                const float2 sx = get_sums();
 #pragma unroll
                 for (int t = 0; t < kMaxFcTiles; ++t) {
                     __syncthreads();  // Bt
@@ -747,7 +779,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                         const float2 b = deq(tile_pair(1), fs2[t], fz2[t], sx);
                         if (w8 == 0)
                             gr_store(dst + (bid + t * kG) * 8 + pg, ep,
-                                     bfpair(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv)));
+                                     hpair(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv)));
                     }
                     buf ^= 1;
                 }
@@ -766,7 +798,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 const unsigned ep = ebase + edge;
                 const int n_loads = p.H / 4, half_l = (n_loads + 1) / 2;
                 const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
-                float sxp = 0.f;
+                float2 sxp = {0.f, 0.f};
                 for (int c0 = first; c0 < end; c0 += 8 * 64) {
                     u32x4 v[8];
                     sweep<8>(p, rs_gh, (unsigned)hpar * (unsigned)(p.H / 2) * 8u, c0, end, ep, v, 0x500u + edge);
@@ -775,19 +807,18 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                         const int i = c0 + k * 64 + lane;
                         if (i < end) {
                             *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
-                            sxp += pair_sum(v[k][0]) + pair_sum(v[k][2]);
+                            pair_sums(sxp, v[k][0], v[k][2]);
                         }
                     }
                 }
-                sxp = group_sum(sxp, 64);
-                if (lane == 0) misc[4 + gw] = sxp;
+                put_sums(sxp);
                 hpar ^= 1;
                 ++edge;
                 FS_GSTAMP(11);
                 __syncthreads();  // B1
                 __syncthreads();  // Bt
                 if (gw == 0) {
-                    const float2 d = deq(tile_pair(0), s1, z1, misc[4] + misc[5]);
+                    const float2 d = deq(tile_pair(0), s1, z1, get_sums());
                     xres.x += d.x;
                     xres.y += d.y;
                     publish_x(xres, gn);
@@ -815,7 +846,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             gather_x();
             __syncthreads();  // B1
             const float rinv = gw == 0 ? misc[0] : 0.f;
-            const float sx = gw == 0 ? misc[4] + misc[5] : 0.f;
+            const float2 sx = get_sums();
             float best = -INFINITY;
             int bi = 0x7fffffff;
             const int tiles_pad = p.head_turns * 3;

@@ -3,8 +3,8 @@ the oracle and its own protocol properties.
 
 Reference path being replaced: /root/reference generate.py:63-91 -> lit_llama/model.py:76-122 for one token at a time.
 Bars: tokens of a greedy run EQUAL those of the launch-per-operator engine on the same weights; logits within
-0.02 logit-std of it (same bf16 operands, different f32 summation orders) and within the bf16-path bar of 0.05 std of
-the oracle; the step is bit-reproducible; the hand-off protocol never times out (abort word stays 0).
+0.03 logit-std of it (the fused step stages activations as fp16, the launch path as bf16: the distance between the two
+is the launch path's coarser rounding) and within the bf16-path bar of 0.05 std of the oracle; the step is bit-reproducible; the hand-off protocol never times out (abort word stays 0).
 """
 import numpy as np
 import pytest
@@ -70,11 +70,11 @@ def test_fused_step_matches_launch_per_operator_engine(dev):
     eng.fused_enabled = True
     std = float(logits[False].std(-1).mean())
     err = (logits[True] - logits[False]).abs().max().item()
-    assert err <= 0.02 * std, f"fused vs unfused logits: {err:.4f} (std {std:.3f})"
+    assert err <= 0.03 * std, f"fused vs unfused logits: {err:.4f} (std {std:.3f})"
     # free-running tokens may only part where the launch path's own top-2 margin is inside twice that tolerance
     top2 = torch.topk(logits[False], 2, dim=-1).values
     margins = (top2[:, 0] - top2[:, 1]).tolist()
-    first_tie = next((i for i, m_ in enumerate(margins) if m_ <= 2 * 0.02 * std), len(margins))
+    first_tie = next((i for i, m_ in enumerate(margins) if m_ <= 2 * 0.03 * std), len(margins))
     n = 20 + first_tie + 1
     assert torch.equal(outs[True][:n], outs[False][:n]), \
         f"greedy tokens differ before the first near tie (step {first_tie}):\n{outs[True].tolist()}\n{outs[False].tolist()}"
