@@ -22,7 +22,9 @@ __device__ __forceinline__ unsigned payload(int wg, int i, int it) { return (uns
 // PIECES: 1-KiB wave loads per streamer wave and phase (ring held in registers), NGW: gatherer waves,
 // ORD 0: the ring is refilled while it is consumed (the refill queues in front of the publish store in the CU's
 // memory pipeline), ORD 1: the refill waits (third barrier) until the gatherer has published
-template <int PIECES, int NGW, int ORD>
+// REP: copies of every granule (copy c read by the workgroups of XCD c % REP): does the all-gather hot-spot the
+// memory channels that hold the 16-KiB vector (every one of the 256 CUs reads the same lines, past its L2)?
+template <int PIECES, int NGW, int ORD, int REP = 1>
 __global__ __launch_bounds__(512 + 64 * NGW) void k_phases(const uint8_t* w, unsigned w_bytes, u64* gran /*[2][G*8]*/,
                                                          unsigned* flags /*[0]=abort [1]=errors [2]=timeouts*/,
                                                          int iters, unsigned epoch0, float* sink) {
@@ -75,22 +77,22 @@ __global__ __launch_bounds__(512 + 64 * NGW) void k_phases(const uint8_t* w, uns
         // ------------------------------------------------ gatherer: every hand-off access
         const int gw = wave - 8;
         const __amdgpu_buffer_rsrc_t grs =
-            __builtin_amdgcn_make_buffer_rsrc((void*)gran, 0, (int)(2 * n_gran * 8), 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void*)gran, 0, (int)(REP * 2 * n_gran * 8), 0x00020000);
         unsigned carry = 0;
         for (int it = 0; it < iters; ++it) {
             const unsigned epoch = epoch0 + (unsigned)it;
             u64* buf = gran + (size_t)(it & 1) * n_gran;
             // publish (depends on the previous phase's combine through `carry`)
-            if (gw == 0 && lane < kGranPerWg)
-                __hip_atomic_store(buf + bid * kGranPerWg + lane,
-                                   ((u64)epoch << 32) | (payload(bid, lane, it) + (carry & 0u)), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (gw == 0 && lane < kGranPerWg * REP)
+                __hip_atomic_store(buf + (size_t)(lane / kGranPerWg) * 2 * n_gran + bid * kGranPerWg + lane % kGranPerWg,
+                                   ((u64)epoch << 32) | (payload(bid, lane % kGranPerWg, it) + (carry & 0u)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (ORD == 1 && it > 0) __syncthreads();  // third barrier of the previous phase: publish issued, refill may go
             // sweep: this wave's share of the granules, 2 per 16-B load
             constexpr int kLoads = 2048 / NGW / 2 / 64;      // 16-B loads per lane (G = 256: 2048 granules)
             constexpr int per_wave = 2048 / NGW;             // granules
             constexpr int loads = kLoads;
-            const unsigned base = ((unsigned)(it & 1) * n_gran + gw * per_wave) * 8u;
+            const unsigned base = ((unsigned)((bid & 7) % REP) * 2 * n_gran + (unsigned)(it & 1) * n_gran + gw * per_wave) * 8u;
             bool done = false;
             unsigned spins = 0;
             while (!done) {
@@ -151,18 +153,18 @@ __global__ __launch_bounds__(512 + 64 * NGW) void k_phases(const uint8_t* w, uns
     }
 }
 
-template <int PIECES, int NGW, int ORD>
+template <int PIECES, int NGW, int ORD, int REP = 1>
 int run(const uint8_t* w, unsigned w_bytes, u64* gran, unsigned* flags, float* sink, int G, int iters, unsigned& epoch) {
     hipStream_t s = 0;
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
     const size_t lds = 100 * 1024;  // one workgroup per CU, as in the real kernel
-    CK(hipFuncSetAttribute((const void*)k_phases<PIECES, NGW, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)k_phases<PIECES, NGW, ORD, REP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipMemset(flags, 0, 16));
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(a, s));
-        hipLaunchKernelGGL((k_phases<PIECES, NGW, ORD>), dim3(G), dim3(512 + 64 * NGW), lds, s, w, w_bytes, gran, flags, iters,
+        hipLaunchKernelGGL((k_phases<PIECES, NGW, ORD, REP>), dim3(G), dim3(512 + 64 * NGW), lds, s, w, w_bytes, gran, flags, iters,
                            epoch, sink);
         CK(hipEventRecord(b, s));
         CK(hipEventSynchronize(b));
@@ -172,8 +174,8 @@ int run(const uint8_t* w, unsigned w_bytes, u64* gran, unsigned* flags, float* s
         unsigned h[4];
         CK(hipMemcpy(h, flags, 16, hipMemcpyDeviceToHost));
         if (rep == 2 || h[0] || h[1])
-            printf("pieces/wave %2d (%3d KiB/CU/phase, %5.1f MB/phase) gatherers %d order %d: %6.2f us/phase  (%4.0f GB/s)  abort %u errors %u timeouts %u\n",
-                   PIECES, PIECES * 8, PIECES * 8.0 * 1024 * G / 1e6, NGW, ORD, ms * 1e3 / iters,
+            printf("pieces/wave %2d (%3d KiB/CU/phase, %5.1f MB/phase) gatherers %d order %d copies %d: %6.2f us/phase  (%4.0f GB/s)  abort %u errors %u timeouts %u\n",
+                   PIECES, PIECES * 8, PIECES * 8.0 * 1024 * G / 1e6, NGW, ORD, REP, ms * 1e3 / iters,
                    PIECES * 8.0 * 1024 * G / (ms * 1e3 / iters) / 1e3, h[0], h[1], h[2]);
         if (h[0]) return 1;
     }
@@ -195,8 +197,8 @@ int main() {
     CK(hipMalloc(&w, w_bytes));
     CK(hipMemset(w, 1, w_bytes));
     u64* gran;
-    CK(hipMalloc(&gran, 2 * 4096 * 8));
-    CK(hipMemset(gran, 0, 2 * 4096 * 8));
+    CK(hipMalloc(&gran, 8 * 2 * 4096 * 8));
+    CK(hipMemset(gran, 0, 8 * 2 * 4096 * 8));
     unsigned* flags;
     CK(hipMalloc(&flags, 16));
     float* sink;
@@ -204,10 +206,14 @@ int main() {
     unsigned epoch = 1;
     const int iters = 400;
     int rc = 0;
-    rc |= run<0, 1, 0>(w, w_bytes, gran, flags, sink, G, iters, epoch);
-    rc |= run<0, 2, 0>(w, w_bytes, gran, flags, sink, G, iters, epoch);
-    rc |= run<4, 1, 0>(w, w_bytes, gran, flags, sink, G, iters, epoch);
-    rc |= run<12, 1, 0>(w, w_bytes, gran, flags, sink, G, iters, epoch);
+    rc |= run<0, 2, 1>(w, w_bytes, gran, flags, sink, G, iters, epoch);
+    rc |= run<0, 2, 1, 2>(w, w_bytes, gran, flags, sink, G, iters, epoch);
+    rc |= run<0, 2, 1, 8>(w, w_bytes, gran, flags, sink, G, iters, epoch);
+    rc |= run<0, 4, 1>(w, w_bytes, gran, flags, sink, G, iters, epoch);
+    rc |= run<0, 4, 1, 8>(w, w_bytes, gran, flags, sink, G, iters, epoch);
+    rc |= run<12, 2, 1, 8>(w, w_bytes, gran, flags, sink, G, iters, epoch);
+    rc |= run<12, 4, 1, 8>(w, w_bytes, gran, flags, sink, G, iters, epoch);
+    rc |= run<12, 4, 1>(w, w_bytes, gran, flags, sink, G, iters, epoch);
     rc |= run<0, 1, 1>(w, w_bytes, gran, flags, sink, G, iters, epoch);
     rc |= run<4, 1, 1>(w, w_bytes, gran, flags, sink, G, iters, epoch);
     rc |= run<4, 2, 1>(w, w_bytes, gran, flags, sink, G, iters, epoch);
