@@ -517,9 +517,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
         auto bfpair = [&](float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); };
         // activation pair granule: fp16 (a, b); ODD pairs of a vector carry a / 16, b / 16 (see nib2f16).  pg is the
         // pair's index inside its 8-pair row, the rows start at even pair indices.
+        // fp16 has 5 exponent bits: the conversion saturates (a finite, if clipped, operand instead of an inf that the
+        // +1024 offsets would turn into NaN), and the residual stream, whose size nothing bounds, is published times a
+        // power of two that brings its rms near 1 (publish_x).
         auto hpair = [&](float a, float b) {
             const float k = (pg & 1) ? 0.0625f : 1.0f;
-            const f16x2 h = {(_Float16)(a * k), (_Float16)(b * k)};
+            const f16x2 h = {(_Float16)__builtin_amdgcn_fmed3f(a * k, -65504.f, 65504.f),
+                             (_Float16)__builtin_amdgcn_fmed3f(b * k, -65504.f, 65504.f)};
             return __builtin_bit_cast(unsigned, h);
         };
         // sums of the staged operands, even pairs in .x and odd pairs in .y (one v_dot2_f32_f16 per dword).  They undo
@@ -552,11 +556,18 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
         if (dbg_on && gw == 0 && lane == 0) p.dbg[bid * 64 + (i)] = wall_clock64();               \
     } while (0)
 
-        // publish an x-type edge: bf16(norm_scale * x) pairs + the partial sum of squares of this workgroup's rows
+        // publish an x-type edge: fp16(x_scale * norm_scale * x) pairs + the partial sum of squares of this workgroup's
+        // rows.  x_scale = the power of two next to 1/rms of the PREVIOUS x edge (the same float in every workgroup: all
+        // of them reduce the same 256 partial sums in the same order; 1 for the embedding): the residual stream changes
+        // by one sub-layer's output between two edges, so the published values stay O(norm weight), far from the fp16
+        // limits both ways.  The consumer folds 1 / x_scale into the 1/rms factor of its epilogue.
+        float x_scale = 1.f;       // applied to the edge published last (= the one gathered next)
+        float rinv_seen = 1.f;     // 1/rms of the x edge gathered last
         auto publish_x = [&](float2 xv, float2 gsc) {
             const unsigned ep = ebase + edge;
             u64* dst = p.gx + (size_t)xpar * 2304;
-            if (w8 == 0) gr_store(dst + bid * 8 + pg, ep, hpair(gsc.x * xv.x, gsc.y * xv.y));
+            x_scale = __uint_as_float((__float_as_uint(rinv_seen) + 0x00400000u) & 0x7F800000u);
+            if (w8 == 0) gr_store(dst + bid * 8 + pg, ep, hpair(x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y));
             float ss = xv.x * xv.x + xv.y * xv.y;  // the same in the 8 lanes of a pair: sum over the 8 pairs
             ss = MI355_DPP_ADD(ss, 0x140);
             ss += lane_xor16(ss);
@@ -646,7 +657,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             __syncthreads();  // B1
             __syncthreads();  // Bt (one virtual tile)
             if (gw == 0) {
-                const float rinv = misc[0];
+                rinv_seen = misc[0];
+                const float rinv = rinv_seen / x_scale;
                 const float2 sx = get_sums();
                 float2 y[3];
 #pragma unroll
@@ -769,7 +781,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 __syncthreads();  // B1
                 const unsigned ep = ebase + edge;
                 u64* dst = p.gh + (size_t)hpar * (p.H / 2);
-                const float rinv = gw == 0 ? misc[0] : 0.f;
+                rinv_seen = misc[0];
+                const float rinv = rinv_seen / x_scale;
                 const float2 sx = get_sums();
 #pragma unroll
                 for (int t = 0; t < kMaxFcTiles; ++t) {
@@ -845,7 +858,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             if (gw == 0) head_sz(0, sct, zt);
             gather_x();
             __syncthreads();  // B1
-            const float rinv = gw == 0 ? misc[0] : 0.f;
+            rinv_seen = misc[0];
+                const float rinv = rinv_seen / x_scale;
             const float2 sx = get_sums();
             float best = -INFINITY;
             int bi = 0x7fffffff;

@@ -169,3 +169,34 @@ def test_engine_is_rebuilt_when_parameters_change(dev):
     e2 = model._engine
     c = lit_llama_amd.generate(model, prompt, 6, top_k=1)
     assert model._engine is not e2 and not torch.equal(b, c)
+
+
+def test_fused_step_survives_an_unbounded_residual_stream(dev):
+    """The model bench.py times: 32 layers of UNIFORM random int4 weights (synth.fill_model_random_int4), whose residual
+    stream grows layer by layer far past what a trained checkpoint shows.  The fused step stages activations as fp16
+    (5 exponent bits): the logits must stay finite and follow the launch-per-operator engine (bf16 staging) — the
+    x edges are published times a power of two near 1/rms, the other edges saturate instead of overflowing."""
+    cfg = LLaMAConfig.from_name("7B")
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
+        model = LLaMA(cfg)
+    model.eval()
+    synth.fill_model_random_int4(model, seed=0)
+    eng = need_fused(model)
+    prompt = synth.make_prompt(16, vocab=cfg.vocab_size, seed=1).to(dev)
+    outs, rows = {}, {}
+    for fused in (False, True):
+        eng.fused_enabled = fused
+        model.reset_cache()
+        outs[fused] = lit_llama_amd.generate(model, prompt, 12, top_k=1, max_seq_length=64).cpu()
+        rows[fused] = teacher_forced(model, outs[False].to(dev), 16, 64, dev)
+        eng.check_status()
+    eng.fused_enabled = True
+    assert torch.isfinite(rows[True]).all(), "fused step: non-finite logits"
+    std = float(rows[False].std(-1).mean())
+    err = (rows[True] - rows[False]).abs().max().item()
+    assert err <= 0.05 * std, f"fused vs unfused logits on the bench model: {err:.4f} (std {std:.3f})"
+    top2 = torch.topk(rows[False], 2, dim=-1).values
+    margins = (top2[:, 0] - top2[:, 1]).tolist()
+    first_tie = next((i for i, m_ in enumerate(margins) if m_ <= 2 * 0.05 * std), len(margins))
+    n = 16 + first_tie + 1
+    assert torch.equal(outs[True][:n], outs[False][:n]), f"{outs[True].tolist()} vs {outs[False].tolist()}"
