@@ -57,16 +57,15 @@ constexpr int kMaxHeadTiles = 8;  // lm_head tiles per workgroup (vocab <= 32768
 constexpr unsigned kSpinLimit = 400000u;
 
 // LDS map (bytes)
-constexpr int kOffMisc = 0;                       // [0] 1/rms, [1] softmax sum, [2] softmax max
+constexpr int kOffMisc = 0;                       // [0] 1/rms, [4..7] operand sums, [16..23] / [24..31] per-wave softmax max / sum
 constexpr int kOffZero = 256;                     // one all-zero unit (idle ring steps read it)
-constexpr int kOffXs = 512;                       // activation vector, bf16, <= 96 units
+constexpr int kOffXs = 512;                       // activation vector, fp16, <= 96 units
 constexpr int kOffPart = kOffXs + 96 * 256;       // [2][8 waves][4][64 lanes][4] f32 partial tiles
 constexpr int kOffStage = kOffPart + 2 * kSW * 4 * 1024;  // 1 KiB epilogue staging
 constexpr int kOffQ = kOffStage + 1024;           // q[128] knew[128] vnew[128] f32
 constexpr int kOffOpart = kOffQ + 3 * 512;        // [8 waves][16] f32
-constexpr int kOffScores = kOffOpart + 512;       // [S] f32
-constexpr int kMaxS = 8192;
-constexpr int kLdsBytes = kOffScores + kMaxS * 4;
+constexpr int kMaxS = 32768;                      // cache rows (the attention keeps no per-row state in LDS)
+constexpr int kLdsBytes = kOffOpart + 512;
 static_assert(kLdsBytes <= 160 * 1024, "LDS map exceeds the CU");
 
 struct FusedParams {
@@ -204,7 +203,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
     float* knew = qs + kHs;
     float* vnew = knew + kHs;
     float* opart = (float*)(smem + kOffOpart);
-    float* scores = (float*)(smem + kOffScores);
 
     // workgroup -> head group: the 8 workgroups of a head sit on one XCD (blocks are dealt round-robin to the 8 XCDs;
     // a speed matter only — the protocol does not depend on placement)
@@ -368,12 +366,16 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                     __builtin_amdgcn_make_buffer_rsrc((void*)kc, 0, pos * (kHs * 2), 0x00020000);
                 const __amdgpu_buffer_rsrc_t rv =
                     __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, pos * (kHs * 2), 0x00020000);
-                const int n_blocks = (pos + 255) >> 8;  // blocks of 256 cached rows
+                const int n_blocks = (pos + 255) >> 8;  // blocks of 256 cached rows: 32 per wave and block
                 u32x4 kr[8], vr;
-                // rows of block 0: requested before q is known
+                // rows of block 0: requested before q is known.  A wave scores the SAME 32 rows it then weighs the
+                // values of (row wave * 32 + u * 4 + lr for the scores, 16 lanes per row; row wave * 32 + rl for the
+                // values, 8 of the workgroup's 16 output dimensions per lane): no score leaves the wave, the softmax is
+                // a per-wave partial (running maximum, sum, weighted values) that gatherer 0 merges — no barrier and no
+                // LDS round trip between scores and values, and no wave re-reads the whole score vector.
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int t = u * 32 + wave * 4 + lr;
+                    const int t = wave * 32 + u * 4 + lr;
                     kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                           rk, t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u, 0, 0));
                 }
@@ -387,15 +389,26 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 float qf[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) qf[j] = qs[li * 8 + j];
+                // lane L (value row rl = L & 31) takes its row's score from the lane group that computed it
+                const int pull = ((((lane_off >> 4) & 3) << 4) | (rl >> 2)) * 4;
+                float m_run = -1.0e30f, l_run = 0.f;
+                float of[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) of[j] = 0.f;
                 for (int blk = 0; blk < n_blocks; ++blk) {
+                    u32x4 vv = vr;
                     if (blk > 0) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
-                            const int t = blk * 256 + u * 32 + wave * 4 + lr;
+                            const int t = blk * 256 + wave * 32 + u * 4 + lr;
                             kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                                   rk, t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u, 0, 0));
                         }
+                        const int t = blk * 256 + wave * 32 + rl;
+                        vv = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                           rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
                     }
+                    float sel = 0.f;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         float dot = 0.f;
@@ -405,57 +418,59 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                             dot += qf[2 * i + 1] * __uint_as_float(kr[u][i] & 0xffff0000u);
                         }
                         dot = group_sum(dot, 16);
-                        const int t = blk * 256 + u * 32 + wave * 4 + lr;
-                        if (li == 0 && t < pos) scores[t] = dot * p.scale;
+                        if ((li & 7) == u) sel = dot;
                     }
-                }
-                if (wave == 0) {  // the new token's own score, from the LDS copy of its key
-                    float dot = qs[lane] * knew[lane] + qs[lane + 64] * knew[lane + 64];
-                    dot = group_sum(dot, 64);
-                    if (lane == 0) scores[pos] = dot * p.scale;
-                }
-                __syncthreads();  // Ba2: scores[0 .. pos] complete
-                FS_SSTAMP(24);
-                const int len = pos + 1;
-                float mx = -1.0e30f;
-                for (int t = lane; t < len; t += 64) mx = fmaxf(mx, scores[t]);
-                mx = fmaxf(mx, lane_xor32(mx));
-                mx = fmaxf(mx, lane_xor16(mx));
-                mx = MI355_DPP_MAX(mx, 0x140);
-                mx = MI355_DPP_MAX(mx, 0x141);
-                mx = MI355_DPP_MAX(mx, 0x4E);
-                mx = MI355_DPP_MAX(mx, 0xB1);
-                float sum = 0.f;
-                for (int t = lane; t < len; t += 64) sum += __expf(scores[t] - mx);
-                sum = group_sum(sum, 64);
-                float of[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) of[j] = 0.f;
-                for (int sb = 0; sb < n_blocks; ++sb) {  // 256 cached rows per pass: 32 per wave, 16 B per lane
-                    const int t = sb * 256 + wave * 32 + rl;
-                    u32x4 vv = vr;
-                    if (sb > 0)
-                        vv = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                           rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
-                    const float pr = t < pos ? __expf(scores[t] - mx) : 0.f;
+                    const int t = blk * 256 + wave * 32 + rl;
+                    float sc = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(sel))) * p.scale;
+                    sc = t < pos ? sc : -1.0e30f;
+                    float bm = fmaxf(sc, lane_xor16(sc));  // maximum over the wave's 32 rows (both halves hold them)
+                    bm = MI355_DPP_MAX(bm, 0x140);
+                    bm = MI355_DPP_MAX(bm, 0x141);
+                    bm = MI355_DPP_MAX(bm, 0x4E);
+                    bm = MI355_DPP_MAX(bm, 0xB1);
+                    float s_new = -1.0e30f;
+                    if (blk == 0 && wave == 0) {  // the new token's own score, from the LDS copy of its key
+                        float dot = qs[lane] * knew[lane] + qs[lane + 64] * knew[lane + 64];
+                        s_new = group_sum(dot, 64) * p.scale;
+                        bm = fmaxf(bm, s_new);
+                    }
+                    const float m_new = fmaxf(m_run, bm);
+                    const float corr = __expf(m_run - m_new);
+                    const float pr = t < pos ? __expf(sc - m_new) : 0.f;
+                    l_run = l_run * corr + pr;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        of[2 * i] += pr * __uint_as_float(vv[i] << 16);
-                        of[2 * i + 1] += pr * __uint_as_float(vv[i] & 0xffff0000u);
+                        of[2 * i] = of[2 * i] * corr + pr * __uint_as_float(vv[i] << 16);
+                        of[2 * i + 1] = of[2 * i + 1] * corr + pr * __uint_as_float(vv[i] & 0xffff0000u);
                     }
-                }
-                if (wave == 0 && rl == 0) {  // the new token's value row
-                    const float pr = __expf(scores[pos] - mx);
+                    if (blk == 0 && wave == 0 && rl == 0) {  // the new token's value row
+                        const float pn = __expf(s_new - m_new);
+                        l_run += pn;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) of[j] += pr * vnew[hj * 16 + half * 8 + j];
+                        for (int j = 0; j < 8; ++j) of[j] += pn * vnew[hj * 16 + half * 8 + j];
+                    }
+                    m_run = m_new;
+                }
+                if (n_blocks == 0 && wave == 0) {  // position 0: the new token attends to itself only
+                    float dot = qs[lane] * knew[lane] + qs[lane + 64] * knew[lane + 64];
+                    m_run = group_sum(dot, 64) * p.scale;
+                    if (rl == 0) {
+                        l_run = 1.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) of[j] = vnew[hj * 16 + half * 8 + j];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) of[j] = group_sum(of[j], 32);
+                l_run = group_sum(l_run, 32);
                 if (rl == 0) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) opart[wave * 16 + half * 8 + j] = of[j];
                 }
-                if (threadIdx.x == 0) misc[1] = sum;
+                if ((threadIdx.x & 63) == 0) {
+                    misc[16 + wave] = m_run;
+                    misc[24 + wave] = l_run;
+                }
                 FS_SSTAMP(25);
                 __syncthreads();  // Ba3: partial outputs of the 8 waves
                 __syncthreads();  // Ba4: the attention output is published
@@ -714,14 +729,19 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 ++edge;
                 FS_GSTAMP(4);
                 __syncthreads();  // Ba1
-                __syncthreads();  // Ba2
                 __syncthreads();  // Ba3
                 FS_GSTAMP(5);
                 if (gw == 0) {
+                    // merge the 8 per-wave softmax partials (running maximum, sum, weighted values)
                     float2 o = *(const float2*)(opart + w8 * 16 + 2 * pg);
-                    o.x = group_sum(o.x, 8);
-                    o.y = group_sum(o.y, 8);
-                    const float inv = 1.0f / misc[1];
+                    const float mw = misc[16 + w8];
+                    float mall = MI355_DPP_MAX(mw, 0xB1);
+                    mall = MI355_DPP_MAX(mall, 0x4E);
+                    mall = MI355_DPP_MAX(mall, 0x141);
+                    const float wsc = __expf(mw - mall);
+                    o.x = group_sum(o.x * wsc, 8);
+                    o.y = group_sum(o.y * wsc, 8);
+                    const float inv = 1.0f / group_sum(misc[24 + w8] * wsc, 8);
                     // attention output elements head * 128 + hj * 16 + 2 pg, + 1 -> one pair granule
                     if (w8 == 0)
                         gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair(o.x * inv, o.y * inv));

@@ -16,10 +16,9 @@ from lit_llama_amd.utils import EmptyInitOnDevice  # noqa: E402
 NAMES = {2: "G  x gathered (c_attn)", 3: "G  q/k/v published", 4: "G  head q gathered", 5: "G  attn partials ready",
          6: "G  attn out published", 7: "G  attn out gathered", 8: "G  c_proj published", 9: "G  x gathered (fc)",
          10: "G  hidden published", 11: "G  hidden gathered", 12: "G  mlp.c_proj published",
-         20: "S  c_attn B1", 21: "S  c_attn consumed", 23: "S  attn q staged", 24: "S  attn scores done",
-         25: "S  attn out done", 26: "S  c_proj B1", 27: "S  c_proj consumed", 28: "S  fc B1", 29: "S  fc consumed",
+         20: "S  c_attn B1", 21: "S  c_attn consumed", 23: "S  attn q staged",          25: "S  attn out done", 26: "S  c_proj B1", 27: "S  c_proj consumed", 28: "S  fc B1", 29: "S  fc consumed",
          30: "S  mproj B1", 31: "S  mproj consumed"}
-ORDER = [2, 20, 21, 3, 4, 23, 24, 25, 5, 6, 7, 26, 27, 8, 9, 28, 29, 10, 11, 30, 31, 12]
+ORDER = [2, 20, 21, 3, 4, 23, 25, 5, 6, 7, 26, 27, 8, 9, 28, 29, 10, 11, 30, 31, 12]
 
 
 def main():

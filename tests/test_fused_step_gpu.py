@@ -200,3 +200,30 @@ def test_fused_step_survives_an_unbounded_residual_stream(dev):
     first_tie = next((i for i, m_ in enumerate(margins) if m_ <= 2 * 0.05 * std), len(margins))
     n = 16 + first_tie + 1
     assert torch.equal(outs[True][:n], outs[False][:n]), f"{outs[True].tolist()} vs {outs[False].tolist()}"
+
+
+@pytest.mark.parametrize("T", [255, 256, 257, 700])
+def test_fused_step_attention_over_several_blocks_of_the_cache(dev, T):
+    """Positions past one 256-row block of the cache: every streamer wave keeps a running softmax partial over its 32
+    rows of each block (rescaled when the maximum moves), gatherer 0 merges the eight partials.  Checked against the
+    launch-per-operator engine (flash-decoding attention kernel) on the same cache."""
+    model, _, cfg = build(1, dev, seed=3)
+    eng = need_fused(model)
+    prompt = synth.make_prompt(T, seed=T).to(dev)
+    S = T + 8
+    rows = {}
+    for fused in (False, True):
+        eng.fused_enabled = fused
+        model.reset_cache()
+        out = lit_llama_amd.generate(model, prompt, 4, top_k=1, max_seq_length=S)
+        rows[fused] = teacher_forced(model, out, T, S, dev) if fused else None
+        if not fused:
+            ref_out = out
+            rows[False] = teacher_forced(model, ref_out, T, S, dev)
+        else:
+            rows[True] = teacher_forced(model, ref_out, T, S, dev)
+        eng.check_status()
+    eng.fused_enabled = True
+    std = float(rows[False].std(-1).mean())
+    err = (rows[True] - rows[False]).abs().max().item()
+    assert err <= 0.03 * std, f"T={T}: fused vs unfused logits {err:.4f} (std {std:.3f})"
