@@ -97,7 +97,8 @@ typedef struct mi355_linear_args {
     const void* norm_scale; /* [K] or NULL */
     int32_t norm_dtype;
     float eps;
-    /* Q4: per-output-row scale and zero ([N], dtype sz_dtype); *2 for the second interleaved matrix */
+    /* Q4: per-output-row scale and zero ([N], dtype sz_dtype; [N, groups] with group_cols); *2 for the second
+     * interleaved matrix */
     const void* scales;
     const void* zeros;
     const void* scales2;
@@ -107,7 +108,9 @@ typedef struct mi355_linear_args {
     const void* bias;   /* [N] of sz_dtype or NULL (STORE/ACCUM only) */
     void* y;            /* [M, ldy] */
     int32_t y_dtype;
-    int32_t reserved0;
+    int32_t group_cols; /* Q4, mi355_linear_fast: input columns per (scale, zero) pair ("groupsize", quantization.py:284-333
+                         * with tile_cols > 0): scales / zeros are then [N, ceil(K / group_cols)] row-major bf16 and
+                         * group_cols must be 32 * 2^n with 16 * groups <= 2048; 0 or >= K: one pair per output row */
     int64_t ldy;
     /* launch tuning; 0 = library default */
     int32_t waves;      /* waves per workgroup (split of K) */
@@ -327,7 +330,7 @@ typedef struct mi355_weight {
     int32_t grid;
     int32_t prefetch;
     int32_t flags;      /* as mi355_linear_args.flags */
-    int32_t reserved0;
+    int32_t group_cols; /* Q4: as mi355_linear_args.group_cols (0: one scale / zero per output row) */
 } mi355_weight;
 
 typedef struct mi355_layer {

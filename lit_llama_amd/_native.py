@@ -35,7 +35,7 @@ class LinearArgs(C.Structure):
         ("norm_scale", c_void_p), ("norm_dtype", c_int32), ("eps", c_float),
         ("scales", c_void_p), ("zeros", c_void_p), ("scales2", c_void_p), ("zeros2", c_void_p),
         ("sz_dtype", c_int32), ("epi", c_int32), ("bias", c_void_p),
-        ("y", c_void_p), ("y_dtype", c_int32), ("reserved0", c_int32), ("ldy", c_int64),
+        ("y", c_void_p), ("y_dtype", c_int32), ("group_cols", c_int32), ("ldy", c_int64),
         ("waves", c_int32), ("grid", c_int32), ("prefetch", c_int32), ("flags", c_int32),
         ("attn_partials", c_void_p), ("attn_splits", c_int32), ("attn_heads", c_int32), ("attn_hs", c_int32),
         ("reserved1", c_int32), ("debug_stamps", c_void_p),
@@ -73,7 +73,7 @@ class Weight(C.Structure):
         ("scales", c_void_p), ("zeros", c_void_p), ("scales2", c_void_p), ("zeros2", c_void_p),
         ("scb", c_void_p), ("scb2", c_void_p),
         ("sz_dtype", c_int32), ("waves", c_int32), ("grid", c_int32), ("prefetch", c_int32),
-        ("flags", c_int32), ("reserved0", c_int32),
+        ("flags", c_int32), ("group_cols", c_int32),
     ]
 
 

@@ -82,7 +82,9 @@ int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x
                const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy, hipStream_t s,
                const float* attn_partials = nullptr) {
     // wide inputs (prompt chunks of >= 32 tokens) of an int4 model: the LDS-tiled MFMA GEMM over the same stream
-    if (w.fmt == MI355_W_Q4 && M >= 32 && m->gemm_ws != nullptr && attn_partials == nullptr && w.N % 4 == 0 && ldy % 4 == 0) {
+    // (grouped scales: the streaming kernel only, in sub-chunks of rows)
+    if (w.fmt == MI355_W_Q4 && M >= 32 && m->gemm_ws != nullptr && attn_partials == nullptr && w.N % 4 == 0 && ldy % 4 == 0 &&
+        w.group_cols == 0) {
         mi355_linear_args a;
         memset(&a, 0, sizeof(a));
         a.fmt = w.fmt;
@@ -108,7 +110,14 @@ int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x
         a.ldy = ldy;
         return mi355_linear_gemm(&a, m->gemm_ws, (size_t)m->gemm_ws_bytes, s);
     }
-    const int cap = mi355_linear_max_rows(w.fmt, w.K, w.R, w.waves);
+    int cap = mi355_linear_max_rows(w.fmt, w.K, w.R, w.waves);
+    if (w.fmt == MI355_W_Q4 && w.group_cols > 0 && w.group_cols < w.K) {
+        // the tile's (scale, zero) table shares the LDS with the activation rows: 2 x 16 R x groups dwords
+        const int groups = (w.K + w.group_cols - 1) / w.group_cols;
+        const int row_bytes = ((w.K + 127) / 128 + 1) * 256 + 16;
+        cap -= (2 * 16 * w.R * groups * 4 + 16 + row_bytes - 1) / row_bytes;
+        if (cap < 1) cap = 1;
+    }
     MI355_CHECK_ARG(cap >= 1, MI355_E_SHAPE, "forward: a row of K=%d does not fit LDS", w.K);
     if (M <= cap) return run_linear_rows(m, w, x, x_dtype, M, ldx, norm_scale, epi, y, y_dtype, ldy, s, attn_partials);
     const int n_sub = (M + cap - 1) / cap, step = (M + n_sub - 1) / n_sub;
@@ -156,6 +165,7 @@ int run_linear_rows(const mi355_model* m, const mi355_weight& w, const void* x, 
     a.grid = w.grid;
     a.prefetch = w.prefetch;
     a.flags = w.flags;
+    a.group_cols = w.group_cols;
     if (attn_partials != nullptr) {
         a.attn_partials = attn_partials;
         a.attn_splits = m->attn_splits;

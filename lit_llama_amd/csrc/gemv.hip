@@ -58,6 +58,9 @@ struct GemvParams {
     int attn_splits, attn_heads, attn_hs;
     unsigned long long* dbg;  // optional wall-clock stamps [grid][8]
     float eps;
+    // grouped scales (GRP kernels): scales / zeros are [N, n_groups] bf16, one pair per 32 << gq_shift input columns
+    int n_groups, gq_shift;
+    float inv_ng;  // 1 / n_groups (element index -> row without an integer division)
 };
 
 template <int FMT>
@@ -282,13 +285,14 @@ __device__ __forceinline__ EpiRsrc make_epi_rsrc(const GemvParams& p, int M) {
     r.sz_shift = p.sz_dtype == MI355_F32 ? 2 : 1;
     r.y_shift = p.y_dtype == MI355_F32 ? 2 : 1;
     const int nb = ((p.N << r.sz_shift) + 3) & ~3;
+    const int nbg = (((p.N * (p.n_groups > 0 ? p.n_groups : 1)) << r.sz_shift) + 3) & ~3;  // [N, n_groups] when grouped
     auto mk = [](const void* ptr, int bytes) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, ptr != nullptr ? bytes : 0, 0x00020000);
     };
-    r.s0 = mk(p.scales, nb);
-    r.z0 = mk(p.zeros, nb);
-    r.s1 = mk(p.scales2, nb);
-    r.z1 = mk(p.zeros2, nb);
+    r.s0 = mk(p.scales, nbg);
+    r.z0 = mk(p.zeros, nbg);
+    r.s1 = mk(p.scales2, nbg);
+    r.z1 = mk(p.zeros2, nbg);
     r.bias = mk(p.bias, nb);
     r.y = mk(p.y, (int)(((((int64_t)(M - 1) * p.ldy + p.N) << r.y_shift) + 3) & ~(int64_t)3));
     return r;
@@ -300,7 +304,7 @@ __device__ __forceinline__ float cvt2(uint32_t raw, int dtype) {
     return dtype == MI355_F32 ? __uint_as_float(raw) : __uint_as_float(raw << 16);
 }
 
-template <int FMT, int R, int EPI>
+template <int FMT, int R, int EPI, bool GRP = false>
 __device__ __forceinline__ void load_epi(const GemvParams& p, const EpiRsrc& er, int tile, int e_row, int e_col,
                                          bool e_owner, EpiOps<R>& o) {
     constexpr bool sw = EPI == MI355_EPI_SWIGLU;
@@ -311,7 +315,7 @@ __device__ __forceinline__ void load_epi(const GemvParams& p, const EpiRsrc& er,
         const bool ok = live && n < p.N;
         const unsigned off = (unsigned)n << er.sz_shift;
         o.sh_sz[r] = er.sz_shift == 2 ? 0u : (off & 2u) * 8u;
-        if constexpr (FMT == MI355_W_Q4) {
+        if constexpr (FMT == MI355_W_Q4 && !GRP) {
             o.s[r] = ld_epi_dword((sw && r == 1) ? er.s1 : er.s0, off, ok);
             o.z[r] = ld_epi_dword((sw && r == 1) ? er.z1 : er.z0, off, ok);
         }
@@ -328,10 +332,12 @@ __device__ __forceinline__ void load_epi(const GemvParams& p, const EpiRsrc& er,
 
 // Combine the W partial 16x16 tiles of `buf` in wave order and write the tile's outputs (stores only).
 // RS = partial tiles per wave: R weight tiles (+ the all-ones tile carrying sum_k x_k for Q4).
-template <int FMT, int R, int EPI, bool MULTI>
+// GRP: the partial tiles are already dequantised (grouped scales are applied inside the k loop).
+template <int FMT, int R, int EPI, bool MULTI, bool GRP = false>
 __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* part, int buf, int W, int tile,
                                               int e_row, int e_col, const EpiOps<R>& o, float rinv) {
-    constexpr int RS = R + (FMT == MI355_W_Q4 ? 1 : 0);
+    constexpr bool kDeq = FMT == MI355_W_Q4 && !GRP;
+    constexpr int RS = R + (kDeq ? 1 : 0);
     // D layout of mfma_f32_16x16x32: lane (row >> 2) * 16 + col holds D[row][col] in register (row & 3)
     float sx = 0.f;
     float v[R];
@@ -347,13 +353,13 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
 #pragma unroll
         for (int r = 0; r < RS; ++r) t[r] = group_sum(t[r], 16);
         if (e_col != 0) return;
-        if constexpr (FMT == MI355_W_Q4) sx = t[R];
+        if constexpr (kDeq) sx = t[RS - 1];
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = t[r];
     } else {
         const int src = ((e_row >> 2) << 4) | e_col;
         const float* base = (const float*)(part + (size_t)(buf * W * RS) * 1024) + src * 4 + (e_row & 3);
-        if constexpr (FMT == MI355_W_Q4) {
+        if constexpr (kDeq) {
             for (int w = 0; w < W; ++w) sx += base[(w * RS + R) * 256];
         }
 #pragma unroll
@@ -366,7 +372,7 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float s = v[r];
-        if constexpr (FMT == MI355_W_Q4)
+        if constexpr (kDeq)
             s = cvt2(o.s[r] >> o.sh_sz[r], p.sz_dtype) * (s - (128.f + cvt2(o.z[r] >> o.sh_sz[r], p.sz_dtype)) * sx);
         v[r] = s * rinv;
     }
@@ -393,13 +399,22 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
 // step) is its own symbol in profiles, and the epilogue carries no runtime switch.
 // Up to 16 waves (1024 threads) per workgroup for the lean Q4 P=4 variants (<= 128 VGPRs); the register-hungrier
 // ones (deep ring, bf16 weights: 4 pieces per unit) stay at 8 waves.
-template <int FMT, int P>
-constexpr int kMaxThreads = (FMT == MI355_W_Q4 && P <= 4) ? 1024 : 512;
+template <int FMT, int P, bool GRP = false>
+constexpr int kMaxThreads = (FMT == MI355_W_Q4 && P <= 4 && !GRP) ? 1024 : 512;
 
 // MULTI = false is the decode step (M == 1): no row loop, no per-row branches — the loop around the row-staging
 // loads alone cost 0.4-1 us per launch through hipcc's conservative vmcnt waits (12.9 -> 11.9 us for the fc pair).
-template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
-__global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvParams p) {
+// GRP (Q4 only): one (scale, zero) pair per output row AND group of 32 << gq_shift input columns (GPTQ "groupsize",
+// quantization.py:284-333 with tile_cols > 0).  A tile's pairs ([16 R rows][n_groups], bf16) are fetched ONE TILE AHEAD
+// with the epilogue-operand trick (fixed number of unconditional buffer loads per thread, kept as raw bits) and parked
+// in LDS at the tile switch; inside the k loop every wave applies  accf += s (acc - (128 + z) sum_x)  at each group
+// boundary of its unit range (sum_x from the all-ones MFMA of the same columns) and restarts acc / sum_x.  The partial
+// tiles that reach the epilogue are then plain sums.
+constexpr int kGrpLoads = 4;  // (scale, zero) pairs per thread, matrix and tile: 16 n_groups <= kGrpLoads x threads
+
+template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI, bool GRP = false>
+__global__ __launch_bounds__((kMaxThreads<FMT, P, GRP>)) void gemv_kernel(const GemvParams p) {
+    static_assert(!GRP || FMT == MI355_W_Q4, "grouped scales are a Q4 feature");
     const int M = MULTI ? p.M : 1;
     constexpr bool NT = true;  // weights are read once: non-temporal
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -408,12 +423,14 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
 
     constexpr int kPieces = Fmt<FMT>::kPieces;
     constexpr int kSlot = R * kPieces;  // 16-B pieces per lane per unit
-    constexpr int RS = R + (FMT == MI355_W_Q4 ? 1 : 0);
+    constexpr int RS = R + ((FMT == MI355_W_Q4 && !GRP) ? 1 : 0);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = blockDim.x >> 6;
     char* xs = part + 2 * W * RS * 1024;
+    // GRP: [2][R * 16 rows][n_groups] dwords (scale bf16 | zero bf16 << 16) behind the activation rows
+    uint32_t* szl = (uint32_t*)(xs + (((size_t)M * p.xs_stride + 15) & ~(size_t)15));
 #define MI355_STAMP(i)                                                                          \
     do {                                                                                        \
         if (p.dbg != nullptr && threadIdx.x == 0) p.dbg[blockIdx.x * 8 + (i)] = wall_clock64(); \
@@ -470,7 +487,48 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
 #pragma unroll
     for (int r = 0; r < R; ++r) eo.s[r] = eo.z[r] = eo.bias[r] = eo.old[r] = eo.sh_sz[r] = eo.sh_y[r] = 0u;
     const EpiRsrc er = make_epi_rsrc(p, M);
-    load_epi<FMT, R, EPI>(p, er, bid, e_row, e_col, e_owner, eo);
+    load_epi<FMT, R, EPI, GRP>(p, er, bid, e_row, e_col, e_owner, eo);
+    // GRP: the (scale, zero) pairs of a tile, element e = thread + k * threads of the [16][n_groups] block of matrix r
+    uint32_t gs[GRP ? R : 1][kGrpLoads], gz[GRP ? R : 1][kGrpLoads];
+    auto grp_load = [&](int t) {
+        if constexpr (GRP) {
+            constexpr bool sw = EPI == MI355_EPI_SWIGLU;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int k = 0; k < kGrpLoads; ++k) {
+                    const int e = (int)threadIdx.x + k * (int)blockDim.x;
+                    const int row = (int)(((float)e + 0.5f) * p.inv_ng);
+                    const int grp = e - row * p.n_groups;
+                    const int n = sw ? t * 16 + row : (t * R + r) * 16 + row;
+                    const bool ok = row < 16 && t < p.n_tiles && n < p.N;
+                    const unsigned off = (unsigned)(n * p.n_groups + grp) * 2u;
+                    gs[r][k] = ld_epi_dword((sw && r == 1) ? er.s1 : er.s0, off, ok);
+                    gz[r][k] = ld_epi_dword((sw && r == 1) ? er.z1 : er.z0, off, ok);
+                }
+            }
+        }
+    };
+    auto grp_park = [&](int t, int b) {  // raw bits -> LDS block b; rows past N carry (0, 0): they multiply zeros
+        if constexpr (GRP) {
+            constexpr bool sw = EPI == MI355_EPI_SWIGLU;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int k = 0; k < kGrpLoads; ++k) {
+                    const int e = (int)threadIdx.x + k * (int)blockDim.x;
+                    const int row = (int)(((float)e + 0.5f) * p.inv_ng);
+                    const int grp = e - row * p.n_groups;
+                    const int n = sw ? t * 16 + row : (t * R + r) * 16 + row;
+                    const unsigned sh = ((unsigned)(n * p.n_groups + grp) & 1u) * 16u;
+                    if (row < 16)
+                        szl[((b * R + r) * 16 + row) * p.n_groups + grp] =
+                            ((gs[r][k] >> sh) & 0xFFFFu) | ((gz[r][k] >> sh) << 16);
+                }
+            }
+        }
+    };
+    grp_load(bid);
 
 #pragma unroll
     for (int j = 0; j < P; ++j) MI355_ISSUE(j);
@@ -494,6 +552,8 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
         stager.load(p, m);
         stage_row(m);
     }
+    grp_park(bid, 0);
+    grp_load(bid + nb);
     __syncthreads();
     MI355_STAMP(2);
 
@@ -505,8 +565,11 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
     }
 
     f32x4 acc[R], acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accf[GRP ? R : 1];  // GRP: the dequantised sums of the groups finished so far
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < (GRP ? R : 1); ++r) accf[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int tile = bid, buf = 0;
 
@@ -524,6 +587,57 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
 #pragma unroll
         for (int d = 0; d < 4; ++d) b[d] = *(const bf16x8*)(xb + 16 * d);
 
+        if constexpr (GRP) {
+            // The k dimension of ONE MFMA is spread over the unit (lane group g holds columns 32 g + 8 d .. + 7 of
+            // MFMA d), so the four MFMAs of a unit always add up whole 128-column units.  Groups of >= 128 columns
+            // end at unit boundaries; groups of 32 / 64 columns are lane groups {g} / {g >> 1} of the B operand:
+            // one pass per sub-group with the other lane groups' activations zeroed (the matrix pipe is idle
+            // otherwise; the conversions are redone per pass — this layout is the rare one).
+            const bool real = uu < nu;
+            const int unit = u0 + uu;
+            const int sub_shift = p.gq_shift < 2 ? p.gq_shift : 2;      // lane groups per sub-group = 1 << sub_shift
+            const int nsub = 4 >> sub_shift;                            // passes over the unit: 4, 2 or 1
+#pragma unroll 1
+            for (int sub = 0; sub < nsub; ++sub) {
+                const bool mine = (g >> sub_shift) == sub;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const u32x4 raw = __builtin_bit_cast(u32x4, b[d]);
+                    const bf16x8 bm = as_bf16x8(mine ? raw : u32x4{0u, 0u, 0u, 0u});
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ones), bm, acc1, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t v = ring[j][r][d];
+                        u32x4 a;
+                        a[0] = (v & 0x000F000Fu) | 0x43004300u;
+                        a[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
+                        a[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
+                        a[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), bm, acc[r], 0, 0, 0);
+                    }
+                }
+                // end of a group (sub-unit groups: every pass; wider ones: the group's last unit), or the last unit
+                // of this wave's range (wave-uniform)
+                const int q_end = unit * 4 + ((sub + 1) << sub_shift);  // 32-column blocks up to here
+                if (real && (((q_end & ((1 << p.gq_shift) - 1)) == 0) || (uu == nu - 1 && sub == nsub - 1))) {
+                    int grp = (q_end - 1) >> p.gq_shift;
+                    grp = grp < p.n_groups ? grp : p.n_groups - 1;  // stream padding past K: x is zero there
+                    const uint32_t* sz = szl + ((buf * R) * 16 + 4 * g) * p.n_groups + grp;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const uint32_t w = sz[(r * 16 + rr) * p.n_groups];
+                            const float sc = __uint_as_float(w << 16), zp = __uint_as_float(w & 0xffff0000u);
+                            accf[r][rr] += sc * (acc[r][rr] - (128.f + zp) * acc1[rr]);
+                        }
+                        acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            return;
+        }
         if constexpr (FMT == MI355_W_Q4) {
             // sum_k x_k of the rounded operands, from the otherwise idle matrix pipe
 #pragma unroll
@@ -557,21 +671,28 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P>)) void gemv_kernel(const GemvP
         f32x4* pp = (f32x4*)(part + (size_t)((buf * W + wave) * RS) * 1024) + lane;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            pp[r * 64] = acc[r];
+            if constexpr (GRP) {
+                pp[r * 64] = accf[r];
+                accf[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                pp[r * 64] = acc[r];
+            }
             acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if constexpr (FMT == MI355_W_Q4) {
-            pp[R * 64] = acc1;
-            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        if constexpr (FMT == MI355_W_Q4 && !GRP) pp[R * 64] = acc1;
+        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        // GRP: the next tile's pairs (requested a tile ago) go to the other LDS block, which no wave reads any more:
+        // its tile ended at the previous flush's barrier
+        grp_park(tile + nb, buf ^ 1);
         if (tile == bid) MI355_STAMP(3);
         __syncthreads();
         if (e_owner || (!MULTI && threadIdx.x < 256))
-            tile_epilogue<FMT, R, EPI, MULTI>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
+            tile_epilogue<FMT, R, EPI, MULTI, GRP>(p, part, buf, W, tile, e_row, e_col, eo, rinv);
         if (tile == bid) MI355_STAMP(4);
         tile += nb;
         buf ^= 1;
-        load_epi<FMT, R, EPI>(p, er, tile, e_row, e_col, e_owner, eo);
+        load_epi<FMT, R, EPI, GRP>(p, er, tile, e_row, e_col, e_owner, eo);
+        grp_load(tile + nb);
     };
 
     // Every wave steps through nu_pad (a multiple of P) units per tile, so a tile can only end after slot P - 1:
@@ -719,19 +840,19 @@ __global__ void i8_repack_kernel(const int8_t* c0, const int8_t* c1, int N, int 
 }
 
 
-template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI>
+template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI, bool GRP>
 int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>,
+        attr_err = hipFuncSetAttribute((const void*)gemv_kernel<FMT, R, P, EPI, VMODE, MULTI, GRP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     });
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
-    if (waves * 64 > kMaxThreads<FMT, P>) {  // the host split (u_q / u_r) was computed for `waves`
+    if (waves * 64 > kMaxThreads<FMT, P, GRP>) {  // the host split (u_q / u_r) was computed for `waves`
         mi355_set_error("internal: %d waves exceed the variant's workgroup size", waves);
         return MI355_E_ARG;
     }
@@ -740,39 +861,39 @@ int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStrea
         // timestamps, i.e. the duration rocprofv3 reports for this launch
         hipEvent_t e0 = t_time_start, e1 = t_time_stop;
         t_time_start = t_time_stop = nullptr;
-        hipExtLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>), dim3(grid), dim3(waves * 64), (uint32_t)lds,
+        hipExtLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI, GRP>), dim3(grid), dim3(waves * 64), (uint32_t)lds,
                               stream, e0, e1, 0, p);
     } else {
-        hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI>), dim3(grid), dim3(waves * 64), lds, stream, p);
+        hipLaunchKernelGGL((gemv_kernel<FMT, R, P, EPI, VMODE, MULTI, GRP>), dim3(grid), dim3(waves * 64), lds, stream, p);
     }
     MI355_LAUNCH_CHECK();
     return 0;
 }
 
-template <int FMT, int R, int P, int EPI, int VMODE>
+template <int FMT, int R, int P, int EPI, int VMODE, bool GRP>
 int launch_gemv_v(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     if constexpr (VMODE == 3) {  // split-attention input exists for M = 1 only (host check)
-        return launch_gemv_m<FMT, R, P, EPI, VMODE, false>(p, grid, waves, lds, stream);
+        return launch_gemv_m<FMT, R, P, EPI, VMODE, false, GRP>(p, grid, waves, lds, stream);
     } else {
-        return p.M > 1 ? launch_gemv_m<FMT, R, P, EPI, VMODE, true>(p, grid, waves, lds, stream)
-                       : launch_gemv_m<FMT, R, P, EPI, VMODE, false>(p, grid, waves, lds, stream);
+        return p.M > 1 ? launch_gemv_m<FMT, R, P, EPI, VMODE, true, GRP>(p, grid, waves, lds, stream)
+                       : launch_gemv_m<FMT, R, P, EPI, VMODE, false, GRP>(p, grid, waves, lds, stream);
     }
 }
 
-template <int FMT, int R, int P, int EPI>
+template <int FMT, int R, int P, int EPI, bool GRP>
 int launch_gemv_epi(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     switch (p.vec_mode) {
         case 1:
-            if constexpr (EPI != MI355_EPI_ACCUM) return launch_gemv_v<FMT, R, P, EPI, 1>(p, grid, waves, lds, stream);
+            if constexpr (EPI != MI355_EPI_ACCUM) return launch_gemv_v<FMT, R, P, EPI, 1, GRP>(p, grid, waves, lds, stream);
             break;
         case 4:
-            if constexpr (EPI != MI355_EPI_ACCUM) return launch_gemv_v<FMT, R, P, EPI, 4>(p, grid, waves, lds, stream);
+            if constexpr (EPI != MI355_EPI_ACCUM) return launch_gemv_v<FMT, R, P, EPI, 4, GRP>(p, grid, waves, lds, stream);
             break;
         case 2:
-            if constexpr (EPI != MI355_EPI_SWIGLU) return launch_gemv_v<FMT, R, P, EPI, 2>(p, grid, waves, lds, stream);
+            if constexpr (EPI != MI355_EPI_SWIGLU) return launch_gemv_v<FMT, R, P, EPI, 2, GRP>(p, grid, waves, lds, stream);
             break;
         case 3:
-            if constexpr (EPI != MI355_EPI_SWIGLU) return launch_gemv_v<FMT, R, P, EPI, 3>(p, grid, waves, lds, stream);
+            if constexpr (EPI != MI355_EPI_SWIGLU) return launch_gemv_v<FMT, R, P, EPI, 3, GRP>(p, grid, waves, lds, stream);
             break;
         default: break;
     }
@@ -780,16 +901,16 @@ int launch_gemv_epi(const GemvParams& p, int grid, int waves, size_t lds, hipStr
         mi355_set_error("split-attention prologue is not available for this epilogue");
         return MI355_E_ARG;
     }
-    return launch_gemv_v<FMT, R, P, EPI, 0>(p, grid, waves, lds, stream);
+    return launch_gemv_v<FMT, R, P, EPI, 0, GRP>(p, grid, waves, lds, stream);
 }
 
-template <int FMT, int R, int P>
+template <int FMT, int R, int P, bool GRP>
 int launch_gemv(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     switch (p.epi) {
-        case MI355_EPI_STORE: return launch_gemv_epi<FMT, R, P, MI355_EPI_STORE>(p, grid, waves, lds, stream);
-        case MI355_EPI_ACCUM: return launch_gemv_epi<FMT, R, P, MI355_EPI_ACCUM>(p, grid, waves, lds, stream);
+        case MI355_EPI_STORE: return launch_gemv_epi<FMT, R, P, MI355_EPI_STORE, GRP>(p, grid, waves, lds, stream);
+        case MI355_EPI_ACCUM: return launch_gemv_epi<FMT, R, P, MI355_EPI_ACCUM, GRP>(p, grid, waves, lds, stream);
         default:
-            if constexpr (R == 2) return launch_gemv_epi<FMT, R, P, MI355_EPI_SWIGLU>(p, grid, waves, lds, stream);
+            if constexpr (R == 2) return launch_gemv_epi<FMT, R, P, MI355_EPI_SWIGLU, GRP>(p, grid, waves, lds, stream);
             mi355_set_error("SwiGLU epilogue needs R == 2");
             return MI355_E_ARG;
     }
@@ -802,7 +923,10 @@ int dispatch_p(const GemvParams& p, int /*prefetch*/, int grid, int waves, size_
     // delays the activation loads; scripts/sweep_gemv.py) and doubled the code size; `prefetch` is accepted and
     // ignored.
     constexpr int PA = FMT == MI355_W_Q4 ? 4 : 2;
-    return launch_gemv<FMT, R, PA>(p, grid, waves, lds, s);
+    if constexpr (FMT == MI355_W_Q4) {
+        if (p.n_groups > 0) return launch_gemv<FMT, R, PA, true>(p, grid, waves, lds, s);
+    }
+    return launch_gemv<FMT, R, PA, false>(p, grid, waves, lds, s);
 }
 
 int g_num_cus = 0;
@@ -942,7 +1066,7 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
     p.eps = a->eps;
     int waves = a->waves > 0 ? a->waves : 8;
     if (waves > 16) waves = 16;
-    if (a->fmt != MI355_W_Q4 && waves > 8) waves = 8;  // see kMaxThreads
+    if ((a->fmt != MI355_W_Q4 || (a->group_cols > 0 && a->group_cols < a->K)) && waves > 8) waves = 8;  // see kMaxThreads
     if (waves < 4) waves = 4;  // the combine step needs 256 owner threads
     {
         const int esz = a->x_dtype == MI355_F32 ? 4 : 2;
@@ -972,8 +1096,28 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
         p.w_bytes = (unsigned)wb;
     }
 
-    const int RS = a->R + (a->fmt == MI355_W_Q4 ? 1 : 0);
-    const size_t lds = kLdsHeader + (size_t)2 * waves * RS * 1024 + (size_t)a->M * p.xs_stride;
+    // grouped scales: group_cols = input columns per (scale, zero) pair; 0 or >= K: one pair per output row
+    p.n_groups = 0;
+    p.gq_shift = 0;
+    p.inv_ng = 0.f;
+    const int group_cols = a->group_cols;
+    if (a->fmt == MI355_W_Q4 && group_cols > 0 && group_cols < a->K) {
+        int sh = 0;
+        while ((32 << sh) < group_cols) ++sh;
+        MI355_CHECK_ARG((32 << sh) == group_cols, MI355_E_SHAPE,
+                        "linear_fast: group size %d is not 32 * 2^n (use the generic kernel)", group_cols);
+        MI355_CHECK_ARG(a->sz_dtype == MI355_BF16, MI355_E_DTYPE, "linear_fast: grouped scales / zeros must be bf16");
+        p.n_groups = (a->K + group_cols - 1) / group_cols;
+        p.gq_shift = sh;
+        p.inv_ng = 1.0f / (float)p.n_groups;
+        MI355_CHECK_ARG(16 * p.n_groups <= kGrpLoads * waves * 64, MI355_E_SHAPE,
+                        "linear_fast: %d groups per row exceed what %d waves prefetch per tile (%d)", p.n_groups, waves,
+                        kGrpLoads * waves * 4);
+        MI355_CHECK_ARG((int64_t)a->N * p.n_groups * 2 < 0x7FFFFFF0ll, MI355_E_SHAPE, "linear_fast: scale table too large");
+    }
+    const int RS = a->R + ((a->fmt == MI355_W_Q4 && p.n_groups == 0) ? 1 : 0);
+    const size_t lds = kLdsHeader + (size_t)2 * waves * RS * 1024 + (((size_t)a->M * p.xs_stride + 15) & ~(size_t)15) +
+                       (size_t)2 * a->R * 16 * p.n_groups * 4;
     MI355_CHECK_ARG(lds <= (size_t)kMaxLds, MI355_E_SHAPE,
                     "linear_fast: M=%d x K=%d activations do not fit LDS (%zu B > %d B); chunk M", a->M, a->K, lds,
                     kMaxLds);

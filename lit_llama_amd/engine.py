@@ -79,8 +79,11 @@ def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: 
         s0, z0 = mod.scales.reshape(-1).contiguous(), mod.zeros.reshape(-1).contiguous()
         d.fmt, d.w, d.N, d.K = W_Q4, ptr(stream), N, K
         d.scales, d.zeros, d.sz_dtype = ptr(s0), ptr(z0), dtype_code(s0.dtype)
+        d.group_cols = mod.tile_cols if mod.scales.shape[1] > 1 else 0  # grouped: [N, groups] tables, streamed per tile
+        if pair is not None and (pair.tile_cols != mod.tile_cols or pair.scales.shape != mod.scales.shape):
+            raise EngineUnavailable("c_fc1 / c_fc2 use different group sizes")
         pw.keep += [stream, s0, z0]
-        pw.side_bytes = 2 * N * s0.element_size()
+        pw.side_bytes = 2 * s0.numel() * s0.element_size()
         if pair is not None:
             s1, z1 = pair.scales.reshape(-1).contiguous(), pair.zeros.reshape(-1).contiguous()
             if s1.dtype != s0.dtype:
@@ -141,8 +144,8 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
         return None
     first = model.transformer.h[0]
     for mod in (first.attn.c_attn, first.attn.c_proj, first.mlp.c_fc1, first.mlp.c_fc2, first.mlp.c_proj, model.lm_head):
-        if not mod.fast_eligible(torch.bfloat16) or mod.scales.dtype != torch.bfloat16:
-            return None
+        if not mod.fast_eligible(torch.bfloat16) or mod.scales.dtype != torch.bfloat16 or mod.scales.shape[1] != 1:
+            return None  # (grouped scales: launch-per-operator engine)
     sizes = [ops.packed_bytes(W_Q4, 3 * C_, C_, 1, False), ops.packed_bytes(W_Q4, C_, C_, 1, False),
              ops.packed_bytes(W_Q4, H, C_, 2, True), ops.packed_bytes(W_Q4, C_, H, 1, False)]
     offs = [0, sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2]]

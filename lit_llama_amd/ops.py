@@ -97,8 +97,10 @@ def linear_fast(
     prefetch: int = 0,
     flags: int = 0,
     attn_partials: Optional[torch.Tensor] = None,
+    group_cols: int = 0,
 ) -> torch.Tensor:
     """y[M, N] = epi(x2d[M, K] . W^T) through the MFMA weight-streaming kernel; M is chunked to fit LDS.
+    `group_cols` (Q4): input columns per (scale, zero) pair; scales / zeros are then [N, ceil(K / group_cols)] bf16.
     With `attn_partials` ([M, heads, splits, hs + 4] f32 records of a split attention) the activations are the
     combined attention output and x2d only provides M / dtype / device (it is not read)."""
     require_gpu(x2d, "linear_fast")
@@ -122,7 +124,14 @@ def linear_fast(
     a.y_dtype = dtype_code(out.dtype)
     a.ldy = out.stride(0)
     a.waves, a.grid, a.prefetch, a.flags = waves, grid, prefetch, flags
+    a.group_cols = group_cols if 0 < group_cols < K else 0
     step = fast_linear_max_m(K, R, fmt, waves or 8)
+    if a.group_cols:
+        # the tile's (scale, zero) table sits behind the activation rows in LDS (2 x 16 R x groups dwords)
+        assert scales is not None and scales.dtype == torch.bfloat16 and scales.is_contiguous() and zeros.is_contiguous()
+        n_groups = -(-K // a.group_cols)
+        row_bytes = (-(-K // 128) + 1) * 256 + 16
+        step = max(1, min(step, step - -(-(2 * 16 * R * n_groups * 4 + 16) // row_bytes)))
     if step < 1:
         raise nat.NativeError(f"linear_fast: K={K} does not fit LDS even for M=1")
     s = stream_ptr()

@@ -85,14 +85,20 @@ class ColBlockQuantizedLinear(torch.nn.Module):
 
     # ---- hot path -----------------------------------------------------------------------------------
     def fast_eligible(self, dtype: torch.dtype) -> bool:
-        """MFMA weight-streaming kernel: 4 bits, one scale/zero per row (gptq.int4's tile_cols = -1), bf16 I/O."""
+        """MFMA weight-streaming kernel: 4 bits, bf16 I/O, one scale/zero per row (gptq.int4's tile_cols = -1) or per
+        row and group of 32 * 2^n columns (bf16 tables, at most 128 groups: `grouped_fast`)."""
         return (
             self.bits == 4
-            and self.scales.shape[1] == 1
+            and (self.scales.shape[1] == 1 or self.grouped_fast())
             and dtype == torch.bfloat16
             and self.scales.dtype in (torch.bfloat16, torch.float32)
             and self.in_features % 2 == 0
         )
+
+    def grouped_fast(self) -> bool:
+        g, ng = self.tile_cols, self.scales.shape[1]
+        return (ng > 1 and g >= 32 and (g & (g - 1)) == 0 and ng <= 128 and self.scales.dtype == torch.bfloat16
+                and ng == -(-self.in_features // g))
 
     def weight_stream(self, R: int = 1) -> torch.Tensor:
         key = (self.quant_weight.data_ptr(), self.quant_weight._version, R)
@@ -107,7 +113,9 @@ class ColBlockQuantizedLinear(torch.nn.Module):
         x2d = inp.reshape(-1, inp.shape[-1])
         if x2d.stride(-1) != 1:
             x2d = x2d.contiguous()
-        if self.fast_eligible(inp.dtype) and x2d.shape[0] >= 32 and self.out_features % 4 == 0 and self.bias is None:
+        grouped = self.scales.shape[1] > 1
+        if (self.fast_eligible(inp.dtype) and not grouped and x2d.shape[0] >= 32 and self.out_features % 4 == 0
+                and self.bias is None):
             # wide input (prompt / no-cache evaluation, evaluate/full.py:120-129): LDS-tiled MFMA GEMM over the stream
             y = ops.linear_gemm(x2d, self.weight_stream(1), 1, self.out_features, self.in_features,
                                 scales=self.scales.reshape(-1), zeros=self.zeros.reshape(-1), out_dtype=inp.dtype)
@@ -117,7 +125,7 @@ class ColBlockQuantizedLinear(torch.nn.Module):
                 x2d, self.weight_stream(R), nat.W_Q4, R, self.out_features, self.in_features,
                 scales=self.scales.reshape(-1), zeros=self.zeros.reshape(-1),
                 bias=None if self.bias is None else self.bias.to(self.scales.dtype),
-                out_dtype=inp.dtype,
+                out_dtype=inp.dtype, group_cols=self.tile_cols if grouped else 0,
             )
         else:
             y = ops.linear_colblock(x2d, self.quant_weight, self.scales, self.zeros, self.bits, self.tile_cols,

@@ -74,9 +74,11 @@ def make_state_dict(
     device: str = "cpu",
     outlier_channels: int = 0,
     bf16_exact: bool = True,
+    group_cols: int = 0,
 ) -> Dict[str, torch.Tensor]:
     """Synthetic checkpoint.  mode None / "llm.int8": float weights in `dtype`; "gptq.int4": packed buffers with
-    scales / zeros in `dtype`.  With `bf16_exact` every float value is rounded to bf16 once at generation time
+    scales / zeros in `dtype` (one pair per row, or per row and group of `group_cols` input columns: the
+    ColBlockQuantizedLinear layout with tile_cols = group_cols, lit_llama/quantization.py:350-374).  With `bf16_exact` every float value is rounded to bf16 once at generation time
     (and stored in `dtype`), so a bf16 GPU model and the f32 CPU oracle hold identical parameters."""
     assert mode in (None, "gptq.int4", "llm.int8")
     gen = torch.Generator(device=device)
@@ -100,7 +102,17 @@ def make_state_dict(
         sd[k] = rnd(v).to(dtype)
     for prefix, N, K in linear_shapes(cfg):
         w = _randn((N, K), gen, device, std=K**-0.5)
-        if mode == "gptq.int4":
+        if mode == "gptq.int4" and 0 < group_cols < K:
+            ng = -(-K // group_cols)
+            q = torch.empty((N, K), dtype=torch.uint8, device=device)
+            scale, zero = torch.empty((N, ng), device=device), torch.empty((N, ng), device=device)
+            for j in range(ng):
+                sl = slice(j * group_cols, (j + 1) * group_cols)
+                q[:, sl], scale[:, j], zero[:, j] = rtn_quantize_rows(w[:, sl], 4)
+            sd[prefix + ".quant_weight"] = pack_colblock(q, 4)
+            sd[prefix + ".scales"] = scale.to(torch.bfloat16).float().to(dtype)
+            sd[prefix + ".zeros"] = zero.to(dtype)
+        elif mode == "gptq.int4":
             q, scale, zero = rtn_quantize_rows(w, 4)
             scale = scale.to(torch.bfloat16).float()  # rounded once; identical on both sides
             sd[prefix + ".quant_weight"] = pack_colblock(q, 4)

@@ -172,6 +172,113 @@ def test_q4_linear_swiglu_pair(dev):
     assert (y.double() - ref).abs().max().item() <= 2e-3 * _rms(ref)
 
 
+# ---- grouped scales ("groupsize": one (scale, zero) pair per output row and group of columns, quantization.py:284-333
+# with tile_cols > 0) in the MFMA streaming kernel
+def _q4_grouped_problem(N, K, M, g, seed, dev):
+    gen = torch.Generator().manual_seed(seed)
+    w = torch.randn((N, K), generator=gen) * K**-0.5 * (1 + torch.arange(K) % 7)[None, :]  # group-dependent ranges
+    ng = -(-K // g)
+    q = torch.empty((N, K), dtype=torch.uint8)
+    scale, zero = torch.empty((N, ng)), torch.empty((N, ng))
+    for j in range(ng):
+        qj, sj, zj = synth.rtn_quantize_rows(w[:, j * g:(j + 1) * g])
+        q[:, j * g:(j + 1) * g], scale[:, j], zero[:, j] = qj, sj, zj
+    scale = scale.to(torch.bfloat16).float()
+    x = torch.randn((M, K), generator=gen)
+    wdq = (q.float() - zero.repeat_interleave(g, 1)[:, :K]) * scale.repeat_interleave(g, 1)[:, :K]
+    return dict(q=q, packed=synth.pack_colblock(q).to(dev), scale=scale, zero=zero, x=x, wdq=wdq)
+
+
+def test_q4_grouped_fast_kernel_matches_reference_golden(dev, golden):
+    """The reference module's own output for a 64-column-group layer (tests/golden/colblock.npz, generated from
+    /root/reference lit_llama/quantization.py by oracle/gen_golden.py).  The fast kernel rounds x and the scale table to
+    bf16: checked tightly against the same arithmetic on the rounded operands, loosely against the f32 golden."""
+    g = golden("colblock")
+    N, K, bits, tc = (int(v) for v in g["b4_g64_meta"])
+    assert (bits, tc) == (4, 64)
+    q = _t(g["b4_g64_q"]).t().contiguous().t().to(dev)
+    scales, zeros, x = _t(g["b4_g64_scales"]), _t(g["b4_g64_zeros"]), _t(g["b4_g64_x"])
+    sb, zb, xb = scales.to(torch.bfloat16), zeros.to(torch.bfloat16), x.to(torch.bfloat16)
+    for R in (1, 2):
+        stream = ops.repack_q4(q, None, N, K, R)
+        y = ops.linear_fast(x.to(dev), stream, nat.W_Q4, R, N, K, scales=sb.to(dev).reshape(-1).contiguous(),
+                            zeros=zb.to(dev).reshape(-1).contiguous(), out_dtype=torch.float32, group_cols=tc).cpu()
+        wdq = _t(g["b4_g64_wdq"])  # (q - z) * s with the f32 tables
+        ref = _t(g["b4_g64_y"])
+        assert (y - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+        # exact arithmetic on the rounded operands: levels recovered from the golden dequantised weight
+        lev = torch.round(wdq / scales.repeat_interleave(tc, 1) + zeros.repeat_interleave(tc, 1))
+        w2 = (lev - zb.float().repeat_interleave(tc, 1)) * sb.float().repeat_interleave(tc, 1)
+        ref2 = xb.double() @ w2.double().t()
+        assert (y.double() - ref2).abs().max().item() <= 1e-3 * _rms(ref2)
+
+
+GROUPED_SHAPES = [
+    # N, K, M, R, group, waves
+    (4096, 4096, 1, 1, 128, 0),     # VERDICT r1 item 6: 7B attn.c_proj with groupsize 128
+    (4096, 4096, 7, 1, 128, 0),
+    (12288, 4096, 1, 2, 128, 0),    # 7B c_attn, two row groups per tile
+    (4096, 11008, 1, 1, 128, 0),    # 7B mlp.c_proj: 86 groups, uneven unit split (groups end inside a wave's range)
+    (4096, 11008, 3, 1, 256, 8),    # a group spans two units; 43 groups
+    (512, 4096, 2, 1, 32, 8),       # a group per MFMA k-block: 128 groups
+    (96, 1024, 1, 2, 64, 4),        # two groups per unit
+    (40, 200, 1, 1, 64, 0),         # K and N padded: the last group is short
+    (64, 512, 16, 1, 512, 0),       # group size == K: one group (per-row path)
+]
+
+
+@pytest.mark.parametrize("N,K,M,R,g,waves", GROUPED_SHAPES)
+def test_q4_grouped_linear_matches_oracle(dev, N, K, M, R, g, waves):
+    p = _q4_grouped_problem(N, K, M, g, seed=N + K + M + g, dev=dev)
+    xb = p["x"].to(torch.bfloat16)
+    stream = ops.repack_q4(p["packed"], None, N, K, R)
+    sc = p["scale"].to(torch.bfloat16).to(dev).reshape(-1).contiguous()
+    ze = p["zero"].to(torch.bfloat16).to(dev).reshape(-1).contiguous()
+    y = ops.linear_fast(xb.to(dev), stream, nat.W_Q4, R, N, K, scales=sc, zeros=ze, out_dtype=torch.float32,
+                        waves=waves, group_cols=g).cpu()
+    ref64 = xb.double() @ p["wdq"].double().t()
+    err = (y.double() - ref64).abs().max().item()
+    assert err <= 1e-3 * _rms(ref64), f"max err {err:.3e} vs rms {_rms(ref64):.3e}"
+    yo = oracle.colblock_linear(xb.float(), synth.pack_colblock(p["q"]).contiguous(), p["scale"], p["zero"], 4, g)
+    assert (y - yo).abs().max().item() <= 1e-3 * _rms(ref64)
+    # the generic (scalar) kernel on the reference layout agrees: two independent HIP implementations
+    yg = ops.linear_colblock(xb.to(dev).float(), p["packed"], p["scale"].to(dev), p["zero"].to(dev), 4, g, None, K).cpu()
+    assert (y - yg).abs().max().item() <= 1e-3 * _rms(ref64)
+    y2 = ops.linear_fast(xb.to(dev), stream, nat.W_Q4, R, N, K, scales=sc, zeros=ze, out_dtype=torch.float32,
+                         waves=waves, grid=5, group_cols=g).cpu()
+    assert torch.equal(y, y2)  # bit-reproducible, independent of the tile -> workgroup mapping
+
+
+def test_q4_grouped_swiglu_pair_norm_and_accumulate(dev):
+    N, K, M, g = 11008, 4096, 2, 128   # 7B c_fc1 / c_fc2 with groupsize 128, fused RMSNorm prologue
+    a = _q4_grouped_problem(N, K, M, g, seed=51, dev=dev)
+    b = _q4_grouped_problem(N, K, M, g, seed=52, dev=dev)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn((M, K), generator=gen) * 3
+    nscale = (1 + 0.1 * torch.randn(K, generator=gen)).to(torch.bfloat16)
+    # the kernel stages bf16(x * norm_scale) and applies 1 / rms to the finished dot products
+    xnb = (x * nscale.float()).to(torch.bfloat16)
+    rinv = torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5).double()
+    stream = ops.repack_q4(a["packed"], b["packed"], N, K, 2)
+    bf = lambda t: t.to(torch.bfloat16).to(dev).reshape(-1).contiguous()  # noqa: E731
+    y = ops.linear_fast(x.to(dev), stream, nat.W_Q4, 2, N, K, scales=bf(a["scale"]), zeros=bf(a["zero"]),
+                        scales2=bf(b["scale"]), zeros2=bf(b["zero"]), norm_scale=nscale.to(dev), eps=1e-5,
+                        epi=nat.EPI_SWIGLU, out_dtype=torch.float32, group_cols=g).cpu()
+    h1 = (xnb.double() @ a["wdq"].double().t()) * rinv
+    h2 = (xnb.double() @ b["wdq"].double().t()) * rinv
+    ref = torch.nn.functional.silu(h1) * h2
+    assert (y.double() - ref).abs().max().item() <= 2e-3 * _rms(ref)
+    # accumulate epilogue (residual add) on a c_proj-shaped grouped layer
+    c = _q4_grouped_problem(512, 4096, 3, g, seed=53, dev=dev)
+    xb = c["x"].to(torch.bfloat16)
+    out = torch.randn((3, 512), generator=gen)
+    acc = out.clone().to(dev)
+    ops.linear_fast(xb.to(dev), ops.repack_q4(c["packed"], None, 512, 4096, 1), nat.W_Q4, 1, 512, 4096,
+                    scales=bf(c["scale"]), zeros=bf(c["zero"]), epi=nat.EPI_ACCUM, out=acc, group_cols=g)
+    ref2 = out.double() + xb.double() @ c["wdq"].double().t()
+    assert (acc.cpu().double() - ref2).abs().max().item() <= 1e-3 * _rms(ref2)
+
+
 def test_q4_fast_kernel_agrees_with_generic_kernel_at_full_size(dev):
     """Two independent HIP implementations (MFMA stream kernel on the repacked layout vs the scalar kernel on
     the reference layout) on a 7B-sized matrix, plus linearity — size-independent checks at BASELINE sizes."""

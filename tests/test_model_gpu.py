@@ -464,3 +464,51 @@ def test_full_7b_int4_model_size_independent_properties(dev):
     std = float(lg_mod.std(-1).mean())
     err = (lg_mod - lg_graph[:lg_mod.shape[0]]).abs().max().item()
     assert err <= 0.05 * std, f"engine vs module path at 7B: {err:.4f} (std {std:.3f})"
+
+
+def test_grouped_int4_model_streams_through_the_engine_and_matches_oracle(dev):
+    """gptq.int4 with a group size (ColBlockQuantizedLinear tile_cols = 128: scales / zeros [out, in / 128],
+    lit_llama/quantization.py:350-374): every linear goes through the grouped MFMA streaming kernel — module by module
+    (ColBlockQuantizedLinear.forward) and inside the native engine (prefill in row chunks, decode under a hipGraph) —
+    and follows the CPU oracle's dequantise-then-F.linear arithmetic."""
+    from lit_llama_amd.quantization import ColBlockQuantizedLinear
+
+    kw = dict(n_layer=2, n_head=4, n_embd=512)
+    cfg = LLaMAConfig(**kw)
+    sd = synth.make_state_dict(cfg, seed=4, mode="gptq.int4", group_cols=128)
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
+        model = LLaMA(cfg)
+    # the reference's quantised modules are built with tile_cols = -1; a grouped checkpoint needs grouped modules
+    for name, mod in list(model.named_modules()):
+        for cname, child in list(mod.named_children()):
+            if isinstance(child, ColBlockQuantizedLinear):
+                g = ColBlockQuantizedLinear(child.in_features, child.out_features, bias=False, bits=4, tile_cols=128)
+                setattr(mod, cname, g.to(device=dev, dtype=torch.bfloat16))
+    model.load_state_dict(sd)
+    model.eval()
+    first = model.transformer.h[0].attn.c_attn
+    assert first.scales.shape == (3 * 512, 4) and first.grouped_fast()
+    eng = model.engine()
+    assert eng is not None, model._engine_failed
+    assert eng.fused is None  # the persistent step is written for one pair per row
+    T, n_new = 40, 6  # a prompt wider than 32 rows: the engine must NOT take the per-row GEMM path
+    prompt = synth.make_prompt(T)
+    om = oracle.Model(oracle.Config(**kw), sd, mode="gptq.int4")
+    ref = oracle.generate(om, prompt, n_new, top_k=1)
+    om.reset_cache()
+    ref_logits = oracle.teacher_forced_logits(om, ref, T)
+    S = T + n_new
+    got = teacher_forced(model, ref.to(dev), T, S, dev)
+    std = float(ref_logits.std(-1).mean())
+    err = float((got - ref_logits).abs().max())
+    assert err <= 0.05 * std, f"grouped int4 engine: logits off by {err:.4f} (std {std:.3f})"
+    model.use_engine = False
+    got_mod = teacher_forced(model, ref.to(dev), T, S, dev)
+    model.use_engine = True
+    assert float((got_mod - ref_logits).abs().max()) <= 0.05 * std
+    top2 = torch.topk(ref_logits, 2, dim=-1).values
+    decisive = (top2[:, 0] - top2[:, 1]) > 0.1 * std
+    assert torch.equal(got.argmax(-1)[decisive], ref_logits.argmax(-1)[decisive])
+    out = lit_llama_amd.generate(model, prompt.to(dev), n_new, top_k=1, max_seq_length=S).cpu()
+    n = T + 1 + next((i for i, d in enumerate(decisive.tolist()) if not d), n_new)
+    assert torch.equal(out[:n], ref[:n])
