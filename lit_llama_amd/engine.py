@@ -38,6 +38,7 @@ class _PackedWeight:
         self.keep: List[torch.Tensor] = []
         self.stream_bytes = 0
         self.side_bytes = 0
+        self.q4_stream, self.q4_mods = None, []  # Q4: the stream and the module(s) whose weights it holds
 
 
 def _kind(mod: nn.Module) -> str:
@@ -83,6 +84,7 @@ def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: 
         if pair is not None and (pair.tile_cols != mod.tile_cols or pair.scales.shape != mod.scales.shape):
             raise EngineUnavailable("c_fc1 / c_fc2 use different group sizes")
         pw.keep += [stream, s0, z0]
+        pw.q4_stream, pw.q4_mods = stream, [mod] + ([pair] if pair is not None else [])
         pw.side_bytes = 2 * s0.numel() * s0.element_size()
         if pair is not None:
             s1, z1 = pair.scales.reshape(-1).contiguous(), pair.zeros.reshape(-1).contiguous()
@@ -300,6 +302,18 @@ class DecodeEngine:
         self.fused_enabled = True  # tests / measurements switch between the persistent launch and the 162-launch step
         if self.fused_plan is not None:
             self._build_fused(model, head)
+        # The int4 weights now exist twice: as the modules' reference-layout buffers and as this engine's streams.  Give
+        # the first copy back (3.3 GB for 7B, 32.5 GB for 65B); ColBlockQuantizedLinear rebuilds it from the stream when
+        # anything asks for it (state_dict(), the module's own forward, a new engine).  MI355_RELEASE_REFERENCE_LAYOUT=0
+        # keeps both.
+        self.released_bytes = 0
+        if tp_world == 1 and _env_int("MI355_RELEASE_REFERENCE_LAYOUT", 1):
+            for pw in self.packed:
+                for which, mod in enumerate(pw.q4_mods):
+                    self.released_bytes += mod._buffers["quant_weight"].numel()
+                    mod.release_reference_layout(pw.q4_stream, pw.desc.R, len(pw.q4_mods) == 2, which)
+            if self.released_bytes:
+                self.fingerprint = model_fingerprint(model)
 
     # ---- fused decode step (csrc/fused_step.hip) -------------------------------------------------------
     def _build_fused(self, model, head) -> None:

@@ -48,6 +48,30 @@ def repack_q4(q0: torch.Tensor, q1: Optional[torch.Tensor], N: int, K: int, R: i
     return out
 
 
+def unpack_q4_stream(stream: torch.Tensor, N: int, K: int, R: int, pair: bool, which: int = 0) -> torch.Tensor:
+    """Inverse of `repack_q4` for ONE matrix of a Q4 stream: the reference layout `quant_weight` [N, K / 2] uint8 with
+    stride (1, N), byte j of row n = q[n, 2j] | q[n, 2j + 1] << 4 (lit_llama/quantization.py:350-359, 387-390).
+    Plain tensor ops on the stream's device (a state_dict() after the reference-layout buffers were released, not a hot
+    path).  Stream: [tile][unit][r][lane = 16 g + row][dword d]; nibble p of dword d holds
+    k = 128 u + 32 g + 8 d + j with j = 2 (p & 3) + (p >> 2); `pair`: r selects the matrix (`which`), else the row group."""
+    assert stream.dtype == torch.uint8 and stream.dim() == 1 and K % 2 == 0
+    units = (K + 127) // 128
+    rows_per_tile = 16 if pair else 16 * R
+    tiles = (N + rows_per_tile - 1) // rows_per_tile
+    assert stream.numel() == tiles * units * R * 1024, "stream size does not match (N, K, R, pair)"
+    b = stream.view(tiles, units, R, 64, 4, 4)
+    if pair:
+        b = b[:, :, which:which + 1]
+    nib = torch.stack((b & 15, b >> 4), dim=-1).reshape(*b.shape[:4], 4, 8)  # nibble p = 2 * byte + half
+    perm = torch.tensor([(j >> 1) + 4 * (j & 1) for j in range(8)], device=stream.device)
+    q = nib.index_select(-1, perm)                                            # [tile, unit, r, lane, d, j]
+    Rr = q.shape[2]
+    q = q.view(tiles, units, Rr, 4, 16, 4, 8).permute(0, 2, 4, 1, 3, 5, 6)    # [tile, r, row, unit, g, d, j]
+    q = q.reshape(tiles * Rr * 16, units * 128)[:N, :K]
+    packed = q[:, 0::2] | (q[:, 1::2] << 4)
+    return packed.t().contiguous().t()
+
+
 def repack_bf16(w0: torch.Tensor, w1: Optional[torch.Tensor], R: int) -> torch.Tensor:
     require_gpu(w0, "repack_bf16")
     N, K = w0.shape

@@ -51,6 +51,50 @@ class ColBlockQuantizedLinear(torch.nn.Module):
             self.register_buffer("bias", None)
         self._stream: Optional[torch.Tensor] = None  # repacked weight stream (fast path)
         self._stream_key = None
+        # (stream, R, pair, which) while the reference-layout buffer is released: see release_reference_layout
+        self._packed_src = None
+        self.register_state_dict_pre_hook(lambda mod, prefix, keep_vars: mod._materialize())
+
+    # ---- the reference-layout buffer can be given up while a native engine holds the same weights as a stream ----
+    @property
+    def quant_weight(self) -> torch.Tensor:
+        """The `quant_weight` buffer (lit_llama/quantization.py:350-359).  Rebuilt from the engine's weight stream on
+        first use after `release_reference_layout` (state_dict(), the module's own forward, a re-quantisation)."""
+        try:
+            if self._packed_src is not None:
+                self._materialize()
+            return self._buffers["quant_weight"]
+        except KeyError:
+            raise AttributeError("quant_weight") from None
+
+    def release_reference_layout(self, stream: torch.Tensor, R: int, pair: bool, which: int = 0) -> None:
+        """The engine has repacked this weight into `stream` (csrc/gemv.hip layout): drop the reference-layout copy
+        (one more copy of the whole model otherwise: 3.3 GB for 7B, 32.5 GB for 65B).  The buffer stays registered
+        (empty) and is rebuilt from the stream on demand."""
+        if self.bits != 4 or self._packed_src is not None:
+            return
+        self._stream, self._stream_key = None, None
+        self._packed_src = (stream, R, pair, which)
+        self._buffers["quant_weight"] = torch.empty((self.out_features, 0), dtype=torch.uint8, device=stream.device)
+
+    def _materialize(self) -> None:
+        src, self._packed_src = self._packed_src, None
+        if src is not None:
+            stream, R, pair, which = src
+            self._buffers["quant_weight"] = ops.unpack_q4_stream(stream, self.out_features, self.in_features, R, pair,
+                                                                which)
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda(): the stream stays where the engine put it
+        self._materialize()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        if self._packed_src is not None:  # about to be overwritten: only the shape matters
+            dev = self._packed_src[0].device
+            self._packed_src = None
+            self._buffers["quant_weight"] = torch.empty(
+                (self.out_features, self.in_features // self.entries_per_byte), dtype=torch.uint8, device=dev).t().contiguous().t()
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     # ---- format utilities (device agnostic tensor reshuffling; not on the hot path) -----------------
     def pack_weight(self, weight):
@@ -101,6 +145,8 @@ class ColBlockQuantizedLinear(torch.nn.Module):
                 and ng == -(-self.in_features // g))
 
     def weight_stream(self, R: int = 1) -> torch.Tensor:
+        if self._packed_src is not None and self._packed_src[1] == R and not self._packed_src[2]:
+            return self._packed_src[0]  # the engine's own stream of this matrix
         key = (self.quant_weight.data_ptr(), self.quant_weight._version, R)
         if self._stream is None or self._stream_key != key:
             self._stream = ops.repack_q4(self.quant_weight, None, self.out_features, self.in_features, R)
@@ -109,7 +155,7 @@ class ColBlockQuantizedLinear(torch.nn.Module):
 
     def forward(self, inp):
         nat.require_gpu(inp, "ColBlockQuantizedLinear.forward")
-        nat.require_gpu(self.quant_weight, "ColBlockQuantizedLinear.forward (module buffers)")
+        nat.require_gpu(self._buffers["quant_weight"], "ColBlockQuantizedLinear.forward (module buffers)")
         x2d = inp.reshape(-1, inp.shape[-1])
         if x2d.stride(-1) != 1:
             x2d = x2d.contiguous()

@@ -227,3 +227,45 @@ def test_fused_step_attention_over_several_blocks_of_the_cache(dev, T):
     std = float(rows[False].std(-1).mean())
     err = (rows[True] - rows[False]).abs().max().item()
     assert err <= 0.03 * std, f"T={T}: fused vs unfused logits {err:.4f} (std {std:.3f})"
+
+
+def test_engine_releases_the_reference_layout_copy_and_rebuilds_it_on_demand(dev):
+    """after the arena repack the int4 weights existed twice.  The engine gives the modules' reference-layout
+    buffers back; state_dict() (lit_llama/quantization.py:350-374 contract) rebuilds them bit for bit from the stream,
+    and the next generate() notices the new buffers and packs a fresh engine."""
+    import os
+
+    model, sd, cfg = build(2, dev, seed=2)
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated(dev)
+    os.environ["MI355_RELEASE_REFERENCE_LAYOUT"] = "0"
+    try:
+        need_fused(model)
+        both = torch.cuda.memory_allocated(dev) - before  # engine streams next to the modules' buffers
+    finally:
+        del os.environ["MI355_RELEASE_REFERENCE_LAYOUT"]
+    model._drop_engine()
+    torch.cuda.synchronize()
+    eng = need_fused(model)
+    one = torch.cuda.memory_allocated(dev) - before
+    assert both - one >= 0.95 * eng.released_bytes, (both, one, eng.released_bytes)
+    mods = [m for m in model.modules() if type(m).__name__ == "ColBlockQuantizedLinear"]
+    assert eng.released_bytes == sum(v.numel() for k, v in sd.items() if k.endswith("quant_weight")) > 0
+    assert all(m._buffers["quant_weight"].numel() == 0 for m in mods)
+    prompt = synth.make_prompt(8).to(dev)
+    a = lit_llama_amd.generate(model, prompt, 8, top_k=1)
+    got = model.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(got[k].cpu(), v.to(got[k].dtype)), k
+        if k.endswith("quant_weight"):
+            assert got[k].stride() == (1, v.shape[0])
+    e1 = model._engine
+    b = lit_llama_amd.generate(model, prompt, 8, top_k=1)  # buffers are back: new fingerprint, new engine, same tokens
+    assert model._engine is not e1 and torch.equal(a, b)
+    # the module path (no engine) of a released model reuses or rebuilds as needed
+    model.use_engine = False
+    model.reset_cache()
+    x = prompt.view(1, -1)
+    lg = model(x, 16, torch.arange(0, 8, device=dev))
+    model.use_engine = True
+    assert torch.isfinite(lg).all()

@@ -192,3 +192,58 @@ def test_stream_layout_statements_are_self_consistent():
         lo = np.array([pair & 0xFFFF], dtype=np.uint32) << 16
         hi = np.array([pair & 0xFFFF0000], dtype=np.uint32)
         assert lo.view(np.float32)[0] == 128.0 + qq[0, 2 * i] and hi.view(np.float32)[0] == 128.0 + qq[0, 2 * i + 1]
+
+
+@pytest.mark.parametrize("N,K,R,pair", [(48, 256, 1, False), (40, 200, 2, False), (96, 384, 2, True), (33, 130, 1, False)])
+def test_unpack_q4_stream_inverts_the_stream_layout(N, K, R, pair):
+    """ops.unpack_q4_stream (the lazy rebuild of `quant_weight` after the engine released the reference-layout copy)
+    against the numpy statement of the stream layout (tests/layouts.py) and synth.pack_colblock."""
+    import numpy as np
+
+    import layouts
+    from lit_llama_amd import ops, synth
+
+    gen = torch.Generator().manual_seed(N * K + R)
+    q0 = torch.randint(0, 16, (N, K), generator=gen, dtype=torch.uint8)
+    q1 = torch.randint(0, 16, (N, K), generator=gen, dtype=torch.uint8) if pair else None
+    stream = torch.from_numpy(layouts.q4_levels_to_stream(q0.numpy(), q1.numpy() if pair else None, R).copy())
+    for which, q in enumerate([q0, q1] if pair else [q0]):
+        got = ops.unpack_q4_stream(stream, N, K, R, pair, which)
+        ref = synth.pack_colblock(q)
+        assert got.shape == ref.shape and got.stride() == ref.stride() and torch.equal(got, ref)
+
+
+def test_released_reference_layout_is_rebuilt_on_demand():
+    """ColBlockQuantizedLinear.release_reference_layout: the buffer is given up, stays in the state dict contract
+    (lit_llama/quantization.py:350-374 key names / layout) and comes back bit for bit when asked for."""
+    import layouts
+
+    N, K = 48, 256
+    gen = torch.Generator().manual_seed(3)
+    q = torch.randint(0, 16, (N, K), generator=gen, dtype=torch.uint8)
+    mod = ColBlockQuantizedLinear(K, N, bias=False, bits=4, tile_cols=-1)
+    mod.quant_weight.copy_(synth.pack_colblock(q))
+    mod.scales.fill_(0.5)
+    mod.zeros.fill_(7.0)
+    ref = mod.quant_weight.clone()
+    stream = torch.from_numpy(layouts.q4_levels_to_stream(q.numpy(), None, 2).copy())
+    mod.release_reference_layout(stream, 2, False)
+    assert mod._buffers["quant_weight"].numel() == 0 and mod._packed_src is not None
+    assert mod.weight_stream(2) is stream          # the module's own fast path would reuse the engine's stream
+    assert mod._buffers["quant_weight"].numel() == 0
+    sd = mod.state_dict()                           # pre-hook: rebuilt
+    assert set(sd) == {"quant_weight", "scales", "zeros"}
+    assert torch.equal(sd["quant_weight"], ref) and sd["quant_weight"].stride() == ref.stride()
+    assert mod._packed_src is None
+    # attribute access rebuilds as well; loading a checkpoint into a released module needs no rebuild
+    mod.release_reference_layout(stream, 2, False)
+    assert torch.equal(mod.quant_weight, ref)
+    mod.release_reference_layout(stream, 2, False)
+    other = ColBlockQuantizedLinear(K, N, bias=False, bits=4, tile_cols=-1)
+    other.quant_weight.copy_(synth.pack_colblock(15 - q))
+    other.scales.fill_(0.25)
+    other.zeros.fill_(8.0)
+    mod.load_state_dict(other.state_dict())
+    assert torch.equal(mod.quant_weight, other.quant_weight) and float(mod.scales[0, 0]) == 0.25
+    w = mod.get_weight(torch.float32)
+    assert torch.equal(w, (15.0 - q.float() - 8.0) * 0.25)
