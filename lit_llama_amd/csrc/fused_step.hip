@@ -117,9 +117,12 @@ __device__ __forceinline__ void raise_abort(const FusedParams& p, unsigned code)
 // counts of the workgroup stay balanced).
 template <int NL>
 __device__ __forceinline__ bool sweep(const FusedParams& p, __amdgpu_buffer_rsrc_t rs, unsigned base, int first, int end,
-                                      unsigned epoch, u32x4 (&v)[NL], unsigned code) {
+                                      unsigned epoch, u32x4 (&v)[NL], unsigned code, unsigned* iters = nullptr) {
     const int lane = threadIdx.x & 63;
     for (unsigned spins = 0;; ++spins) {
+#ifdef MI355_FUSED_COUNT_SWEEPS
+        if (iters != nullptr) *iters = spins + 1;
+#endif
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
@@ -590,6 +593,19 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             if (lane == 0) gr_store(dst + 2048 + bid, ep, __float_as_uint(ss));
         };
         // gather an x-type edge into xs (fp16), 1/rms into misc[0], the operand sums into misc[4 .. 7]
+        // profiling aid (-DMI355_FUSED_COUNT_SWEEPS, scripts/fused_timeline.py): sweep iterations of gatherer 0 per hand-off.
+        // Measured (profiles/r02_fused_step_sweep_iterations.txt): the x edges ALWAYS succeed on the first sweep — a
+        // loaded hand-off is one slow memory round trip behind the ring turn, not a retry.  Off by default: the counter
+        // costs registers on the hand-off path (56 spill instructions, 925 -> 988 us per step).
+        unsigned n_sweeps = 0;
+#ifdef MI355_FUSED_COUNT_SWEEPS
+#define FS_GCOUNT(i)                                                                              \
+    do {                                                                                          \
+        if (dbg_on && gw == 0 && lane == 0) p.dbg[bid * 64 + (i)] = n_sweeps;                     \
+    } while (0)
+#else
+#define FS_GCOUNT(i) do { } while (0)
+#endif
         auto gather_x = [&]() {
             const unsigned ep = ebase + edge;
             const unsigned base = (unsigned)xpar * 2304u * 8u;
@@ -597,6 +613,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 u32x4 v[8];
                 // loads 0 .. 383 of the pair region (6 per lane) and the 128 loads of the sums of squares (2 per lane)
                 for (unsigned spins = 0;; ++spins) {
+#ifdef MI355_FUSED_COUNT_SWEEPS
+                    n_sweeps = spins + 1;
+#endif
                     bool ok = true;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -669,6 +688,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
             }
             gather_x();
             FS_GSTAMP(2);
+            FS_GCOUNT(40);
             __syncthreads();  // B1
             __syncthreads();  // Bt (one virtual tile)
             if (gw == 0) {
@@ -705,7 +725,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 const unsigned ep = ebase + edge;
                 if (gw == 0) {
                     u32x4 v[2];
-                    sweep<2>(p, rs_gq, (unsigned)((qpar * kHeads + head) * 256) * 8u, 0, 128, ep, v, 0x300u + edge);
+                    sweep<2>(p, rs_gq, (unsigned)((qpar * kHeads + head) * 256) * 8u, 0, 128, ep, v, 0x300u + edge, &n_sweeps);
+                    FS_GCOUNT(41);
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
 #pragma unroll
@@ -759,7 +780,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 }
                 const unsigned ep = ebase + edge;
                 u32x4 v[8];
-                sweep<8>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, ep, v, 0x400u + edge);
+                sweep<8>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, ep, v, 0x400u + edge, &n_sweeps);
+                FS_GCOUNT(42);
                 float2 sxp = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -798,6 +820,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 }
                 gather_x();
                 FS_GSTAMP(9);
+                FS_GCOUNT(43);
                 __syncthreads();  // B1
                 const unsigned ep = ebase + edge;
                 u64* dst = p.gh + (size_t)hpar * (p.H / 2);
@@ -834,7 +857,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 float2 sxp = {0.f, 0.f};
                 for (int c0 = first; c0 < end; c0 += 8 * 64) {
                     u32x4 v[8];
-                    sweep<8>(p, rs_gh, (unsigned)hpar * (unsigned)(p.H / 2) * 8u, c0, end, ep, v, 0x500u + edge);
+                    sweep<8>(p, rs_gh, (unsigned)hpar * (unsigned)(p.H / 2) * 8u, c0, end, ep, v, 0x500u + edge, &n_sweeps);
+                    if (c0 == first) FS_GCOUNT(44);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const int i = c0 + k * 64 + lane;

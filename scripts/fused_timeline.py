@@ -59,6 +59,13 @@ def main():
         col = st[:, i] - t0
         print(f"  {NAMES[i]:28s} min {col.min():7.2f}  med {np.median(col):7.2f}  max {col.max():7.2f}   (+{np.median(col) - prev:5.2f})")
         prev = np.median(col)
+    raw = stamps.cpu().numpy()
+    print("sweep iterations of gatherer 0 per hand-off (a failed sweep costs a memory round trip):")
+    for i, nm in ((40, "x edge into c_attn"), (41, "q / k / v head exchange"), (42, "attention out edge"),
+                  (43, "x edge into fc"), (44, "hidden edge (first chunk)")):
+        c = raw[:, i]
+        hist = np.bincount(np.clip(c, 0, 8).astype(np.int64), minlength=9)
+        print(f"  {nm:28s} mean {c.mean():5.2f}  max {c.max():3d}   histogram 1..8+: {hist[1:].tolist()}")
 
 
 if __name__ == "__main__":
