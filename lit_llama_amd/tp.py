@@ -205,9 +205,15 @@ class NativeComm:
             return
         self._one(eng, 0, n)
 
+    MAX_CALLS = 1024  # csrc/tp_comm.hip kMaxCalls: collective calls per device step counter value
+
     def _one(self, eng, off: int, n: int) -> None:
         from ._native import check, lib
 
+        if self._call >= self.MAX_CALLS - 2:
+            # a prompt chunk reduced row by row can need more calls than one step's tag space holds (65B: 160 per row):
+            # open the next step (every rank issues the same sequence, so the tags stay in lockstep)
+            self.step_begin(eng.stream)
         check(lib().mi355_tp_allreduce(C.byref(self.c), eng.partial.data_ptr() + 4 * off, eng.x.data_ptr() + 4 * off, n,
                                        self._call, 1, eng.stream.cuda_stream), "mi355_tp_allreduce")
         self._call += 1

@@ -235,6 +235,9 @@ def test_tp_loopback_two_engine_shards_match_single_engine(dev):
     assert bool(same.all()), f"TP tokens {out.tolist()} vs {ref.tolist()} (first near tie at step {first_tie})"
 
 
+LONG_T = 300  # tokens of the long-prompt case of the two-process test
+
+
 def _native_tp_worker(rank, world, port, ret):
     """One process per rank, BOTH on cuda:0: native engine shards + the peer-write all-reduce through HIP IPC."""
     import torch.distributed as dist
@@ -276,10 +279,17 @@ def _native_tp_worker(rank, world, port, ret):
         toks_graph = dec.generate_chained(prompt, 8, max_seq_length=S)
         toks_eager = dec.generate_chained(prompt, 8, max_seq_length=S, use_graph=False)
         dist.barrier()
+        # a prompt long enough that its row-by-row all-reduces exhaust one step's tag space (1024 calls): the
+        # communicator has to open further steps in lockstep on every rank
+        long_prompt = synth.make_prompt(LONG_T, seed=9).to(dev)
+        toks_long = dec.generate_chained(long_prompt, 3, max_seq_length=LONG_T + 4, use_graph=False)
+        comm.check_status()
+        dist.barrier()
         if rank == 0:
             ret["logits"] = torch.stack(rows).numpy()
             ret["toks_graph"] = toks_graph.cpu().numpy()
             ret["toks_eager"] = toks_eager.cpu().numpy()
+            ret["toks_long"] = toks_long.cpu().numpy()
         comm.close()
     finally:
         dist.destroy_process_group()
@@ -333,3 +343,21 @@ def test_tp_native_allreduce_two_processes_on_one_gpu_bit_identical_to_loopback(
     chain = [int(r.argmax()) for r in ref]
     assert list(ret["toks_graph"][7:]) == chain, f"{list(ret['toks_graph'])} vs {chain}"
     assert list(ret["toks_eager"]) == list(ret["toks_graph"])
+    # the long prompt (more collective calls than one step's tag space) against the loop-back shards
+    long_prompt = synth.make_prompt(LONG_T, seed=9).to(dev)
+    assert 2 * cfg.n_layer * LONG_T > tp.NativeComm.MAX_CALLS
+    with torch.cuda.stream(run):
+        for s_ in shards:
+            s_.eng._ensure_cache(LONG_T + 4)
+        pos, nxt, chain_long = 0, None, []
+        for step in range(3):
+            chunk = long_prompt if step == 0 else nxt
+            n = chunk.numel()
+            for s_ in shards:
+                s_.eng.set_step(chunk, n, pos)
+            lg = tp.tp_forward(shards, tp.LoopbackComm(world), n, cfg.n_layer)[0].float()
+            nxt = lg[-1 if lg.shape[0] > 1 else 0].argmax().to(torch.int32).view(1)
+            chain_long.append(int(nxt))
+            pos += n
+    run.synchronize()
+    assert list(ret["toks_long"][LONG_T:]) == chain_long, f"{list(ret['toks_long'][LONG_T:])} vs {chain_long}"
