@@ -43,6 +43,9 @@ constexpr int kSW = 8;          // streamer waves
 constexpr int kGW = 2;          // gatherer waves
 constexpr int kThreads = 64 * (kSW + kGW);
 constexpr int kRing = 12;       // ring pieces (1 KiB each) per streamer wave
+#ifndef MI355_FUSED_HSWEEP
+#define MI355_FUSED_HSWEEP 2  // chunks of the hidden edge in flight per gatherer wave (2: 8 + 4 loads per lane, 3: 3 x 8)
+#endif
 #ifndef MI355_FUSED_WINDOW
 #define MI355_FUSED_WINDOW 4
 #endif
@@ -116,20 +119,28 @@ __device__ __forceinline__ void raise_abort(const FusedParams& p, unsigned code)
 // Returns false after a time-out / abort (the values are then garbage, the caller keeps going so that the barrier
 // counts of the workgroup stay balanced).
 template <int NL>
+__device__ __forceinline__ void sweep_issue(__amdgpu_buffer_rsrc_t rs, unsigned base, int first, int end, u32x4 (&v)[NL],
+                                            int lane) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int i = first + k * 64 + lane;
+        const unsigned off = i < end ? base + (unsigned)i * 16u : 0xFFFFFFF0u;
+        v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));  // sc1
+    }
+}
+// `preissued`: the caller has requested v already (sweep_issue) — several chunks of one edge in flight at once
+template <int NL>
 __device__ __forceinline__ bool sweep(const FusedParams& p, __amdgpu_buffer_rsrc_t rs, unsigned base, int first, int end,
-                                      unsigned epoch, u32x4 (&v)[NL], unsigned code, unsigned* iters = nullptr) {
-    const int lane = threadIdx.x & 63;
+                                      unsigned epoch, u32x4 (&v)[NL], unsigned code, int lane, unsigned* iters = nullptr,
+                                      bool preissued = false) {
+    // (lane: the caller's per-layer opaque copy of the lane id — from threadIdx the offsets of every sweep site are
+    // loop invariants, which hipcc computes once in the kernel prologue and then spills)
     for (unsigned spins = 0;; ++spins) {
 #ifdef MI355_FUSED_COUNT_SWEEPS
         if (iters != nullptr) *iters = spins + 1;
 #endif
         bool ok = true;
-#pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            const int i = first + k * 64 + lane;
-            const unsigned off = i < end ? base + (unsigned)i * 16u : 0xFFFFFFF0u;
-            v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));  // sc1
-        }
+        if (!(preissued && spins == 0)) sweep_issue<NL>(rs, base, first, end, v, lane);
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             const int i = first + k * 64 + lane;
@@ -619,8 +630,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                     bool ok = true;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const unsigned off = k < 6 ? base + (unsigned)(k * 64 + lane) * 16u
-                                                   : base + 2048u * 8u + (unsigned)((k - 6) * 64 + lane) * 16u;
+                        const unsigned off = k < 6 ? base + (unsigned)(k * 64 + lane_v) * 16u
+                                                   : base + 2048u * 8u + (unsigned)((k - 6) * 64 + lane_v) * 16u;
                         v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gx, off, 0, 16));
                     }
 #pragma unroll
@@ -635,7 +646,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 float2 sx = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    *(u64*)(xs + (size_t)(k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                    *(u64*)(xs + (size_t)(k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
                     pair_sums(sx, v[k][0], v[k][2]);
                 }
                 float ss = ((__uint_as_float(v[6][0]) + __uint_as_float(v[6][2])) + __uint_as_float(v[7][0])) +
@@ -645,11 +656,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 if (lane == 0) misc[0] = rsqrtf(ss / (float)kC + p.eps);
             } else {
                 u32x4 v[10];
-                sweep<10>(p, rs_gx, base, 384, 1024, ep, v, 0x200u + edge);
+                sweep<10>(p, rs_gx, base, 384, 1024, ep, v, 0x200u + edge, lane_v);
                 float2 sx = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 10; ++k) {
-                    *(u64*)(xs + (size_t)(384 + k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                    *(u64*)(xs + (size_t)(384 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
                     pair_sums(sx, v[k][0], v[k][2]);
                 }
                 put_sums(sx);
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 const unsigned ep = ebase + edge;
                 if (gw == 0) {
                     u32x4 v[2];
-                    sweep<2>(p, rs_gq, (unsigned)((qpar * kHeads + head) * 256) * 8u, 0, 128, ep, v, 0x300u + edge, &n_sweeps);
+                    sweep<2>(p, rs_gq, (unsigned)((qpar * kHeads + head) * 256) * 8u, 0, 128, ep, v, 0x300u + edge, lane_v, &n_sweeps);
                     FS_GCOUNT(41);
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
@@ -780,12 +791,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 }
                 const unsigned ep = ebase + edge;
                 u32x4 v[8];
-                sweep<8>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, ep, v, 0x400u + edge, &n_sweeps);
+                sweep<8>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, ep, v, 0x400u + edge, lane_v, &n_sweeps);
                 FS_GCOUNT(42);
                 float2 sxp = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                    *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
                     pair_sums(sxp, v[k][0], v[k][2]);
                 }
                 put_sums(sxp);
@@ -855,19 +866,77 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                 const int n_loads = p.H / 4, half_l = (n_loads + 1) / 2;
                 const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
                 float2 sxp = {0.f, 0.f};
-                for (int c0 = first; c0 < end; c0 += 8 * 64) {
-                    u32x4 v[8];
-                    sweep<8>(p, rs_gh, (unsigned)hpar * (unsigned)(p.H / 2) * 8u, c0, end, ep, v, 0x500u + edge, &n_sweeps);
-                    if (c0 == first) FS_GCOUNT(44);
+                {
+                    // up to three chunks of 8 loads per lane (H <= 12288), TWO in flight: only the first one waits for
+                    // producers; issued one after the other each later chunk cost its own memory round trip on the
+                    // longest hand-off of the layer (44 KB of granules)
+                    const unsigned hbase = (unsigned)hpar * (unsigned)(p.H / 2) * 8u;
+                    int lh = lane_v;
+                    asm volatile("" : "+v"(lh));  // addresses of this block are computed here, not hoisted and spilled
+#if MI355_FUSED_HSWEEP == 3
+                    // all three chunks of 8 loads per lane (24 >= 12288 / 4 / 2 / 64) in flight at once
+                    u32x4 va[8], vb[8], vc[8];
+                    auto stage8 = [&](const u32x4 (&v)[8], int c0) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int i = c0 + k * 64 + lane;
-                        if (i < end) {
-                            *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
-                            pair_sums(sxp, v[k][0], v[k][2]);
+                        for (int k = 0; k < 8; ++k) {
+                            const int i = c0 + k * 64 + lh;
+                            if (i < end) {
+                                *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                                pair_sums(sxp, v[k][0], v[k][2]);
+                            }
                         }
-                    }
+                    };
+                    const int c1 = first + 512, c2 = first + 1024;
+                    sweep_issue<8>(rs_gh, hbase, first, end, va, lh);
+                    sweep_issue<8>(rs_gh, hbase, c1, end, vb, lh);
+                    sweep_issue<8>(rs_gh, hbase, c2, end, vc, lh);
+                    sweep<8>(p, rs_gh, hbase, first, end, ep, va, 0x500u + edge, lh, &n_sweeps, true);
+                    FS_GCOUNT(44);
+                    stage8(va, first);
+                    sweep<8>(p, rs_gh, hbase, c1, end, ep, vb, 0x500u + edge, lh, nullptr, true);
+                    stage8(vb, c1);
+                    sweep<8>(p, rs_gh, hbase, c2, end, ep, vc, 0x500u + edge, lh, nullptr, true);
+                    stage8(vc, c2);
                 }
+#else
+                    // chunks of 8, 4, 8, 4 loads per lane (24 >= 12288 / 4 / 2 / 64), two in flight
+                    u32x4 va[8], vb[4];
+                    auto stage_a = [&](int c0) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int i = c0 + k * 64 + lh;
+                            if (i < end) {
+                                *(u64*)(xs + (size_t)i * 8) = ((u64)va[k][2] << 32) | va[k][0];
+                                pair_sums(sxp, va[k][0], va[k][2]);
+                            }
+                        }
+                    };
+                    auto stage_b = [&](int c0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int i = c0 + k * 64 + lh;
+                            if (i < end) {
+                                *(u64*)(xs + (size_t)i * 8) = ((u64)vb[k][2] << 32) | vb[k][0];
+                                pair_sums(sxp, vb[k][0], vb[k][2]);
+                            }
+                        }
+                    };
+                    const int c1 = first + 512, c2 = first + 768, c3 = first + 1280;
+                    sweep_issue<8>(rs_gh, hbase, first, end, va, lh);
+                    sweep_issue<4>(rs_gh, hbase, c1, end, vb, lh);
+                    sweep<8>(p, rs_gh, hbase, first, end, ep, va, 0x500u + edge, lh, &n_sweeps, true);
+                    FS_GCOUNT(44);
+                    stage_a(first);
+                    sweep_issue<8>(rs_gh, hbase, c2, end, va, lh);
+                    sweep<4>(p, rs_gh, hbase, c1, end, ep, vb, 0x500u + edge, lh, nullptr, true);
+                    stage_b(c1);
+                    sweep_issue<4>(rs_gh, hbase, c3, end, vb, lh);
+                    sweep<8>(p, rs_gh, hbase, c2, end, ep, va, 0x500u + edge, lh, nullptr, true);
+                    stage_a(c2);
+                    sweep<4>(p, rs_gh, hbase, c3, end, ep, vb, 0x500u + edge, lh, nullptr, true);
+                    stage_b(c3);
+                }
+#endif
                 put_sums(sxp);
                 hpar ^= 1;
                 ++edge;
@@ -953,7 +1022,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_kernel(const FusedParams 
                     }
                     if (bid == 0) {
                         u32x4 v[4];
-                        const bool ok = sweep<4>(p, rs_gm, 0u, 0, 256, ep, v, 0x600u + edge);
+                        const bool ok = sweep<4>(p, rs_gm, 0u, 0, 256, ep, v, 0x600u + edge, lane_v);
                         float bv = -INFINITY;
                         int bx = 0x7fffffff;
 #pragma unroll
