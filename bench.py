@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--model", default="7B")
     ap.add_argument("--quantize", default="gptq.int4", choices=["gptq.int4", "llm.int8", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tp-timeout", type=float, default=300.0, help="seconds after which a hanging TP leg is abandoned")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-tp", action="store_true", help="skip the tensor-parallel leg (65B gptq.int4, TP = --gpus)")
     ap.add_argument("--tp-model", default="65B")
@@ -469,11 +470,31 @@ def main():
         model._engine = None
         del model
         torch.cuda.empty_cache()
-        try:
-            tp_res = tp_leg(args, dev, rank, world, dist)
-        except Exception as e:  # the TP leg must never take the headline down with it
-            tp_res = {"error": repr(e)}
+        # The TP leg must never take the headline down with it: exceptions are reported in the `tp` object, and a leg
+        # that HANGS (a rank that failed alone leaves its peers in a collective / a peer-write that never arrives) is
+        # abandoned after --tp-timeout seconds — the headline line is printed and the process exits without joining it.
+        import threading
+
+        box = {}
+
+        def _run_tp():
+            try:
+                torch.cuda.set_device(dev)
+                box["res"] = tp_leg(args, dev, rank, world, dist)
+            except BaseException as e:  # noqa: BLE001
+                box["res"] = {"error": repr(e)}
+
+        th = threading.Thread(target=_run_tp, daemon=True)
+        th.start()
+        th.join(args.tp_timeout)
+        tp_hung = th.is_alive()
+        tp_res = {"error": f"timeout: the tensor-parallel leg did not finish within {args.tp_timeout} s"} if tp_hung \
+            else box.get("res")
+    else:
+        tp_hung = False
     if rank != 0:
+        if tp_hung:
+            os._exit(0)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -541,6 +562,9 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"failed: {e!r}"}
     print(json.dumps(out), flush=True)
+    if tp_hung:
+        sys.stdout.flush()
+        os._exit(0)  # a hung collective cannot be joined
     if dist is not None:
         dist.destroy_process_group()
 
