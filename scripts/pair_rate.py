@@ -29,7 +29,6 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         tot, n = 0.0, 60
         for i in range(n):
-            nat.check(nat.lib().mi355_debug_time_next_launch(e0.cuda_event if hasattr(e0, "cuda_event") else None, None), "hook") if False else None
             e0.record()
             ops.linear_fast(x, streams[i % 6], nat.W_Q4, 2, N, K, **kw)
             e1.record()

@@ -212,16 +212,12 @@ def test_fused_step_attention_over_several_blocks_of_the_cache(dev, T):
     prompt = synth.make_prompt(T, seed=T).to(dev)
     S = T + 8
     rows = {}
+    eng.fused_enabled = False
+    model.reset_cache()
+    ref_out = lit_llama_amd.generate(model, prompt, 4, top_k=1, max_seq_length=S)  # tokens of the launch-per-operator step
     for fused in (False, True):
         eng.fused_enabled = fused
-        model.reset_cache()
-        out = lit_llama_amd.generate(model, prompt, 4, top_k=1, max_seq_length=S)
-        rows[fused] = teacher_forced(model, out, T, S, dev) if fused else None
-        if not fused:
-            ref_out = out
-            rows[False] = teacher_forced(model, ref_out, T, S, dev)
-        else:
-            rows[True] = teacher_forced(model, ref_out, T, S, dev)
+        rows[fused] = teacher_forced(model, ref_out, T, S, dev)
         eng.check_status()
     eng.fused_enabled = True
     std = float(rows[False].std(-1).mean())
