@@ -48,8 +48,10 @@ def _kind(mod: nn.Module) -> str:
         return "q4"
     if isinstance(mod, Linear8bitLt):
         return "i8"
-    if type(mod) is nn.Linear:
+    if type(mod) is nn.Linear or getattr(mod, "_mi355_plain_weight", False):
         return "bf16"
+    if hasattr(mod, "lora_A"):
+        raise EngineUnavailable("LoRA update not merged into the weight yet: call model.eval()")
     raise EngineUnavailable(f"unsupported linear type {type(mod).__name__}")
 
 

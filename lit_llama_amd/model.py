@@ -79,8 +79,8 @@ def _linear(mod: nn.Module, x: torch.Tensor) -> torch.Tensor:
     """Apply one of the hot-path linears.  Quantised plug-ins carry their own kernels; a stock `nn.Linear`
     (no-quant configs) goes to the bf16 weight-streaming kernel for skinny inputs, to the exact f32 kernel for
     f32 models, and to rocBLAS (a plain library GEMM) for wide bf16 prefill."""
-    if type(mod) is not nn.Linear:
-        return mod(x)
+    if type(mod) is not nn.Linear and not getattr(mod, "_mi355_plain_weight", False):
+        return mod(x)  # (lora.MergedLinear sets _mi355_plain_weight once its update is merged: then it IS a plain linear)
     nat.require_gpu(x, "Linear.forward")
     x2d = x.reshape(-1, x.shape[-1])
     if x2d.stride(-1) != 1:

@@ -183,6 +183,46 @@ def block_cases():
     np.savez_compressed(OUT / "blocks.npz", **fix)
 
 
+def lora_cases():
+    """lit_llama/lora.py `MergedLinear` (the c_attn of the LoRA attention block, enable_lora = [True, False, True]):
+    merged weight after `.eval()` in f32 and bf16, and the unmerged forward, for seeded W / A / B."""
+    from lit_llama.lora import MergedLinear as RefMerged
+
+    out = {}
+    C, r, alpha = 64, 4, 16
+    gen = torch.Generator().manual_seed(11)
+    W = torch.randn((3 * C, C), generator=gen) * C**-0.5
+    A = torch.randn((2 * r, C), generator=gen) * 0.3
+    B = torch.randn((2 * C, r), generator=gen) * 0.3
+    x = torch.randn((1, 5, C), generator=gen)  # (batch, T, features): the reference's zero_pad assumes 3-D activations
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        m = RefMerged(C, 3 * C, r=r, lora_alpha=alpha, lora_dropout=0.0, enable_lora=[True, False, True],
+                      fan_in_fan_out=False, merge_weights=True, bias=False).to(dt)
+        with torch.no_grad():
+            m.weight.copy_(W.to(dt))
+            m.lora_A.copy_(A.to(dt))
+            m.lora_B.copy_(B.to(dt))
+        m.train(True)
+        y_unmerged = m(x.to(dt)).detach().float()
+        m.train(False)
+        merged = m.weight.detach().float()
+        y_merged = m(x.to(dt)).detach().float()
+        # the restatement must reproduce the reference before anything is written
+        om = oracle.lora_merge(W.to(dt), A.to(dt), B.to(dt), alpha).float()
+        tol = 0.0 if dt == torch.float32 else 2.0**-7
+        assert (om - merged).abs().max().item() <= tol * merged.abs().max().item() + (1e-6 if dt == torch.float32 else 0), name
+        oy = oracle.lora_forward_unmerged(x.to(dt), W.to(dt), A.to(dt), B.to(dt), alpha).float()
+        assert (oy - y_unmerged).abs().max().item() <= (1e-5 if dt == torch.float32 else 0.1), name
+        out[f"{name}_merged"] = merged.numpy()
+        out[f"{name}_y_unmerged"] = y_unmerged.numpy()
+        out[f"{name}_y_merged"] = y_merged.numpy()
+    out.update(W=W.numpy(), A=A.numpy(), B=B.numpy(), x=x.numpy(), meta=np.array([C, r, alpha], dtype=np.int64))
+    sd_keys = sorted(k for k in RefMerged(C, 3 * C, r=r, lora_alpha=alpha, enable_lora=[True, False, True], bias=False).state_dict())
+    out["state_dict_keys"] = np.array(sd_keys)
+    np.savez_compressed(OUT / "lora.npz", **out)
+    print("lora.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
+
+
 def big_case():
     """BASELINE.json configs[2] at FULL depth: LLaMA-7B (32 layers) gptq.int4 with seeded synthetic weights, prompt of 8,
     six greedy tokens, teacher-forced logits (probes / argmax / margins).  ~25 forwards of the real reference on the
@@ -194,6 +234,10 @@ def big_case():
 
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--lora" in sys.argv:
+        print("generating the LoRA fixture from", REF)
+        lora_cases()
+        return
     if "--big" in sys.argv:
         print("generating the full-depth 7B fixture from", REF)
         big_case()

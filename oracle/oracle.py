@@ -108,6 +108,46 @@ def colblock_linear(inp, quant_weight, scales, zeros, bits: int, tile_cols: int,
     return F.linear(inp, weight, bias)
 
 
+# ------------------------------------------------------------------------------------------ LoRA (inference variant)
+def lora_delta(lora_A: torch.Tensor, lora_B: torch.Tensor, enable_lora=(True, False, True)) -> torch.Tensor:
+    """The weight update of lit_llama/lora.py `MergedLinear` before scaling, zero-padded to the rows of the fused
+    q / k / v weight (lora.py:272-279 with zero_pad :205-241): lora_A [r * n_on, in], lora_B [out / n * n_on, r];
+    group g of the enabled projections gets B_g @ A_g (the reference spells it as a grouped 1x1 conv1d), the disabled
+    ones zeros.  Computed in the parameters' dtype, like the reference."""
+    n, n_on = len(enable_lora), sum(enable_lora)
+    r = lora_B.shape[1]
+    rows = lora_B.shape[0] // n_on
+    out = lora_A.new_zeros((rows * n, lora_A.shape[1]))
+    g = 0
+    for j, on in enumerate(enable_lora):
+        if on:
+            out[j * rows:(j + 1) * rows] = lora_B[g * rows:(g + 1) * rows] @ lora_A[g * r:(g + 1) * r]
+            g += 1
+    return out
+
+
+def lora_merge(weight: torch.Tensor, lora_A: torch.Tensor, lora_B: torch.Tensor, alpha: float,
+               enable_lora=(True, False, True)) -> torch.Tensor:
+    """`MergedLinear.train(False)` (lora.py:243-280): W + zero_pad((B A) * alpha / r), every step rounded in W's dtype."""
+    r = lora_B.shape[1]
+    return weight + lora_delta(lora_A, lora_B, enable_lora) * (alpha / r)
+
+
+def lora_forward_unmerged(x, weight, lora_A, lora_B, alpha: float, enable_lora=(True, False, True)):
+    """`MergedLinear.forward` with separate LoRA matrices and dropout 0 (lora.py:308-326)."""
+    r = lora_B.shape[1]
+    n, n_on = len(enable_lora), sum(enable_lora)
+    rows = lora_B.shape[0] // n_on
+    y = F.linear(x, weight)
+    after_a = F.linear(x, lora_A)
+    g = 0
+    for j, on in enumerate(enable_lora):
+        if on:
+            y[..., j * rows:(j + 1) * rows] += F.linear(after_a[..., g * r:(g + 1) * r], lora_B[g * rows:(g + 1) * rows]) * (alpha / r)
+            g += 1
+    return y
+
+
 # ------------------------------------------------------------------------------------------ LLM.int8 (parity unpinned)
 MM_DEQUANT_CONST = 6.200012e-05  # 1 / (127 * 127) as bitsandbytes spells it
 
