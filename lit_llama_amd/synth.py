@@ -123,6 +123,21 @@ def make_state_dict(
     return sd
 
 
+def make_adapter_state(cfg, *, seed: int = 0, adapter_prompt_length: int = 10, adapter_start_layer: int = 2,
+                       dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
+    """Seeded LLaMA-Adapter parameters (lit_llama/adapter.py:79-86 key names and shapes): prefix rows and NON-zero gating
+    factors (a zero gate, the reference's initial value, would hide the prefix term), bf16-exact values."""
+    gen = torch.Generator()
+    gen.manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for i in range(adapter_start_layer, cfg.n_layer):
+        pre = f"transformer.h.{i}.attn."
+        out[pre + "adapter_wte.weight"] = (torch.randn((adapter_prompt_length, cfg.n_embd), generator=gen)
+                                           ).to(torch.bfloat16).to(dtype)
+        out[pre + "gating_factor"] = (0.5 * torch.randn((1, cfg.n_head, 1, 1), generator=gen)).to(torch.bfloat16).to(dtype)
+    return out
+
+
 def make_prompt(length: int, vocab: int = 32000, seed: int = 1234, device: str = "cpu") -> torch.Tensor:
     """BOS (id 1) followed by uniform ids, int32 1-D (tokenizer.py:43 returns torch.int)."""
     gen = torch.Generator(device="cpu")

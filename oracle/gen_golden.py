@@ -223,6 +223,40 @@ def lora_cases():
     print("lora.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
 
 
+ADAPTER_CFG = dict(n_layer=3, n_head=4, n_embd=64, vocab_size=128, block_size=64)
+
+
+def adapter_case():
+    """lit_llama/adapter.py LLaMA (adapter_prompt_length 10, adapter_start_layer 2, non-zero gates) through the
+    reference's generate(): greedy tokens and teacher-forced logits, f32 on the CPU."""
+    import lit_llama.adapter as ref_adapter
+
+    ours = OurConfig(**ADAPTER_CFG)
+    sd = synth.make_state_dict(ours, seed=21, mode=None, dtype=torch.float32)
+    sd.update(synth.make_adapter_state(ours, seed=22))
+    model = ref_adapter.LLaMA(ref_adapter.LLaMAConfig(**ADAPTER_CFG))
+    model.load_state_dict(sd)
+    model.eval()
+    prompt = synth.make_prompt(6, vocab=ADAPTER_CFG["vocab_size"], seed=5)
+    T, new = 6, 12
+    toks = ref_generate.generate(model, prompt, new, top_k=1)
+    logits = ref_teacher_forced(model, toks, T, T + new)
+    # the same model WITHOUT the adapter term must differ (the fixture exercises the prefix attention)
+    plain = ref.LLaMA(ref.LLaMAConfig(**ADAPTER_CFG))
+    plain.load_state_dict({k: v for k, v in sd.items() if "adapter_wte" not in k and "gating_factor" not in k})
+    lp = ref_teacher_forced(plain.eval(), toks, T, T + new)
+    assert (lp - logits).abs().max().item() > 0.05 * float(logits.std(-1).mean())
+    om = oracle.AdapterModel(oracle.Config(**ADAPTER_CFG), sd)
+    ot = oracle.generate(om, prompt, new, top_k=1)
+    om.reset_cache()
+    ol = oracle.teacher_forced_logits(om, toks, T)
+    assert torch.equal(ot, toks) and (ol - logits).abs().max().item() <= 1e-4, "oracle.AdapterModel does not reproduce the reference"
+    out = dict(tokens=toks.numpy().astype(np.int32), prompt_len=np.int64(T), max_seq_length=np.int64(T + new),
+               logits=logits.numpy().astype(np.float32), **summarize(logits, ADAPTER_CFG["vocab_size"]))
+    np.savez_compressed(OUT / "adapter.npz", **out)
+    print("adapter.npz: tokens", toks.tolist(), "min margin", float(out["margin"].min()), "std", float(out["std"].mean()))
+
+
 def big_case():
     """BASELINE.json configs[2] at FULL depth: LLaMA-7B (32 layers) gptq.int4 with seeded synthetic weights, prompt of 8,
     six greedy tokens, teacher-forced logits (probes / argmax / margins).  ~25 forwards of the real reference on the
@@ -234,6 +268,10 @@ def big_case():
 
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--adapter" in sys.argv:
+        print("generating the LLaMA-Adapter fixture from", REF)
+        adapter_case()
+        return
     if "--lora" in sys.argv:
         print("generating the LoRA fixture from", REF)
         lora_cases()

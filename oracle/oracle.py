@@ -321,6 +321,51 @@ class Model:
     __call__ = forward
 
 
+class AdapterModel(Model):
+    """LLaMA-Adapter (lit_llama/adapter.py:62-171): from layer `adapter_start_layer` on, the attention output gets
+    gating_factor * softmax(q ak^T / sqrt(hs)) av added, where ak / av are the k / v projections (no RoPE) of the
+    `adapter_prompt_length` learned prefix rows `adapter_wte.weight` and q is the RoPE'd query of the token."""
+
+    def __init__(self, cfg: Config, sd: StateDict, mode: Optional[str] = None, dtype=torch.float32,
+                 adapter_prompt_length: int = 10, adapter_start_layer: int = 2):
+        super().__init__(cfg, sd, mode, dtype)
+        self.adapter_prompt_length, self.adapter_start_layer = adapter_prompt_length, adapter_start_layer
+
+    def attention(self, i: int, x, rope, mask, max_seq_length, input_pos=None, kv_cache=None):
+        cfg = self.cfg
+        pre = f"transformer.h.{i}.attn."
+        B, T, C = x.size()
+        q, k, v = linear(self.sd, pre + "c_attn", x, self.mode).split(cfg.n_embd, dim=2)
+        hs = C // cfg.n_head
+        k = k.view(B, T, cfg.n_head, hs)
+        q = q.view(B, T, cfg.n_head, hs)
+        v = v.view(B, T, cfg.n_head, hs)
+        q = apply_rope(q, rope)
+        k = apply_rope(k, rope)
+        k, q, v = k.transpose(1, 2), q.transpose(1, 2), v.transpose(1, 2)
+        if kv_cache is not None:
+            cache_k, cache_v = kv_cache
+            if input_pos[-1] >= max_seq_length:
+                input_pos = torch.tensor(max_seq_length - 1)
+                cache_k = torch.roll(cache_k, -1, dims=2)
+                cache_v = torch.roll(cache_v, -1, dims=2)
+            k = cache_k.index_copy(2, input_pos, k)
+            v = cache_v.index_copy(2, input_pos, v)
+            kv_cache = k, v
+        y = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0)
+        if i >= self.adapter_start_layer:  # adapter.py:134-151
+            prefix = self.p(pre + "adapter_wte.weight").reshape(1, self.adapter_prompt_length, C)
+            aT = prefix.size(1)
+            _, ak, av = linear(self.sd, pre + "c_attn", prefix, self.mode).split(cfg.n_embd, dim=2)
+            ak = ak.view(1, aT, cfg.n_head, hs).repeat(B, 1, 1, 1).transpose(1, 2)
+            av = av.view(1, aT, cfg.n_head, hs).repeat(B, 1, 1, 1).transpose(1, 2)
+            amask = torch.ones(q.shape[-2], ak.shape[-2], dtype=torch.bool)
+            ay = F.scaled_dot_product_attention(q, ak, av, attn_mask=amask, dropout_p=0.0, is_causal=False)
+            y = y + self.p(pre + "gating_factor") * ay
+        y = y.transpose(1, 2).contiguous().view(B, T, C)
+        return linear(self.sd, pre + "c_proj", y, self.mode), kv_cache
+
+
 @torch.no_grad()
 def generate(model: Model, idx: torch.Tensor, max_new_tokens: int, *, max_seq_length: Optional[int] = None,
              temperature: float = 1.0, top_k: Optional[int] = None, eos_id: Optional[int] = None,

@@ -1,0 +1,59 @@
+"""LLaMA-Adapter inference variant: the oracle restatement (oracle.AdapterModel) against the reference's own run
+(tests/golden/adapter.npz, from /root/reference lit_llama/adapter.py by `python oracle/gen_golden.py --adapter`), and the
+host-side contract of lit_llama_amd/adapter.py (state-dict layout, caches, old-checkpoint gating factors)."""
+import numpy as np
+import torch
+
+from lit_llama_amd import adapter as A
+from lit_llama_amd import synth
+from lit_llama_amd.model import LLaMAConfig as BaseConfig
+from oracle import oracle
+
+CFG = dict(n_layer=3, n_head=4, n_embd=64, vocab_size=128, block_size=64)  # oracle/gen_golden.py ADAPTER_CFG
+
+
+def adapter_state_dict(dtype=torch.float32):
+    base = BaseConfig(**CFG)
+    sd = synth.make_state_dict(base, seed=21, mode=None, dtype=dtype)
+    sd.update(synth.make_adapter_state(base, seed=22, dtype=dtype))
+    return sd
+
+
+def test_oracle_adapter_model_reproduces_the_reference(golden):
+    g = golden("adapter")
+    T = int(g["prompt_len"])
+    toks = torch.from_numpy(g["tokens"]).long()
+    om = oracle.AdapterModel(oracle.Config(**CFG), adapter_state_dict())
+    out = oracle.generate(om, toks[:T].int(), toks.numel() - T, top_k=1)
+    assert torch.equal(out.long(), toks)
+    om.reset_cache()
+    logits = oracle.teacher_forced_logits(om, toks.int(), T)
+    assert (logits - torch.from_numpy(g["logits"])).abs().max().item() <= 1e-4
+    # without the prefix term the logits move by much more than any tolerance used downstream
+    plain = oracle.Model(oracle.Config(**CFG), {k: v for k, v in adapter_state_dict().items()
+                                                if "adapter_wte" not in k and "gating_factor" not in k})
+    lp = oracle.teacher_forced_logits(plain, toks.int(), T)
+    assert (lp - logits).abs().max().item() > 0.05 * float(logits.std(-1).mean())
+
+
+def test_adapter_module_layout_and_cache_contract():
+    cfg = A.LLaMAConfig(**CFG)
+    assert (cfg.adapter_prompt_length, cfg.adapter_start_layer) == (10, 2)
+    model = A.LLaMA(cfg)
+    sd = adapter_state_dict()
+    assert set(model.state_dict()) == set(sd)  # the reference's key names (adapter.py:79-86, 226-236)
+    model.load_state_dict(sd)
+    assert not hasattr(model.transformer.h[1].attn, "adapter_wte") and hasattr(model.transformer.h[2].attn, "adapter_wte")
+    assert model.transformer.h[2].attn.gating_factor.shape == (1, 4, 1, 1)
+    assert model.engine() is None and "Adapter" in model._engine_failed
+    assert set(A.adapter_state_from_state_dict(sd)) == {k for k in sd if "adapter_wte" in k or "gating_factor" in k}
+    A.mark_only_adapter_as_trainable(model)
+    assert {n for n, p_ in model.named_parameters() if p_.requires_grad} == set(A.adapter_state_from_state_dict(sd))
+    # checkpoints from before the per-head gate hold one value (adapter.py:173-183)
+    old = dict(sd)
+    old["transformer.h.2.attn.gating_factor"] = torch.tensor([0.25])
+    model.load_state_dict(old)
+    assert torch.equal(model.transformer.h[2].attn.gating_factor, torch.full((1, 4, 1, 1), 0.25))
+    model.adapter_kv_caches = [None, None, (torch.zeros(1), torch.zeros(1))]
+    model.reset_cache()
+    assert model.adapter_kv_caches == [] and model.kv_caches == []
