@@ -48,6 +48,8 @@ def _kind(mod: nn.Module) -> str:
         return "q4"
     if isinstance(mod, Linear8bitLt):
         return "i8"
+    if getattr(mod, "adapter_scale", None) is not None:
+        raise EngineUnavailable("LLaMA-Adapter v2 scale / bias on a linear: such models run op by op")
     if type(mod) is nn.Linear or getattr(mod, "_mi355_plain_weight", False):
         return "bf16"
     if hasattr(mod, "lora_A"):

@@ -99,6 +99,9 @@ def _linear(mod: nn.Module, x: torch.Tensor) -> torch.Tensor:
     else:
         y = ops.linear_dense(x2d, w.detach().to(x.dtype), mod.bias)
     y = y.view(*x.shape[:-1], w.shape[0])
+    if getattr(mod, "adapter_scale", None) is not None:
+        # LLaMA-Adapter v2 (lit_llama/adapter_v2.py:29-32): scale * (W x + bias), one learned pair per output feature
+        y = mod.adapter_scale.detach().to(y.dtype) * (y + mod.adapter_bias.detach().to(y.dtype))
     # this path bypasses nn.Module.__call__; forward hooks (GPTQ calibration statistics, lit_llama_amd/gptq.py)
     # still see (module, inputs, output)
     for hook in list(mod._forward_hooks.values()):

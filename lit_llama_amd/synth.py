@@ -138,6 +138,21 @@ def make_adapter_state(cfg, *, seed: int = 0, adapter_prompt_length: int = 10, a
     return out
 
 
+def make_adapter_v2_state(sd: Dict[str, torch.Tensor], *, seed: int = 0, dtype: torch.dtype = torch.float32):
+    """Seeded LLaMA-Adapter v2 parameters for every linear of `sd` (lit_llama/adapter_v2.py:35-40 names): scales around 1,
+    small biases, bf16-exact values."""
+    gen = torch.Generator()
+    gen.manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for k in sorted(sd):
+        if k.endswith(".weight") and sd[k].dim() == 2 and "wte" not in k:
+            n = sd[k].shape[0]
+            pre = k[: -len("weight")]
+            out[pre + "adapter_scale"] = (1.0 + 0.1 * torch.randn(n, generator=gen)).to(torch.bfloat16).to(dtype)
+            out[pre + "adapter_bias"] = (0.1 * torch.randn(n, generator=gen)).to(torch.bfloat16).to(dtype)
+    return out
+
+
 def make_prompt(length: int, vocab: int = 32000, seed: int = 1234, device: str = "cpu") -> torch.Tensor:
     """BOS (id 1) followed by uniform ids, int32 1-D (tokenizer.py:43 returns torch.int)."""
     gen = torch.Generator(device="cpu")

@@ -257,6 +257,37 @@ def adapter_case():
     print("adapter.npz: tokens", toks.tolist(), "min margin", float(out["margin"].min()), "std", float(out["std"].mean()))
 
 
+def adapter_v2_case():
+    """lit_llama/adapter_v2.py: the adapter model of `adapter_case` plus scale / bias on every linear."""
+    import lit_llama.adapter as ref_adapter
+    import lit_llama.adapter_v2 as ref_v2
+
+    ours = OurConfig(**ADAPTER_CFG)
+    sd = synth.make_state_dict(ours, seed=21, mode=None, dtype=torch.float32)
+    sd.update(synth.make_adapter_state(ours, seed=22))
+    sd.update(synth.make_adapter_v2_state(sd, seed=23))
+    model = ref_adapter.LLaMA(ref_adapter.LLaMAConfig(**ADAPTER_CFG))
+    ref_v2.add_adapter_v2_parameters_to_linear_layers(model)
+    model.load_state_dict(sd)
+    model.eval()
+    prompt = synth.make_prompt(6, vocab=ADAPTER_CFG["vocab_size"], seed=5)
+    T, new = 6, 12
+    toks = ref_generate.generate(model, prompt, new, top_k=1)
+    logits = ref_teacher_forced(model, toks, T, T + new)
+    om = oracle.AdapterModel(oracle.Config(**ADAPTER_CFG), sd)
+    ot = oracle.generate(om, prompt, new, top_k=1)
+    om.reset_cache()
+    ol = oracle.teacher_forced_logits(om, toks, T)
+    assert torch.equal(ot, toks) and (ol - logits).abs().max().item() <= 1e-4, "oracle does not reproduce adapter v2"
+    v1 = np.load(OUT / "adapter.npz")
+    assert not np.array_equal(v1["tokens"], toks.numpy()) or np.abs(v1["logits"] - logits.numpy()).max() > 0.05
+    out = dict(tokens=toks.numpy().astype(np.int32), prompt_len=np.int64(T), max_seq_length=np.int64(T + new),
+               logits=logits.numpy().astype(np.float32), state_dict_keys=np.array(sorted(model.state_dict())),
+               **summarize(logits, ADAPTER_CFG["vocab_size"]))
+    np.savez_compressed(OUT / "adapter_v2.npz", **out)
+    print("adapter_v2.npz: tokens", toks.tolist(), "min margin", float(out["margin"].min()), "std", float(out["std"].mean()))
+
+
 def big_case():
     """BASELINE.json configs[2] at FULL depth: LLaMA-7B (32 layers) gptq.int4 with seeded synthetic weights, prompt of 8,
     six greedy tokens, teacher-forced logits (probes / argmax / margins).  ~25 forwards of the real reference on the
@@ -268,6 +299,10 @@ def big_case():
 
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--adapter-v2" in sys.argv:
+        print("generating the LLaMA-Adapter v2 fixture from", REF)
+        adapter_v2_case()
+        return
     if "--adapter" in sys.argv:
         print("generating the LLaMA-Adapter fixture from", REF)
         adapter_case()

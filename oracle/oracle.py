@@ -224,7 +224,10 @@ def linear(sd: StateDict, prefix: str, x: torch.Tensor, mode: Optional[str]) -> 
             sd[key] = int8_quant_rows(w)
         cb, scb = sd[key]
         return llm_int8_linear(x, cb, scb)
-    return F.linear(x, w.to(x.dtype))
+    y = F.linear(x, w.to(x.dtype))
+    if prefix + ".adapter_scale" in sd:  # LLaMA-Adapter v2, lit_llama/adapter_v2.py:29-32: scale * (W x + bias)
+        y = sd[prefix + ".adapter_scale"].to(x.dtype) * (y + sd[prefix + ".adapter_bias"].to(x.dtype))
+    return y
 
 
 class Model:

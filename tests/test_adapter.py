@@ -57,3 +57,40 @@ def test_adapter_module_layout_and_cache_contract():
     model.adapter_kv_caches = [None, None, (torch.zeros(1), torch.zeros(1))]
     model.reset_cache()
     assert model.adapter_kv_caches == [] and model.kv_caches == []
+
+
+def adapter_v2_state_dict(dtype=torch.float32):
+    sd = adapter_state_dict(dtype)
+    sd.update(synth.make_adapter_v2_state(sd, seed=23, dtype=dtype))
+    return sd
+
+
+def test_oracle_reproduces_adapter_v2_and_module_layout(golden):
+    """lit_llama/adapter_v2.py: scale * (W x + bias) on every linear, on top of the v1 prefix attention."""
+    from lit_llama_amd import adapter_v2 as V2
+
+    g = golden("adapter_v2")
+    T = int(g["prompt_len"])
+    toks = torch.from_numpy(g["tokens"]).long()
+    sd = adapter_v2_state_dict()
+    om = oracle.AdapterModel(oracle.Config(**CFG), sd)
+    out = oracle.generate(om, toks[:T].int(), toks.numel() - T, top_k=1)
+    assert torch.equal(out.long(), toks)
+    om.reset_cache()
+    logits = oracle.teacher_forced_logits(om, toks.int(), T)
+    assert (logits - torch.from_numpy(g["logits"])).abs().max().item() <= 1e-4
+    model = A.LLaMA(A.LLaMAConfig(**CFG))
+    V2.add_adapter_v2_parameters_to_linear_layers(model)
+    assert sorted(model.state_dict()) == [str(k) for k in g["state_dict_keys"]]
+    lin = model.transformer.h[0].mlp.c_fc1
+    assert torch.equal(lin.adapter_scale, torch.ones(lin.weight.shape[0])) and float(lin.adapter_bias.detach().abs().max()) == 0.0
+    model.load_state_dict(sd)
+    assert set(V2.adapter_v2_state_from_state_dict(sd)) == {k for k in sd if any(s in k for s in V2.get_adapter_substrings())}
+    V2.mark_only_adapter_v2_as_trainable(model)
+    assert model.transformer.ln_f.scale.requires_grad and not model.lm_head.weight.requires_grad
+    # a plain model with v2 parameters must not reach the native engine silently
+    from lit_llama_amd.engine import EngineUnavailable, _kind
+
+    import pytest
+    with pytest.raises(EngineUnavailable, match="Adapter v2"):
+        _kind(lin)
