@@ -10,7 +10,7 @@
 //   epilogue : f16(((acc * 1/127^2) * SCA[m]) * SCB[n] + bias)  +  f16(sum_{k in outliers} x[m,k] *
 //              f16(CB[n,k] * SCB[n] / 127)), added in f16, then cast to the output dtype.
 // bitsandbytes is not vendored, pinned or tested by the reference: this arithmetic is the restatement
-// written down in oracle/llm_int8.py ("parity unpinned").
+// written down in oracle/oracle.py (`int8_quant_rows`, `llm_int8_linear`; "parity unpinned").
 #include <mutex>
 
 #include "common.h"
