@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--model", default="7B")
     ap.add_argument("--quantize", default="gptq.int4", choices=["gptq.int4", "llm.int8", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tp-timeout", type=float, default=300.0, help="seconds after which a hanging TP leg is abandoned")
+    ap.add_argument("--tp-timeout", type=float, default=180.0, help="seconds after which a hanging TP leg is abandoned")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-tp", action="store_true", help="skip the tensor-parallel leg (65B gptq.int4, TP = --gpus)")
     ap.add_argument("--tp-model", default="65B")
