@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tp-timeout", type=float, default=180.0, help="seconds after which a hanging TP leg is abandoned")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="check the launch contract only (ranks, world size); no GPU work")
     ap.add_argument("--no-tp", action="store_true", help="skip the tensor-parallel leg (65B gptq.int4, TP = --gpus)")
     ap.add_argument("--tp-model", default="65B")
     ap.add_argument("--tp-steps", type=int, default=48)
@@ -329,13 +330,46 @@ def args_model_name(cfg):
     return {4096: "7B", 5120: "13B", 6656: "30B", 8192: "65B"}.get(cfg.n_embd, f"n_embd={cfg.n_embd}")
 
 
+def spawn_command(n: int, argv):
+    """`python bench.py --gpus N` without a launcher -> the launch line the driver uses for N > 1 (one rank per GPU,
+    rendezvous on 127.0.0.1: the container hostname may not resolve)."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N` (the form used for N = 1): start the N ranks ourselves, one per GPU
+        import subprocess
+
+        cmd = spawn_command(args.gpus, sys.argv[1:])
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the job must have one rank per requested GPU")
+    if args.dry_run:
+        # launch-contract check without a GPU (tests/test_host_logic.py): every rank joins a gloo group, rank 0 reports
+        seen = [(rank, local_rank)]
+        if world > 1:
+            import torch.distributed as dist_
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist_.init_process_group("gloo")
+            seen = [None] * world
+            dist_.all_gather_object(seen, (rank, local_rank))
+            dist_.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": sorted(r for r, _ in seen)}))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback for the hot path")
     dev = torch.device("cuda", local_rank)

@@ -416,7 +416,8 @@ extern "C" int mi355_sample(const float* logits, int V, float temperature, int t
     MI355_CHECK_ARG(!advance || tokens != nullptr, MI355_E_ARG, "sample: advance needs the token slot");
     if (V <= kT * kCH) {
         static hipError_t attr_err =
-            hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kT * (kCH + 1) * 4);
+            hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (kT * kCH + kT * kCH / 32 + 1) * 4);  // = the request below at V = kT * kCH, the documented bound
         MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "sample: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
         hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(kT), (size_t)(V + V / 32 + 1) * 4, (hipStream_t)stream, logits, V,
                            temperature, top_k, uniforms, next_token, out_tokens, tokens, pos, advance, probs_out);

@@ -24,7 +24,7 @@ constexpr int kMaxCalls = 1024;          // call indices per step (2 per layer +
 constexpr u64 kTimeoutTicks = 400000000ull;  // 4 s of the 100 MHz wall clock (two processes may time-slice one GPU)
 
 struct ArParams {
-    u64* peer[kMaxWorld];  // receive buffer of every rank: [2 parities][world][slot_floats] granules
+    u64* peer[kMaxWorld];  // receive buffer of every rank: [2 parities + arg-max plane][world][slot_floats] granules
     const float* partial;
     float* x;
     unsigned* state;       // local: [0] step counter, [1] abort code
@@ -86,7 +86,10 @@ struct AmParams {
 __global__ __launch_bounds__(1024) void tp_argmax_kernel(const AmParams p) {
     const int bi = block_argmax_first(p.logits, p.v_local);
     const unsigned epoch = p.state[0] * (unsigned)kMaxCalls + (unsigned)p.call_index + 1u;
-    const size_t slot0 = (size_t)(p.call_index & 1) * p.world * p.slot_floats;
+    // the arg-max exchange has a plane of its own: its call index (2 n_layer) has the parity of the NEXT step's first
+    // all-reduce and the plane of the all-reduce just before it is still being summed by slow peers, so in either
+    // parity plane a fast rank's granules 0 / 1 could overwrite a pair a peer has not read yet (spin to the time-out)
+    const size_t slot0 = (size_t)2 * p.world * p.slot_floats;
     if ((int)threadIdx.x < p.world) {
         const int r = threadIdx.x;
         u64* dst = p.peer[r] + slot0 + (size_t)p.rank * p.slot_floats;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(1024) void tp_argmax_kernel(const AmParams p) {
 
 extern "C" size_t mi355_tp_comm_bytes(int world, int slot_floats) {
     if (world < 1 || world > kMaxWorld || slot_floats < 1) return 0;
-    return (size_t)2 * world * slot_floats * sizeof(u64);
+    return (size_t)3 * world * slot_floats * sizeof(u64);  // two parity planes for the all-reduces + the arg-max plane
 }
 
 extern "C" int mi355_tp_buffer_alloc(size_t bytes, void** out) {

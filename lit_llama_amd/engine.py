@@ -534,4 +534,9 @@ class DecodeEngine:
             else:
                 logits = self.prefill(idx, pos0, all_logits=True)
         cur.wait_stream(self.stream)
+        if T == 1 and self.fused is not None:
+            # raw `model(idx, S, input_pos)` callers (the reference's generate loop) never see the abort word of the
+            # persistent step otherwise: a timed-out hand-off would hand them garbage logits, silently and for good
+            # (the word is sticky).  One 4-byte read; this path synchronises with the host per token anyway.
+            self.check_status()
         return logits.view(1, T, -1)

@@ -80,7 +80,12 @@ def _linear(mod: nn.Module, x: torch.Tensor) -> torch.Tensor:
     (no-quant configs) goes to the bf16 weight-streaming kernel for skinny inputs, to the exact f32 kernel for
     f32 models, and to rocBLAS (a plain library GEMM) for wide bf16 prefill."""
     if type(mod) is not nn.Linear and not getattr(mod, "_mi355_plain_weight", False):
-        return mod(x)  # (lora.MergedLinear sets _mi355_plain_weight once its update is merged: then it IS a plain linear)
+        y = mod(x)  # (lora.MergedLinear sets _mi355_plain_weight once its update is merged: then it IS a plain linear)
+        if getattr(mod, "adapter_scale", None) is not None:
+            # LLaMA-Adapter v2 on a quantised plug-in (generate/adapter_v2.py accepts --quantize llm.int8; Linear8bitLt
+            # subclasses nn.Linear, so add_adapter_v2_parameters_to_linear_layers attaches the pair to it as well)
+            y = mod.adapter_scale.detach().to(y.dtype) * (y + mod.adapter_bias.detach().to(y.dtype))
+        return y
     nat.require_gpu(x, "Linear.forward")
     x2d = x.reshape(-1, x.shape[-1])
     if x2d.stride(-1) != 1:

@@ -89,11 +89,16 @@ class ColBlockQuantizedLinear(torch.nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
-        if self._packed_src is not None:  # about to be overwritten: only the shape matters
-            dev = self._packed_src[0].device
-            self._packed_src = None
-            self._buffers["quant_weight"] = torch.empty(
-                (self.out_features, self.in_features // self.entries_per_byte), dtype=torch.uint8, device=dev).t().contiguous().t()
+        if self._packed_src is not None:
+            if prefix + "quant_weight" in state_dict:  # about to be overwritten: only the shape matters
+                dev = self._packed_src[0].device
+                self._packed_src = None
+                self._buffers["quant_weight"] = torch.empty(
+                    (self.out_features, self.in_features // self.entries_per_byte), dtype=torch.uint8, device=dev).t().contiguous().t()
+            else:
+                # a partial load (strict=False: adapter / LoRA / any subset of the keys) leaves this weight alone; the
+                # stream is the only copy since release_reference_layout, and the model drops its engine on load
+                self._materialize()
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     # ---- format utilities (device agnostic tensor reshuffling; not on the hot path) -----------------

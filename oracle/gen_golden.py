@@ -297,8 +297,57 @@ def big_case():
                nocache=False)
 
 
+def big_long_case():
+    """The same checkpoint with a 128-token prompt and 16 greedy tokens (VERDICT r2 item 2 ii): the prompt goes through
+    the wide path of the engine (GEMM + flash attention) at full depth, the decode steps start at position 128."""
+    torch.set_num_threads(max(8, (torch.get_num_threads() or 8)))
+    model_case("cfg2_7b_int4_long", dict(n_layer=32, n_head=32, n_embd=4096), "gptq.int4", prompt_len=128, new_tokens=16,
+               nocache=False)
+
+
+def big_bf16_case(name="cfg2_7b_int4"):
+    """Calibrates the engine's parity bar: the REFERENCE ITSELF in bf16 on the CPU (what `--precision bf16-true` makes
+    of it: parameters, scales / zeros and activations in bf16, generate.py:123-134) on the tokens of the f32 fixture,
+    teacher-forced.  Stored: its logit probes / argmax and its distance from the reference's own f32 run, in units of
+    the f32 run's logit std.  The reference states one tolerance for this comparison (bf16 device run vs f32 CPU run):
+    atol 5e-3 + rtol 1e-3 (tests/test_model.py:133)."""
+    torch.set_num_threads(max(8, (torch.get_num_threads() or 8)))
+    fx = np.load(OUT / f"{name}.npz")
+    cfg_kwargs = dict(n_layer=32, n_head=32, n_embd=4096)
+    ref_cfg = ref.LLaMAConfig(**cfg_kwargs)
+    sd = synth.make_state_dict(OurConfig(**cfg_kwargs), seed=int(fx["seed"]), mode="gptq.int4")
+    with ref_quantization("gptq.int4"):
+        model = ref.LLaMA(ref_cfg)
+    model.load_state_dict(sd)
+    del sd
+    model = model.to(torch.bfloat16).eval()  # quant_weight stays uint8; scales / zeros / wte / norms become bf16
+    toks = torch.from_numpy(fx["tokens"].astype(np.int32))
+    T = int(fx["prompt_len"])
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)  # Fabric's bf16-true runs forward under this default (rope cache dtype)
+    try:
+        logits = ref_teacher_forced(model, toks, T, int(fx["max_seq_length"]))
+    finally:
+        torch.set_default_dtype(old)
+    probes_bf = logits[:, torch.from_numpy(probe_index(ref_cfg.padded_vocab_size))].numpy().astype(np.float32)
+    d = np.abs(probes_bf - fx["probes"]).max(axis=1) / fx["std"]
+    out = dict(probes=probes_bf, argmax=logits.argmax(-1).numpy().astype(np.int32), dist_std=d.astype(np.float32),
+               max_dist_std=np.float32(d.max()), source=np.array(name))
+    np.savez_compressed(OUT / f"{name}_bf16ref.npz", **out)
+    print(f"{name}_bf16ref.npz: reference bf16 vs reference f32, max |dlogit| / std per step:", np.round(d, 4).tolist(),
+          "argmax equal:", bool((out["argmax"] == fx["argmax"]).all()))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--big-long" in sys.argv:
+        print("generating the long full-depth 7B fixture from", REF)
+        big_long_case()
+        return
+    if "--big-bf16" in sys.argv:
+        print("running the reference in bf16 on the full-depth fixture from", REF)
+        big_bf16_case("cfg2_7b_int4_long" if "--long" in sys.argv else "cfg2_7b_int4")
+        return
     if "--adapter-v2" in sys.argv:
         print("generating the LLaMA-Adapter v2 fixture from", REF)
         adapter_v2_case()

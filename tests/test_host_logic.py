@@ -247,3 +247,33 @@ def test_released_reference_layout_is_rebuilt_on_demand():
     assert torch.equal(mod.quant_weight, other.quant_weight) and float(mod.scales[0, 0]) == 0.25
     w = mod.get_weight(torch.float32)
     assert torch.equal(w, (15.0 - q.float() - 8.0) * 0.25)
+    # a PARTIAL load (strict=False without this weight: an adapter / LoRA / subset checkpoint) must leave the weight
+    # intact: the stream is its only copy after the release (it used to install an uninitialised buffer)
+    keep = mod.quant_weight.clone()
+    mod.release_reference_layout(torch.from_numpy(layouts.q4_levels_to_stream((15 - q).numpy(), None, 2).copy()), 2, False)
+    assert mod._buffers["quant_weight"].numel() == 0
+    res = mod.load_state_dict({"scales": torch.full_like(mod.scales, 0.125)}, strict=False)
+    assert "quant_weight" in res.missing_keys and float(mod.scales[0, 0]) == 0.125
+    assert torch.equal(mod.quant_weight, keep)
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` without a launcher must start 2 ranks itself (it used to run one GPU and
+    report n_gpus 1), and a job whose WORLD_SIZE disagrees with --gpus must fail.  --dry-run: launch contract only."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out == {"dry_run": True, "n_gpus": 2, "ranks": [0, 1]}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
