@@ -16,7 +16,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libmi355llama.so"
 OBJ_DIR = PKG / "csrc" / "_obj"
-SOURCES = ["generic.hip", "gemv.hip", "int8.hip", "attention.hip", "engine.hip", "gptq.hip", "fused_step.hip", "tp_comm.hip", "gemm.hip", "flash_prefill.hip", "sample.hip"]
+SOURCES = ["generic.hip", "gemv.hip", "int8.hip", "attention.hip", "engine.hip", "gptq.hip", "fused_step.hip", "fused_step_ring.hip", "tp_comm.hip", "gemm.hip", "flash_prefill.hip", "sample.hip"]
 ARCH = "gfx950"
 
 
@@ -37,7 +37,7 @@ def _stale(target: Path, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> Path:
     hipcc = _hipcc()
     OBJ_DIR.mkdir(exist_ok=True)
-    headers = [CSRC / "common.h", PKG.parent / "include" / "mi355_llama.h"]
+    headers = [CSRC / "common.h", CSRC / "fused_step_common.h", PKG.parent / "include" / "mi355_llama.h"]
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
     def compile_one(name: str):

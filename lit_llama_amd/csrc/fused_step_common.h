@@ -1,0 +1,45 @@
+// Definitions shared by the two implementations of the persistent decode step (fused_step.hip, fused_step_ring.hip).
+#pragma once
+#include "common.h"
+
+typedef unsigned long long u64;
+
+struct FusedParams {
+    const uint8_t* w;        // weight arena: layer l at w + l * layer_stride
+    u64 layer_stride;
+    unsigned off_attn, off_proj, off_fc, off_mproj, layer_bytes;
+    unsigned head_bytes;
+    const uint8_t* w_head;
+    const bf16_t* sz;        // per layer: s_attn[3C] z_attn[3C] s_proj[C] z_proj[C] s_fc1[H] z_fc1[H] s_fc2[H] z_fc2[H] s_mp[C] z_mp[C]
+    const bf16_t* sz_head;   // s[V] z[V]
+    const bf16_t* norms;     // [n_layer][2][C], then ln_f[C]
+    const bf16_t* wte;
+    const float* rope;       // [block_size][hs/2][2]
+    bf16_t* kv;              // [n_layer][2][n_head][S][hs]
+    int32_t* tokens;
+    int32_t* pos;
+    int32_t* next_token;
+    int32_t* out_tokens;
+    float* logits;
+    u64* gx;                 // [2][2048 + 256]   x-type edges (bf16 pairs + partial sums of squares)
+    u64* ga;                 // [2][2048]         attention output
+    u64* gh;                 // [2][H / 2]        MLP hidden
+    u64* gq;                 // [2][n_head][8][32] q / new k / new v of a head
+    u64* gm;                 // [512]             arg-max candidates
+    unsigned* state;         // [0] abort code, [1] step counter
+    u64* dbg;                // optional [kG][64] wall-clock stamps
+    unsigned sz_layer_stride;
+    int n_layer, H, V, S;
+    int units_h, fc_tiles, head_tiles, head_turns;
+    int mode;                // bit 0: greedy arg-max, bit 1: chained (advance tokens[0] / pos[0])
+    int dbg_layer;           // layer whose phases are stamped into dbg
+    float eps, scale;
+};
+
+
+// workspace map (bytes), see mi355_fused_step_workspace_bytes
+constexpr size_t kFsWsState = 0, kFsWsGx = 256, kFsWsGa = kFsWsGx + 2 * 2304 * 8, kFsWsGq = kFsWsGa + 2 * 2048 * 8,
+                 kFsWsGm = kFsWsGq + 2 * 32 * 256 * 8, kFsWsGh = kFsWsGm + 512 * 8;
+
+int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
+int fused_step_ring_occupancy_ok();  // the device admits one workgroup of the kernel per CU (queried once)

@@ -1,0 +1,1076 @@
+// THE DEFAULT implementation of the persistent decode step (mi355_fused_step, host side in fused_step.hip): weights in a
+// 12-piece REGISTER ring per streamer wave, requested per phase after the previous phase's publish.  fused_step.hip holds
+// the round-3 alternative (LDS-DMA rings that stream across phase boundaries, MI355_FUSED_IMPL=lds), which keeps every
+// phase's weights landed before its hand-off completes and is still slower end to end: see DESIGN.md section 5.
+//
+// The whole T = 1 decode step of a 7B-class gptq.int4 LLaMA as ONE persistent launch on gfx950.
+//
+// Replaces, per generated token, the 161 operator calls of /root/reference lit_llama/model.py:76-122 (Block.forward
+// :165-168, CausalSelfAttention.forward :194-237, MLP.forward :251-254, RMSNorm :274-277, apply_rope :306-323) and the
+// greedy sampling of generate.py:68-85 — and this repository's own 162-launch step (engine.hip), whose launches are
+// latency-bound: ~4.2 us of dispatch + cold-cache prologue + drain each against 1.3-7 us of streaming.
+//
+// Structure (measured first as a protocol: scripts/micro/allgather.hip, profiles/r02_allgather_microbench.txt):
+//  * 256 workgroups, one per CU, all resident for the whole step.  A workgroup is 8 STREAMER waves that own every
+//    weight load (12-deep ring of 1-KiB non-temporal wave loads held in registers = 96 KiB per CU in flight, int4 ->
+//    fp16 by one shift + four v_and_or_b32 per 8 weights (nib2f16 below), MFMA 16x16x32 f16 with the activation vector
+//    as the B operand) and 2 GATHERER waves that own every other global access.
+//  * Activations move between the phases of a layer as 8-byte {tag, value} granules written with ONE sc1
+//    (write-through) store and swept with sc1 loads until every tag equals the phase's epoch: the data is the
+//    flag, there is no fence and no barrier between workgroups.  Tags are unique per (step, edge) — the step
+//    counter lives in device memory — so nothing needs zeroing between launches or graph replays.
+//  * The weights of phase k + 1 do not depend on activations: the streamers request its first ring turn right
+//    AFTER the gatherers have issued phase k's publish stores (a refill queued in front of the publish in the CU's
+//    in-order memory pipeline delays the whole chip: 6.2 -> 4.2 us per 96-KiB phase) and BEFORE the all-gather, so
+//    the HBM stream runs through the hand-off.
+//  * c_attn, RoPE, the KV-cache row write and the attention of a head are local to the 8 workgroups of that head
+//    (same XCD): they exchange q and the new k / v row (2 KiB) among themselves; each workgroup then computes the
+//    softmax over the whole context and its own 16 dimensions of the head's output.
+//  * The residual stream never leaves the chip: workgroup b owns rows 16 b .. 16 b + 15 in registers for the
+//    whole step; what travels is fp16(2^e * norm_scale * x) and the partial sums of x^2 (RMSNorm's 1/rms is applied in
+//    the consumer's epilogue, as in gemv.hip; 2^e: see publish_x).
+// Every spin is bounded; a time-out raises the abort word, all other spins then give up at once and the host
+// reports MI355_E_STATE (mi355_fused_step_status).
+#include <math.h>
+
+#include <mutex>
+
+#include <hip/hip_ext.h>
+
+#include "common.h"
+#include "fused_step_common.h"
+
+namespace {
+
+constexpr int kG = 256;         // workgroups
+constexpr int kSW = 8;          // streamer waves
+constexpr int kGW = 2;          // gatherer waves
+constexpr int kThreads = 64 * (kSW + kGW);
+constexpr int kRing = 12;       // ring pieces (1 KiB each) per streamer wave
+#ifndef MI355_FUSED_HSWEEP
+#define MI355_FUSED_HSWEEP 2  // chunks of the hidden edge in flight per gatherer wave (2: 8 + 4 loads per lane, 3: 3 x 8)
+#endif
+#ifndef MI355_FUSED_WINDOW
+#define MI355_FUSED_WINDOW 4
+#endif
+constexpr int kWin = MI355_FUSED_WINDOW;  // pieces per wave in flight while a first ring turn is requested
+constexpr int kC = 4096;        // n_embd
+constexpr int kHeads = 32;
+constexpr int kHs = 128;
+constexpr int kGs = kG / kHeads;  // workgroups per head
+constexpr int kUnitsC = kC / 128;
+constexpr int kMaxFcTiles = 3;    // c_fc1/c_fc2 pair tiles per workgroup (n_hidden <= 12288)
+constexpr int kMaxHeadTiles = 8;  // lm_head tiles per workgroup (vocab <= 32768)
+constexpr unsigned kSpinLimit = 400000u;
+
+// LDS map (bytes)
+constexpr int kOffMisc = 0;                       // [0] 1/rms, [4..7] operand sums, [16..23] / [24..31] per-wave softmax max / sum
+constexpr int kOffZero = 256;                     // one all-zero unit (idle ring steps read it)
+constexpr int kOffXs = 512;                       // activation vector, fp16, <= 96 units
+constexpr int kOffPart = kOffXs + 96 * 256;       // [2][8 waves][4][64 lanes][4] f32 partial tiles
+constexpr int kOffStage = kOffPart + 2 * kSW * 4 * 1024;  // 1 KiB epilogue staging
+constexpr int kOffQ = kOffStage + 1024;           // q[128] knew[128] vnew[128] f32
+constexpr int kOffOpart = kOffQ + 3 * 512;        // [8 waves][16] f32
+constexpr int kMaxS = 32768;                      // cache rows (the attention keeps no per-row state in LDS)
+constexpr int kLdsBytes = kOffOpart + 512;
+static_assert(kLdsBytes <= 160 * 1024, "LDS map exceeds the CU");
+
+// ------------------------------------------------------------------------------------------------ granules
+__device__ __forceinline__ void gr_store(u64* p, unsigned tag, unsigned val) {
+    __hip_atomic_store(p, ((u64)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // one 8-B sc1 store
+}
+__device__ __forceinline__ bool aborted(const FusedParams& p) {
+    return __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+__device__ __forceinline__ void raise_abort(const FusedParams& p, unsigned code) {
+    __hip_atomic_store(p.state, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave sweeps 16-B loads (two granules each) number first + k * 64 + lane, k < NL, of the granule buffer behind
+// `rs` (load i covers bytes base + 16 i ..) until every tag equals `epoch`; loads at or past `end` are skipped.
+// Returns false after a time-out / abort (the values are then garbage, the caller keeps going so that the barrier
+// counts of the workgroup stay balanced).
+template <int NL>
+__device__ __forceinline__ void sweep_issue(__amdgpu_buffer_rsrc_t rs, unsigned base, int first, int end, u32x4 (&v)[NL],
+                                            int lane) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int i = first + k * 64 + lane;
+        const unsigned off = i < end ? base + (unsigned)i * 16u : 0xFFFFFFF0u;
+        v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));  // sc1
+    }
+}
+// `preissued`: the caller has requested v already (sweep_issue) — several chunks of one edge in flight at once
+template <int NL>
+__device__ __forceinline__ bool sweep(const FusedParams& p, __amdgpu_buffer_rsrc_t rs, unsigned base, int first, int end,
+                                      unsigned epoch, u32x4 (&v)[NL], unsigned code, int lane, unsigned* iters = nullptr,
+                                      bool preissued = false) {
+    // (lane: the caller's per-layer opaque copy of the lane id — from threadIdx the offsets of every sweep site are
+    // loop invariants, which hipcc computes once in the kernel prologue and then spills)
+    for (unsigned spins = 0;; ++spins) {
+#ifdef MI355_FUSED_COUNT_SWEEPS
+        if (iters != nullptr) *iters = spins + 1;
+#endif
+        bool ok = true;
+        if (!(preissued && spins == 0)) sweep_issue<NL>(rs, base, first, end, v, lane);
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = first + k * 64 + lane;
+            ok &= i >= end || (v[k][1] == epoch && v[k][3] == epoch);
+        }
+        if (__all(ok)) return true;
+        if (spins > kSpinLimit || aborted(p)) {
+            if (lane == 0) raise_abort(p, code);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ streamers
+struct PhaseW {  // one phase as a streamer wave sees it (all wave-uniform)
+    unsigned base;  // byte offset of the stream inside the layer's descriptor
+    int tile0, tstride, ntiles, units, u0, nu;
+};
+
+// Scalar byte offset of the piece consumed at global step `gstep` of the phase, row group r; ok = false for an idle
+// piece (padding of the ring turn: the load then goes through a zero-sized descriptor = zeros, no memory request).
+// The offset travels in the load's SGPR operand and the lane's 16 B in ONE shared VGPR: per-piece address VGPRs are
+// loop-invariant over the layers, get hoisted and spill.
+template <int SPT, bool PAIR, bool QKV>
+__device__ __forceinline__ unsigned piece_off(const PhaseW& ph, int gstep, int r, bool& ok) {
+    const int ti = gstep / SPT, st = gstep - ti * SPT;
+    int tile;
+    if constexpr (QKV) {
+        tile = ph.tile0 + r * ph.tstride;  // the q, k and v tiles of this workgroup share the activation operand
+        ok = ti == 0 && st < ph.nu;
+    } else {
+        tile = ph.tile0 + ti * ph.tstride;
+        ok = ti < ph.ntiles && st < ph.nu;
+    }
+    return ph.base + (unsigned)((tile * ph.units + ph.u0 + st) * (PAIR ? 2 : 1) + (PAIR ? r : 0)) * 1024u;
+}
+// int4 -> MFMA operand, 5 VALU ops per 8 weights.  The conversion is what bounds a compute phase of the fused step, so
+// the operands are fp16, whose 10-bit mantissa holds TWO nibble positions under one exponent pattern:
+//   (x & 0x000F000F) | 0x64006400 = the fp16 pair (1024 + nibble 0, 1024 + nibble 4)
+//   (x & 0x00F000F0) | 0x64006400 = the fp16 pair (1024 + 16 nibble 1, 1024 + 16 nibble 5)
+// and the same two masks on x >> 8 give nibbles 2 / 6 and 16 x nibbles 3 / 7: one shift + four v_and_or_b32 (the bf16
+// form, 7-bit mantissa, needed a shift per nibble position: 7 ops).  The factor 16 is undone on the activation side:
+// the producers publish every ODD pair of the activation vector divided by 16 (exact in fp16), and the epilogue
+// subtracts 1024 (S_even + S_odd) + zero (S_even + 16 S_odd) with the two sums taken while the vector is staged.
+// With literal constants hipcc emits v_and + v_or (a gfx9 VOP3 cannot carry two literals); with the masks in SGPRs and
+// the exponent pattern in a VGPR whose values the compiler cannot see, it selects v_and_or_b32 itself (and pads the
+// VALU -> MFMA hazard, which an inline-asm v_and_or_b32 does not get: that variant produced NaNs).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+__device__ __forceinline__ uint32_t nib2f16(uint32_t x, uint32_t mask_s, uint32_t magic_v) { return (x & mask_s) | magic_v; }
+__device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rs_null, bool ok,
+                                           unsigned lane_off, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rs : rs_null, lane_off, ok ? soff : 0u, 2));
+}
+
+#define FS_STAMP(i)                                                                   \
+    do {                                                                              \
+        if (p.dbg != nullptr && (threadIdx.x & 63) == 0) p.dbg[bid * 64 + (i)] = wall_clock64(); \
+    } while (0)
+
+}  // namespace
+
+__global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* misc = (float*)(smem + kOffMisc);
+    char* xs = smem + kOffXs;
+    char* part = smem + kOffPart;
+    float* stage = (float*)(smem + kOffStage);
+    float* qs = (float*)(smem + kOffQ);
+    float* knew = qs + kHs;
+    float* vnew = knew + kHs;
+    float* opart = (float*)(smem + kOffOpart);
+
+    // workgroup -> head group: the 8 workgroups of a head sit on one XCD (blocks are dealt round-robin to the 8 XCDs;
+    // a speed matter only — the protocol does not depend on placement)
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int head = xcd * (kHeads / 8) + slot / kGs;
+    const int hj = slot % kGs;  // which 16 dimensions of the head
+
+    const int pos = p.pos[0];
+    const int token = p.tokens[0];
+    const unsigned step_id = p.state[1];
+    const unsigned ebase = step_id * 1024u + 1u;
+    const int n_fc = (p.fc_tiles - bid + kG - 1) / kG;       // this workgroup's pair tiles (2 or 3 for 7B)
+    const int n_head_t = (p.head_tiles - bid + kG - 1) / kG;  // lm_head tiles (7 or 8)
+
+    // entered outside the cache (the host takes the cache-roll regime of model.py:214-218 elsewhere) or with a token id
+    // outside the embedding table: refuse before anything is written.  Uniform over the grid, so no hand-off hangs.
+    if (pos < 0 || pos >= p.S || token < 0 || token >= p.V) {
+        if (bid == 0 && threadIdx.x == 0) raise_abort(p, 0x10u);
+        return;
+    }
+    if (threadIdx.x < 64) ((unsigned*)(smem + kOffZero))[threadIdx.x] = 0u;
+    FS_STAMP(0);
+
+    if (wave < kSW) {
+        // =========================================================================================== streamers
+        unsigned lane_off = lane * 16;
+        const int g = lane >> 4;
+        uint32_t magic = 0x64006400u;
+        uint32_t nmask = 0x000F000Fu, nmask16 = 0x00F000F0u;
+        asm volatile("" : "+v"(magic));  // opaque register values (see nib2f16)
+        asm volatile("" : "+s"(nmask));
+        asm volatile("" : "+s"(nmask16));
+        u32x4 ring[kRing];
+        int buf = 0;
+
+        PhaseW ph_attn, ph_proj, ph_fc, ph_mp, ph_head;
+        ph_attn = {p.off_attn, head * 8 + hj, kC / 16, 1, kUnitsC, wave * 4, 4};
+        ph_proj = {p.off_proj, bid, kG, 1, kUnitsC, wave * 4, 4};
+        ph_fc = {p.off_fc, bid, kG, n_fc, kUnitsC, wave * 4, 4};
+        {
+            const int uq = p.units_h / kSW, ur = p.units_h % kSW;
+            ph_mp = {p.off_mproj, bid, kG, 1, p.units_h, wave * uq + (wave < ur ? wave : ur), uq + (wave < ur ? 1 : 0)};
+        }
+        ph_head = {0u, bid, kG, n_head_t, kUnitsC, wave * 4, 4};
+
+        __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.layer_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_h =
+            __builtin_amdgcn_make_buffer_rsrc((void*)p.w_head, 0, (int)p.head_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
+
+        // ---- first ring turn of a phase (12 pieces), requested right after the previous phase's publish
+#define FS_BURST(RS_, R_, SPT_, PAIR_, QKV_, PH_)                                                             \
+    do {                                                                                                     \
+        _Pragma("unroll") for (int pc__ = 0; pc__ < kRing; ++pc__) {                                         \
+            bool ok__;                                                                                       \
+            const unsigned so__ = piece_off<SPT_, PAIR_, QKV_>(PH_, pc__ / (R_), pc__ % (R_), ok__);          \
+            ring[pc__] = ring_load(RS_, rs_null, ok__, lane_off, so__);                                      \
+            __builtin_amdgcn_sched_barrier(0); /* issue order = consumption order (VMEM returns in order) */ \
+            /* sliding window: at most kWin pieces per wave (8 kWin KiB per CU) are in flight; a deeper     */ \
+            /* queue only stands in front of the gatherers' sweep in the CU's in-order memory pipeline (the */ \
+            /* hand-offs into fc / mlp.c_proj took 5.5 / 5.0 us instead of ~3), and whole chunks separated  */ \
+            /* by vmcnt(0) serialise the memory latency (3 x 2 us for 96 KiB)                               */ \
+            if (pc__ + 1 >= kWin && pc__ + 1 < kRing) {                                                      \
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWin - 1) : "memory");                               \
+                __builtin_amdgcn_sched_barrier(0);                                                           \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
+
+        // ---- one phase: BODIES x TURNS ring turns of 12 / R steps; a step = R pieces against one activation unit
+#define FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_)                                             \
+    do {                                                                                                             \
+        constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
+        const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
+        /* two accumulators per row group (even / odd k-quarter): halves the dependent MFMA chain */                  \
+        f32x4 acc__[R__][2];                                                                                          \
+        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+        __syncthreads(); /* B1: the activation vector is staged */                                                   \
+        FS_SSTAMP(STAMP_);                                                                                            \
+        /* B operands (activation unit of a step) are read one step ahead: a step otherwise starts with an LDS */     \
+        /* round trip (~150 cycles x 12 steps on the hand-off chain)                                           */     \
+        f16x8 bn__[4];                                                                                                \
+        {                                                                                                             \
+            const char* xb0__ = xs + ((PH_).u0) * 256 + g * 64;                                                       \
+            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const f16x8*)(xb0__ + 16 * d__);       \
+        }                                                                                                             \
+        for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
+            _Pragma("unroll") for (int t__ = 0; t__ < (TURNS_); ++t__) {                                              \
+                _Pragma("unroll") for (int s__ = 0; s__ < STEPS__; ++s__) {                                           \
+                    const int gstep__ = (body__ * (TURNS_) + t__) * STEPS__ + s__;                                    \
+                    const int ti__ = gstep__ / SPT__, st__ = gstep__ - ti__ * SPT__;                                  \
+                    f16x8 b__[4];                                                                                     \
+                    _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) b__[d__] = bn__[d__];                         \
+                    {                                                                                                 \
+                        const int nst__ = (st__ + 1 == SPT__) ? 0 : st__ + 1;                                         \
+                        const char* xbn__ = xs + ((PH_).u0 + (nst__ < (PH_).nu ? nst__ : 0)) * 256 + g * 64;          \
+                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const f16x8*)(xbn__ + 16 * d__); \
+                    }                                                                                                 \
+                    /* idle steps (padding of the ring turn) carry no data: skip their MFMAs (wave-uniform) */        \
+                    if (st__ < (PH_).nu && ((QKV_) || ti__ < (PH_).ntiles)) {                                         \
+                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                         \
+                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                   \
+                                const uint32_t v__ = ring[s__ * R__ + r__][d__];                                      \
+                                const uint32_t v8__ = v__ >> 8;                                                       \
+                                u32x4 a__;                                                                            \
+                                a__[0] = nib2f16(v__, nmask, magic);                                                  \
+                                a__[1] = nib2f16(v__, nmask16, magic);                                                \
+                                a__[2] = nib2f16(v8__, nmask, magic);                                                 \
+                                a__[3] = nib2f16(v8__, nmask16, magic);                                               \
+                                acc__[r__][d__ & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                         \
+                                    __builtin_bit_cast(f16x8, a__), b__[d__], acc__[r__][d__ & 1], 0, 0, 0);          \
+                            }                                                                                         \
+                        }                                                                                             \
+                    }                                                                                                 \
+                    /* refill with the same slots of the next turn of THIS phase (nothing past its end) */            \
+                    _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                           \
+                        const int nstep__ = gstep__ + STEPS__;                                                        \
+                        bool ok__;                                                                                    \
+                        const unsigned so__ = piece_off<SPT__, PAIR_, QKV_>(PH_, nstep__, r__, ok__);                 \
+                        ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
+                    }                                                                                                 \
+                    if ((t__ * STEPS__ + s__ + 1) % SPT__ == 0) {                                                     \
+                        /* tile done: publish this wave's partial 16x16 tiles */                                      \
+                        if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
+                        f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * 1024) + lane;                \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
+                            pp__[r__ * 64] = acc__[r__][0] + acc__[r__][1];                                           \
+                            acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                                \
+                        }                                                                                             \
+                        __syncthreads(); /* Bt */                                                                     \
+                        buf ^= 1;                                                                                     \
+                    }                                                                                                 \
+                    /* keep a step's conversions next to its MFMAs: hipcc otherwise hoists the shifts / masks of */   \
+                    /* all 12 pieces to the top of the turn and spills                                           */   \
+                    __builtin_amdgcn_sched_barrier(0);                                                                \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+        __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
+    } while (0)
+
+        FS_BURST(rs_l, 3, 4, false, true, ph_attn);
+        const bf16_t* kv_l = (const bf16_t*)p.kv;
+        bool dbg_on = false;
+#define FS_SSTAMP(i)                                                                      \
+    do {                                                                                  \
+        if (dbg_on && threadIdx.x == 0) p.dbg[bid * 64 + (i)] = wall_clock64();            \
+    } while (0)
+        for (int l = 0; l < p.n_layer; ++l) {
+            dbg_on = p.dbg != nullptr && l == p.dbg_layer;
+            asm volatile("" : "+v"(lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
+            // ---------------- c_attn (q, k, v tiles of this workgroup's 16 dimensions of its head)
+            FS_RUN(rs_l, 3, 4, false, true, 1, ph_attn, 1, 20);
+            // ---------------- attention: scores over the whole context, then this workgroup's 16 output dims
+            {
+                const bf16_t* kc = kv_l + (size_t)head * p.S * kHs;
+                const bf16_t* vc = kc + (size_t)kHeads * p.S * kHs;
+                const int li = (lane_off >> 4) & 15, lr = lane_off >> 8;
+                const int half = lane_off >> 9, rl = (lane_off >> 4) & 31;
+                const __amdgpu_buffer_rsrc_t rk =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)kc, 0, pos * (kHs * 2), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rv =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, pos * (kHs * 2), 0x00020000);
+                const int n_blocks = (pos + 255) >> 8;  // blocks of 256 cached rows: 32 per wave and block
+                u32x4 kr[8], vr;
+                // rows of block 0: requested before q is known.  A wave scores the SAME 32 rows it then weighs the
+                // values of (row wave * 32 + u * 4 + lr for the scores, 16 lanes per row; row wave * 32 + rl for the
+                // values, 8 of the workgroup's 16 output dimensions per lane): no score leaves the wave, the softmax is
+                // a per-wave partial (running maximum, sum, weighted values) that gatherer 0 merges — no barrier and no
+                // LDS round trip between scores and values, and no wave re-reads the whole score vector.
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = wave * 32 + u * 4 + lr;
+                    kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                          rk, t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u, 0, 0));
+                }
+                {
+                    const int t = wave * 32 + rl;
+                    vr = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
+                }
+                __syncthreads();  // Ba1: q / new k / new v of the head are in LDS
+                FS_SSTAMP(23);
+                float qf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[j] = qs[li * 8 + j];
+                // lane L (value row rl = L & 31) takes its row's score from the lane group that computed it
+                const int pull = ((((lane_off >> 4) & 3) << 4) | (rl >> 2)) * 4;
+                float m_run = -1.0e30f, l_run = 0.f;
+                float of[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) of[j] = 0.f;
+                for (int blk = 0; blk < n_blocks; ++blk) {
+                    u32x4 vv = vr;
+                    if (blk > 0) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int t = blk * 256 + wave * 32 + u * 4 + lr;
+                            kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                  rk, t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u, 0, 0));
+                        }
+                        const int t = blk * 256 + wave * 32 + rl;
+                        vv = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                           rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
+                    }
+                    float sel = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        float dot = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            dot += qf[2 * i] * __uint_as_float(kr[u][i] << 16);
+                            dot += qf[2 * i + 1] * __uint_as_float(kr[u][i] & 0xffff0000u);
+                        }
+                        dot = group_sum(dot, 16);
+                        if ((li & 7) == u) sel = dot;
+                    }
+                    const int t = blk * 256 + wave * 32 + rl;
+                    float sc = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(sel))) * p.scale;
+                    sc = t < pos ? sc : -1.0e30f;
+                    float bm = fmaxf(sc, lane_xor16(sc));  // maximum over the wave's 32 rows (both halves hold them)
+                    bm = MI355_DPP_MAX(bm, 0x140);
+                    bm = MI355_DPP_MAX(bm, 0x141);
+                    bm = MI355_DPP_MAX(bm, 0x4E);
+                    bm = MI355_DPP_MAX(bm, 0xB1);
+                    float s_new = -1.0e30f;
+                    if (blk == 0 && wave == 0) {  // the new token's own score, from the LDS copy of its key
+                        float dot = qs[lane] * knew[lane] + qs[lane + 64] * knew[lane + 64];
+                        s_new = group_sum(dot, 64) * p.scale;
+                        bm = fmaxf(bm, s_new);
+                    }
+                    const float m_new = fmaxf(m_run, bm);
+                    const float corr = __expf(m_run - m_new);
+                    const float pr = t < pos ? __expf(sc - m_new) : 0.f;
+                    l_run = l_run * corr + pr;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        of[2 * i] = of[2 * i] * corr + pr * __uint_as_float(vv[i] << 16);
+                        of[2 * i + 1] = of[2 * i + 1] * corr + pr * __uint_as_float(vv[i] & 0xffff0000u);
+                    }
+                    if (blk == 0 && wave == 0 && rl == 0) {  // the new token's value row
+                        const float pn = __expf(s_new - m_new);
+                        l_run += pn;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) of[j] += pn * vnew[hj * 16 + half * 8 + j];
+                    }
+                    m_run = m_new;
+                }
+                if (n_blocks == 0 && wave == 0) {  // position 0: the new token attends to itself only
+                    float dot = qs[lane] * knew[lane] + qs[lane + 64] * knew[lane + 64];
+                    m_run = group_sum(dot, 64) * p.scale;
+                    if (rl == 0) {
+                        l_run = 1.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) of[j] = vnew[hj * 16 + half * 8 + j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) of[j] = group_sum(of[j], 32);
+                l_run = group_sum(l_run, 32);
+                if (rl == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) opart[wave * 16 + half * 8 + j] = of[j];
+                }
+                if ((threadIdx.x & 63) == 0) {
+                    misc[16 + wave] = m_run;
+                    misc[24 + wave] = l_run;
+                }
+                FS_SSTAMP(25);
+                __syncthreads();  // Ba3: partial outputs of the 8 waves
+                __syncthreads();  // Ba4: the attention output is published
+            }
+            // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows)
+            FS_BURST(rs_l, 1, 12, false, false, ph_proj);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_proj, 1, 26);
+            FS_BURST(rs_l, 2, 4, true, false, ph_fc);
+            FS_RUN(rs_l, 2, 4, true, false, 2, ph_fc, 1, 28);
+            FS_BURST(rs_l, 1, 12, false, false, ph_mp);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_mp, 1, 30);
+            // next layer (or the head)
+            kv_l += (size_t)2 * kHeads * p.S * kHs;
+            if (l + 1 < p.n_layer) {
+                rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (size_t)(l + 1) * p.layer_stride), 0,
+                                                         (int)p.layer_bytes, 0x00020000);
+                FS_BURST(rs_l, 3, 4, false, true, ph_attn);
+            } else {
+                FS_BURST(rs_h, 1, 4, false, false, ph_head);
+            }
+        }
+        dbg_on = false;
+        FS_RUN(rs_h, 1, 4, false, false, 1, ph_head, p.head_turns, 32);
+        if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
+#undef FS_RUN
+#undef FS_BURST
+#undef FS_SSTAMP
+    } else {
+        // =========================================================================================== gatherers
+        const int gw = wave - kSW;  // 0: combines / publishes, 1: helps with the sweeps
+        unsigned edge = 0;   // edges published so far in this step (the epoch of the next one is ebase + edge)
+        int xpar = 0, apar = 0, hpar = 0, qpar = 0;
+        int buf = 0;
+        const __amdgpu_buffer_rsrc_t rs_gx = __builtin_amdgcn_make_buffer_rsrc((void*)p.gx, 0, 2 * 2304 * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_ga = __builtin_amdgcn_make_buffer_rsrc((void*)p.ga, 0, 2 * 2048 * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_gh = __builtin_amdgcn_make_buffer_rsrc((void*)p.gh, 0, 2 * (p.H / 2) * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_gq =
+            __builtin_amdgcn_make_buffer_rsrc((void*)p.gq, 0, 2 * kHeads * 256 * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_gm = __builtin_amdgcn_make_buffer_rsrc((void*)p.gm, 0, 512 * 8, 0x00020000);
+
+        // ---- epilogue mapping of gatherer 0: lane = (pair pg = lane >> 3, streamer wave w8 = lane & 7).  A lane reads
+        // rows 2 pg, 2 pg + 1 of ONE wave's partial tile (8 B), the 8 lanes of a pair are summed with DPP (fixed
+        // order), and every lane then holds both outputs of its pair: RoPE pairs, bf16 pair granules and the residual
+        // rows stay in registers (the first version staged them through LDS: 0.6-1.1 us per phase on the chain).
+        int lane_v = lane;  // made opaque once per layer: per-lane pointers are otherwise hoisted out of the layer loop
+                            // (a few dozen 64-bit addresses) and spilled to scratch, i.e. to VMEM on the hand-off path
+        int pg = lane >> 3, w8 = lane & 7;
+        int psrc = ((pg >> 1) << 4) * 4 + ((2 * pg) & 3);  // float index of D[2 pg][0] in a wave's partial tile
+        auto tile_pair = [&](int r) {
+            float2 t = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * 1024) + psrc);
+            t.x = group_sum(t.x, 8);
+            t.y = group_sum(t.y, 8);
+            return t;
+        };
+        auto ldpair = [&](const bf16_t* q) {  // two consecutive bf16 (4-byte aligned) as floats
+            const unsigned v = *(const unsigned*)q;
+            return float2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+        };
+        auto bfpair = [&](float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); };
+        // activation pair granule: fp16 (a, b); ODD pairs of a vector carry a / 16, b / 16 (see nib2f16).  pg is the
+        // pair's index inside its 8-pair row, the rows start at even pair indices.
+        // fp16 has 5 exponent bits: the conversion saturates (a finite, if clipped, operand instead of an inf that the
+        // +1024 offsets would turn into NaN), and the residual stream, whose size nothing bounds, is published times a
+        // power of two that brings its rms near 1 (publish_x).
+        // Every clip is COUNTED in state[2] (mi355_fused_step_status / DecodeEngine.check_status report it): the step's
+        // outputs then differ from the unclipped arithmetic of the reference.
+        auto hpair = [&](float a, float b) {
+            const float k = (pg & 1) ? 0.0625f : 1.0f;
+            const float ak = a * k, bk = b * k;
+            if (fmaxf(fabsf(ak), fabsf(bk)) > 65504.f) atomicAdd(p.state + 2, 1u);
+            const f16x2 h = {(_Float16)__builtin_amdgcn_fmed3f(ak, -65504.f, 65504.f),
+                             (_Float16)__builtin_amdgcn_fmed3f(bk, -65504.f, 65504.f)};
+            return __builtin_bit_cast(unsigned, h);
+        };
+        // sums of the staged operands, even pairs in .x and odd pairs in .y (one v_dot2_f32_f16 per dword).  They undo
+        // the +1024 / zero-point offsets of the int4 operands:
+        //   y = scale (acc - 1024 (S_even + S_odd) - zero (S_even + 16 S_odd));
+        // every workgroup needs the same sums, so they are taken while the vector is staged instead of by all-ones
+        // MFMAs in every streamer wave.
+        const f16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
+        auto pair_sums = [&](float2& sx, unsigned even, unsigned odd) {
+            sx.x = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, even), ones2, sx.x, false);
+            sx.y = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, odd), ones2, sx.y, false);
+        };
+        // misc[4 + gw] / misc[6 + gw]: this gatherer wave's S_even / S_odd; the epilogue form {A, B}:
+        // y = scale (acc - A - zero B)
+        auto put_sums = [&](float2 sx) {
+            sx.x = group_sum(sx.x, 64);
+            sx.y = group_sum(sx.y, 64);
+            if (lane == 0) {
+                misc[4 + gw] = sx.x;
+                misc[6 + gw] = sx.y;
+            }
+        };
+        auto get_sums = [&]() {
+            const float se = misc[4] + misc[5], so = misc[6] + misc[7];
+            return float2{1024.f * (se + so), se + 16.f * so};
+        };
+        bool dbg_on = false;
+#define FS_GSTAMP(i)                                                                              \
+    do {                                                                                          \
+        if (dbg_on && gw == 0 && lane == 0) p.dbg[bid * 64 + (i)] = wall_clock64();               \
+    } while (0)
+
+        // publish an x-type edge: fp16(x_scale * norm_scale * x) pairs + the partial sum of squares of this workgroup's
+        // rows.  x_scale = the power of two next to 1/rms of the PREVIOUS x edge (the same float in every workgroup: all
+        // of them reduce the same 256 partial sums in the same order; 1 for the embedding): the residual stream changes
+        // by one sub-layer's output between two edges, so the published values stay O(norm weight), far from the fp16
+        // limits both ways.  The consumer folds 1 / x_scale into the 1/rms factor of its epilogue.
+        float x_scale = 1.f;       // applied to the edge published last (= the one gathered next)
+        float rinv_seen = 1.f;     // 1/rms of the x edge gathered last
+        auto publish_x = [&](float2 xv, float2 gsc) {
+            const unsigned ep = ebase + edge;
+            u64* dst = p.gx + (size_t)xpar * 2304;
+            x_scale = __uint_as_float((__float_as_uint(rinv_seen) + 0x00400000u) & 0x7F800000u);
+            if (w8 == 0) gr_store(dst + bid * 8 + pg, ep, hpair(x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y));
+            float ss = xv.x * xv.x + xv.y * xv.y;  // the same in the 8 lanes of a pair: sum over the 8 pairs
+            ss = MI355_DPP_ADD(ss, 0x140);
+            ss += lane_xor16(ss);
+            ss += lane_xor32(ss);
+            if (lane == 0) gr_store(dst + 2048 + bid, ep, __float_as_uint(ss));
+        };
+        // gather an x-type edge into xs (fp16), 1/rms into misc[0], the operand sums into misc[4 .. 7]
+        // profiling aid (-DMI355_FUSED_COUNT_SWEEPS, scripts/fused_timeline.py): sweep iterations of gatherer 0 per hand-off.
+        // Measured (profiles/r02_fused_step_sweep_iterations.txt): the x edges ALWAYS succeed on the first sweep — a
+        // loaded hand-off is one slow memory round trip behind the ring turn, not a retry.  Off by default: the counter
+        // costs registers on the hand-off path (56 spill instructions, 925 -> 988 us per step).
+        unsigned n_sweeps = 0;
+#ifdef MI355_FUSED_COUNT_SWEEPS
+#define FS_GCOUNT(i)                                                                              \
+    do {                                                                                          \
+        if (dbg_on && gw == 0 && lane == 0) p.dbg[bid * 64 + (i)] = n_sweeps;                     \
+    } while (0)
+#else
+#define FS_GCOUNT(i) do { } while (0)
+#endif
+        auto gather_x = [&]() {
+            const unsigned ep = ebase + edge;
+            const unsigned base = (unsigned)xpar * 2304u * 8u;
+            if (gw == 0) {
+                u32x4 v[8];
+                // loads 0 .. 383 of the pair region (6 per lane) and the 128 loads of the sums of squares (2 per lane)
+                for (unsigned spins = 0;; ++spins) {
+#ifdef MI355_FUSED_COUNT_SWEEPS
+                    n_sweeps = spins + 1;
+#endif
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned off = k < 6 ? base + (unsigned)(k * 64 + lane_v) * 16u
+                                                   : base + 2048u * 8u + (unsigned)((k - 6) * 64 + lane_v) * 16u;
+                        v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gx, off, 0, 16));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ok &= v[k][1] == ep && v[k][3] == ep;
+                    if (__all(ok)) break;
+                    if (spins > kSpinLimit || aborted(p)) {
+                        if (lane == 0) raise_abort(p, 0x100u + edge);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                float2 sx = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    *(u64*)(xs + (size_t)(k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                    pair_sums(sx, v[k][0], v[k][2]);
+                }
+                float ss = ((__uint_as_float(v[6][0]) + __uint_as_float(v[6][2])) + __uint_as_float(v[7][0])) +
+                           __uint_as_float(v[7][2]);
+                ss = group_sum(ss, 64);
+                put_sums(sx);
+                if (lane == 0) misc[0] = rsqrtf(ss / (float)kC + p.eps);
+            } else {
+                u32x4 v[10];
+                sweep<10>(p, rs_gx, base, 384, 1024, ep, v, 0x200u + edge, lane_v);
+                float2 sx = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    *(u64*)(xs + (size_t)(384 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                    pair_sums(sx, v[k][0], v[k][2]);
+                }
+                put_sums(sx);
+            }
+            xpar ^= 1;
+            ++edge;
+        };
+        auto deq = [&](float2 t, float2 sc_, float2 z_, float2 sx) {
+            return float2{sc_.x * (t.x - sx.x - z_.x * sx.y), sc_.y * (t.y - sx.x - z_.y * sx.y)};
+        };
+
+        // ---- the residual rows of this workgroup: embedding of the step's token (model.py:102)
+        int r0 = bid * 16 + 2 * pg;  // first row of this lane's pair among the n_embd residual rows
+        float2 xres = ldpair(p.wte + (size_t)token * kC + r0);
+        const bf16_t* norms_l = p.norms;
+        const bf16_t* sz_l = p.sz;
+        bf16_t* kv_l = p.kv;
+        const float2 cs = *(const float2*)(p.rope + ((size_t)pos * (kHs / 2) + hj * 8 + pg) * 2);
+        if (gw == 0) publish_x(xres, ldpair(norms_l + r0));
+        for (int l = 0; l < p.n_layer; ++l) {
+            dbg_on = p.dbg != nullptr && l == p.dbg_layer;
+            asm volatile("" : "+v"(lane_v));
+            pg = lane_v >> 3;
+            w8 = lane_v & 7;
+            psrc = ((pg >> 1) << 4) * 4 + ((2 * pg) & 3);
+            r0 = bid * 16 + 2 * pg;
+            // ================= c_attn
+            const int nq = (head * 8 + hj) * 16 + 2 * pg;  // q rows of this lane's pair; k at + C, v at + 2 C
+            float2 sc[3], zr[3];
+            if (gw == 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    sc[r] = ldpair(sz_l + nq + r * kC);
+                    zr[r] = ldpair(sz_l + 3 * kC + nq + r * kC);
+                }
+            }
+            gather_x();
+            FS_GSTAMP(2);
+            FS_GCOUNT(40);
+            __syncthreads();  // B1
+            __syncthreads();  // Bt (one virtual tile)
+            if (gw == 0) {
+                rinv_seen = misc[0];
+                const float rinv = rinv_seen / x_scale;
+                const float2 sx = get_sums();
+                float2 y[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    y[r] = deq(tile_pair(r), sc[r], zr[r], sx);
+                    y[r].x *= rinv;
+                    y[r].y *= rinv;
+                }
+                // RoPE (model.py:306-323) of the q / k pair, publish to the head group, write the cache row
+                const unsigned ep = ebase + edge;
+                u64* dst = p.gq + ((size_t)qpar * kHeads + head) * 256 + hj * 32;
+                bf16_t* krow = kv_l + ((size_t)head * p.S + pos) * kHs + hj * 16;
+                bf16_t* vrow = krow + (size_t)kHeads * p.S * kHs;
+                const float qa = y[0].x * cs.x - y[0].y * cs.y, qb = y[0].y * cs.x + y[0].x * cs.y;
+                const unsigned kp = bfpair(y[1].x * cs.x - y[1].y * cs.y, y[1].y * cs.x + y[1].x * cs.y);
+                const unsigned vp = bfpair(y[2].x, y[2].y);
+                if (w8 == 0) gr_store(dst + 2 * pg, ep, __float_as_uint(qa));
+                if (w8 == 1) gr_store(dst + 2 * pg + 1, ep, __float_as_uint(qb));
+                if (w8 == 2) gr_store(dst + 16 + pg, ep, kp);
+                if (w8 == 3) gr_store(dst + 24 + pg, ep, vp);
+                if (w8 == 4) ((unsigned*)krow)[pg] = kp;
+                if (w8 == 5) ((unsigned*)vrow)[pg] = vp;
+            }
+            FS_GSTAMP(3);
+            buf ^= 1;
+            __syncthreads();  // B3
+            // ================= attention
+            {
+                const unsigned ep = ebase + edge;
+                if (gw == 0) {
+                    u32x4 v[2];
+                    sweep<2>(p, rs_gq, (unsigned)((qpar * kHeads + head) * 256) * 8u, 0, 128, ep, v, 0x300u + edge, lane_v, &n_sweeps);
+                    FS_GCOUNT(41);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const int gi = (k * 64 + lane_v) * 2 + e2;  // granule index inside the head's 256 (lane_v: not hoisted)
+                            const int jj = gi >> 5, e = gi & 31;
+                            const unsigned val = v[k][2 * e2];
+                            if (e < 16) {
+                                qs[jj * 16 + e] = __uint_as_float(val);
+                            } else if (e < 24) {
+                                knew[jj * 16 + 2 * (e - 16)] = __uint_as_float(val << 16);
+                                knew[jj * 16 + 2 * (e - 16) + 1] = __uint_as_float(val & 0xffff0000u);
+                            } else {
+                                vnew[jj * 16 + 2 * (e - 24)] = __uint_as_float(val << 16);
+                                vnew[jj * 16 + 2 * (e - 24) + 1] = __uint_as_float(val & 0xffff0000u);
+                            }
+                        }
+                    }
+                }
+                qpar ^= 1;
+                ++edge;
+                FS_GSTAMP(4);
+                __syncthreads();  // Ba1
+                __syncthreads();  // Ba3
+                FS_GSTAMP(5);
+                if (gw == 0) {
+                    // merge the 8 per-wave softmax partials (running maximum, sum, weighted values)
+                    float2 o = *(const float2*)(opart + w8 * 16 + 2 * pg);
+                    const float mw = misc[16 + w8];
+                    float mall = MI355_DPP_MAX(mw, 0xB1);
+                    mall = MI355_DPP_MAX(mall, 0x4E);
+                    mall = MI355_DPP_MAX(mall, 0x141);
+                    const float wsc = __expf(mw - mall);
+                    o.x = group_sum(o.x * wsc, 8);
+                    o.y = group_sum(o.y * wsc, 8);
+                    const float inv = 1.0f / group_sum(misc[24 + w8] * wsc, 8);
+                    // attention output elements head * 128 + hj * 16 + 2 pg, + 1 -> one pair granule
+                    if (w8 == 0)
+                        gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair(o.x * inv, o.y * inv));
+                }
+                FS_GSTAMP(6);
+                __syncthreads();  // Ba4
+            }
+            // ================= attn.c_proj (+ residual)
+            {
+                float2 s1 = {0.f, 0.f}, z1 = {0.f, 0.f}, gn = {0.f, 0.f};
+                if (gw == 0) {
+                    s1 = ldpair(sz_l + 6 * kC + r0);
+                    z1 = ldpair(sz_l + 7 * kC + r0);
+                    gn = ldpair(norms_l + kC + r0);  // rms_2
+                }
+                const unsigned ep = ebase + edge;
+                u32x4 v[8];
+                sweep<8>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, ep, v, 0x400u + edge, lane_v, &n_sweeps);
+                FS_GCOUNT(42);
+                float2 sxp = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                    pair_sums(sxp, v[k][0], v[k][2]);
+                }
+                put_sums(sxp);
+                apar ^= 1;
+                ++edge;
+                FS_GSTAMP(7);
+                __syncthreads();  // B1
+                __syncthreads();  // Bt
+                if (gw == 0) {
+                    const float2 d = deq(tile_pair(0), s1, z1, get_sums());
+                    xres.x += d.x;
+                    xres.y += d.y;
+                    publish_x(xres, gn);
+                }
+                FS_GSTAMP(8);
+                buf ^= 1;
+                __syncthreads();  // B3
+            }
+            // ================= c_fc1 / c_fc2 + SwiGLU
+            {
+                const bf16_t* s_fc = sz_l + 8 * kC;
+                float2 fs1[kMaxFcTiles], fz1[kMaxFcTiles], fs2[kMaxFcTiles], fz2[kMaxFcTiles];
+                if (gw == 0) {
+#pragma unroll
+                    for (int t = 0; t < kMaxFcTiles; ++t) {
+                        const int n = (bid + (t < n_fc ? t : 0) * kG) * 16 + 2 * pg;
+                        fs1[t] = ldpair(s_fc + n);
+                        fz1[t] = ldpair(s_fc + p.H + n);
+                        fs2[t] = ldpair(s_fc + 2 * p.H + n);
+                        fz2[t] = ldpair(s_fc + 3 * p.H + n);
+                    }
+                }
+                gather_x();
+                FS_GSTAMP(9);
+                FS_GCOUNT(43);
+                __syncthreads();  // B1
+                const unsigned ep = ebase + edge;
+                u64* dst = p.gh + (size_t)hpar * (p.H / 2);
+                rinv_seen = misc[0];
+                const float rinv = rinv_seen / x_scale;
+                const float2 sx = get_sums();
+#pragma unroll
+                for (int t = 0; t < kMaxFcTiles; ++t) {
+                    __syncthreads();  // Bt
+                    if (gw == 0 && t < n_fc) {
+                        const float2 a = deq(tile_pair(0), fs1[t], fz1[t], sx);
+                        const float2 b = deq(tile_pair(1), fs2[t], fz2[t], sx);
+                        if (w8 == 0)
+                            gr_store(dst + (bid + t * kG) * 8 + pg, ep,
+                                     hpair(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv)));
+                    }
+                    buf ^= 1;
+                }
+                FS_GSTAMP(10);
+                __syncthreads();  // B3
+            }
+            // ================= mlp.c_proj (+ residual) -> next layer's x edge
+            {
+                float2 s1 = {0.f, 0.f}, z1 = {0.f, 0.f}, gn = {0.f, 0.f};
+                const bf16_t* s_mp = sz_l + 8 * kC + 4 * p.H;
+                if (gw == 0) {
+                    s1 = ldpair(s_mp + r0);
+                    z1 = ldpair(s_mp + kC + r0);
+                    gn = ldpair(norms_l + 2 * kC + r0);  // rms_1 of the next layer, or ln_f after the last
+                }
+                const unsigned ep = ebase + edge;
+                const int n_loads = p.H / 4, half_l = (n_loads + 1) / 2;
+                const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
+                float2 sxp = {0.f, 0.f};
+                {
+                    // up to three chunks of 8 loads per lane (H <= 12288), TWO in flight: only the first one waits for
+                    // producers; issued one after the other each later chunk cost its own memory round trip on the
+                    // longest hand-off of the layer (44 KB of granules)
+                    const unsigned hbase = (unsigned)hpar * (unsigned)(p.H / 2) * 8u;
+                    int lh = lane_v;
+                    asm volatile("" : "+v"(lh));  // addresses of this block are computed here, not hoisted and spilled
+#if MI355_FUSED_HSWEEP == 3
+                    // all three chunks of 8 loads per lane (24 >= 12288 / 4 / 2 / 64) in flight at once
+                    u32x4 va[8], vb[8], vc[8];
+                    auto stage8 = [&](const u32x4 (&v)[8], int c0) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int i = c0 + k * 64 + lh;
+                            if (i < end) {
+                                *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                                pair_sums(sxp, v[k][0], v[k][2]);
+                            }
+                        }
+                    };
+                    const int c1 = first + 512, c2 = first + 1024;
+                    sweep_issue<8>(rs_gh, hbase, first, end, va, lh);
+                    sweep_issue<8>(rs_gh, hbase, c1, end, vb, lh);
+                    sweep_issue<8>(rs_gh, hbase, c2, end, vc, lh);
+                    sweep<8>(p, rs_gh, hbase, first, end, ep, va, 0x500u + edge, lh, &n_sweeps, true);
+                    FS_GCOUNT(44);
+                    stage8(va, first);
+                    sweep<8>(p, rs_gh, hbase, c1, end, ep, vb, 0x500u + edge, lh, nullptr, true);
+                    stage8(vb, c1);
+                    sweep<8>(p, rs_gh, hbase, c2, end, ep, vc, 0x500u + edge, lh, nullptr, true);
+                    stage8(vc, c2);
+                }
+#else
+                    // chunks of 8, 4, 8, 4 loads per lane (24 >= 12288 / 4 / 2 / 64), two in flight
+                    u32x4 va[8], vb[4];
+                    auto stage_a = [&](int c0) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int i = c0 + k * 64 + lh;
+                            if (i < end) {
+                                *(u64*)(xs + (size_t)i * 8) = ((u64)va[k][2] << 32) | va[k][0];
+                                pair_sums(sxp, va[k][0], va[k][2]);
+                            }
+                        }
+                    };
+                    auto stage_b = [&](int c0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int i = c0 + k * 64 + lh;
+                            if (i < end) {
+                                *(u64*)(xs + (size_t)i * 8) = ((u64)vb[k][2] << 32) | vb[k][0];
+                                pair_sums(sxp, vb[k][0], vb[k][2]);
+                            }
+                        }
+                    };
+                    const int c1 = first + 512, c2 = first + 768, c3 = first + 1280;
+                    sweep_issue<8>(rs_gh, hbase, first, end, va, lh);
+                    sweep_issue<4>(rs_gh, hbase, c1, end, vb, lh);
+                    sweep<8>(p, rs_gh, hbase, first, end, ep, va, 0x500u + edge, lh, &n_sweeps, true);
+                    FS_GCOUNT(44);
+                    stage_a(first);
+                    sweep_issue<8>(rs_gh, hbase, c2, end, va, lh);
+                    sweep<4>(p, rs_gh, hbase, c1, end, ep, vb, 0x500u + edge, lh, nullptr, true);
+                    stage_b(c1);
+                    sweep_issue<4>(rs_gh, hbase, c3, end, vb, lh);
+                    sweep<8>(p, rs_gh, hbase, c2, end, ep, va, 0x500u + edge, lh, nullptr, true);
+                    stage_a(c2);
+                    sweep<4>(p, rs_gh, hbase, c3, end, ep, vb, 0x500u + edge, lh, nullptr, true);
+                    stage_b(c3);
+                }
+#endif
+                put_sums(sxp);
+                hpar ^= 1;
+                ++edge;
+                FS_GSTAMP(11);
+                __syncthreads();  // B1
+                __syncthreads();  // Bt
+                if (gw == 0) {
+                    const float2 d = deq(tile_pair(0), s1, z1, get_sums());
+                    xres.x += d.x;
+                    xres.y += d.y;
+                    publish_x(xres, gn);
+                }
+                FS_GSTAMP(12);
+                buf ^= 1;
+                __syncthreads();  // B3
+            }
+            norms_l += 2 * kC;
+            sz_l += p.sz_layer_stride;
+            kv_l += (size_t)2 * kHeads * p.S * kHs;
+        }
+        dbg_on = false;
+        // ================= ln_f + lm_head (+ greedy arg-max, generate.py:68-85 with top_k = 1)
+        {
+            // scale / zero of a tile's rows are requested one tile ahead
+            auto head_sz = [&](int t, float2& sc_, float2& z_) {
+                const int n = (bid + t * kG) * 16 + 2 * pg;
+                const bool ok = t < n_head_t && n + 1 < p.V;
+                sc_ = ok ? ldpair(p.sz_head + n) : float2{0.f, 0.f};
+                z_ = ok ? ldpair(p.sz_head + p.V + n) : float2{0.f, 0.f};
+            };
+            float2 sct = {0.f, 0.f}, zt = {0.f, 0.f};
+            if (gw == 0) head_sz(0, sct, zt);
+            gather_x();
+            __syncthreads();  // B1
+            rinv_seen = misc[0];
+                const float rinv = rinv_seen / x_scale;
+            const float2 sx = get_sums();
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+            const int tiles_pad = p.head_turns * 3;
+            for (int t = 0; t < tiles_pad; ++t) {
+                float2 scn = {0.f, 0.f}, zn = {0.f, 0.f};
+                if (gw == 0) head_sz(t + 1, scn, zn);
+                __syncthreads();  // Bt
+                if (gw == 0 && t < n_head_t) {
+                    const int n = (bid + t * kG) * 16 + 2 * pg;
+                    float2 y = deq(tile_pair(0), sct, zt, sx);
+                    y.x *= rinv;
+                    y.y *= rinv;
+                    if (n + 1 < p.V) {  // vocab sizes are even (host check): a pair is inside or outside
+                        if (w8 == 0) *(float2*)(p.logits + n) = y;
+                        if (y.x > best || (y.x == best && n < bi)) {
+                            best = y.x;
+                            bi = n;
+                        }
+                        if (y.y > best || (y.y == best && n + 1 < bi)) {
+                            best = y.y;
+                            bi = n + 1;
+                        }
+                    }
+                }
+                sct = scn;
+                zt = zn;
+                buf ^= 1;
+            }
+            __syncthreads();  // B3
+            if (p.mode & 1) {
+                if (gw == 0) {
+                    // best of this workgroup's rows (the 8 lanes of a pair agree), lowest index on ties
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) {
+                        const float ov = __shfl_xor(best, o, 64);
+                        const int oi = __shfl_xor(bi, o, 64);
+                        if (ov > best || (ov == best && oi < bi)) {
+                            best = ov;
+                            bi = oi;
+                        }
+                    }
+                    const unsigned ep = ebase + edge;
+                    if (lane == 0) {
+                        gr_store(p.gm + 2 * bid, ep, __float_as_uint(best));
+                        gr_store(p.gm + 2 * bid + 1, ep, (unsigned)bi);
+                    }
+                    if (bid == 0) {
+                        u32x4 v[4];
+                        const bool ok = sweep<4>(p, rs_gm, 0u, 0, 256, ep, v, 0x600u + edge, lane_v);
+                        float bv = -INFINITY;
+                        int bx = 0x7fffffff;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float cv = __uint_as_float(v[k][0]);
+                            const int ci = (int)v[k][2];
+                            if (cv > bv || (cv == bv && ci < bx)) {
+                                bv = cv;
+                                bx = ci;
+                            }
+                        }
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const float ov = __shfl_xor(bv, o, 64);
+                            const int oi = __shfl_xor(bx, o, 64);
+                            if (ov > bv || (ov == bv && oi < bx)) {
+                                bv = ov;
+                                bx = oi;
+                            }
+                        }
+                        if (bx == 0x7fffffff) bx = 0;
+                        if (lane == 0 && ok && !aborted(p)) {
+                            p.next_token[0] = bx;
+                            if (p.out_tokens != nullptr) p.out_tokens[pos + 1] = bx;
+                            if (p.mode & 2) {
+                                p.tokens[0] = bx;
+                                p.pos[0] = pos + 1;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (bid == 0 && gw == 0 && lane == 0) p.state[1] = step_id + 1u;
+        }
+    }
+    FS_STAMP(1);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+// The step needs all 256 workgroups resident at once (they wait for each other).  A plain launch and a cooperative launch
+// get the same residency; the cooperative one costs 15-19 us of host time per launch and only adds the launch-time check
+// of the grid against the occupancy query (MI355X_MICROARCH.md, "coop-launch"), so the query is made once here and a
+// kernel that does not fit one workgroup per CU is refused up front.  Kernels of OTHER streams that hold CUs while a step
+// starts only delay it: workgroups are admitted as CUs drain, every spin is bounded (kSpinLimit sweeps, ~1 s), and a
+// step that gives up raises the abort word instead of hanging.
+int fused_step_ring_occupancy_ok() {
+    static int ok = -1;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int per_cu = 0;
+        (void)hipFuncSetAttribute((const void*)fused_step_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fused_step_ring_kernel, kThreads, kLdsBytes);
+        ok = (e == hipSuccess && per_cu >= 1) ? 1 : 0;
+    });
+    return ok;
+}
+
+// launched by mi355_fused_step (fused_step.hip)
+int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute((const void*)fused_step_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    });
+    MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "fused_step: hipFuncSetAttribute failed: %s",
+                    hipGetErrorString(attr_err));
+    if (e0 != nullptr) {
+        hipExtLaunchKernelGGL(fused_step_ring_kernel, dim3(kG), dim3(kThreads), (uint32_t)kLdsBytes, stream, e0, e1, 0, p);
+    } else {
+        hipLaunchKernelGGL(fused_step_ring_kernel, dim3(kG), dim3(kThreads), kLdsBytes, stream, p);
+    }
+    MI355_LAUNCH_CHECK();
+    return 0;
+}

@@ -352,6 +352,7 @@ class DecodeEngine:
         self._fused_keep = [sz, sz_head, norms, ws]
         self._fused_ws = ws
         self._fused_warm = False
+        self.fused_clipped = 0  # fp16 granules clipped by the persistent step so far (check_status)
 
     def fused_ready(self) -> bool:
         return (self.fused is not None and self.fused_enabled and self.fused.kv is not None and self.fused.S == self.S
@@ -362,7 +363,18 @@ class DecodeEngine:
         call it where the host synchronises anyway (end of generate, after a timed loop, in tests)."""
         if self.fused is None:
             return
-        code = int(self._fused_ws[:4].view(torch.int32).item())
+        words = self._fused_ws[:12].view(torch.int32).tolist()  # [0] abort code, [1] step counter, [2] clipped fp16 granules
+        code, clipped = words[0], words[2]
+        if clipped:
+            # the attention-output / SwiGLU edges travel as fp16 and saturate at +-65504 (csrc/fused_step.hip hpair): the
+            # steps since the last check computed with clipped activations, i.e. NOT what the reference computes
+            self._fused_ws[8:12].zero_()
+            self.fused_clipped += clipped
+            import warnings
+
+            warnings.warn(f"fused decode step: {clipped} activation pairs exceeded the fp16 range and were clipped since the "
+                          "last check; set MI355_FUSED=0 to decode such a checkpoint on the launch-per-operator path",
+                          RuntimeWarning, stacklevel=2)
         if code != 0:
             self._fused_ws[:4].zero_()
             raise nat.NativeError(f"fused decode step aborted (code 0x{code:x}): a workgroup hand-off timed out or the "

@@ -60,6 +60,13 @@ def main():
         print(f"  {NAMES[i]:28s} min {col.min():7.2f}  med {np.median(col):7.2f}  max {col.max():7.2f}   (+{np.median(col) - prev:5.2f})")
         prev = np.median(col)
     raw = stamps.cpu().numpy()
+    if raw[:, 32].any():
+        print("ring state of streamer wave 0 at the start of a phase (quads of 4 KiB; LDS-DMA kernel only):")
+        for k3, nm, b1 in ((0, "c_attn", 20), (1, "attn.c_proj", 26), (2, "c_fc1/c_fc2", 28)):
+            o = 32 + 4 * k3
+            print(f"  {nm:12s} known landed {raw[:, o + 2].mean():.2f}  requested {raw[:, o + 3].mean():.2f}   "
+                  f"requesting took {np.median(st[:, o] - st[:, b1]):.2f} us, waiting for the first group "
+                  f"{np.median(st[:, o + 1] - st[:, o]):.2f} us")
     print("sweep iterations of gatherer 0 per hand-off (a failed sweep costs a memory round trip):")
     for i, nm in ((40, "x edge into c_attn"), (41, "q / k / v head exchange"), (42, "attention out edge"),
                   (43, "x edge into fc"), (44, "hidden edge (first chunk)")):
