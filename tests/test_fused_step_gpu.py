@@ -265,3 +265,115 @@ def test_engine_releases_the_reference_layout_copy_and_rebuilds_it_on_demand(dev
     lg = model(x, 16, torch.arange(0, 8, device=dev))
     model.use_engine = True
     assert torch.isfinite(lg).all()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("pos", [1100, 2040])
+def test_fused_step_long_context_against_oracle(dev, pos):
+    """The persistent step at positions far beyond one 256-row cache block — 1100 (five blocks) and 2040 (the last rows of
+    block_size 2048) — against the ORACLE, not against another HIP kernel: one 7B-width layer, the prompt
+    through the wide path (GEMM + flash attention fill the cache), then ONE decode step whose logits must equal row `pos`
+    of the oracle's no-cache forward over tokens[0 .. pos] (causal attention: the same quantity, model.py:97-106)."""
+    model, sd, cfg = build(1, dev, seed=2)
+    eng = need_fused(model)
+    toks = synth.make_prompt(pos + 1, seed=9)
+    om = oracle.Model(oracle.Config(n_layer=1, **W7B), {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()},
+                      mode="gptq.int4")
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    ref = om(toks.view(1, -1).long())[0, -1].float()
+    S = cfg.block_size
+    model.reset_cache()
+    ip = torch.arange(0, pos, device=dev)
+    ip._mi355_pos0 = 0
+    model(toks[:pos].to(dev).view(1, -1), S, ip)          # prompt: fills cache rows 0 .. pos - 1
+    ip = torch.tensor([pos], device=dev)
+    ip._mi355_pos0 = pos
+    assert eng.fused_ready()
+    got = model(toks[pos:].to(dev).view(1, -1), S, ip)[0, -1].float().cpu()  # the fused step at position `pos`
+    eng.check_status()
+    std = float(ref.std())
+    err = (got - ref).abs().max().item()
+    assert err <= 0.05 * std, f"fused step at position {pos}: logits off by {err:.4f} ({err / std:.4f} std)"
+    top2 = torch.topk(ref, 2).values
+    if float(top2[0] - top2[1]) > 0.1 * std:
+        assert int(got.argmax()) == int(ref.argmax())
+    # the launch-per-operator step on the same cache agrees as well
+    eng.fused_enabled = False
+    try:
+        got2 = model(toks[pos:].to(dev).view(1, -1), S, ip)[0, -1].float().cpu()
+    finally:
+        eng.fused_enabled = True
+    assert (got2 - ref).abs().max().item() <= 0.05 * std
+
+
+@torch.no_grad()
+def test_fused_step_counts_clipped_fp16_granules(dev):
+    """The attention-output / SwiGLU edges of the persistent step travel as fp16 and saturate at +-65504
+    (csrc/fused_step_ring.hip hpair).  A checkpoint whose value projection is 3e5 times too large must not decode silently
+    with clipped activations: the clips are counted next to the abort word and check_status() reports them."""
+    cfg = LLaMAConfig(n_layer=1, **W7B)
+    sd = synth.make_state_dict(cfg, seed=0, mode="gptq.int4")
+    C_ = cfg.n_embd
+    sd["transformer.h.0.attn.c_attn.scales"][2 * C_:] *= 3.0e5  # the V rows of [Q; K; V] (model.py:197)
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
+        model = LLaMA(cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    eng = need_fused(model)
+    prompt = synth.make_prompt(6).to(dev)
+    lit_llama_amd.generate(model, prompt, 1, top_k=1, max_seq_length=16)  # prompt on the launch path, no fused step yet
+    eng.check_status()
+    assert eng.fused_clipped == 0
+    with pytest.warns(RuntimeWarning, match="clipped"):
+        lit_llama_amd.generate(model, prompt, 3, top_k=1, max_seq_length=16)
+        eng.check_status()
+    assert eng.fused_clipped > 0
+    # the same weights scaled back decode without a clip
+    sd["transformer.h.0.attn.c_attn.scales"][2 * C_:] /= 3.0e5
+    model.load_state_dict(sd)
+    eng = need_fused(model)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        lit_llama_amd.generate(model, prompt, 3, top_k=1, max_seq_length=16)
+        eng.check_status()
+    assert eng.fused_clipped == 0
+
+
+def test_lds_dma_implementation_matches_the_default_kernel(dev):
+    """csrc/fused_step.hip (MI355_FUSED_IMPL=lds: weights through LDS-DMA rings) computes the same arithmetic as the default
+    register-ring kernel up to the order of a few partial sums: same greedy tokens, logits equal to rounding.  The
+    implementation is chosen once per process, so each runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "import lit_llama_amd\n"
+        "from lit_llama_amd import synth\n"
+        "from lit_llama_amd.model import LLaMA, LLaMAConfig\n"
+        "from lit_llama_amd.utils import EmptyInitOnDevice\n"
+        "dev = torch.device('cuda:0'); cfg = LLaMAConfig(n_layer=2, n_head=32, n_embd=4096)\n"
+        "sd = synth.make_state_dict(cfg, seed=0, mode='gptq.int4')\n"
+        "with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode='gptq.int4'):\n"
+        "    model = LLaMA(cfg)\n"
+        "model.load_state_dict(sd); model.eval(); eng = model.engine()\n"
+        "assert eng is not None and eng.fused is not None\n"
+        "out = lit_llama_amd.generate(model, synth.make_prompt(20).to(dev), 24, top_k=1, max_seq_length=64)\n"
+        "eng.check_status()\n"
+        "print('TOKENS', out.cpu().tolist()); print('PROBES', ' '.join(f'{float(v):.6f}' for v in eng.logits[0][7::500].float().cpu()))\n"
+    ) % str(root)
+    outs = {}
+    for impl in ("ring", "lds"):
+        env = dict(os.environ, MI355_FUSED_IMPL=impl)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[impl] = [ln for ln in r.stdout.splitlines() if ln.startswith(("TOKENS", "PROBES"))]
+    assert outs["ring"][0] == outs["lds"][0], f"greedy tokens differ:\n{outs['ring'][0]}\n{outs['lds'][0]}"
+    a = np.array([float(x) for x in outs["ring"][1].split()[1:]])
+    b = np.array([float(x) for x in outs["lds"][1].split()[1:]])
+    assert a.size == 64 and np.abs(a - b).max() <= 0.01 * max(1.0, float(a.std())), np.abs(a - b).max()

@@ -5,10 +5,20 @@ top_k = 1, then teacher-forced logits; oracle/gen_golden.py --big, which also pi
 max |dlogit| = 0).  Here the same checkpoint goes through the engine: prefill on the launch path, decode steps on
 the fused persistent step.
 
-Bar (bf16 operands, bf16 KV cache, f32 residual stream vs the reference's f32 CPU arithmetic): teacher-forced logits
-within 0.03 logit-std on the probe columns; argmax equal wherever the reference's top-2 margin exceeds twice that;
-free-running greedy tokens equal up to the first step inside that margin.
-Rebuilding the 3.6 GB checkpoint from its seed takes a minute or two of host time.
+A second fixture of the same checkpoint, cfg2_7b_int4_long.npz (--big-long), has a 128-token prompt (the wide path of the
+engine at full depth: GEMM + flash attention) and 16 decode steps starting at position 128.
+
+The bar is CALIBRATED on the reference itself: tests/golden/cfg2_7b_int4*_bf16ref.npz (oracle/gen_golden.py --big-bf16)
+hold the reference's OWN bf16 run (parameters, scales and activations in bf16, what `--precision bf16-true` makes of
+generate.py:123-134) on the same tokens: it sits 0.052-0.086 logit-std (short fixture) and 0.071-0.122 (long) from the
+reference's f32 run.  The only tolerance the reference states for "bf16 run vs f32 run" is atol 5e-3 + rtol 1e-3
+(tests/test_model.py:133, one block of a model with its init scale); at full depth its own bf16 path is 0.05-0.12 std
+away, so that number cannot be the bar for 32 layers.  Bar here (bf16 operands, bf16 KV cache, f32 residual stream vs the
+reference's f32 CPU arithmetic): teacher-forced logits on the probe columns within HALF the reference's own bf16 distance
+(measured: 0.0235 std on the short fixture, i.e. 27 % of it) and within 0.03 std on the short fixture as a regression
+bar; argmax equal wherever the reference's top-2 margin exceeds twice the tolerance; free-running greedy tokens equal up
+to the first step inside that margin.
+Rebuilding the 3.6 GB checkpoint from its seed takes a minute or two of host time (once for both fixtures).
 """
 import numpy as np
 import pytest
@@ -26,10 +36,10 @@ PROBES = (np.arange(64) * (32000 // 64) + 7) % 32000
 
 @torch.no_grad()
 def test_full_depth_7b_int4_against_the_reference_golden_run(dev, golden):
-    g = golden("cfg2_7b_int4")
+    g0 = golden("cfg2_7b_int4")
     cfg = LLaMAConfig.from_name("7B")
     torch.set_num_threads(max(torch.get_num_threads(), 16))
-    sd = synth.make_state_dict(cfg, seed=int(g["seed"]), mode="gptq.int4")
+    sd = synth.make_state_dict(cfg, seed=int(g0["seed"]), mode="gptq.int4")
     with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
         model = LLaMA(cfg)
     model.load_state_dict(sd)
@@ -37,35 +47,44 @@ def test_full_depth_7b_int4_against_the_reference_golden_run(dev, golden):
     model.eval()
     eng = model.engine()
     assert eng is not None, model._engine_failed
-    T, S = int(g["prompt_len"]), int(g["max_seq_length"])
-    toks = torch.from_numpy(g["tokens"]).to(dev)
-    std = float(g["std"].mean())
-    tol = 0.03 * std  # tighter than the 0.05 of the small fixtures (measured at full depth: 0.023 std)
-    for fused in ([True, False] if eng.fused is not None else [False]):
-        eng.fused_enabled = fused
-        # teacher-forced on the reference's tokens
-        model.reset_cache()
-        rows = []
-        input_pos = torch.arange(0, T, device=dev)
-        pos0 = 0
-        for _ in range(toks.numel() - T):
-            x = toks.index_select(0, input_pos).view(1, -1)
-            input_pos._mi355_pos0 = pos0
-            rows.append(model(x, S, input_pos)[0, -1].float().cpu())
-            pos0 += input_pos.numel()
-            input_pos = input_pos[-1:] + 1
-        logits = torch.stack(rows)
-        eng.check_status()
-        err = np.abs(logits[:, PROBES].numpy() - g["probes"]).max()
-        assert err <= tol, f"fused={fused}: 7B logits off by {err:.4f} (std {std:.3f}, tol {tol:.4f})"
-        assert np.abs(logits.std(-1).numpy() - g["std"]).max() <= 0.02 * std
-        decisive = g["margin"] > 2 * tol
-        assert np.array_equal(logits.argmax(-1).numpy()[decisive], g["argmax"][decisive])
-        # free running (generate.py:63-91): equal up to the first near tie
-        model.reset_cache()
-        out = lit_llama_amd.generate(model, toks[:T], toks.numel() - T, top_k=1).cpu()
-        first_tie = next((i for i, m_ in enumerate(g["margin"]) if m_ <= 2 * tol), len(g["margin"]))
-        n = T + first_tie
-        assert torch.equal(out[:n], torch.from_numpy(g["tokens"])[:n]), f"fused={fused}: {out.tolist()} vs {g['tokens'].tolist()}"
-        print(f"fused={fused}: max |dlogit| {err:.4f} = {err / std:.4f} std; margins {g['margin'].tolist()}")
+    for name, regression_bar in (("cfg2_7b_int4", 0.03), ("cfg2_7b_int4_long", None)):
+        g, ref_bf16 = golden(name), golden(name + "_bf16ref")
+        assert int(g["seed"]) == int(g0["seed"])
+        T, S = int(g["prompt_len"]), int(g["max_seq_length"])
+        toks = torch.from_numpy(g["tokens"]).to(dev)
+        std = float(g["std"].mean())
+        ref_dist = float(ref_bf16["max_dist_std"])  # the reference's own bf16 run vs its f32 run, in logit std
+        assert 0.02 < ref_dist < 0.5
+        tol = 0.5 * ref_dist * std
+        if regression_bar is not None:
+            tol = min(tol, regression_bar * std)
+        for fused in ([True, False] if eng.fused is not None else [False]):
+            eng.fused_enabled = fused
+            # teacher-forced on the reference's tokens
+            model.reset_cache()
+            rows = []
+            input_pos = torch.arange(0, T, device=dev)
+            pos0 = 0
+            for _ in range(toks.numel() - T):
+                x = toks.index_select(0, input_pos).view(1, -1)
+                input_pos._mi355_pos0 = pos0
+                rows.append(model(x, S, input_pos)[0, -1].float().cpu())
+                pos0 += input_pos.numel()
+                input_pos = input_pos[-1:] + 1
+            logits = torch.stack(rows)
+            eng.check_status()
+            assert getattr(eng, "fused_clipped", 0) == 0
+            err = np.abs(logits[:, PROBES].numpy() - g["probes"]).max()
+            assert err <= tol, f"{name} fused={fused}: 7B logits off by {err:.4f} (std {std:.3f}, tol {tol:.4f})"
+            assert np.abs(logits.std(-1).numpy() - g["std"]).max() <= 0.02 * std
+            decisive = g["margin"] > 2 * tol
+            assert np.array_equal(logits.argmax(-1).numpy()[decisive], g["argmax"][decisive])
+            # free running (generate.py:63-91): equal up to the first near tie
+            model.reset_cache()
+            out = lit_llama_amd.generate(model, toks[:T], toks.numel() - T, top_k=1).cpu()
+            first_tie = next((i for i, m_ in enumerate(g["margin"]) if m_ <= 2 * tol), len(g["margin"]))
+            n = T + first_tie
+            assert torch.equal(out[:n], torch.from_numpy(g["tokens"])[:n]), f"{name} fused={fused}: {out.tolist()} vs {g['tokens'].tolist()}"
+            print(f"{name} fused={fused}: max |dlogit| {err:.4f} = {err / std:.4f} std (reference bf16 vs f32: {ref_dist:.4f} std); "
+                  f"min margin {g['margin'].min():.3f}")
     eng.fused_enabled = True
