@@ -1283,7 +1283,7 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     MI355_CHECK_ARG(a->w && a->w_head && a->sz && a->sz_head && a->norms && a->wte && a->rope && a->kv && a->tokens &&
                         a->pos && a->logits && a->workspace,
                     MI355_E_ARG, "fused_step: null pointer");
-    MI355_CHECK_ARG(a->n_layer >= 1 && a->n_layer * 5 + 8 < 1024, MI355_E_SHAPE, "fused_step: n_layer %d", a->n_layer);
+    MI355_CHECK_ARG(a->n_layer >= 1 && a->n_layer * 6 + 8 < 1024, MI355_E_SHAPE, "fused_step: n_layer %d", a->n_layer);
     MI355_CHECK_ARG(!(a->mode & 1) || a->next_token != nullptr, MI355_E_ARG, "fused_step: arg-max without next_token");
     MI355_CHECK_ARG(a->mode >= 0 && a->mode <= 3 && a->mode != 2, MI355_E_ARG, "fused_step: mode must be 0, 1 or 3");
     MI355_CHECK_ARG(((uintptr_t)a->w | (uintptr_t)a->w_head | (uintptr_t)a->workspace | a->layer_stride | a->off_attn |
@@ -1330,6 +1330,7 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     p.ga = (u64*)(ws + kFsWsGa);
     p.gq = (u64*)(ws + kFsWsGq);
     p.gm = (u64*)(ws + kFsWsGm);
+    p.gp = (u64*)(ws + kFsWsGp);
     p.gh = (u64*)(ws + kFsWsGh);
     p.dbg = (u64*)a->debug_stamps;
     p.dbg_layer = a->reserved0;  // with debug_stamps: the layer whose phases are stamped

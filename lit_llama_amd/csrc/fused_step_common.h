@@ -26,6 +26,7 @@ struct FusedParams {
     u64* gh;                 // [2][H / 2]        MLP hidden
     u64* gq;                 // [2][n_head][8][32] q / new k / new v of a head
     u64* gm;                 // [512]             arg-max candidates
+    u64* gp;                 // [2][n_head][8][136] row-split attention: a workgroup's (128 weighted values, max, sum)
     unsigned* state;         // [0] abort code, [1] step counter
     u64* dbg;                // optional [kG][64] wall-clock stamps
     unsigned sz_layer_stride;
@@ -39,7 +40,8 @@ struct FusedParams {
 
 // workspace map (bytes), see mi355_fused_step_workspace_bytes
 constexpr size_t kFsWsState = 0, kFsWsGx = 256, kFsWsGa = kFsWsGx + 2 * 2304 * 8, kFsWsGq = kFsWsGa + 2 * 2048 * 8,
-                 kFsWsGm = kFsWsGq + 2 * 32 * 256 * 8, kFsWsGh = kFsWsGm + 512 * 8;
+                 kFsWsGm = kFsWsGq + 2 * 32 * 256 * 8, kFsWsGp = kFsWsGm + 512 * 8,
+                 kFsWsGh = kFsWsGp + 2 * 32 * 8 * 136 * 8;
 
 int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
 int fused_step_ring_occupancy_ok();  // the device admits one workgroup of the kernel per CU (queried once)

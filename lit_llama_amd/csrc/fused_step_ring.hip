@@ -62,6 +62,11 @@ constexpr int kUnitsC = kC / 128;
 constexpr int kMaxFcTiles = 3;    // c_fc1/c_fc2 pair tiles per workgroup (n_hidden <= 12288)
 constexpr int kMaxHeadTiles = 8;  // lm_head tiles per workgroup (vocab <= 32768)
 constexpr unsigned kSpinLimit = 400000u;
+#ifndef MI355_FUSED_SPLIT_POS
+#define MI355_FUSED_SPLIT_POS 384
+#endif
+constexpr int kSplitPos = MI355_FUSED_SPLIT_POS;  // from this position on the attention splits rows, not dimensions
+constexpr int kPartStride = 136;  // granules per workgroup partial of the row-split attention: 128 values, max, sum, pad
 
 // LDS map (bytes)
 constexpr int kOffMisc = 0;                       // [0] 1/rms, [4..7] operand sums, [16..23] / [24..31] per-wave softmax max / sum
@@ -202,6 +207,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
     const unsigned ebase = step_id * 1024u + 1u;
     const int n_fc = (p.fc_tiles - bid + kG - 1) / kG;       // this workgroup's pair tiles (2 or 3 for 7B)
     const int n_head_t = (p.head_tiles - bid + kG - 1) / kG;  // lm_head tiles (7 or 8)
+    const bool split = pos >= kSplitPos;  // long context: the head group splits the cache rows (attention phase)
 
     // entered outside the cache (the host takes the cache-roll regime of model.py:214-218 elsewhere) or with a token id
     // outside the embedding table: refuse before anything is written.  Uniform over the grid, so no hand-off hangs.
@@ -352,110 +358,210 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     __builtin_amdgcn_make_buffer_rsrc((void*)kc, 0, pos * (kHs * 2), 0x00020000);
                 const __amdgpu_buffer_rsrc_t rv =
                     __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, pos * (kHs * 2), 0x00020000);
-                const int n_blocks = (pos + 255) >> 8;  // blocks of 256 cached rows: 32 per wave and block
-                u32x4 kr[8], vr;
-                // rows of block 0: requested before q is known.  A wave scores the SAME 32 rows it then weighs the
-                // values of (row wave * 32 + u * 4 + lr for the scores, 16 lanes per row; row wave * 32 + rl for the
-                // values, 8 of the workgroup's 16 output dimensions per lane): no score leaves the wave, the softmax is
-                // a per-wave partial (running maximum, sum, weighted values) that gatherer 0 merges — no barrier and no
-                // LDS round trip between scores and values, and no wave re-reads the whole score vector.
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int t = wave * 32 + u * 4 + lr;
-                    kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          rk, t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u, 0, 0));
-                }
-                {
-                    const int t = wave * 32 + rl;
-                    vr = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                       rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
-                }
-                __syncthreads();  // Ba1: q / new k / new v of the head are in LDS
-                FS_SSTAMP(23);
-                float qf[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) qf[j] = qs[li * 8 + j];
-                // lane L (value row rl = L & 31) takes its row's score from the lane group that computed it
-                const int pull = ((((lane_off >> 4) & 3) << 4) | (rl >> 2)) * 4;
-                float m_run = -1.0e30f, l_run = 0.f;
-                float of[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) of[j] = 0.f;
-                for (int blk = 0; blk < n_blocks; ++blk) {
-                    u32x4 vv = vr;
-                    if (blk > 0) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int t = blk * 256 + wave * 32 + u * 4 + lr;
-                            kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                                  rk, t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u, 0, 0));
-                        }
-                        const int t = blk * 256 + wave * 32 + rl;
-                        vv = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                           rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
-                    }
-                    float sel = 0.f;
+                if (!split) {
+                    const int n_blocks = (pos + 255) >> 8;  // blocks of 256 cached rows: 32 per wave and block
+                    u32x4 kr[8], vr;
+                    // rows of block 0: requested before q is known.  A wave scores the SAME 32 rows it then weighs the
+                    // values of (row wave * 32 + u * 4 + lr for the scores, 16 lanes per row; row wave * 32 + rl for the
+                    // values, 8 of the workgroup's 16 output dimensions per lane): no score leaves the wave, the softmax is
+                    // a per-wave partial (running maximum, sum, weighted values) that gatherer 0 merges — no barrier and no
+                    // LDS round trip between scores and values, and no wave re-reads the whole score vector.
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        float dot = 0.f;
+                        const int t = wave * 32 + u * 4 + lr;
+                        kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                              rk, t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u, 0, 0));
+                    }
+                    {
+                        const int t = wave * 32 + rl;
+                        vr = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                           rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
+                    }
+                    __syncthreads();  // Ba1: q / new k / new v of the head are in LDS
+                    FS_SSTAMP(23);
+                    float qf[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) qf[j] = qs[li * 8 + j];
+                    // lane L (value row rl = L & 31) takes its row's score from the lane group that computed it
+                    const int pull = ((((lane_off >> 4) & 3) << 4) | (rl >> 2)) * 4;
+                    float m_run = -1.0e30f, l_run = 0.f;
+                    float of[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) of[j] = 0.f;
+                    for (int blk = 0; blk < n_blocks; ++blk) {
+                        u32x4 vv = vr;
+                        if (blk > 0) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int t = blk * 256 + wave * 32 + u * 4 + lr;
+                                kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                      rk, t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u, 0, 0));
+                            }
+                            const int t = blk * 256 + wave * 32 + rl;
+                            vv = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                               rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
+                        }
+                        float sel = 0.f;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            float dot = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                dot += qf[2 * i] * __uint_as_float(kr[u][i] << 16);
+                                dot += qf[2 * i + 1] * __uint_as_float(kr[u][i] & 0xffff0000u);
+                            }
+                            dot = group_sum(dot, 16);
+                            if ((li & 7) == u) sel = dot;
+                        }
+                        const int t = blk * 256 + wave * 32 + rl;
+                        float sc = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(sel))) * p.scale;
+                        sc = t < pos ? sc : -1.0e30f;
+                        float bm = fmaxf(sc, lane_xor16(sc));  // maximum over the wave's 32 rows (both halves hold them)
+                        bm = MI355_DPP_MAX(bm, 0x140);
+                        bm = MI355_DPP_MAX(bm, 0x141);
+                        bm = MI355_DPP_MAX(bm, 0x4E);
+                        bm = MI355_DPP_MAX(bm, 0xB1);
+                        float s_new = -1.0e30f;
+                        if (blk == 0 && wave == 0) {  // the new token's own score, from the LDS copy of its key
+                            float dot = qs[lane] * knew[lane] + qs[lane + 64] * knew[lane + 64];
+                            s_new = group_sum(dot, 64) * p.scale;
+                            bm = fmaxf(bm, s_new);
+                        }
+                        const float m_new = fmaxf(m_run, bm);
+                        const float corr = __expf(m_run - m_new);
+                        const float pr = t < pos ? __expf(sc - m_new) : 0.f;
+                        l_run = l_run * corr + pr;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            dot += qf[2 * i] * __uint_as_float(kr[u][i] << 16);
-                            dot += qf[2 * i + 1] * __uint_as_float(kr[u][i] & 0xffff0000u);
+                            of[2 * i] = of[2 * i] * corr + pr * __uint_as_float(vv[i] << 16);
+                            of[2 * i + 1] = of[2 * i + 1] * corr + pr * __uint_as_float(vv[i] & 0xffff0000u);
                         }
-                        dot = group_sum(dot, 16);
-                        if ((li & 7) == u) sel = dot;
+                        if (blk == 0 && wave == 0 && rl == 0) {  // the new token's value row
+                            const float pn = __expf(s_new - m_new);
+                            l_run += pn;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) of[j] += pn * vnew[hj * 16 + half * 8 + j];
+                        }
+                        m_run = m_new;
                     }
-                    const int t = blk * 256 + wave * 32 + rl;
-                    float sc = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(sel))) * p.scale;
-                    sc = t < pos ? sc : -1.0e30f;
-                    float bm = fmaxf(sc, lane_xor16(sc));  // maximum over the wave's 32 rows (both halves hold them)
-                    bm = MI355_DPP_MAX(bm, 0x140);
-                    bm = MI355_DPP_MAX(bm, 0x141);
-                    bm = MI355_DPP_MAX(bm, 0x4E);
-                    bm = MI355_DPP_MAX(bm, 0xB1);
-                    float s_new = -1.0e30f;
-                    if (blk == 0 && wave == 0) {  // the new token's own score, from the LDS copy of its key
+                    if (n_blocks == 0 && wave == 0) {  // position 0: the new token attends to itself only
                         float dot = qs[lane] * knew[lane] + qs[lane + 64] * knew[lane + 64];
-                        s_new = group_sum(dot, 64) * p.scale;
-                        bm = fmaxf(bm, s_new);
-                    }
-                    const float m_new = fmaxf(m_run, bm);
-                    const float corr = __expf(m_run - m_new);
-                    const float pr = t < pos ? __expf(sc - m_new) : 0.f;
-                    l_run = l_run * corr + pr;
+                        m_run = group_sum(dot, 64) * p.scale;
+                        if (rl == 0) {
+                            l_run = 1.f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        of[2 * i] = of[2 * i] * corr + pr * __uint_as_float(vv[i] << 16);
-                        of[2 * i + 1] = of[2 * i + 1] * corr + pr * __uint_as_float(vv[i] & 0xffff0000u);
+                            for (int j = 0; j < 8; ++j) of[j] = vnew[hj * 16 + half * 8 + j];
+                        }
                     }
-                    if (blk == 0 && wave == 0 && rl == 0) {  // the new token's value row
-                        const float pn = __expf(s_new - m_new);
-                        l_run += pn;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) of[j] += pn * vnew[hj * 16 + half * 8 + j];
-                    }
-                    m_run = m_new;
-                }
-                if (n_blocks == 0 && wave == 0) {  // position 0: the new token attends to itself only
-                    float dot = qs[lane] * knew[lane] + qs[lane + 64] * knew[lane + 64];
-                    m_run = group_sum(dot, 64) * p.scale;
+                    for (int j = 0; j < 8; ++j) of[j] = group_sum(of[j], 32);
+                    l_run = group_sum(l_run, 32);
                     if (rl == 0) {
-                        l_run = 1.f;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) of[j] = vnew[hj * 16 + half * 8 + j];
+                        for (int j = 0; j < 8; ++j) opart[wave * 16 + half * 8 + j] = of[j];
                     }
-                }
+                    if ((threadIdx.x & 63) == 0) {
+                        misc[16 + wave] = m_run;
+                        misc[24 + wave] = l_run;
+                    }
+                } else {
+                    // ---- long context: the ROWS of the cache are split across the 8 workgroups of the head (chunks of 32
+                    // rows: chunk c belongs to workgroup c % 8, wave (c / 8) % 8), every wave weighs ALL 128 dimensions of
+                    // its rows, and the head group exchanges (max, sum, 128 weighted values) partials once more (gatherer
+                    // 0 below).  With the dimension split above each of the 8 workgroups reads every K row: 8-fold
+                    // redundant K traffic and dot products, 11 us per layer at position 1950 (783 tok/s).
+                    const int n_chunks = (pos + 31) >> 5;
+                    const int c0 = wave * 8 + hj;
+                    u32x4 kr[8], vr[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) of[j] = group_sum(of[j], 32);
-                l_run = group_sum(l_run, 32);
-                if (rl == 0) {
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = c0 * 32 + u * 4 + lr;
+                        const unsigned off = t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u;
+                        kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+                        vr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
+                    }
+                    __syncthreads();  // Ba1: q / new k / new v of the head are in LDS
+                    FS_SSTAMP(23);
+                    float qf[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) opart[wave * 16 + half * 8 + j] = of[j];
-                }
-                if ((threadIdx.x & 63) == 0) {
-                    misc[16 + wave] = m_run;
-                    misc[24 + wave] = l_run;
+                    for (int j = 0; j < 8; ++j) qf[j] = qs[li * 8 + j];
+                    float m_run = -1.0e30f, l_run = 0.f;  // l_run: over THIS lane group's rows (u, lr); summed over lr below
+                    float of[8];                           // dims li * 8 .. + 7, over this lane group's rows
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) of[j] = 0.f;
+                    for (int c = c0; c < n_chunks; c += 64) {
+                        if (c != c0) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int t = c * 32 + u * 4 + lr;
+                                const unsigned off = t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u;
+                                kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+                                vr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
+                            }
+                        }
+                        float sc[8];
+                        float bm = -1.0e30f;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            float dot = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                dot += qf[2 * i] * __uint_as_float(kr[u][i] << 16);
+                                dot += qf[2 * i + 1] * __uint_as_float(kr[u][i] & 0xffff0000u);
+                            }
+                            dot = group_sum(dot, 16) * p.scale;  // every lane of the row's 16 holds the score
+                            sc[u] = c * 32 + u * 4 + lr < pos ? dot : -1.0e30f;
+                            bm = fmaxf(bm, sc[u]);
+                        }
+                        bm = fmaxf(bm, lane_xor16(bm));  // over the 4 row groups lr: the maximum of the wave's 32 rows
+                        bm = fmaxf(bm, lane_xor32(bm));
+                        float s_new = -1.0e30f;
+                        const bool own = c == 0 && wave == 0 && hj == 0;  // the new token's own row rides with chunk 0
+                        if (own) {
+                            float dot = qs[lane] * knew[lane] + qs[lane + 64] * knew[lane + 64];
+                            s_new = group_sum(dot, 64) * p.scale;
+                            bm = fmaxf(bm, s_new);
+                        }
+                        const float m_new = fmaxf(m_run, bm);
+                        const float corr = __expf(m_run - m_new);
+                        l_run *= corr;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) of[j] *= corr;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const float pr = c * 32 + u * 4 + lr < pos ? __expf(sc[u] - m_new) : 0.f;
+                            l_run += pr;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                of[2 * i] += pr * __uint_as_float(vr[u][i] << 16);
+                                of[2 * i + 1] += pr * __uint_as_float(vr[u][i] & 0xffff0000u);
+                            }
+                        }
+                        if (own && lr == 0) {  // (one of the four row groups: they are summed below)
+                            const float pn = __expf(s_new - m_new);
+                            l_run += pn;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) of[j] += pn * vnew[li * 8 + j];
+                        }
+                        m_run = m_new;
+                    }
+                    // sum over the four row groups (lanes that differ in lr hold different rows of the same dimensions)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        of[j] += lane_xor16(of[j]);
+                        of[j] += lane_xor32(of[j]);
+                    }
+                    l_run += lane_xor16(l_run);
+                    l_run += lane_xor32(l_run);
+                    float* op2 = (float*)part;  // [8 waves][128] f32: the partial-tile buffer is idle during the attention
+                    if (lr == 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) op2[wave * 128 + li * 8 + j] = of[j];
+                    }
+                    if ((threadIdx.x & 63) == 0) {
+                        misc[16 + wave] = m_run;
+                        misc[24 + wave] = l_run;
+                    }
                 }
                 FS_SSTAMP(25);
                 __syncthreads();  // Ba3: partial outputs of the 8 waves
@@ -488,7 +594,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         // =========================================================================================== gatherers
         const int gw = wave - kSW;  // 0: combines / publishes, 1: helps with the sweeps
         unsigned edge = 0;   // edges published so far in this step (the epoch of the next one is ebase + edge)
-        int xpar = 0, apar = 0, hpar = 0, qpar = 0;
+        int xpar = 0, apar = 0, hpar = 0, qpar = 0, ppar = 0;
         int buf = 0;
         const __amdgpu_buffer_rsrc_t rs_gx = __builtin_amdgcn_make_buffer_rsrc((void*)p.gx, 0, 2 * 2304 * 8, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_ga = __builtin_amdgcn_make_buffer_rsrc((void*)p.ga, 0, 2 * 2048 * 8, 0x00020000);
@@ -496,6 +602,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         const __amdgpu_buffer_rsrc_t rs_gq =
             __builtin_amdgcn_make_buffer_rsrc((void*)p.gq, 0, 2 * kHeads * 256 * 8, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_gm = __builtin_amdgcn_make_buffer_rsrc((void*)p.gm, 0, 512 * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_gp =
+            __builtin_amdgcn_make_buffer_rsrc((void*)p.gp, 0, 2 * kHeads * kGs * kPartStride * 8, 0x00020000);
 
         // ---- epilogue mapping of gatherer 0: lane = (pair pg = lane >> 3, streamer wave w8 = lane & 7).  A lane reads
         // rows 2 pg, 2 pg + 1 of ONE wave's partial tile (8 B), the 8 lanes of a pair are summed with DPP (fixed
@@ -739,7 +847,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 __syncthreads();  // Ba1
                 __syncthreads();  // Ba3
                 FS_GSTAMP(5);
-                if (gw == 0) {
+                if (gw == 0 && !split) {
                     // merge the 8 per-wave softmax partials (running maximum, sum, weighted values)
                     float2 o = *(const float2*)(opart + w8 * 16 + 2 * pg);
                     const float mw = misc[16 + w8];
@@ -753,6 +861,64 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     // attention output elements head * 128 + hj * 16 + 2 pg, + 1 -> one pair granule
                     if (w8 == 0)
                         gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair(o.x * inv, o.y * inv));
+                }
+                if (split) {
+                    // row-split attention: this workgroup's partial over ITS rows (all 128 dimensions) goes to the head
+                    // group, every workgroup then merges the 8 partials for its own 16 output dimensions
+                    const unsigned ep1 = ebase + edge;
+                    if (gw == 0) {
+                        const float* op2 = (const float*)part;
+                        float mall = misc[16];
+#pragma unroll
+                        for (int w = 1; w < kSW; ++w) mall = fmaxf(mall, misc[16 + w]);
+                        float2 o = {0.f, 0.f};
+                        float lsum = 0.f;
+#pragma unroll
+                        for (int w = 0; w < kSW; ++w) {
+                            const float wsc = __expf(misc[16 + w] - mall);
+                            const float2 t = *(const float2*)(op2 + w * 128 + 2 * lane_v);
+                            o.x += wsc * t.x;
+                            o.y += wsc * t.y;
+                            lsum += wsc * misc[24 + w];
+                        }
+                        u64* dstp = p.gp + (((size_t)ppar * kHeads + head) * kGs + hj) * kPartStride;
+                        gr_store(dstp + 2 * lane_v, ep1, __float_as_uint(o.x));
+                        gr_store(dstp + 2 * lane_v + 1, ep1, __float_as_uint(o.y));
+                        if (lane_v == 0) {
+                            gr_store(dstp + 128, ep1, __float_as_uint(mall));
+                            gr_store(dstp + 129, ep1, __float_as_uint(lsum));
+                        }
+                    }
+                    ++edge;
+                    if (gw == 0) {
+                        // lane = (pair pg of this workgroup's 16 output dimensions, partial w8 of the head group)
+                        const unsigned hbase = (unsigned)(((ppar * kHeads + head) * kGs) * kPartStride) * 8u;
+                        const unsigned off1 = hbase + (unsigned)(w8 * kPartStride + hj * 16 + 2 * pg) * 8u;
+                        const unsigned off2 = hbase + (unsigned)(w8 * kPartStride + 128) * 8u;
+                        u32x4 v1, v2;
+                        for (unsigned spins = 0;; ++spins) {
+                            v1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gp, off1, 0, 16));
+                            v2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gp, off2, 0, 16));
+                            const bool ok = v1[1] == ep1 && v1[3] == ep1 && v2[1] == ep1 && v2[3] == ep1;
+                            if (__all(ok)) break;
+                            if (spins > kSpinLimit || aborted(p)) {
+                                if (lane == 0) raise_abort(p, 0x380u + edge);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        const float mj = __uint_as_float(v2[0]), lj = __uint_as_float(v2[2]);
+                        float mall = MI355_DPP_MAX(mj, 0xB1);
+                        mall = MI355_DPP_MAX(mall, 0x4E);
+                        mall = MI355_DPP_MAX(mall, 0x141);
+                        const float wsc = __expf(mj - mall);
+                        const float ox = group_sum(__uint_as_float(v1[0]) * wsc, 8);
+                        const float oy = group_sum(__uint_as_float(v1[2]) * wsc, 8);
+                        const float inv = 1.0f / group_sum(lj * wsc, 8);
+                        if (w8 == 0)
+                            gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair(ox * inv, oy * inv));
+                    }
+                    ppar ^= 1;
                 }
                 FS_GSTAMP(6);
                 __syncthreads();  // Ba4
