@@ -40,6 +40,13 @@ for st in $STAGES; do
       ls $OUT/pmc | head; [ -n "$f" ] && head -3 "$f"
       [ -n "$f" ] && python scripts/pmc_summary.py "$f" --json $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt
       find $OUT/pmc -name '*.csv' -size +20M -delete ;;
+    mfma)
+      rm -rf $OUT/mfma
+      timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -o mfma -- python scripts/prefill_run.py 2048 > $OUT/mfma_run.txt 2> $OUT/mfma.err
+      echo "mfma pmc exit $?" | tee -a $OUT/session.log
+      f=$(find $OUT/mfma -name '*counter_collection.csv' | head -1)
+      [ -n "$f" ] && python scripts/mfma_summary.py "$f" > $OUT/mfma_summary.txt 2>&1; cat $OUT/mfma_summary.txt; tail -3 $OUT/mfma_run.txt
+      find $OUT/mfma -name '*.csv' -size +20M -delete ;;
     sweep)
       timeout 1200 python scripts/sweep_gemv.py --out $OUT/sweep_best.json > $OUT/sweep.log 2>&1
       echo "sweep exit $?" | tee -a $OUT/session.log; grep BEST $OUT/sweep.log ;;

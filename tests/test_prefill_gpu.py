@@ -104,3 +104,28 @@ def _pos(T, dev):
     p = torch.arange(T, device=dev)
     p._mi355_pos0 = 0
     return p
+
+
+@torch.no_grad()
+def test_evaluate_style_nll_at_block_size_matches_oracle(dev):
+    """The reference's own quality check for a quantised model, at its own length (evaluate/full.py:120-129): a NO-CACHE
+    forward over block_size = 2048 tokens, then the mean next-token negative log-likelihood.  One 7B-width layer: the
+    2048-row GEMMs and the flash kernel over 2048 x 2048 (the shapes bench.py's prefill line times) against the oracle —
+    logits at every position, and the NLL itself."""
+    model, om, cfg = build(dev, seed=4)
+    T = cfg.block_size
+    assert T == 2048
+    toks = synth.make_prompt(T, seed=31)
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    got = model(toks.view(1, -1).long().to(dev))[0].float().cpu()
+    ref = om(toks.view(1, -1).long())[0].float()
+    e = check(got, ref, "no-cache forward at T = 2048")
+    tgt = toks[1:].long()
+    nll_got = torch.nn.functional.cross_entropy(got[:-1], tgt).item()
+    nll_ref = torch.nn.functional.cross_entropy(ref[:-1], tgt).item()
+    assert abs(nll_got - nll_ref) <= 2e-3 * max(1.0, abs(nll_ref)), (nll_got, nll_ref)
+    # per-token NLL: no position is off by more than the logit bar allows (a wrong row would hide in the mean)
+    d = (torch.nn.functional.cross_entropy(got[:-1], tgt, reduction="none") -
+         torch.nn.functional.cross_entropy(ref[:-1], tgt, reduction="none")).abs().max().item()
+    assert d <= 0.1 * float(ref.std(-1).mean()), d
+    print(f"T = 2048 no-cache: max |dlogit| {e:.4f} std; NLL {nll_got:.5f} vs oracle {nll_ref:.5f}; max per-token |dNLL| {d:.4f}")
