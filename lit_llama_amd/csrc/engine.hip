@@ -83,8 +83,8 @@ int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x
                const float* attn_partials = nullptr) {
     // wide inputs (prompt chunks of >= 32 tokens) of an int4 model: the LDS-tiled MFMA GEMM over the same stream
     // (grouped scales: the streaming kernel only, in sub-chunks of rows)
-    if (w.fmt == MI355_W_Q4 && M >= 32 && m->gemm_ws != nullptr && attn_partials == nullptr && w.N % 4 == 0 && ldy % 4 == 0 &&
-        w.group_cols == 0) {
+    if (((w.fmt == MI355_W_Q4 && w.group_cols == 0) || w.fmt == MI355_W_BF16) && M >= 32 && m->gemm_ws != nullptr &&
+        attn_partials == nullptr && w.N % 4 == 0 && ldy % 4 == 0) {
         mi355_linear_args a;
         memset(&a, 0, sizeof(a));
         a.fmt = w.fmt;

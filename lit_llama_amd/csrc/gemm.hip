@@ -1,4 +1,4 @@
-// Wide (M >= 32 tokens) int4-weight linear for gfx950: prompt prefill and no-cache evaluation.
+// Wide (M >= 32 tokens) linear over the int4 or the bf16 weight stream for gfx950: prompt prefill and no-cache evaluation.
 //
 // Replaces the reference's Triton `linear_kernel_4bit_weight` (/root/reference lit_llama/quantization.py:187-333,
 // reached from ColBlockQuantizedLinear.forward :413-421) at the shapes of evaluate/full.py:120-129 (T = 2048, no cache)
@@ -95,8 +95,12 @@ __global__ __launch_bounds__(256) void stage_rows_kernel(const void* x, int x_dt
     }
 }
 
-template <int EPI, bool PAIR>
+// FMT = MI355_W_Q4: int4 stream, one 1-KiB piece per (tile, unit), converted below; MI355_W_BF16: unquantised weights
+// (BASELINE configs[1]), four 1-KiB pieces per (tile, unit) whose piece d IS the A fragment of k-quarter d — same k
+// order as the int4 conversion produces, no conversion, scale 1 / zero-point 0 in the epilogue
+template <int EPI, bool PAIR, int FMT>
 __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
+    constexpr int kWP = FMT == MI355_W_BF16 ? 4 : 1;  // pieces per (tile, unit)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -127,12 +131,14 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
     const unsigned xbytes = (unsigned)((int64_t)p.M * p.ldxb * 2);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.xb, 0, (int)xbytes, 0x00020000);
     const unsigned lane_off = lane * 16;
-    auto wload = [&](int t, int u) {
+    auto wload = [&](int t, int u, u32x4 (&dst)[kWP]) {
         // past the last unit / tile the load goes through a zero-sized descriptor: the scalar offset operand of a raw
         // buffer load is NOT range-checked (an unconditional prefetch of unit `units` of the last tile faulted)
         const bool ok = tile[t] < p.n_tiles && u < p.units;
-        const unsigned off = (unsigned)((tile[t] * p.units + u) * (PAIR ? 2 : 1) + rr[t]) * 1024u;
-        return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rw : rw0, lane_off, ok ? off : 0u, 0));
+        const unsigned off = (unsigned)((tile[t] * p.units + u) * (PAIR ? 2 : 1) + rr[t]) * (1024u * kWP);
+#pragma unroll
+        for (int d = 0; d < kWP; ++d)
+            dst[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rw : rw0, lane_off, ok ? off + d * 1024u : 0u, 0));
     };
     // activation block of unit u: 2048 chunks of 16 B, kXChunks per thread; chunk = (token, 16-B column)
     u32x4 stage[kXChunks];
@@ -161,9 +167,9 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
 #pragma unroll
         for (int tt = 0; tt < 8; ++tt) acc[t][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 wcur[kTPW], wnext[kTPW];
+    u32x4 wcur[kTPW][kWP], wnext[kTPW][kWP];
 #pragma unroll
-    for (int t = 0; t < kTPW; ++t) wcur[t] = wload(t, 0);
+    for (int t = 0; t < kTPW; ++t) wload(t, 0, wcur[t]);
     xload(0);
     xstore(0);
     __syncthreads();
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
         // tile or out of the descriptors (zeros) and the values are never used
         xload(u + 1);
 #pragma unroll
-        for (int t = 0; t < kTPW; ++t) wnext[t] = wload(t, u + 1);
+        for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
         const char* xs = smem + buf * (kBM * 256);
         // (explicitly software-pipelined B-fragment reads — 16 fragments in registers, pinned with sched_barrier —
         // measured SLOWER, 600-670 vs 760-800 TFLOP/s: with 4 waves per SIMD the hardware hides the LDS latency itself)
@@ -185,13 +191,17 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
             bf16x8 a[kTPW];
 #pragma unroll
             for (int t = 0; t < kTPW; ++t) {
-                const uint32_t v = wcur[t][d];
-                u32x4 f;
-                f[0] = (v & 0x000F000Fu) | 0x43004300u;
-                f[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
-                f[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
-                f[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
-                a[t] = __builtin_bit_cast(bf16x8, f);
+                if constexpr (FMT == MI355_W_BF16) {
+                    a[t] = __builtin_bit_cast(bf16x8, wcur[t][d]);
+                } else {
+                    const uint32_t v = wcur[t][0][d];
+                    u32x4 f;
+                    f[0] = (v & 0x000F000Fu) | 0x43004300u;
+                    f[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
+                    f[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
+                    f[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+                    a[t] = __builtin_bit_cast(bf16x8, f);
+                }
             }
 #pragma unroll
             for (int tt = 0; tt < 8; ++tt) {
@@ -203,7 +213,9 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
         }
         xstore(buf ^ 1);
 #pragma unroll
-        for (int t = 0; t < kTPW; ++t) wcur[t] = wnext[t];
+        for (int t = 0; t < kTPW; ++t)
+#pragma unroll
+            for (int d = 0; d < kWP; ++d) wcur[t][d] = wnext[t][d];
         __syncthreads();
     }
 
@@ -217,8 +229,13 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
             const bool ok = n < p.N;
             const void* sp = (PAIR && rr[t] == 1) ? p.scales2 : p.scales;
             const void* zq = (PAIR && rr[t] == 1) ? p.zeros2 : p.zeros;
-            sc[t][r] = ok ? ldsz(sp, n, p.sz_dtype) : 0.f;
-            zp[t][r] = ok ? 128.f + ldsz(zq, n, p.sz_dtype) : 0.f;
+            if constexpr (FMT == MI355_W_BF16) {
+                sc[t][r] = ok ? 1.f : 0.f;
+                zp[t][r] = 0.f;
+            } else {
+                sc[t][r] = ok ? ldsz(sp, n, p.sz_dtype) : 0.f;
+                zp[t][r] = ok ? 128.f + ldsz(zq, n, p.sz_dtype) : 0.f;
+            }
         }
 #pragma unroll
     for (int tt = 0; tt < 8; ++tt) {
@@ -271,9 +288,9 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
     }
 }
 
-template <int EPI, bool PAIR>
+template <int EPI, bool PAIR, int FMT>
 int launch_gemm(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row tiles (pair tiles for the SwiGLU stream)
-    static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR>,
+    static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR, FMT>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute(gemm) failed: %s", hipGetErrorString(attr_err));
@@ -284,9 +301,15 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row tile
     q.n_blocks = (p.n_tiles + per_block - 1) / per_block;
     q.total_blocks = q.n_blocks * ((p.M + kBM - 1) / kBM);
     q.per_xcd = (q.total_blocks + 7) / 8;
-    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR>), dim3(8 * q.per_xcd), dim3(kThreads), kLds, s, q);
+    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR, FMT>), dim3(8 * q.per_xcd), dim3(kThreads), kLds, s, q);
     MI355_LAUNCH_CHECK();
     return 0;
+}
+template <int FMT>
+int launch_gemm_epi(const GemmParams& p, int epi, hipStream_t s) {
+    if (epi == MI355_EPI_SWIGLU) return launch_gemm<MI355_EPI_SWIGLU, true, FMT>(p, s);
+    if (epi == MI355_EPI_ACCUM) return launch_gemm<MI355_EPI_ACCUM, false, FMT>(p, s);
+    return launch_gemm<MI355_EPI_STORE, false, FMT>(p, s);
 }
 
 }  // namespace
@@ -300,17 +323,21 @@ extern "C" size_t mi355_linear_gemm_workspace_bytes(int M, int K) {
 extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, size_t workspace_bytes,
                                  mi355_stream_t stream) {
     MI355_CHECK_ARG(a != nullptr && workspace != nullptr, MI355_E_ARG, "linear_gemm: null argument");
-    MI355_CHECK_ARG(a->fmt == MI355_W_Q4, MI355_E_ARG, "linear_gemm: the wide path handles the Q4 stream only (fmt %d)", a->fmt);
-    MI355_CHECK_ARG(a->w && a->x && a->y && a->scales && a->zeros, MI355_E_ARG, "linear_gemm: null w/x/y/scales/zeros");
+    MI355_CHECK_ARG(a->fmt == MI355_W_Q4 || a->fmt == MI355_W_BF16, MI355_E_ARG,
+                    "linear_gemm: the wide path handles the Q4 and BF16 streams (fmt %d)", a->fmt);
+    const bool q4 = a->fmt == MI355_W_Q4;
+    MI355_CHECK_ARG(a->w && a->x && a->y && (!q4 || (a->scales && a->zeros)), MI355_E_ARG, "linear_gemm: null w/x/y/scales/zeros");
+    MI355_CHECK_ARG(!q4 || a->group_cols == 0 || a->group_cols >= a->K, MI355_E_ARG,
+                    "linear_gemm: grouped scales take the streaming kernel (mi355_linear_fast)");
     MI355_CHECK_ARG(a->M >= 1 && a->N > 0 && a->K > 0, MI355_E_SHAPE, "linear_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     MI355_CHECK_ARG(a->attn_partials == nullptr && a->bias == nullptr, MI355_E_ARG, "linear_gemm: no bias / attention prologue");
     const bool swiglu = a->epi == MI355_EPI_SWIGLU;
     MI355_CHECK_ARG(a->epi >= MI355_EPI_STORE && a->epi <= MI355_EPI_SWIGLU, MI355_E_ARG, "linear_gemm: bad epi");
-    MI355_CHECK_ARG(swiglu ? (a->R == 2 && a->scales2 && a->zeros2 && a->y_dtype == MI355_BF16) : a->R == 1, MI355_E_ARG,
+    MI355_CHECK_ARG(swiglu ? (a->R == 2 && (!q4 || (a->scales2 && a->zeros2)) && a->y_dtype == MI355_BF16) : a->R == 1, MI355_E_ARG,
                     "linear_gemm: STORE / ACCUM take the R = 1 stream, SWIGLU the interleaved R = 2 stream with bf16 output");
     MI355_CHECK_ARG(a->N % 4 == 0 && a->ldy % 4 == 0, MI355_E_SHAPE, "linear_gemm: N and ldy must be multiples of 4");
     auto two = [](int d) { return d == MI355_F32 || d == MI355_BF16; };
-    MI355_CHECK_ARG(two(a->x_dtype) && two(a->y_dtype) && two(a->sz_dtype), MI355_E_DTYPE, "linear_gemm: dtypes must be f32 or bf16");
+    MI355_CHECK_ARG(two(a->x_dtype) && two(a->y_dtype) && (!q4 || two(a->sz_dtype)), MI355_E_DTYPE, "linear_gemm: dtypes must be f32 or bf16");
     MI355_CHECK_ARG(a->norm_scale == nullptr || two(a->norm_dtype), MI355_E_DTYPE, "linear_gemm: norm scale dtype");
     MI355_CHECK_ARG(workspace_bytes >= mi355_linear_gemm_workspace_bytes(a->M, a->K) && (uintptr_t)workspace % 16 == 0,
                     MI355_E_SHAPE, "linear_gemm: workspace of %zu bytes is too small (need %zu)", workspace_bytes,
@@ -327,7 +354,7 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
     memset(&p, 0, sizeof(p));
     p.w = (const uint8_t*)a->w;
     {
-        const size_t wb = mi355_packed_bytes(MI355_W_Q4, a->N, a->K, a->R, swiglu ? 1 : 0);
+        const size_t wb = mi355_packed_bytes(a->fmt, a->N, a->K, a->R, swiglu ? 1 : 0);
         MI355_CHECK_ARG(wb > 0 && wb < 0xFFFFFFF0ull, MI355_E_SHAPE, "linear_gemm: weight stream of %zu B", wb);
         p.w_bytes = (unsigned)wb;
     }
@@ -349,7 +376,6 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
     p.n_tiles = (a->N + 15) / 16;
     p.sz_dtype = a->sz_dtype;
     p.y_dtype = a->y_dtype;
-    if (swiglu) return launch_gemm<MI355_EPI_SWIGLU, true>(p, s);
-    if (a->epi == MI355_EPI_ACCUM) return launch_gemm<MI355_EPI_ACCUM, false>(p, s);
-    return launch_gemm<MI355_EPI_STORE, false>(p, s);
+    if (q4) return launch_gemm_epi<MI355_W_Q4>(p, a->epi, s);
+    return launch_gemm_epi<MI355_W_BF16>(p, a->epi, s);
 }

@@ -245,12 +245,12 @@ class DecodeEngine:
                 max_T = 0
             if max_T < 1:
                 raise EngineUnavailable("hidden size does not fit LDS")
-            # int4 models: prompt chunks of >= 32 tokens go through the wide MFMA GEMM + flash attention (csrc/gemm.hip,
+            # int4 and bf16 models: prompt chunks of >= 32 tokens go through the wide MFMA GEMM + flash attention (csrc/gemm.hip,
             # flash_prefill.hip), so the chunk is bounded by scratch memory only (0.5 GB at 2048 tokens of a 7B model,
             # most of it the f32 logits rows).  Large chunks matter: the [n_embd]-wide outputs (c_proj, mlp.c_proj) are
             # 16 row blocks, so 512 tokens fill only a quarter of the chip (9 % vs 27-36 % of the MFMA peak at 2048)
             self.gemm_ws = None
-            if kinds == {"q4"} and _env_int("MI355_PREFILL_GEMM", 1):
+            if kinds <= {"q4", "bf16"} and _env_int("MI355_PREFILL_GEMM", 1):
                 max_T = max(max_T, min(_env_int("MI355_PREFILL_T", 2048), cfg.block_size))
                 need = int(lib().mi355_linear_gemm_workspace_bytes(max_T, max(C_, self.n_hidden)))
                 self.gemm_ws = torch.empty(need, dtype=torch.uint8, device=self.device)

@@ -77,8 +77,8 @@ def _tp(config) -> int:
 
 def _linear(mod: nn.Module, x: torch.Tensor) -> torch.Tensor:
     """Apply one of the hot-path linears.  Quantised plug-ins carry their own kernels; a stock `nn.Linear`
-    (no-quant configs) goes to the bf16 weight-streaming kernel for skinny inputs, to the exact f32 kernel for
-    f32 models, and to rocBLAS (a plain library GEMM) for wide bf16 prefill."""
+    (no-quant configs) goes to the bf16 weight-streaming kernel for skinny inputs, to the MFMA GEMM over the same
+    stream for wide bf16 inputs, and to the exact f32 kernel for f32 models."""
     if type(mod) is not nn.Linear and not getattr(mod, "_mi355_plain_weight", False):
         y = mod(x)  # (lora.MergedLinear sets _mi355_plain_weight once its update is merged: then it IS a plain linear)
         if getattr(mod, "adapter_scale", None) is not None:
@@ -92,15 +92,20 @@ def _linear(mod: nn.Module, x: torch.Tensor) -> torch.Tensor:
         x2d = x2d.contiguous()
     M = x2d.shape[0]
     w = mod.weight
-    if x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and M <= 64:
+    if x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16:
         key = (w.data_ptr(), w._version)
         cached = getattr(mod, "_mi355_stream", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.repack_bf16(w.detach(), None, 1))
             mod._mi355_stream = cached
-        y = ops.linear_fast(x2d, cached[1], nat.W_BF16, 1, w.shape[0], w.shape[1], bias=mod.bias, out_dtype=x.dtype)
-    elif x.dtype == torch.bfloat16:
-        y = torch.nn.functional.linear(x2d, w, mod.bias)
+        if M <= 64 or w.shape[0] % 4 != 0:
+            y = ops.linear_fast(x2d, cached[1], nat.W_BF16, 1, w.shape[0], w.shape[1], bias=mod.bias, out_dtype=x.dtype)
+        else:
+            # wide bf16 inputs: the same LDS-tiled MFMA GEMM as the int4 models, over the BF16 stream (round 2 handed this
+            # case to rocBLAS: a library GEMM on the product path of BASELINE configs[1])
+            y = ops.linear_gemm(x2d, cached[1], 1, w.shape[0], w.shape[1], out_dtype=x.dtype, fmt=nat.W_BF16)
+            if mod.bias is not None:
+                y = y + mod.bias.to(y.dtype)
     else:
         y = ops.linear_dense(x2d, w.detach().to(x.dtype), mod.bias)
     y = y.view(*x.shape[:-1], w.shape[0])

@@ -177,12 +177,14 @@ def linear_fast(
 _GEMM_WS = {}  # device -> scratch tensor of the wide linear (staged bf16 operands + row statistics)
 
 
-def linear_gemm(x2d: torch.Tensor, stream: torch.Tensor, R: int, N: int, K: int, *, scales: torch.Tensor,
-                zeros: torch.Tensor, scales2: Optional[torch.Tensor] = None, zeros2: Optional[torch.Tensor] = None,
+def linear_gemm(x2d: torch.Tensor, stream: torch.Tensor, R: int, N: int, K: int, *, scales: Optional[torch.Tensor] = None,
+                zeros: Optional[torch.Tensor] = None, scales2: Optional[torch.Tensor] = None, zeros2: Optional[torch.Tensor] = None,
                 norm_scale: Optional[torch.Tensor] = None, eps: float = 1e-5, epi: int = EPI_STORE,
-                out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """y[M, N] = epi(x2d[M, K] . W^T) for WIDE inputs through the LDS-tiled MFMA GEMM over the Q4 stream
-    (mi355_linear_gemm, csrc/gemm.hip): prompt prefill / no-cache evaluation (evaluate/full.py:120-129)."""
+                out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, fmt: int = W_Q4) -> torch.Tensor:
+    """y[M, N] = epi(x2d[M, K] . W^T) for WIDE inputs through the LDS-tiled MFMA GEMM over the Q4 stream (scales / zeros
+    per output row) or the BF16 stream (`fmt=W_BF16`, unquantised weights) — mi355_linear_gemm, csrc/gemm.hip: prompt
+    prefill / no-cache evaluation (evaluate/full.py:120-129)."""
+    assert fmt in (W_Q4, W_BF16) and (fmt == W_BF16 or (scales is not None and zeros is not None))
     require_gpu(x2d, "linear_gemm")
     assert x2d.dim() == 2 and x2d.shape[1] == K and x2d.stride(1) == 1
     M = x2d.shape[0]
@@ -196,13 +198,13 @@ def linear_gemm(x2d: torch.Tensor, stream: torch.Tensor, R: int, N: int, K: int,
         ws = torch.empty(max(need, 1 << 22), dtype=torch.uint8, device=x2d.device)
         _GEMM_WS[x2d.device] = ws
     a = LinearArgs()
-    a.fmt, a.R, a.w, a.N, a.K, a.M = W_Q4, R, ptr(stream), N, K, M
+    a.fmt, a.R, a.w, a.N, a.K, a.M = fmt, R, ptr(stream), N, K, M
     a.x, a.x_dtype, a.ldx = ptr(x2d), dtype_code(x2d.dtype), x2d.stride(0)
     a.norm_scale = ptr(norm_scale)
     a.norm_dtype = dtype_code(norm_scale.dtype) if norm_scale is not None else F32
     a.eps = eps
     a.scales, a.zeros, a.scales2, a.zeros2 = ptr(scales), ptr(zeros), ptr(scales2), ptr(zeros2)
-    a.sz_dtype = dtype_code(scales.dtype)
+    a.sz_dtype = dtype_code(scales.dtype) if scales is not None else BF16
     a.epi = epi
     a.y, a.y_dtype, a.ldy = ptr(out), dtype_code(out.dtype), out.stride(0)
     check(lib().mi355_linear_gemm(C.byref(a), ptr(ws), ws.numel(), stream_ptr()), "mi355_linear_gemm")

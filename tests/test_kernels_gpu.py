@@ -587,3 +587,37 @@ def test_linear_gemm_with_fused_rmsnorm_matches_the_skinny_kernel(dev):
     b = ops.linear_fast(x, stream, nat.W_Q4, 1, N, K, scales=scales, zeros=zeros, norm_scale=g, eps=1e-5,
                         out_dtype=torch.float32)
     assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(32, 64, 128, "store"), (200, 4096, 4096, "accum"), (257, 11008, 4096, "swiglu"),
+                                        (96, 4096, 11008, "store"), (40, 72, 200, "store")])
+def test_linear_gemm_over_the_bf16_stream(dev, M, N, K, epi):
+    """The same GEMM over UNQUANTISED weights (BASELINE configs[1]; FMT = BF16 of csrc/gemm.hip: a stream piece is an MFMA
+    A fragment as it lies) against x @ W^T in f32 on the CPU (nn.Linear of lit_llama/model.py:57,177-179,247-249) within
+    the bf16-operand tolerance, and against the skinny streaming kernel over the same stream (same products, other order)."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    w0 = (torch.randn((N, K), generator=gen) * K**-0.5).to(torch.bfloat16)
+    x = torch.randn((M, K), generator=gen).to(torch.bfloat16)
+    xd = x.to(dev)
+    if epi == "swiglu":
+        w1 = (torch.randn((N, K), generator=gen) * K**-0.5).to(torch.bfloat16)
+        stream = ops.repack_bf16(w0.to(dev), w1.to(dev), 2)
+        got = ops.linear_gemm(xd, stream, 2, N, K, epi=nat.EPI_SWIGLU, out_dtype=torch.bfloat16, fmt=nat.W_BF16).float().cpu()
+        skinny = ops.linear_fast(xd, stream, nat.W_BF16, 2, N, K, epi=nat.EPI_SWIGLU, out_dtype=torch.bfloat16).float().cpu()
+        ref = torch.nn.functional.silu(x.float() @ w0.float().t()) * (x.float() @ w1.float().t())
+    else:
+        stream = ops.repack_bf16(w0.to(dev), None, 1)
+        ref = x.float() @ w0.float().t()
+        if epi == "accum":
+            base = torch.randn((M, N), generator=gen)
+            o1, o2 = base.clone().to(dev), base.clone().to(dev)
+            got = ops.linear_gemm(xd, stream, 1, N, K, epi=nat.EPI_ACCUM, out=o1, fmt=nat.W_BF16).float().cpu()
+            skinny = ops.linear_fast(xd, stream, nat.W_BF16, 1, N, K, epi=nat.EPI_ACCUM, out=o2).float().cpu()
+            ref = base + ref
+        else:
+            got = ops.linear_gemm(xd, stream, 1, N, K, out_dtype=torch.float32, fmt=nat.W_BF16).float().cpu()
+            skinny = ops.linear_fast(xd, stream, nat.W_BF16, 1, N, K, out_dtype=torch.float32).float().cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-2 * scale + 1e-3, f"vs f32 reference: {(got - ref).abs().max().item():.4e} (scale {scale:.3f})"
+    assert (got - skinny).abs().max().item() <= (8e-3 if epi == "swiglu" else 1e-4) * scale + 1e-5, \
+        f"vs skinny kernel: {(got - skinny).abs().max().item():.4e} (scale {scale:.3f})"

@@ -129,3 +129,30 @@ def test_evaluate_style_nll_at_block_size_matches_oracle(dev):
          torch.nn.functional.cross_entropy(ref[:-1], tgt, reduction="none")).abs().max().item()
     assert d <= 0.1 * float(ref.std(-1).mean()), d
     print(f"T = 2048 no-cache: max |dlogit| {e:.4f} std; NLL {nll_got:.5f} vs oracle {nll_ref:.5f}; max per-token |dNLL| {d:.4f}")
+
+
+@torch.no_grad()
+def test_bf16_model_prompt_takes_the_wide_path_and_matches_oracle(dev):
+    """BASELINE configs[1] (no quantisation): a 150-token prompt of a 7B-width bf16 layer through the engine — the MFMA GEMM
+    over the BF16 stream + flash attention (round 2 fed such prompts through <= 16-row chunks of the streaming kernel and
+    the module path through rocBLAS) — and a no-cache module forward, both against the oracle."""
+    cfg = LLaMAConfig(**W7B)
+    sd = synth.make_state_dict(cfg, seed=6, mode=None, dtype=torch.bfloat16)
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16):
+        model = LLaMA(cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    om = oracle.Model(oracle.Config(**W7B), {k: v.float() for k, v in sd.items()})
+    eng = model.engine()
+    assert eng is not None and eng.max_T >= 512 and eng.gemm_ws is not None, model._engine_failed
+    T, S = 150, 160
+    toks = synth.make_prompt(T, seed=12)
+    got = model(toks.view(1, -1).to(dev), S, _pos(T, dev))[0].float().cpu()
+    ref = om(toks.view(1, -1), S, torch.arange(T))[0].float()
+    e1 = check(got, ref, "bf16 prefill through the engine")
+    model.reset_cache()
+    got2 = model(toks.view(1, -1).long().to(dev))[0].float().cpu()  # module path: _linear -> ops.linear_gemm(fmt = BF16)
+    om.reset_cache()
+    ref2 = om(toks.view(1, -1).long())[0].float()
+    e2 = check(got2, ref2, "bf16 no-cache forward")
+    print(f"bf16 7B-width layer, {T} tokens: engine prefill {e1:.4f} std, module path {e2:.4f} std")
