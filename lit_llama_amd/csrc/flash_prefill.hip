@@ -4,30 +4,42 @@
 // :230 for T >= 32 query tokens (evaluate/full.py:120-129 runs T = 2048): the one-workgroup-per-(head, query) kernel
 // of attention.hip re-reads a head's K / V once per query.
 //
-// One workgroup = 128 queries of one head (8 waves x 16), walking the keys 32 at a time up to the causal limit:
-//   * S^T = K Q^T (keys x queries) rather than Q K^T: the MFMA result then has a QUERY per lane column and 4 + 4 keys
-//     per lane in registers, which is exactly the B-operand shape of the next product O^T = V^T P^T (32 keys x 16
-//     queries) — up to a fixed permutation of the 32 keys, which a sum over keys does not care about as long as V^T
-//     uses the same one.  So the probabilities never leave their registers (no LDS round trip, no transposition of
-//     P), and the online-softmax rescale is a per-lane scalar.  Row maxima / sums run over the 8 registers and two
-//     permlane swaps (lane ^ 16, lane ^ 32).
-//   * K tiles go to LDS as they are (16-B chunks XOR-swizzled by key & 15: conflict-free fragment reads); V tiles are TRANSPOSED on the way in (d-major, keys in
-//     the permuted order, rows padded to 96 B: conflict-free 16-B fragment reads), both double buffered.  The
-//     transposition happens in registers: a thread loads the same 8 dimensions of 4 consecutive keys and writes 8-byte
-//     groups of 4 keys (v_perm_b32), the row it writes rotated by its column so that the 16 columns of an instruction
-//     hit 16 different bank groups (2-byte stores were 8-way bank conflicted and bounded the kernel: 339 us per layer
-//     at T = 2048).
+// One workgroup = 128 queries of one head (4 waves x 32), walking the keys 64 at a time up to the causal limit, on
+// v_mfma_f32_32x32x16_bf16 (round 3; the round-2 kernel gave a wave 16 queries on 16x16x32 tiles and a barrier per 32
+// keys: every wave re-read the whole K and V^T tiles from LDS for 16 queries, and the PMC pass showed the matrix pipes
+// 7.5 % busy — profiles/r03_rocprofv3_pmc_mfma_util_prefill.txt):
+//   * S^T = K Q^T (keys x queries) rather than Q K^T: the MFMA result then has a QUERY per lane column and 16 keys per
+//     lane in registers, which is the B-operand shape of the next product O^T = V^T P^T (16 keys x 32 queries per
+//     instruction) — up to a fixed permutation of the keys inside a group of 16, which a sum over keys does not care
+//     about as long as V^T uses the same one (result register i of lane half h is key (i & 3) + 8 (i >> 2) + 4 h of the
+//     32-key tile; as a B operand the same registers are k-slots 8 h + (i & 7): the runs of 4 keys 0-3 | 4-7 | 8-11 |
+//     12-15 sit at slots 0-3 | 8-11 | 4-7 | 12-15).  So the probabilities never leave their registers, and the
+//     online-softmax rescale is a per-lane scalar; row maxima / sums run over the 16 registers and one permlane32 swap.
+//   * K tiles go to LDS as they are (16-B chunks XOR-swizzled by key & 15: conflict-free fragment reads); V tiles are
+//     TRANSPOSED on the way in (d-major, keys in the permuted order, rows padded to 144 B: conflict-free 16-B fragment
+//     reads), both double buffered.  The transposition happens in registers: a thread loads the same 8 dimensions of 4
+//     consecutive keys and writes 8-byte groups of 4 keys (v_perm_b32), the row it writes rotated by its column.
 //   * q is RoPE'd in registers while it is loaded (f32 qkv rows, rope row = the token's position); the new K / V rows
 //     were written to the cache by rope_kv_write_kernel before this launch.
 #include "common.h"
 
 namespace {
 
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+// two f32 -> packed bf16, round to nearest even (one v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    const bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 constexpr int kHs = 128;
-constexpr int kBQ = 128;   // queries per workgroup (8 waves x 16)
-constexpr int kThreadsF = 512;
-constexpr int kBK = 32;    // keys per step
-constexpr int kVtRow = 96; // bytes per d-row of the transposed V tile (32 keys x 2 B, padded: conflict-free b128 reads)
+constexpr int kBQ = 128;    // queries per workgroup (4 waves x 32)
+constexpr int kThreadsF = 256;
+constexpr int kBK = 64;     // keys per step (two 32-key score tiles)
+constexpr int kVtRow = 144; // bytes per d-row of the transposed V tile (64 keys x 2 B, padded: conflict-free b128 reads)
 constexpr int kKTile = kBK * 256, kVTile = kHs * kVtRow;
 constexpr int kLds = 2 * (kKTile + kVTile);
 
@@ -43,16 +55,23 @@ struct FlashParams {
     float scale;
 };
 
-__global__ __launch_bounds__(kThreadsF) void flash_prefill_kernel(const FlashParams p) {
+__global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const FlashParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware order (workgroup b runs on XCD b % 8): all query blocks of a head on one XCD, whose L2 then holds that
     // head's K / V once; the longest (last) query blocks first
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int h = xcd + 8 * (idx / p.q_blocks), qb = p.q_blocks - 1 - idx % p.q_blocks;
+    const int h = xcd + 8 * (idx / p.q_blocks);
     if (h >= p.n_head) return;
+    // Causal work grows with the query block (block qb walks 2 (qb + 1) key steps), and at T = 2048 every workgroup of
+    // the launch is resident at once, two per CU: what counts is WHICH two share a CU.  An XCD hands its workgroups to
+    // its 32 CUs in order, so workgroups idx and idx + 32 meet: every second group of 32 walks the query blocks upwards
+    // instead of downwards, and a long block sits next to a short one (34 key steps per CU instead of 4 .. 64).
+    const int jq = idx % p.q_blocks;
+    const bool up = (32 % p.q_blocks == 0) && ((idx >> 5) & 1);
+    const int qb = up ? jq : p.q_blocks - 1 - jq;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, c = lane & 15;
-    const int q_idx = qb * kBQ + wave * 16 + c;  // this lane's query (column of every MFMA result below)
+    const int hh = lane >> 5, c = lane & 31;      // lane half (k-slots 8 hh .. + 7 of an operand), column / row 0 .. 31
+    const int q_idx = qb * kBQ + wave * 32 + c;  // this lane's query (column of every MFMA result below)
     const bool q_ok = q_idx < p.T;
     const int q_row = q_ok ? q_idx : p.T - 1;
     const int q_abs = p.pos != nullptr ? p.pos[q_row] : q_row;
@@ -61,15 +80,21 @@ __global__ __launch_bounds__(kThreadsF) void flash_prefill_kernel(const FlashPar
     const int q_last = p.pos != nullptr ? p.pos[q_lrow] : q_lrow;
     const int n_keys = q_last + 1 < p.S ? q_last + 1 : p.S;
     const int n_kb = (n_keys + kBK - 1) / kBK;
+    // the smallest position among the wave's queries: key steps entirely at or below it need no mask
+    int q_min = q_abs;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q_min = min(q_min, __shfl_xor(q_min, o, 64));
+    q_min = __builtin_amdgcn_readfirstlane(q_min);
 
-    // ---- Q^T as B operands: bq[dc] = q[32 dc + 8 g .. + 8), RoPE'd (model.py:306-323), bf16
-    bf16x8 bq[4];
+    // ---- Q^T as B operands: bq[ks] = q[16 ks + 8 hh .. + 8), RoPE'd (model.py:306-323), bf16
+    bf16x8 bq[8];
     {
         const int64_t qoff = (int64_t)q_row * p.ld_qkv + h * kHs;
         const float* rrow = p.rope + (int64_t)(p.rope_gathered ? q_row : q_abs) * kHs;  // 64 pairs x (cos, sin)
+        const float qs = p.scale * 1.44269504088896340736f;
 #pragma unroll
-        for (int dc = 0; dc < 4; ++dc) {
-            const int d0 = 32 * dc + 8 * g;
+        for (int ks = 0; ks < 8; ++ks) {
+            const int d0 = 16 * ks + 8 * hh;
             f32x4 a, b;
             if (p.qkv_dtype == MI355_F32) {
                 a = *(const f32x4*)((const float*)p.qkv + qoff + d0);
@@ -82,12 +107,14 @@ __global__ __launch_bounds__(kThreadsF) void flash_prefill_kernel(const FlashPar
                           __uint_as_float(raw[3] << 16), __uint_as_float(raw[3] & 0xffff0000u)};
             }
             const f32x4 r0 = *(const f32x4*)(rrow + d0), r1 = *(const f32x4*)(rrow + d0 + 4);  // (c, s, c, s)
+            // the softmax scale and log2(e) ride on q (f32, before the one rounding to bf16): the scores leave the MFMA in
+            // the exp2 domain and the 16 scores per lane and tile need no multiply
             u32x4 o;
-            o[0] = (uint32_t)f32_to_bf16(a[0] * r0[0] - a[1] * r0[1]) | ((uint32_t)f32_to_bf16(a[1] * r0[0] + a[0] * r0[1]) << 16);
-            o[1] = (uint32_t)f32_to_bf16(a[2] * r0[2] - a[3] * r0[3]) | ((uint32_t)f32_to_bf16(a[3] * r0[2] + a[2] * r0[3]) << 16);
-            o[2] = (uint32_t)f32_to_bf16(b[0] * r1[0] - b[1] * r1[1]) | ((uint32_t)f32_to_bf16(b[1] * r1[0] + b[0] * r1[1]) << 16);
-            o[3] = (uint32_t)f32_to_bf16(b[2] * r1[2] - b[3] * r1[3]) | ((uint32_t)f32_to_bf16(b[3] * r1[2] + b[2] * r1[3]) << 16);
-            bq[dc] = __builtin_bit_cast(bf16x8, o);
+            o[0] = (uint32_t)f32_to_bf16(qs * (a[0] * r0[0] - a[1] * r0[1])) | ((uint32_t)f32_to_bf16(qs * (a[1] * r0[0] + a[0] * r0[1])) << 16);
+            o[1] = (uint32_t)f32_to_bf16(qs * (a[2] * r0[2] - a[3] * r0[3])) | ((uint32_t)f32_to_bf16(qs * (a[3] * r0[2] + a[2] * r0[3])) << 16);
+            o[2] = (uint32_t)f32_to_bf16(qs * (b[0] * r1[0] - b[1] * r1[1])) | ((uint32_t)f32_to_bf16(qs * (b[1] * r1[0] + b[0] * r1[1])) << 16);
+            o[3] = (uint32_t)f32_to_bf16(qs * (b[2] * r1[2] - b[3] * r1[3])) | ((uint32_t)f32_to_bf16(qs * (b[3] * r1[2] + b[2] * r1[3])) << 16);
+            bq[ks] = __builtin_bit_cast(bf16x8, o);
         }
     }
 
@@ -95,39 +122,44 @@ __global__ __launch_bounds__(kThreadsF) void flash_prefill_kernel(const FlashPar
     const bf16_t* vc = p.vcache + (int64_t)h * p.S * kHs;
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kc, 0, n_keys * 256, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, n_keys * 256, 0x00020000);
-    // tile staging.  K: 512 chunks of 16 B, one per thread: chunk = (key, 16-B column).  V: threads 0..127 take
-    // (group of 4 consecutive keys, 16-B column): 4 loads, transposed in registers.
-    u32x4 ks, vs[4];
-    const int vgrp = threadIdx.x >> 4, vcol = threadIdx.x & 15;  // key group 0..7 (threads < 128), column 0..15
+    // tile staging.  K: 1024 chunks of 16 B, four per thread: chunk = (key, 16-B column).  V: one (run of 4 consecutive
+    // keys, 16-B column) per thread: 4 loads, transposed in registers.
+    u32x4 ks_[4], vs[4];
+    // a wave covers all 16 runs of the 64-key tile for 4 of the 16 columns: one store instruction of the transposition
+    // below then writes 16 different 8-byte slots of the SAME 4 d-rows (2-way bank conflicts at most) with compile-time
+    // register indices (the round-2 mapping, 16 columns per instruction, needed a per-lane rotation of the rows: dynamic
+    // register selects, ~100 VALU instructions per step)
+    const int vrun = threadIdx.x & 15, vcol = (threadIdx.x >> 6) * 4 + ((threadIdx.x >> 4) & 3);
     auto tload = [&](int kb) {
-        {
-            const int key = kb * kBK + (threadIdx.x >> 4);
-            const unsigned off = key < n_keys ? (unsigned)key * 256u + (unsigned)(threadIdx.x & 15) * 16u : 0xFFFFFFF0u;
-            ks = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
-        }
-        if (threadIdx.x < 128) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kb * kBK + vgrp * 4 + r;
-                const unsigned off = key < n_keys ? (unsigned)key * 256u + (unsigned)vcol * 16u : 0xFFFFFFF0u;
-                vs[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int ch = i * kThreadsF + threadIdx.x;
+            const int key = kb * kBK + (ch >> 4);
+            const unsigned off = key < n_keys ? (unsigned)key * 256u + (unsigned)(ch & 15) * 16u : 0xFFFFFFF0u;
+            ks_[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kb * kBK + vrun * 4 + r;
+            const unsigned off = key < n_keys ? (unsigned)key * 256u + (unsigned)vcol * 16u : 0xFFFFFFF0u;
+            vs[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
         }
     };
     auto tstore = [&](int buf) {
         char* kt = smem + buf * (kKTile + kVTile);
         char* vt = kt + kKTile;
-        {
-            const int key = threadIdx.x >> 4, col = threadIdx.x & 15;
-            *(u32x4*)(kt + key * 256 + ((col ^ (key & 15)) << 4)) = ks;
-        }
-        if (threadIdx.x < 128) {
-            // keys 4 vg' .. + 3 of 16-key tile kt16 sit at positions 8 g' + (kt16 ? 4 : 0) + 0..3 of a d-row: 8 bytes
-            const int kt16 = vgrp >> 2, gq = vgrp & 3;
-            const int pbyte = (8 * gq + (kt16 ? 4 : 0)) * 2;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = (i + vcol) & 7;  // rotate the row by the column: spreads an instruction over the banks
+        for (int i = 0; i < 4; ++i) {
+            const int ch = i * kThreadsF + threadIdx.x;
+            const int key = ch >> 4, col = ch & 15;
+            *(u32x4*)(kt + key * 256 + ((col ^ (key & 15)) << 4)) = ks_[i];
+        }
+        {
+            // run r of 16-key group G sits at k-slots 4 perm[r] .. + 3 of the group (perm = 0, 2, 1, 3): 8 bytes
+            const int G = vrun >> 2, r = vrun & 3;
+            const int pbyte = (G * 16 + 4 * ((r & 1) * 2 + (r >> 1))) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
                 const int dw = e >> 1;
                 u32x2 o;
                 if (e & 1) {
@@ -142,9 +174,11 @@ __global__ __launch_bounds__(kThreadsF) void flash_prefill_kernel(const FlashPar
         }
     };
 
-    f32x4 acc[8];
+    f32x16 acc[4];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[dt][i] = 0.f;
     float m_run = -1.0e30f, l_run = 0.f;
 
     tload(0);
@@ -152,83 +186,99 @@ __global__ __launch_bounds__(kThreadsF) void flash_prefill_kernel(const FlashPar
     __syncthreads();
     for (int kb = 0; kb < n_kb; ++kb) {
         const int buf = kb & 1;
+#ifndef FLASH_NO_STAGE
         tload(kb + 1);  // unconditional (past the last block: offsets beyond n_keys read zeros): no vmcnt drain at a join
+#endif
         const char* kt = smem + buf * (kKTile + kVTile);
         const char* vt = kt + kKTile;
-        // every fragment of the block is requested up front: K (8 x 16 B) for the scores, V^T (8 x 16 B) lands while the
-        // softmax arithmetic runs
-        bf16x8 ka[2][4], va[8];
+        // ---- S^T[key][q] of the two 32-key tiles: 2 x 8 MFMAs over the 128 dimensions, two independent accumulators
+        f32x16 st[2];
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const int key = t2 * 16 + c;  // A-operand row of this lane
+        for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int dc = 0; dc < 4; ++dc) ka[t2][dc] = *(const bf16x8*)(kt + key * 256 + (((4 * dc + g) ^ (key & 15)) << 4));
+            for (int i = 0; i < 16; ++i) st[t2][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int key = t2 * 32 + c;  // A-operand row of this lane
+                const bf16x8 ka = *(const bf16x8*)(kt + key * 256 + (((2 * ks + hh) ^ (key & 15)) << 4));
+                st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, bq[ks], st[t2], 0, 0, 0);
+            }
         }
+        // ---- causal mask (only where the step reaches the wave's diagonal: wave-uniform), online softmax over this
+        // lane's query in the exp2 domain (32 keys here, the other 32 in lane ^ 32)
+        if (kb * kBK + kBK - 1 > q_min) {
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) va[dt] = *(const bf16x8*)(vt + (dt * 16 + c) * kVtRow + g * 16);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- S^T[key][q] for the two 16-key tiles
-        f32x4 st[2];
+            for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            st[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int dc = 0; dc < 4; ++dc) st[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[t2][dc], bq[dc], st[t2], 0, 0, 0);
+                for (int i = 0; i < 16; ++i) {
+                    const int key_abs = kb * kBK + t2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    st[t2][i] = key_abs <= q_abs ? st[t2][i] : -1.0e30f;
+                }
         }
-        // ---- causal mask, online softmax over this lane's query (8 keys here, the rest in lanes ^ 16, ^ 32)
-        float sv[8];
         float m_blk = -1.0e30f;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key_abs = kb * kBK + t2 * 16 + 4 * g + r;
-                const float s = key_abs <= q_abs ? st[t2][r] * p.scale : -1.0e30f;
-                sv[t2 * 4 + r] = s;
-                m_blk = fmaxf(m_blk, s);
-            }
-        m_blk = fmaxf(m_blk, lane_xor16(m_blk));
+            for (int i = 0; i < 16; i += 2) m_blk = fmaxf(m_blk, fmaxf(st[t2][i], st[t2][i + 1]));
         m_blk = fmaxf(m_blk, lane_xor32(m_blk));
-        const float m_new = fmaxf(m_run, m_blk);
-        const float corr = __expf(m_run - m_new);
+        // Lazy rescale: the running reference maximum m_run of a query moves only when the step's maximum exceeds it by
+        // more than 2^8 (exp2 domain) — probabilities then stay below 256, which bf16 and the f32 sums hold easily — and
+        // the 64 accumulator registers (which live in AGPRs: every VALU touch is a v_accvgpr round trip) are rescaled
+        // only in the steps where some query of the wave moves: the first one and a handful after it.
+        const bool move = m_blk > m_run + 8.0f;
+        if (__any(move)) {
+            const float m_new = move ? m_blk : m_run;
+            const float corr = exp2_fast(m_run - m_new);  // (first step: exp2(-1e30 - m) = 0 on all-zero accumulators)
+            l_run *= corr;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[dt][i] *= corr;
+        }
         float psum = 0.f;
-        u32x4 pb;
+        u32x4 pb[2][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float p0 = sv[2 * i] > -1.0e29f ? __expf(sv[2 * i] - m_new) : 0.f;
-            const float p1 = sv[2 * i + 1] > -1.0e29f ? __expf(sv[2 * i + 1] - m_new) : 0.f;
-            const bf16_t h0 = f32_to_bf16(p0), h1 = f32_to_bf16(p1);
-            psum += bf16_to_f32(h0) + bf16_to_f32(h1);  // the sum of what the MFMA will multiply
-            pb[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        }
-        l_run = l_run * corr + psum;
-        m_run = m_new;
-        // ---- O^T[d][q] = O^T * corr + V^T P^T
-        const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb);
+        for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            f32x4 a = acc[dt];
-            a[0] *= corr;
-            a[1] *= corr;
-            a[2] *= corr;
-            a[3] *= corr;
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[dt], pfrag, a, 0, 0, 0);
+            for (int i = 0; i < 8; ++i) {
+                // masked scores are -1e30: exp2 underflows to exactly 0.  The denominator sums the f32 probabilities, the
+                // numerator their bf16 roundings (v_cvt_pk_bf16_f32): zero-mean relative differences of 2^-9 per key
+                const float p0 = exp2_fast(st[t2][2 * i] - m_run), p1 = exp2_fast(st[t2][2 * i + 1] - m_run);
+                psum += p0 + p1;
+                pb[t2][i >> 2][i & 3] = pack_bf16x2(p0, p1);
+            }
+        l_run += psum;
+        // ---- O^T[d][q] += V^T P^T: four 16-key groups x four 32-dimension tiles
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb[sg >> 1][sg & 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 va = *(const bf16x8*)(vt + (dt * 32 + c) * kVtRow + sg * 32 + hh * 16);
+                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pfrag, acc[dt], 0, 0, 0);
+            }
         }
+#ifndef FLASH_NO_STAGE
         tstore(buf ^ 1);
+#endif
         __syncthreads();
     }
-    float l = l_run + lane_xor16(l_run);
-    l += lane_xor32(l);
+    float l = l_run + lane_xor32(l_run);
     if (q_ok) {
         const float inv = 1.0f / l;
         bf16_t* yrow = p.y + (int64_t)q_idx * p.ldy + h * kHs;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            u32x2 o;
-            o[0] = (uint32_t)f32_to_bf16(acc[dt][0] * inv) | ((uint32_t)f32_to_bf16(acc[dt][1] * inv) << 16);
-            o[1] = (uint32_t)f32_to_bf16(acc[dt][2] * inv) | ((uint32_t)f32_to_bf16(acc[dt][3] * inv) << 16);
-            *(u32x2*)(yrow + dt * 16 + 4 * g) = o;
-        }
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                u32x2 o;
+                o[0] = (uint32_t)f32_to_bf16(acc[dt][4 * gq] * inv) | ((uint32_t)f32_to_bf16(acc[dt][4 * gq + 1] * inv) << 16);
+                o[1] = (uint32_t)f32_to_bf16(acc[dt][4 * gq + 2] * inv) | ((uint32_t)f32_to_bf16(acc[dt][4 * gq + 3] * inv) << 16);
+                *(u32x2*)(yrow + dt * 32 + 8 * gq + 4 * hh) = o;
+            }
     }
 }
 
