@@ -13,7 +13,7 @@ ONE JSON line.  With N > 1 every GPU decodes its own independent stream (the bs=
 SURVEY.md §8e: "replicas only"), so scaling is "weak" and `value` is the sum over ranks.
 
 Extra objects on the same line:
-  roofline     — the dominant kernel: with the fused step that is `fused_step_kernel`, one launch = one token
+  roofline     — the dominant kernel: with the fused step that is `fused_step_ring_kernel`, one launch = one token
                  (algorithmic bytes = every weight byte once + scales / zeros + norm scales + the KV rows read at
                  that position); otherwise the c_fc1/c_fc2 + SwiGLU weight-streaming launch.  Algorithmic bytes per
                  launch / average launch duration — the dispatch's own begin / end timestamps, delivered into HIP
@@ -113,7 +113,7 @@ def build_model(args, dev):
 
 
 def measure_fused_step(eng, n: int = 48):
-    """Average duration of the fused_step_kernel launch (one token), dispatch timestamps via hipExtLaunchKernel; the
+    """Average duration of the fused_step_ring_kernel launch (one token), dispatch timestamps via hipExtLaunchKernel; the
     steps are chained greedy steps continuing the timed loop (state on the device)."""
     from lit_llama_amd._native import check, lib
 
@@ -562,7 +562,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "fused_step_kernel (the whole decode step, one launch per token)" if fused else
+            "kernel": "fused_step_ring_kernel (the whole decode step, one launch per token)" if fused else
                       {"gptq.int4": "gemv_kernel<Q4,R=2,SwiGLU>", "none": "gemv_kernel<BF16,R=2,SwiGLU>",
                        "llm.int8": "int8_gemv_kernel<R=2>"}[args.quantize] + " (c_fc1/c_fc2 pair)",
             "achieved": round(algo / avg_s / 1e9, 1),

@@ -40,6 +40,15 @@ for st in $STAGES; do
       ls $OUT/pmc | head; [ -n "$f" ] && head -3 "$f"
       [ -n "$f" ] && python scripts/pmc_summary.py "$f" --json $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt
       find $OUT/pmc -name '*.csv' -size +20M -delete ;;
+    cfgs)
+      # the other BASELINE configurations and the long-context point (profiles/rNN_bench_cfg_*.json, rNN_bench_longctx.json)
+      timeout 400 python bench.py --quantize none --steps 64 --no-cpu-baseline --no-tp > $OUT/bench_cfg_none.json 2>> $OUT/bench.err
+      timeout 400 python bench.py --quantize llm.int8 --steps 64 --no-cpu-baseline --no-tp > $OUT/bench_cfg_llm.int8.json 2>> $OUT/bench.err
+      timeout 500 python bench.py --model 13B --steps 64 --no-cpu-baseline --no-tp > $OUT/bench_cfg_13B.json 2>> $OUT/bench.err
+      timeout 900 python bench.py --model 65B --steps 32 --no-cpu-baseline --no-tp > $OUT/bench_cfg_65B.json 2>> $OUT/bench.err
+      timeout 400 python bench.py --prompt-len 1900 --steps 64 --warmup 16 --no-cpu-baseline --no-tp > $OUT/bench_longctx.json 2>> $OUT/bench.err
+      for f in none llm.int8 13B 65B; do tail -1 $OUT/bench_cfg_$f.json | cut -c1-200; done; tail -1 $OUT/bench_longctx.json | cut -c1-200
+      echo "cfgs done" | tee -a $OUT/session.log ;;
     mfma)
       rm -rf $OUT/mfma
       timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -o mfma -- python scripts/prefill_run.py 2048 > $OUT/mfma_run.txt 2> $OUT/mfma.err

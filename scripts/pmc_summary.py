@@ -46,7 +46,7 @@ def main():
     cands = [(k, v) for k, v in res.items() if k.startswith("gemv_kernel<") and targs(k)[:2] == ["0", "2"] and targs(k)[3] == "2"]
     cands.sort(key=lambda kv: (targs(kv[0])[5:6] != ["false"], -kv[1]["launches"]))
     fc = cands[0][1] if cands else None
-    fused = next((v for k, v in res.items() if k.startswith("fused_step_kernel")), None)
+    fused = next((v for k, v in res.items() if k.startswith("fused_step")), None)  # fused_step_ring_kernel / fused_step_kernel
     if out_json and (fc or fused):
         out = {"note": "rocprofv3 --pmc FETCH_SIZE, KiB x 1024 x 2 (gfx950 wide-read correction)", "kernels": res}
         if fc:

@@ -25,6 +25,12 @@ SHAPES_7B = {
     "lm_head": (32000, 4096, 2, nat.EPI_STORE),
     "attn1": (12288, 4096, 1, nat.EPI_STORE),
     "lm_head1": (32000, 4096, 1, nat.EPI_STORE),
+    # 13B (n_embd 5120, n_hidden 13824), as the engine packs them (R = 1 except the c_fc1 / c_fc2 pair)
+    "attn13": (15360, 5120, 1, nat.EPI_STORE),
+    "proj13": (5120, 5120, 1, nat.EPI_ACCUM),
+    "fc13": (13824, 5120, 2, nat.EPI_SWIGLU),
+    "mproj13": (5120, 13824, 1, nat.EPI_ACCUM),
+    "lm_head13": (32000, 5120, 1, nat.EPI_STORE),
 }
 
 
