@@ -423,7 +423,8 @@ int mi355_graph_destroy(mi355_graph* g);
 /* ------------------------------------------------------------------------------------------
  * The whole T = 1 decode step (LLaMA.forward for one token + greedy sampling, lit_llama/model.py:76-122,
  * generate.py:68-85) as ONE persistent launch: 7B-class gptq.int4 models on a 256-CU device
- * (csrc/fused_step.hip; mi355_fused_step_supported tells).  Everything the launch touches is laid out in
+ * (kernel csrc/fused_step_ring.hip, host entry csrc/fused_step.hip; mi355_fused_step_supported tells; MI355_FUSED_IMPL=lds in
+ * the environment selects the LDS-DMA implementation of the same step, csrc/fused_step.hip).  Everything the launch touches is laid out in
  * arenas so that a layer is addressed by a stride:
  *   w        Q4 streams (mi355_q4_repack) of layer l at w + l * layer_stride: c_attn (R = 1) at off_attn, attn.c_proj
  *            (R = 1) at off_proj, the interleaved c_fc1 / c_fc2 pair (R = 2) at off_fc, mlp.c_proj (R = 1) at off_mproj;
@@ -436,7 +437,9 @@ int mi355_graph_destroy(mi355_graph* g);
  *   tokens / pos   device int32: the step's token id and position (pos[0] < S)
  *   workspace      mi355_fused_step_workspace_bytes(n_hidden) bytes, zeroed ONCE by the caller, then owned by the
  *            library: word 0 = abort code (0 = fine; a non-zero value after the launch means a hand-off timed
- *            out and the outputs are garbage), word 1 = step counter
+ *            out and the outputs are garbage), word 1 = step counter, word 2 = fp16 activation pairs that had to be
+ *            clipped at +-65504 on the attention-output / SwiGLU edges since the caller last zeroed the word (non-zero:
+ *            the steps computed with saturated activations, not what lit_llama/model.py computes)
  *   mode     0: logits only; 1: + greedy arg-max into next_token[0] / out_tokens[pos + 1]; 3: + chaining
  *            (tokens[0] = arg-max, pos[0] += 1), so a captured launch replays the loop of generate.py:63-91
  *   logits   f32 [vocab]
