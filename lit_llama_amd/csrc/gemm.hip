@@ -33,10 +33,9 @@ constexpr int kBM = 128;     // tokens per block
 #define MI355_GEMM_TPW 2
 #endif
 constexpr int kTPW = MI355_GEMM_TPW;  // 16-row tile slots per wave: one B fragment read from LDS feeds kTPW MFMAs
-constexpr int kWaves = 8;
-constexpr int kSlots = kWaves * kTPW;  // tile slots per block
-constexpr int kThreads = 64 * kWaves;
-constexpr int kXChunks = kBM * 16 / kThreads;  // 16-B activation chunks per thread and unit
+// Waves per workgroup: 8 (a block = 16 row tiles x 128 tokens) for prompts that fill the chip; 2 (4 row tiles) when the
+// launch would otherwise be a few dozen workgroups — a 128-token prompt of a 7B model is ONE token block, i.e. 16 workgroups
+// for attn.c_proj / mlp.c_proj (N = 4096) on 256 CUs, each streaming its 0.5-1.4 MB of weights alone: ~96 us per launch.
 constexpr int kLds = 2 * kBM * 256;  // two buffers of 128 tokens x 128 k bf16
 
 struct GemmParams {
@@ -54,7 +53,16 @@ struct GemmParams {
     int64_t ldy;
     int M, N, K, units, n_tiles, n_blocks, per_xcd, total_blocks;
     int sz_dtype, y_dtype;
+    // split-K (few blocks: short prompts against N = 4096): slice ks of the units -> part[ks][M][N] f32, summed in order
+    // by splitk_reduce_kernel; sx then holds [M][ksplit] per-slice operand sums
+    int ksplit;
+    float* part;
 };
+
+constexpr size_t kSplitBudget = (size_t)32 << 20;  // bytes of split-K partials a workspace holds
+constexpr int kMaxSplit = 8;
+// first unit of K-slice s of `ksplit` (slice s = units [lo(s), lo(s + 1)))
+__host__ __device__ __forceinline__ int slice_lo(int s, int units, int ksplit) { return (int)((int64_t)s * units / ksplit); }
 
 // 16-B chunk swizzle of an activation row in LDS (see the header): bits 0, 1 of the token stay, bit 2 -> 8, bit 3 -> 12
 #ifdef MI355_NO_SWZ
@@ -67,39 +75,86 @@ __device__ __forceinline__ float ldsz(const void* p, int i, int dtype) {
     return dtype == MI355_F32 ? ((const float*)p)[i] : bf16_to_f32(((const bf16_t*)p)[i]);
 }
 
-// one row per workgroup: xb = bf16(norm_scale * x), rinv = rsqrt(mean(x^2) + eps) (1 without norm), sx = sum_k xb
+// one row per workgroup: xb = bf16(norm_scale * x), rinv = rsqrt(mean(x^2) + eps) (1 without norm), sx[m][s] = sum of xb over
+// K-slice s (ksplit = 1: the whole row)
 __global__ __launch_bounds__(256) void stage_rows_kernel(const void* x, int x_dtype, int64_t ldx, const void* norm_scale,
                                                          int norm_dtype, float eps, int K, int Kp, bf16_t* xb, int64_t ldxb,
-                                                         float* rinv, float* sx) {
+                                                         float* rinv, float* sx, int ksplit) {
     __shared__ float red[32];
     const int m = blockIdx.x;
-    float ss = 0.f, sum = 0.f;
-    for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
-        bf16_t o = 0;
-        if (k < K) {
-            float v = ld_as_f32(x, (int64_t)m * ldx + k, x_dtype);
-            if (norm_scale != nullptr) {
-                ss += v * v;
-                v *= ld_as_f32(norm_scale, k, norm_dtype);
+    const int units = Kp >> 7;
+    float ss = 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+        const int k_lo = slice_lo(s, units, ksplit) << 7, k_hi = slice_lo(s + 1, units, ksplit) << 7;
+        float sum = 0.f;
+        for (int k = k_lo + threadIdx.x; k < k_hi; k += blockDim.x) {
+            bf16_t o = 0;
+            if (k < K) {
+                float v = ld_as_f32(x, (int64_t)m * ldx + k, x_dtype);
+                if (norm_scale != nullptr) {
+                    ss += v * v;
+                    v *= ld_as_f32(norm_scale, k, norm_dtype);
+                }
+                o = f32_to_bf16(v);
+                sum += bf16_to_f32(o);
             }
-            o = f32_to_bf16(v);
-            sum += bf16_to_f32(o);
+            xb[(int64_t)m * ldxb + k] = o;
         }
-        xb[(int64_t)m * ldxb + k] = o;
+        const float tot = block_sum(sum, red);
+        if (threadIdx.x == 0) sx[(int64_t)m * ksplit + s] = tot;
     }
-    const float tot = block_sum(sum, red);
     const float tss = block_sum(ss, red);
-    if (threadIdx.x == 0) {
-        sx[m] = tot;
-        rinv[m] = norm_scale != nullptr ? rsqrtf(tss / (float)K + eps) : 1.0f;
+    if (threadIdx.x == 0) rinv[m] = norm_scale != nullptr ? rsqrtf(tss / (float)K + eps) : 1.0f;
+}
+
+// y[m][n] (+)= sum over the K-slices, in slice order (deterministic)
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, int ksplit, int M, int N, void* y, int y_dtype,
+                                                            int64_t ldy) {
+    const int64_t n4 = N >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)M * n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == MI355_EPI_SWIGLU) {
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < ksplit; ++s) {
+                const float* row = part + ((int64_t)s * M + m) * (2 * (int64_t)N);
+                o += *(const f32x4*)(row + n);
+                b += *(const f32x4*)(row + N + n);
+            }
+            bf16_t* dst = (bf16_t*)y + (int64_t)m * ldy + n;
+            u32x2 pk;
+            pk[0] = (uint32_t)f32_to_bf16(swiglu_f32(o[0], b[0])) | ((uint32_t)f32_to_bf16(swiglu_f32(o[1], b[1])) << 16);
+            pk[1] = (uint32_t)f32_to_bf16(swiglu_f32(o[2], b[2])) | ((uint32_t)f32_to_bf16(swiglu_f32(o[3], b[3])) << 16);
+            *(u32x2*)dst = pk;
+        } else if (y_dtype == MI355_F32) {
+            float* dst = (float*)y + (int64_t)m * ldy + n;
+            if constexpr (EPI == MI355_EPI_ACCUM) o = *(const f32x4*)dst;
+            for (int s = 0; s < ksplit; ++s) o += *(const f32x4*)(part + ((int64_t)s * M + m) * N + n);
+            *(f32x4*)dst = o;
+        } else {
+            bf16_t* dst = (bf16_t*)y + (int64_t)m * ldy + n;
+            if constexpr (EPI == MI355_EPI_ACCUM) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = bf16_to_f32(dst[r]);
+            }
+            for (int s = 0; s < ksplit; ++s) o += *(const f32x4*)(part + ((int64_t)s * M + m) * N + n);
+            u32x2 pk;
+            pk[0] = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+            pk[1] = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+            *(u32x2*)dst = pk;
+        }
     }
 }
 
 // FMT = MI355_W_Q4: int4 stream, one 1-KiB piece per (tile, unit), converted below; MI355_W_BF16: unquantised weights
 // (BASELINE configs[1]), four 1-KiB pieces per (tile, unit) whose piece d IS the A fragment of k-quarter d — same k
 // order as the int4 conversion produces, no conversion, scale 1 / zero-point 0 in the epilogue
-template <int EPI, bool PAIR, int FMT>
-__global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
+template <int EPI, bool PAIR, int FMT, int kWaves>
+__global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p) {
+    constexpr int kSlots = kWaves * kTPW;          // tile slots per block
+    constexpr int kThreads = 64 * kWaves;
+    constexpr int kXChunks = kBM * 16 / kThreads;  // 16-B activation chunks per thread and unit
     constexpr int kWP = FMT == MI355_W_BF16 ? 4 : 1;  // pieces per (tile, unit)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -109,10 +164,12 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
     // ranges, one per XCD (b % 8): the workgroups an XCD runs side by side share one or two token blocks
     const int n_blocks = p.n_blocks;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int L = xcd * p.per_xcd + j;
-    if (j >= p.per_xcd || L >= p.total_blocks) return;
+    const int L2 = xcd * p.per_xcd + j;
+    if (j >= p.per_xcd || L2 >= p.total_blocks * p.ksplit) return;
+    const int L = L2 / p.ksplit, ks = L2 - L * p.ksplit;  // (ksplit = 1: ks = 0, all units)
     const int mb = L / n_blocks, nb = L - mb * n_blocks;
     const int m0 = mb * kBM;
+    const int u_lo = slice_lo(ks, p.units, p.ksplit), u_hi = slice_lo(ks + 1, p.units, p.ksplit);
 
     // this wave's row tiles
     int tile[kTPW], rr[kTPW];
@@ -134,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
     auto wload = [&](int t, int u, u32x4 (&dst)[kWP]) {
         // past the last unit / tile the load goes through a zero-sized descriptor: the scalar offset operand of a raw
         // buffer load is NOT range-checked (an unconditional prefetch of unit `units` of the last tile faulted)
-        const bool ok = tile[t] < p.n_tiles && u < p.units;
+        const bool ok = tile[t] < p.n_tiles && u < u_hi;
         const unsigned off = (unsigned)((tile[t] * p.units + u) * (PAIR ? 2 : 1) + rr[t]) * (1024u * kWP);
 #pragma unroll
         for (int d = 0; d < kWP; ++d)
@@ -169,12 +226,12 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
 
     u32x4 wcur[kTPW][kWP], wnext[kTPW][kWP];
 #pragma unroll
-    for (int t = 0; t < kTPW; ++t) wload(t, 0, wcur[t]);
-    xload(0);
-    xstore(0);
+    for (int t = 0; t < kTPW; ++t) wload(t, u_lo, wcur[t]);
+    xload(u_lo);
+    xstore(u_lo & 1);
     __syncthreads();
 
-    for (int u = 0; u < p.units; ++u) {
+    for (int u = u_lo; u < u_hi; ++u) {
         const int buf = u & 1;
         // next unit's operands, requested UNCONDITIONALLY (a load inside `if (more)` makes hipcc drain vmcnt at the join,
         // i.e. wait for these very loads before the first MFMA): past the last unit the offsets fall into the next row /
@@ -241,12 +298,23 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
     for (int tt = 0; tt < 8; ++tt) {
         const int m = m0 + tt * 16 + c;
         if (m >= p.M) continue;
-        const float sxm = p.sx[m], ri = p.rinv[m];
+        const float sxm = p.sx[(int64_t)m * p.ksplit + ks], ri = p.rinv[m];
         float v[kTPW][4];
 #pragma unroll
         for (int t = 0; t < kTPW; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[t][r] = sc[t][r] * (acc[t][tt][r] - zp[t][r] * sxm) * ri;
+        if (p.ksplit > 1) {  // partial sums of this K-slice; the SwiGLU pair keeps c_fc1 at column n, c_fc2 at N + n
+            const int64_t ldp = PAIR ? 2 * (int64_t)p.N : (int64_t)p.N;
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) {
+                const int n = tile[t] * 16 + 4 * g;
+                if (n < p.N)
+                    *(f32x4*)(p.part + ((int64_t)ks * p.M + m) * ldp + (PAIR && rr[t] == 1 ? p.N : 0) + n) =
+                        f32x4{v[t][0], v[t][1], v[t][2], v[t][3]};
+            }
+            continue;
+        }
         if constexpr (EPI == MI355_EPI_SWIGLU) {
 #pragma unroll
             for (int t = 0; t < kTPW; t += 2) {
@@ -288,22 +356,38 @@ __global__ __launch_bounds__(kThreads) void gemm_q4_kernel(const GemmParams p) {
     }
 }
 
-template <int EPI, bool PAIR, int FMT>
-int launch_gemm(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row tiles (pair tiles for the SwiGLU stream)
-    static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR, FMT>,
+template <int EPI, bool PAIR, int FMT, int kWaves>
+int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row tiles (pair tiles for the SwiGLU stream)
+    static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR, FMT, kWaves>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute(gemm) failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
+    constexpr int kSlots = kWaves * kTPW;
     const int per_block = PAIR ? kSlots / 2 : kSlots;
     GemmParams q = p;
     q.n_blocks = (p.n_tiles + per_block - 1) / per_block;
     q.total_blocks = q.n_blocks * ((p.M + kBM - 1) / kBM);
-    q.per_xcd = (q.total_blocks + 7) / 8;
-    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR, FMT>), dim3(8 * q.per_xcd), dim3(kThreads), kLds, s, q);
+    q.per_xcd = (q.total_blocks * q.ksplit + 7) / 8;
+    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR, FMT, kWaves>), dim3(8 * q.per_xcd), dim3(64 * kWaves), kLds, s, q);
     MI355_LAUNCH_CHECK();
+    if (q.ksplit > 1) {
+        const int64_t n = (int64_t)p.M * (p.N >> 2);
+        const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3(grid), dim3(256), 0, s, q.part, q.ksplit, p.M, p.N, p.y, p.y_dtype, p.ldy);
+        MI355_LAUNCH_CHECK();
+    }
     return 0;
+}
+template <int EPI, bool PAIR, int FMT>
+int launch_gemm(const GemmParams& p, hipStream_t s) {
+    // blocks of 16 row tiles if that still gives the chip something to do, blocks of 4 otherwise
+    const int per_block8 = PAIR ? 8 * kTPW / 2 : 8 * kTPW;
+    const int blocks8 = ((p.n_tiles + per_block8 - 1) / per_block8) * ((p.M + kBM - 1) / kBM);
+    if (blocks8 >= 128 || p.ksplit > 1) return launch_gemm_w<EPI, PAIR, FMT, 8>(p, s);  // (split-K brings the blocks)
+    if (blocks8 * 4 >= 128) return launch_gemm_w<EPI, PAIR, FMT, 2>(p, s);
+    return launch_gemm_w<EPI, PAIR, FMT, 1>(p, s);
 }
 template <int FMT>
 int launch_gemm_epi(const GemmParams& p, int epi, hipStream_t s) {
@@ -317,7 +401,8 @@ int launch_gemm_epi(const GemmParams& p, int epi, hipStream_t s) {
 extern "C" size_t mi355_linear_gemm_workspace_bytes(int M, int K) {
     if (M <= 0 || K <= 0) return 0;
     const size_t kp = ((size_t)K + 127) / 128 * 128;
-    return (size_t)M * kp * 2 + (size_t)M * 8 + 256;
+    // staged operands, 1/rms, per-slice operand sums, split-K partials (used when a launch would be a few dozen blocks)
+    return (size_t)M * kp * 2 + (size_t)M * 4 * (1 + kMaxSplit) + 256 + kSplitBudget;
 }
 
 extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, size_t workspace_bytes,
@@ -347,8 +432,21 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
     bf16_t* xb = (bf16_t*)workspace;
     float* rinv = (float*)((char*)workspace + (size_t)a->M * kp * 2);
     float* sx = rinv + a->M;
+    // split-K: launches of fewer than 96 blocks (a 128-token prompt against N = 4096 is 16) cut K into up to 8
+    // slices, as many as bring the launch to ~128 workgroups and fit the partial buffer
+    int ksplit = 1;
+    {
+        const int rows_per_block = swiglu ? 16 * 8 * kTPW / 2 : 16 * 8 * kTPW;
+        const int blocks8 = ((a->N + rows_per_block - 1) / rows_per_block) * ((a->M + kBM - 1) / kBM);
+        const size_t row_floats = (size_t)a->N * (swiglu ? 2 : 1);
+        while (ksplit < kMaxSplit && blocks8 * ksplit < 96 && units >= 8 * ksplit &&
+               (size_t)2 * ksplit * a->M * row_floats * 4 <= kSplitBudget)
+            ksplit *= 2;
+    }
+    float* part = (float*)((char*)workspace + (size_t)a->M * kp * 2 + (size_t)a->M * 4 * (1 + kMaxSplit) + 256);
+    part = (float*)(((uintptr_t)part + 15) & ~(uintptr_t)15);
     hipLaunchKernelGGL(stage_rows_kernel, dim3(a->M), dim3(256), 0, s, a->x, a->x_dtype, a->ldx, a->norm_scale, a->norm_dtype,
-                       a->eps, a->K, kp, xb, (int64_t)kp, rinv, sx);
+                       a->eps, a->K, kp, xb, (int64_t)kp, rinv, sx, ksplit);
     MI355_LAUNCH_CHECK();
     GemmParams p;
     memset(&p, 0, sizeof(p));
@@ -376,6 +474,8 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
     p.n_tiles = (a->N + 15) / 16;
     p.sz_dtype = a->sz_dtype;
     p.y_dtype = a->y_dtype;
+    p.ksplit = ksplit;
+    p.part = part;
     if (q4) return launch_gemm_epi<MI355_W_Q4>(p, a->epi, s);
     return launch_gemm_epi<MI355_W_BF16>(p, a->epi, s);
 }

@@ -530,7 +530,10 @@ def test_int8_linear_matches_oracle(dev, N, K, M, R, outliers):
 # ---------------------------------------------------------------------------------------------- wide int4 GEMM (prefill)
 @pytest.mark.parametrize("M,N,K,epi", [(32, 64, 128, "store"), (128, 4096, 4096, "store"), (200, 4096, 4096, "accum"),
                                         (257, 11008, 4096, "swiglu"), (96, 4096, 11008, "accum"), (40, 72, 200, "store"),
-                                        (512, 12288, 4096, "store")])
+                                        (512, 12288, 4096, "store"),
+                                        # short prompts against N = 4096 / 12288: few blocks -> deterministic split-K (8 / 4 / 2 slices)
+                                        (128, 4096, 4096, "accum"), (128, 4096, 11008, "store"), (200, 4096, 4096, "store"),
+                                        (128, 12288, 4096, "store"), (128, 11008, 4096, "swiglu")])
 def test_linear_gemm_matches_the_skinny_kernel_and_oracle(dev, M, N, K, epi):
     """mi355_linear_gemm (LDS-tiled MFMA GEMM over the Q4 stream) against (a) the CPU oracle's dequantise-then-F.linear
     (lit_llama/quantization.py:422-423) within the bf16-operand tolerance and (b) the skinny weight-streaming kernel,
@@ -590,7 +593,7 @@ def test_linear_gemm_with_fused_rmsnorm_matches_the_skinny_kernel(dev):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(32, 64, 128, "store"), (200, 4096, 4096, "accum"), (257, 11008, 4096, "swiglu"),
-                                        (96, 4096, 11008, "store"), (40, 72, 200, "store")])
+                                        (96, 4096, 11008, "store"), (40, 72, 200, "store"), (128, 4096, 4096, "accum")])
 def test_linear_gemm_over_the_bf16_stream(dev, M, N, K, epi):
     """The same GEMM over UNQUANTISED weights (BASELINE configs[1]; FMT = BF16 of csrc/gemm.hip: a stream piece is an MFMA
     A fragment as it lies) against x @ W^T in f32 on the CPU (nn.Linear of lit_llama/model.py:57,177-179,247-249) within
