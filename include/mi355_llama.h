@@ -288,6 +288,14 @@ typedef struct mi355_int8_args {
 
 int mi355_linear_int8(const mi355_int8_args* a, mi355_stream_t stream);
 
+/* The same linear for WIDE inputs (M >= 32 rows: prompt prefill, no-cache evaluation; csrc/int8_gemm.hip): the outlier column
+ * set is determined over ALL M rows of the call, as MatMul8bitLt does (mi355_linear_int8 takes <= 16 rows per launch and a
+ * caller that chunks a longer input gets a per-chunk set), the int8 product runs on the MFMA over 128-row blocks.  bias and
+ * attn_partials must be NULL; waves / grid / prefetch are ignored.  workspace: mi355_linear_int8_gemm_workspace_bytes(M, K)
+ * bytes, 16-B aligned, scratch (f16 operands, int8 operands, row absmax, column mask, outlier list). */
+size_t mi355_linear_int8_gemm_workspace_bytes(int M, int K);
+int mi355_linear_int8_gemm(const mi355_int8_args* a, void* workspace, size_t workspace_bytes, mi355_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * GPTQ weight quantisation (offline producer of the int4 checkpoint format).
  * One block (<= 128 columns) of GPTQQuantizer.quantize's inner loop, lit_llama/quantization.py:573-592,

@@ -155,6 +155,8 @@ PROTOTYPES = {
     "mi355_kv_roll": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mi355_int8_quant_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mi355_linear_int8": (c_int, [C.POINTER(Int8Args), c_void_p]),
+    "mi355_linear_int8_gemm_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mi355_linear_int8_gemm": (c_int, [C.POINTER(Int8Args), c_void_p, c_size_t, c_void_p]),
     "mi355_set_step": (c_int, [C.POINTER(Model), c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mi355_forward": (c_int, [C.POINTER(Model), c_int, c_int, c_int, c_void_p]),
     "mi355_forward_embed": (c_int, [C.POINTER(Model), c_int, c_void_p]),

@@ -110,6 +110,31 @@ int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x
         a.ldy = ldy;
         return mi355_linear_gemm(&a, m->gemm_ws, (size_t)m->gemm_ws_bytes, s);
     }
+    if (w.fmt == MI355_W_I8 && M >= 32 && m->gemm_ws != nullptr && attn_partials == nullptr &&
+        (size_t)m->gemm_ws_bytes >= mi355_linear_int8_gemm_workspace_bytes(M, w.K)) {
+        // LLM.int8 prompt chunks: outlier columns over the whole chunk, int8 product on the MFMA (csrc/int8_gemm.hip)
+        mi355_int8_args a;
+        memset(&a, 0, sizeof(a));
+        a.w = (const int8_t*)w.w;
+        a.scb = w.scb;
+        a.scb2 = w.scb2;
+        a.N = w.N;
+        a.K = w.K;
+        a.x = x;
+        a.x_dtype = x_dtype;
+        a.M = M;
+        a.ldx = ldx;
+        a.norm_scale = norm_scale;
+        a.norm_dtype = m->param_dtype;
+        a.eps = m->eps;
+        a.threshold = m->int8_threshold;
+        a.R = w.R;
+        a.epi = epi;
+        a.y = y;
+        a.y_dtype = y_dtype;
+        a.ldy = ldy;
+        return mi355_linear_int8_gemm(&a, m->gemm_ws, (size_t)m->gemm_ws_bytes, s);
+    }
     int cap = mi355_linear_max_rows(w.fmt, w.K, w.R, w.waves);
     if (w.fmt == MI355_W_Q4 && w.group_cols > 0 && w.group_cols < w.K) {
         // the tile's (scale, zero) table shares the LDS with the activation rows: 2 x 16 R x groups dwords

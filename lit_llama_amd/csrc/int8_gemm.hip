@@ -1,0 +1,427 @@
+// Wide (M >= 32 tokens) LLM.int8 linear for gfx950: prompt prefill / no-cache evaluation of a `--quantize llm.int8` model.
+//
+// Replaces, for B * T >= 32 rows, bitsandbytes' MatMul8bitLt forward as Linear8bitLt reaches it
+// (/root/reference lit_llama/quantization.py:38-77; the algorithm is restated in oracle/oracle.py::llm_int8_linear — PARITY
+// UNPINNED: bitsandbytes is not vendored).  The skinny kernel (int8.hip) feeds such inputs in chunks
+// of <= 16 rows and determines the outlier COLUMN set per chunk; this path determines it over all rows of the call, as the
+// algorithm does, and runs the int8 product on v_mfma_i32_16x16x64_i8 over 128-token blocks:
+//   1. i8_stage_kernel   (one workgroup per row) — xh = f16(norm_scale * x * 1/rms) (or f16(x)), the row's absmax over its
+//                        sub-threshold entries, and the column mask |xh| >= threshold OR-ed over all rows (atomicOr: order
+//                        does not matter);
+//   2. i8_quant_kernel   — CA = rint(xh * 127 / absmax) with the masked columns zeroed, int8; workgroup 0 also writes the
+//                        ascending list of outlier columns;
+//   3. i8_gemm_kernel    — the int8 weight stream of int8.hip ([tile][unit][r][piece e][lane][16 x int8], one piece = one
+//                        MFMA A operand) against CA staged through LDS (128 tokens x 128 k, XOR-swizzled), two row tiles per
+//                        wave, 8 waves; epilogue with the arithmetic of int8.hip, rounding for rounding:
+//                            d = f16((acc * 6.200012e-05 * absmax[m]) * SCB[n]);   o = sum over outlier columns k (ascending) of
+//                            xh[m, k] * f16(CB[n, k] * SCB[n] / 127);   y = f16(d + f16(o))   (the last step only with outliers)
+//                        the outlier operands of the block (128 tokens x n_out, 256 rows x n_out) are staged in LDS first.
+#include "common.h"
+
+namespace {
+
+constexpr int kBM = 128;      // tokens per block
+constexpr int kTPW = 2;       // 16-row tile slots per wave
+constexpr int kWaves = 8;
+constexpr int kSlots = kWaves * kTPW;
+constexpr int kThreads = 64 * kWaves;
+constexpr int kXTile = kBM * 128;        // bytes of one activation tile (int8)
+constexpr int kOutChunk = 64;            // outlier columns staged per pass of the epilogue
+constexpr int kLdsMain = 2 * kXTile;
+constexpr int kLdsEpi = (kBM + kSlots * 16) * kOutChunk * 2;  // f16 [128 tokens + 256 rows][kOutChunk]
+constexpr int kLds = kLdsMain > kLdsEpi ? kLdsMain : kLdsEpi;
+
+__device__ __forceinline__ float f16r(float v) { return f16_to_f32(f32_to_f16(v)); }
+// 16-B chunk swizzle of a 128-B activation row in LDS: rows alternate bank halves (128-B pitch), pairs of rows rotate the
+// 8 chunks — the 16 lanes a ds_read_b128 serves together (tokens {0-3, 12-15} with one k-group, {4-11} with the next)
+// land in 16 different bank groups
+__device__ __forceinline__ int swz8(int tok) { return (tok >> 1) & 7; }
+
+struct I8GemmParams {
+    const uint8_t* w;
+    unsigned w_bytes;
+    const int8_t* ca;      // [M, Kp]
+    const f16_t* xh;       // [M, Kp]
+    const float* sca;      // [M] row absmax
+    const int* olist;      // [0] = n_out, [1 ..] ascending outlier columns
+    const float* scb;
+    const float* scb2;
+    void* y;
+    int64_t ldy;
+    int M, N, K, Kp, units, n_tiles, n_blocks, per_xcd, total_blocks;
+    int y_dtype;
+};
+
+// ---- 1. rows: f16 operand, absmax over the sub-threshold entries, outlier column mask
+__global__ __launch_bounds__(256) void i8_stage_kernel(const void* x, int x_dtype, int64_t ldx, const void* norm_scale,
+                                                       int norm_dtype, float eps, float threshold, int K, int Kp, f16_t* xh,
+                                                       float* sca, unsigned* mask) {
+    __shared__ float red[32];
+    const int m = blockIdx.x;
+    float rinv = 1.f;
+    if (norm_scale != nullptr) {
+        float ss = 0.f;
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            const float v = ld_as_f32(x, (int64_t)m * ldx + k, x_dtype);
+            ss += v * v;
+        }
+        rinv = rsqrtf(block_sum(ss, red) / (float)K + eps);
+    }
+    float amax = 0.f;
+    for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+        f16_t h = 0;
+        if (k < K) {
+            float v = ld_as_f32(x, (int64_t)m * ldx + k, x_dtype);
+            if (norm_scale != nullptr) v = ld_as_f32(norm_scale, k, norm_dtype) * (v * rinv);
+            h = f32_to_f16(v);
+            const float a = fabsf(f16_to_f32(h));
+            if (threshold > 0.f && a >= threshold)
+                atomicOr(mask + (k >> 5), 1u << (k & 31));
+            else
+                amax = fmaxf(amax, a);
+        }
+        xh[(int64_t)m * Kp + k] = h;
+    }
+    amax = block_max(amax, red);
+    if (threadIdx.x == 0) sca[m] = amax;
+}
+
+// ---- 2. rows: int8 operand; workgroup 0: the outlier list
+__global__ __launch_bounds__(256) void i8_quant_kernel(const f16_t* xh, const float* sca, const unsigned* mask, int Kp, int8_t* ca,
+                                                       int* olist) {
+    const int m = blockIdx.x;
+    const float a = sca[m];
+    const float inv = a > 0.f ? __fdiv_rn(127.0f, a) : 0.f;  // IEEE division: parity with the oracle
+    for (int k4 = threadIdx.x; k4 < Kp / 4; k4 += blockDim.x) {
+        const int k = 4 * k4;
+        const unsigned mw = mask[k >> 5] >> (k & 31);
+        const u32x2 hv = *(const u32x2*)(xh + (int64_t)m * Kp + k);
+        uint32_t q4 = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16_t h = (f16_t)((j & 1) ? (hv[j >> 1] >> 16) : (hv[j >> 1] & 0xffffu));
+            const float q = ((mw >> j) & 1u) ? 0.f : rintf(f16_to_f32(h) * inv);
+            q4 |= ((uint32_t)(int)q & 0xffu) << (8 * j);
+        }
+        *(uint32_t*)(ca + (int64_t)m * Kp + k) = q4;
+    }
+    if (m == 0 && threadIdx.x == 0) {
+        int n = 0;
+        for (int w = 0; w < Kp / 32; ++w) {
+            unsigned bits = mask[w];
+            while (bits != 0u) {
+                const int b = __builtin_ctz(bits);
+                olist[1 + n++] = w * 32 + b;
+                bits &= bits - 1u;
+            }
+        }
+        olist[0] = n;
+    }
+}
+
+// ---- 3. the product
+template <int EPI, bool PAIR>
+__global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3;
+    const int L = xcd * p.per_xcd + j0;
+    if (j0 >= p.per_xcd || L >= p.total_blocks) return;
+    const int mb = L / p.n_blocks, nb = L - mb * p.n_blocks;
+    const int m0 = mb * kBM;
+    constexpr int R = PAIR ? 2 : 1;
+
+    int tile[kTPW], rr[kTPW];
+#pragma unroll
+    for (int t = 0; t < kTPW; ++t) {
+        if (PAIR) {
+            tile[t] = nb * (kSlots / 2) + (kTPW / 2) * wave + (t >> 1);  // pair tile: 16 rows of c_fc1 (r = 0) and c_fc2 (r = 1)
+            rr[t] = t & 1;
+        } else {
+            tile[t] = nb * kSlots + kTPW * wave + t;
+            rr[t] = 0;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.ca, 0, (int)((int64_t)p.M * p.Kp), 0x00020000);
+    const unsigned lane_off = lane * 16;
+    auto wload = [&](int t, int u, u32x4 (&dst)[2]) {
+        const bool ok = tile[t] < p.n_tiles && u < p.units;
+        const unsigned off = (unsigned)((tile[t] * p.units + u) * R + rr[t]) * 2048u;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            dst[e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rw : rw0, lane_off, ok ? off + e * 1024u : 0u, 0));
+    };
+    // activation tile of unit u: 1024 chunks of 16 B, two per thread; chunk = (token, 16-B column)
+    u32x4 stage[2];
+    auto xload = [&](int u) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = i * kThreads + threadIdx.x;
+            const int tok = ch >> 3, col = ch & 7;
+            const unsigned off = (unsigned)((int64_t)(m0 + tok) * p.Kp) + (unsigned)u * 128u + (unsigned)col * 16u;
+            stage[i] = __builtin_bit_cast(
+                u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ((m0 + tok) < p.M && u < p.units) ? off : 0xFFFFFFF0u, 0, 0));
+        }
+    };
+    auto xstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = i * kThreads + threadIdx.x;
+            const int tok = ch >> 3, col = ch & 7;
+            *(u32x4*)(smem + buf * kXTile + tok * 128 + ((col ^ swz8(tok)) << 4)) = stage[i];
+        }
+    };
+
+    i32x4 acc[kTPW][8];
+#pragma unroll
+    for (int t = 0; t < kTPW; ++t)
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) acc[t][tt] = i32x4{0, 0, 0, 0};
+
+    u32x4 wcur[kTPW][2], wnext[kTPW][2];
+#pragma unroll
+    for (int t = 0; t < kTPW; ++t) wload(t, 0, wcur[t]);
+    xload(0);
+    xstore(0);
+    __syncthreads();
+    for (int u = 0; u < p.units; ++u) {
+        const int buf = u & 1;
+        xload(u + 1);  // unconditional: past the last unit the offsets are out of the descriptor (zeros, no traffic)
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
+        const char* xs = smem + buf * kXTile;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const int tok = tt * 16 + c;
+                const i32x4 b = *(const i32x4*)(xs + tok * 128 + (((4 * e + g) ^ swz8(tok)) << 4));
+#pragma unroll
+                for (int t = 0; t < kTPW; ++t)
+                    acc[t][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wcur[t][e]), b, acc[t][tt], 0, 0, 0);
+            }
+        }
+        xstore(buf ^ 1);
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t) {
+            wcur[t][0] = wnext[t][0];
+            wcur[t][1] = wnext[t][1];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  lane (g, c) holds rows 4 g .. 4 g + 3 of its tiles for token tt * 16 + c
+    float scb[kTPW][4];
+#pragma unroll
+    for (int t = 0; t < kTPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = tile[t] * 16 + 4 * g + r;
+            scb[t][r] = n < p.N ? ((PAIR && rr[t] == 1) ? p.scb2 : p.scb)[n] : 0.f;
+        }
+    float d[kTPW][8][4];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+        const int m = m0 + tt * 16 + c;
+        const float sa = m < p.M ? p.sca[m] : 0.f;
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[t][tt][r] = f16r((((float)acc[t][tt][r] * 6.200012e-05f) * sa) * scb[t][r]);
+    }
+    const int n_out = p.olist[0];
+    if (n_out > 0) {
+        // mixed-precision decomposition: the outlier columns in f16, ascending k, kOutChunk columns per pass through LDS
+        f16_t* xo = (f16_t*)smem;                     // [128 tokens][kOutChunk]
+        f16_t* so = xo + kBM * kOutChunk;             // [kSlots x 16 rows][kOutChunk]: f16(CB[n, k] * SCB[n] / 127)
+        float o[kTPW][8][4];
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t)
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[t][tt][r] = 0.f;
+        for (int base = 0; base < n_out; base += kOutChunk) {
+            const int nc = n_out - base < kOutChunk ? n_out - base : kOutChunk;
+            __syncthreads();  // (the main loop / the previous pass is done with the LDS)
+            for (int idx = threadIdx.x; idx < kBM * nc; idx += kThreads) {
+                const int tok = idx / nc, i = idx - tok * nc;
+                const int m = m0 + tok;
+                xo[tok * kOutChunk + i] = m < p.M ? p.xh[(int64_t)m * p.Kp + p.olist[1 + base + i]] : (f16_t)0;
+            }
+            for (int idx = threadIdx.x; idx < kSlots * 16 * nc; idx += kThreads) {
+                const int sr = idx / nc, i = idx - sr * nc;  // sr = slot * 16 + row
+                const int slot = sr >> 4, row = sr & 15;
+                const int wv = slot / kTPW, t = slot - wv * kTPW;
+                int tl, r1;
+                if (PAIR) {
+                    tl = nb * (kSlots / 2) + (kTPW / 2) * wv + (t >> 1);
+                    r1 = t & 1;
+                } else {
+                    tl = nb * kSlots + kTPW * wv + t;
+                    r1 = 0;
+                }
+                const int n = tl * 16 + row;
+                f16_t sub = 0;
+                if (tl < p.n_tiles && n < p.N) {
+                    const int k = p.olist[1 + base + i];
+                    const int u = k >> 7, e = (k >> 6) & 1, gg = (k >> 4) & 3, jj = k & 15;
+                    const int64_t off = ((((int64_t)tl * p.units + u) * R + r1) * 2 + e) * 1024 + (gg * 16 + row) * 16 + jj;
+                    const float cb = (float)(int8_t)p.w[off];
+                    const float s = ((PAIR && r1 == 1) ? p.scb2 : p.scb)[n];
+                    sub = f32_to_f16(__fdiv_rn(cb * s, 127.0f));
+                }
+                so[sr * kOutChunk + i] = sub;
+            }
+            __syncthreads();
+            for (int i = 0; i < nc; ++i) {
+                float sv[kTPW][4];
+#pragma unroll
+                for (int t = 0; t < kTPW; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sv[t][r] = f16_to_f32(so[((wave * kTPW + t) * 16 + 4 * g + r) * kOutChunk + i]);
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) {
+                    const float xv = f16_to_f32(xo[(tt * 16 + c) * kOutChunk + i]);
+#pragma unroll
+                    for (int t = 0; t < kTPW; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[t][tt][r] += xv * sv[t][r];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t)
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[t][tt][r] = f16r(d[t][tt][r] + f16r(o[t][tt][r]));
+    }
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+        const int m = m0 + tt * 16 + c;
+        if (m >= p.M) continue;
+        if constexpr (EPI == MI355_EPI_SWIGLU) {
+#pragma unroll
+            for (int t = 0; t < kTPW; t += 2) {
+                const int n = tile[t] * 16 + 4 * g;
+                if (tile[t] < p.n_tiles && n < p.N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N)
+                            st_from_f32(p.y, (int64_t)m * p.ldy + n + r, p.y_dtype, swiglu_f32(d[t][tt][r], d[t + 1][tt][r]));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) {
+                const int n = tile[t] * 16 + 4 * g;
+                if (tile[t] >= p.n_tiles) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r >= p.N) continue;
+                    const int64_t yi = (int64_t)m * p.ldy + n + r;
+                    float v = d[t][tt][r];
+                    if constexpr (EPI == MI355_EPI_ACCUM) v += ld_as_f32(p.y, yi, p.y_dtype);
+                    st_from_f32(p.y, yi, p.y_dtype, v);
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, bool PAIR>
+int launch_i8_gemm(const I8GemmParams& p, hipStream_t s) {
+    static hipError_t attr_err =
+        hipFuncSetAttribute((const void*)i8_gemm_kernel<EPI, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (attr_err != hipSuccess) {
+        mi355_set_error("hipFuncSetAttribute(i8_gemm) failed: %s", hipGetErrorString(attr_err));
+        return (int)attr_err;
+    }
+    const int per_block = PAIR ? kSlots / 2 : kSlots;
+    I8GemmParams q = p;
+    q.n_blocks = (p.n_tiles + per_block - 1) / per_block;
+    q.total_blocks = q.n_blocks * ((p.M + kBM - 1) / kBM);
+    q.per_xcd = (q.total_blocks + 7) / 8;
+    hipLaunchKernelGGL((i8_gemm_kernel<EPI, PAIR>), dim3(8 * q.per_xcd), dim3(kThreads), kLds, s, q);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t pad16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+}  // namespace
+
+extern "C" size_t mi355_linear_int8_gemm_workspace_bytes(int M, int K) {
+    if (M <= 0 || K <= 0) return 0;
+    const size_t kp = ((size_t)K + 127) / 128 * 128;
+    // xh f16 [M, Kp], CA int8 [M, Kp], absmax [M], column mask [Kp / 32], outlier list [1 + Kp]
+    return pad16((size_t)M * kp * 2) + pad16((size_t)M * kp) + pad16((size_t)M * 4) + pad16(kp / 8) + pad16((1 + kp) * 4) + 256;
+}
+
+extern "C" int mi355_linear_int8_gemm(const mi355_int8_args* a, void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
+    MI355_CHECK_ARG(a != nullptr && workspace != nullptr && a->w && a->scb && a->x && a->y, MI355_E_ARG, "linear_int8_gemm: null argument");
+    MI355_CHECK_ARG(a->R == 1 || a->R == 2, MI355_E_ARG, "linear_int8_gemm: R must be 1 or 2");
+    MI355_CHECK_ARG(a->M >= 1 && a->N > 0 && a->K > 0, MI355_E_SHAPE, "linear_int8_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+    MI355_CHECK_ARG(a->epi >= MI355_EPI_STORE && a->epi <= MI355_EPI_SWIGLU, MI355_E_ARG, "linear_int8_gemm: bad epi");
+    const bool swiglu = a->epi == MI355_EPI_SWIGLU;
+    MI355_CHECK_ARG(swiglu ? (a->R == 2 && a->scb2) : a->R == 1, MI355_E_ARG,
+                    "linear_int8_gemm: STORE / ACCUM take the R = 1 stream, SWIGLU the interleaved R = 2 stream");
+    MI355_CHECK_ARG(a->bias == nullptr && a->attn_partials == nullptr, MI355_E_ARG, "linear_int8_gemm: no bias / attention prologue");
+    auto three = [](int d) { return d == MI355_F32 || d == MI355_BF16 || d == MI355_F16; };
+    MI355_CHECK_ARG(three(a->x_dtype) && three(a->y_dtype), MI355_E_DTYPE, "linear_int8_gemm: x / y dtype");
+    MI355_CHECK_ARG(a->norm_scale == nullptr || three(a->norm_dtype), MI355_E_DTYPE, "linear_int8_gemm: norm scale dtype");
+    MI355_CHECK_ARG(workspace_bytes >= mi355_linear_int8_gemm_workspace_bytes(a->M, a->K) && (uintptr_t)workspace % 16 == 0,
+                    MI355_E_SHAPE, "linear_int8_gemm: workspace of %zu bytes is too small (need %zu)", workspace_bytes,
+                    mi355_linear_int8_gemm_workspace_bytes(a->M, a->K));
+    hipStream_t s = (hipStream_t)stream;
+    const int units = (a->K + 127) / 128, kp = units * 128;
+    MI355_CHECK_ARG((size_t)a->M * kp < 0xFFFFFFF0ull, MI355_E_SHAPE, "linear_int8_gemm: M x K too large for one launch");
+    char* ws = (char*)workspace;
+    f16_t* xh = (f16_t*)ws;
+    ws += pad16((size_t)a->M * kp * 2);
+    int8_t* ca = (int8_t*)ws;
+    ws += pad16((size_t)a->M * kp);
+    float* sca = (float*)ws;
+    ws += pad16((size_t)a->M * 4);
+    unsigned* mask = (unsigned*)ws;
+    ws += pad16((size_t)kp / 8);
+    int* olist = (int*)ws;
+    MI355_HIP(hipMemsetAsync(mask, 0, (size_t)kp / 8, s));
+    hipLaunchKernelGGL(i8_stage_kernel, dim3(a->M), dim3(256), 0, s, a->x, a->x_dtype, a->ldx, a->norm_scale, a->norm_dtype, a->eps,
+                       a->threshold, a->K, kp, xh, sca, mask);
+    MI355_LAUNCH_CHECK();
+    hipLaunchKernelGGL(i8_quant_kernel, dim3(a->M), dim3(256), 0, s, xh, sca, mask, kp, ca, olist);
+    MI355_LAUNCH_CHECK();
+    I8GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.w = (const uint8_t*)a->w;
+    {
+        const size_t wb = mi355_packed_bytes(MI355_W_I8, a->N, a->K, a->R, swiglu ? 1 : 0);
+        MI355_CHECK_ARG(wb > 0 && wb < 0xFFFFFFF0ull, MI355_E_SHAPE, "linear_int8_gemm: weight stream of %zu B", wb);
+        p.w_bytes = (unsigned)wb;
+    }
+    p.ca = ca;
+    p.xh = xh;
+    p.sca = sca;
+    p.olist = olist;
+    p.scb = a->scb;
+    p.scb2 = a->scb2;
+    p.y = a->y;
+    p.ldy = a->ldy;
+    p.M = a->M;
+    p.N = a->N;
+    p.K = a->K;
+    p.Kp = kp;
+    p.units = units;
+    p.n_tiles = (a->N + 15) / 16;
+    p.y_dtype = a->y_dtype;
+    if (swiglu) return launch_i8_gemm<MI355_EPI_SWIGLU, true>(p, s);
+    if (a->epi == MI355_EPI_ACCUM) return launch_i8_gemm<MI355_EPI_ACCUM, false>(p, s);
+    return launch_i8_gemm<MI355_EPI_STORE, false>(p, s);
+}

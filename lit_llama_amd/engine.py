@@ -250,9 +250,10 @@ class DecodeEngine:
             # most of it the f32 logits rows).  Large chunks matter: the [n_embd]-wide outputs (c_proj, mlp.c_proj) are
             # 16 row blocks, so 512 tokens fill only a quarter of the chip (9 % vs 27-36 % of the MFMA peak at 2048)
             self.gemm_ws = None
-            if kinds <= {"q4", "bf16"} and _env_int("MI355_PREFILL_GEMM", 1):
+            if kinds <= {"q4", "bf16", "i8"} and _env_int("MI355_PREFILL_GEMM", 1):
                 max_T = max(max_T, min(_env_int("MI355_PREFILL_T", 2048), cfg.block_size))
-                need = int(lib().mi355_linear_gemm_workspace_bytes(max_T, max(C_, self.n_hidden)))
+                need = max(int(lib().mi355_linear_gemm_workspace_bytes(max_T, max(C_, self.n_hidden))),
+                           int(lib().mi355_linear_int8_gemm_workspace_bytes(max_T, max(C_, self.n_hidden))))
                 self.gemm_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             self.max_T = max_T
 

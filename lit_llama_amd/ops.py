@@ -211,6 +211,34 @@ def linear_gemm(x2d: torch.Tensor, stream: torch.Tensor, R: int, N: int, K: int,
     return out
 
 
+def linear_int8_gemm(x2d: torch.Tensor, stream: torch.Tensor, scb: torch.Tensor, R: int, N: int, K: int, *,
+                     scb2: Optional[torch.Tensor] = None, norm_scale: Optional[torch.Tensor] = None, eps: float = 1e-5,
+                     threshold: float = 6.0, epi: int = EPI_STORE, out: Optional[torch.Tensor] = None,
+                     out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """LLM.int8 linear for WIDE inputs (mi355_linear_int8_gemm, csrc/int8_gemm.hip): outlier columns over all rows of the
+    call (what MatMul8bitLt does), int8 product on the MFMA over 128-row blocks."""
+    require_gpu(x2d, "linear_int8_gemm")
+    assert x2d.dim() == 2 and x2d.shape[1] == K and x2d.stride(1) == 1 and scb.dtype == torch.float32
+    M = x2d.shape[0]
+    if out is None:
+        assert epi != EPI_ACCUM
+        out = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
+    need = int(lib().mi355_linear_int8_gemm_workspace_bytes(M, K))
+    ws = _GEMM_WS.get(x2d.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 22), dtype=torch.uint8, device=x2d.device)
+        _GEMM_WS[x2d.device] = ws
+    a = Int8Args()
+    a.w, a.scb, a.scb2, a.N, a.K, a.M, a.R = ptr(stream), ptr(scb), ptr(scb2), N, K, M, R
+    a.x, a.x_dtype, a.ldx = ptr(x2d), dtype_code(x2d.dtype), x2d.stride(0)
+    a.norm_scale = ptr(norm_scale)
+    a.norm_dtype = dtype_code(norm_scale.dtype) if norm_scale is not None else F32
+    a.eps, a.threshold, a.epi = eps, threshold, epi
+    a.y, a.y_dtype, a.ldy = ptr(out), dtype_code(out.dtype), out.stride(0)
+    check(lib().mi355_linear_int8_gemm(C.byref(a), ptr(ws), ws.numel(), stream_ptr()), "mi355_linear_int8_gemm")
+    return out
+
+
 def linear_int8(
     x2d: torch.Tensor,
     stream: torch.Tensor,
@@ -232,7 +260,8 @@ def linear_int8(
     prefetch: int = 0,
     attn_partials: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
-    """LLM.int8 linear (mi355_linear_int8).  Known deviation from bitsandbytes for M > the LDS chunk (<= 16 rows):
+    """LLM.int8 linear (mi355_linear_int8; inputs of >= 32 rows without a bias go to linear_int8_gemm, which has no such
+    deviation).  Known deviation from bitsandbytes for M > the LDS chunk (<= 16 rows):
     the rows are fed in chunks and the outlier COLUMN set (|x| >= threshold anywhere in the column) is determined
     per chunk, whereas MatMul8bitLt determines it over all B * T rows — a column that is an outlier in one chunk only
     takes the int8 path in the others.  Decode (M = 1) and prompts of up to one chunk are unaffected; prefill logits
@@ -263,6 +292,9 @@ def linear_int8(
         assert attn_partials.dtype == torch.float32 and attn_partials.dim() == 4 and M == 1
         a.attn_partials = ptr(attn_partials)
         a.attn_heads, a.attn_splits, a.attn_hs = attn_partials.shape[1], attn_partials.shape[2], attn_partials.shape[3] - 4
+    if M >= 32 and bias is None and attn_partials is None:
+        return linear_int8_gemm(x2d, stream, scb, R, N, K, scb2=scb2, norm_scale=norm_scale, eps=eps, threshold=threshold,
+                                epi=epi, out=out)
     step = fast_linear_max_m(K, R, W_I8, waves or 8)
     if step < 1:
         raise nat.NativeError(f"linear_int8: K={K} does not fit LDS even for M=1")

@@ -156,3 +156,35 @@ def test_bf16_model_prompt_takes_the_wide_path_and_matches_oracle(dev):
     ref2 = om(toks.view(1, -1).long())[0].float()
     e2 = check(got2, ref2, "bf16 no-cache forward")
     print(f"bf16 7B-width layer, {T} tokens: engine prefill {e1:.4f} std, module path {e2:.4f} std")
+
+
+@torch.no_grad()
+def test_llm_int8_prompt_takes_the_int8_gemm_and_matches_oracle(dev):
+    """BASELINE configs[3]: a 100-token prompt of a 7B-width llm.int8 layer through the engine — mi355_linear_int8_gemm (outlier
+    columns over the whole prompt, as MatMul8bitLt determines them; the streaming kernel's <= 16-row chunks each had their own
+    set) + flash attention — and the module path (Linear8bitLt.forward on 100 rows), against the oracle's restatement
+    (PARITY UNPINNED: bitsandbytes is not vendored).  The band is the one of the int8 decode test: int8 rounding of the
+    activations, not kernel error, sets it."""
+    cfg = LLaMAConfig(**W7B)
+    sd = synth.make_state_dict(cfg, seed=8, mode="llm.int8", dtype=torch.bfloat16, outlier_channels=8)
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="llm.int8"):
+        model = LLaMA(cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    om = oracle.Model(oracle.Config(**W7B), {k: v.float() for k, v in sd.items()}, mode="llm.int8")
+    eng = model.engine()
+    assert eng is not None and eng.gemm_ws is not None and eng.max_T >= 512, model._engine_failed
+    T, S = 100, 112
+    toks = synth.make_prompt(T, seed=14)
+    got = model(toks.view(1, -1).to(dev), S, _pos(T, dev))[0].float().cpu()
+    ref = om(toks.view(1, -1), S, torch.arange(T))[0].float()
+    std = float(ref.std(-1).mean())
+    e1 = (got - ref).abs().max().item() / std
+    assert e1 <= 0.15, f"int8 prefill through the engine: {e1:.4f} std"
+    model.reset_cache()
+    om.reset_cache()
+    got2 = model(toks.view(1, -1).long().to(dev))[0].float().cpu()
+    ref2 = om(toks.view(1, -1).long())[0].float()
+    e2 = (got2 - ref2).abs().max().item() / std
+    assert e2 <= 0.15, f"int8 no-cache forward: {e2:.4f} std"
+    print(f"llm.int8 7B-width layer, {T} tokens: engine prefill {e1:.4f} std, module path {e2:.4f} std")
