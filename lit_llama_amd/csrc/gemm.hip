@@ -36,7 +36,6 @@ constexpr int kTPW = MI355_GEMM_TPW;  // 16-row tile slots per wave: one B fragm
 // Waves per workgroup: 8 (a block = 16 row tiles x 128 tokens) for prompts that fill the chip; 2 (4 row tiles) when the
 // launch would otherwise be a few dozen workgroups — a 128-token prompt of a 7B model is ONE token block, i.e. 16 workgroups
 // for attn.c_proj / mlp.c_proj (N = 4096) on 256 CUs, each streaming its 0.5-1.4 MB of weights alone: ~96 us per launch.
-constexpr int kLds = 2 * kBM * 256;  // two buffers of 128 tokens x 128 k bf16
 
 struct GemmParams {
     const uint8_t* w;
@@ -150,11 +149,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
 // FMT = MI355_W_Q4: int4 stream, one 1-KiB piece per (tile, unit), converted below; MI355_W_BF16: unquantised weights
 // (BASELINE configs[1]), four 1-KiB pieces per (tile, unit) whose piece d IS the A fragment of k-quarter d — same k
 // order as the int4 conversion produces, no conversion, scale 1 / zero-point 0 in the epilogue
-template <int EPI, bool PAIR, int FMT, int kWaves>
+template <int EPI, bool PAIR, int FMT, int kWaves, int BM>
 __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p) {
+    constexpr int kTT = BM / 16;                   // 16-token tiles per block
     constexpr int kSlots = kWaves * kTPW;          // tile slots per block
     constexpr int kThreads = 64 * kWaves;
-    constexpr int kXChunks = kBM * 16 / kThreads;  // 16-B activation chunks per thread and unit
+    constexpr int kXChunks = BM * 16 / kThreads;   // 16-B activation chunks per thread and unit
     constexpr int kWP = FMT == MI355_W_BF16 ? 4 : 1;  // pieces per (tile, unit)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
     if (j >= p.per_xcd || L2 >= p.total_blocks * p.ksplit) return;
     const int L = L2 / p.ksplit, ks = L2 - L * p.ksplit;  // (ksplit = 1: ks = 0, all units)
     const int mb = L / n_blocks, nb = L - mb * n_blocks;
-    const int m0 = mb * kBM;
+    const int m0 = mb * BM;
     const int u_lo = slice_lo(ks, p.units, p.ksplit), u_hi = slice_lo(ks + 1, p.units, p.ksplit);
 
     // this wave's row tiles
@@ -214,15 +214,15 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
         for (int i = 0; i < kXChunks; ++i) {
             const int ch = i * kThreads + threadIdx.x;
             const int tok = ch >> 4, col = ch & 15;
-            *(u32x4*)(smem + buf * (kBM * 256) + tok * 256 + ((col ^ swz(tok)) << 4)) = stage[i];
+            *(u32x4*)(smem + buf * (BM * 256) + tok * 256 + ((col ^ swz(tok)) << 4)) = stage[i];
         }
     };
 
-    f32x4 acc[kTPW][8];
+    f32x4 acc[kTPW][kTT];
 #pragma unroll
     for (int t = 0; t < kTPW; ++t)
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) acc[t][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tt = 0; tt < kTT; ++tt) acc[t][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 wcur[kTPW][kWP], wnext[kTPW][kWP];
 #pragma unroll
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
         xload(u + 1);
 #pragma unroll
         for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
-        const char* xs = smem + buf * (kBM * 256);
+        const char* xs = smem + buf * (BM * 256);
         // (explicitly software-pipelined B-fragment reads — 16 fragments in registers, pinned with sched_barrier —
         // measured SLOWER, 600-670 vs 760-800 TFLOP/s: with 4 waves per SIMD the hardware hides the LDS latency itself)
 #pragma unroll
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
                 }
             }
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
+            for (int tt = 0; tt < kTT; ++tt) {
                 const int tok = tt * 16 + c;
                 const bf16x8 b = *(const bf16x8*)(xs + tok * 256 + (((4 * g + d) ^ swz(tok)) << 4));
 #pragma unroll
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
             }
         }
 #pragma unroll
-    for (int tt = 0; tt < 8; ++tt) {
+    for (int tt = 0; tt < kTT; ++tt) {
         const int m = m0 + tt * 16 + c;
         if (m >= p.M) continue;
         const float sxm = p.sx[(int64_t)m * p.ksplit + ks], ri = p.rinv[m];
@@ -356,10 +356,10 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
     }
 }
 
-template <int EPI, bool PAIR, int FMT, int kWaves>
+template <int EPI, bool PAIR, int FMT, int kWaves, int BM>
 int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row tiles (pair tiles for the SwiGLU stream)
-    static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR, FMT, kWaves>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR, FMT, kWaves, BM>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * 256);
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute(gemm) failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
@@ -368,9 +368,9 @@ int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row ti
     const int per_block = PAIR ? kSlots / 2 : kSlots;
     GemmParams q = p;
     q.n_blocks = (p.n_tiles + per_block - 1) / per_block;
-    q.total_blocks = q.n_blocks * ((p.M + kBM - 1) / kBM);
+    q.total_blocks = q.n_blocks * ((p.M + BM - 1) / BM);
     q.per_xcd = (q.total_blocks * q.ksplit + 7) / 8;
-    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR, FMT, kWaves>), dim3(8 * q.per_xcd), dim3(64 * kWaves), kLds, s, q);
+    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR, FMT, kWaves, BM>), dim3(8 * q.per_xcd), dim3(64 * kWaves), 2 * BM * 256, s, q);
     MI355_LAUNCH_CHECK();
     if (q.ksplit > 1) {
         const int64_t n = (int64_t)p.M * (p.N >> 2);
@@ -382,12 +382,21 @@ int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row ti
 }
 template <int EPI, bool PAIR, int FMT>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
-    // blocks of 16 row tiles if that still gives the chip something to do, blocks of 4 otherwise
+    // blocks of 16 row tiles x 128 tokens if that gives every CU two workgroups to overlap; the narrow outputs of a long
+    // prompt (attn.c_proj / mlp.c_proj, N = 4096: 16 row blocks, at T = 2048 one workgroup per CU, matrix pipes 37 % busy
+    // against 53 % for the c_fc1 / c_fc2 pair) take 64-token blocks instead: twice the workgroups, half the LDS each;
+    // short prompts: split-K brings the blocks, or blocks of 4 / 2 row tiles
     const int per_block8 = PAIR ? 8 * kTPW / 2 : 8 * kTPW;
     const int blocks8 = ((p.n_tiles + per_block8 - 1) / per_block8) * ((p.M + kBM - 1) / kBM);
-    if (blocks8 >= 128 || p.ksplit > 1) return launch_gemm_w<EPI, PAIR, FMT, 8>(p, s);  // (split-K brings the blocks)
-    if (blocks8 * 4 >= 128) return launch_gemm_w<EPI, PAIR, FMT, 2>(p, s);
-    return launch_gemm_w<EPI, PAIR, FMT, 1>(p, s);
+    if (p.ksplit > 1) return launch_gemm_w<EPI, PAIR, FMT, 8, kBM>(p, s);
+    if (blocks8 >= 128) {
+#ifndef MI355_GEMM_NO_BM64
+        if (blocks8 < 384 && p.M >= 256) return launch_gemm_w<EPI, PAIR, FMT, 8, 64>(p, s);
+#endif
+        return launch_gemm_w<EPI, PAIR, FMT, 8, kBM>(p, s);
+    }
+    if (blocks8 * 4 >= 128) return launch_gemm_w<EPI, PAIR, FMT, 2, kBM>(p, s);
+    return launch_gemm_w<EPI, PAIR, FMT, 1, kBM>(p, s);
 }
 template <int FMT>
 int launch_gemm_epi(const GemmParams& p, int epi, hipStream_t s) {
