@@ -62,6 +62,9 @@ constexpr int kUnitsC = kC / 128;
 constexpr int kMaxFcTiles = 3;    // c_fc1/c_fc2 pair tiles per workgroup (n_hidden <= 12288)
 constexpr int kMaxHeadTiles = 8;  // lm_head tiles per workgroup (vocab <= 32768)
 constexpr unsigned kSpinLimit = 400000u;
+#ifndef MI355_FUSED_G0_PAIRS
+#define MI355_FUSED_G0_PAIRS 6
+#endif
 #ifndef MI355_FUSED_SPLIT_POS
 #define MI355_FUSED_SPLIT_POS 384
 #endif
@@ -704,22 +707,25 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         auto gather_x = [&]() {
             const unsigned ep = ebase + edge;
             const unsigned base = (unsigned)xpar * 2304u * 8u;
+            // the 1024 16-B loads of the pair region are split kG0 : 16 - kG0 between the two gatherer waves, the 128 loads of
+            // the sums of squares go to gatherer 0, which also has the serial tail (sums, 1/rms).  Measured (same box,
+            // alternating runs): 6 : 10 -> 918 us per step, 7 : 9 (equal load counts) -> 935 us.
+            constexpr int kG0 = MI355_FUSED_G0_PAIRS;
             if (gw == 0) {
-                u32x4 v[8];
-                // loads 0 .. 383 of the pair region (6 per lane) and the 128 loads of the sums of squares (2 per lane)
+                u32x4 v[kG0 + 2];
                 for (unsigned spins = 0;; ++spins) {
 #ifdef MI355_FUSED_COUNT_SWEEPS
                     n_sweeps = spins + 1;
 #endif
                     bool ok = true;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const unsigned off = k < 6 ? base + (unsigned)(k * 64 + lane_v) * 16u
-                                                   : base + 2048u * 8u + (unsigned)((k - 6) * 64 + lane_v) * 16u;
+                    for (int k = 0; k < kG0 + 2; ++k) {
+                        const unsigned off = k < kG0 ? base + (unsigned)(k * 64 + lane_v) * 16u
+                                                     : base + 2048u * 8u + (unsigned)((k - kG0) * 64 + lane_v) * 16u;
                         v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gx, off, 0, 16));
                     }
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) ok &= v[k][1] == ep && v[k][3] == ep;
+                    for (int k = 0; k < kG0 + 2; ++k) ok &= v[k][1] == ep && v[k][3] == ep;
                     if (__all(ok)) break;
                     if (spins > kSpinLimit || aborted(p)) {
                         if (lane == 0) raise_abort(p, 0x100u + edge);
@@ -729,22 +735,22 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 }
                 float2 sx = {0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
+                for (int k = 0; k < kG0; ++k) {
                     *(u64*)(xs + (size_t)(k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
                     pair_sums(sx, v[k][0], v[k][2]);
                 }
-                float ss = ((__uint_as_float(v[6][0]) + __uint_as_float(v[6][2])) + __uint_as_float(v[7][0])) +
-                           __uint_as_float(v[7][2]);
+                float ss = ((__uint_as_float(v[kG0][0]) + __uint_as_float(v[kG0][2])) + __uint_as_float(v[kG0 + 1][0])) +
+                           __uint_as_float(v[kG0 + 1][2]);
                 ss = group_sum(ss, 64);
                 put_sums(sx);
                 if (lane == 0) misc[0] = rsqrtf(ss / (float)kC + p.eps);
             } else {
-                u32x4 v[10];
-                sweep<10>(p, rs_gx, base, 384, 1024, ep, v, 0x200u + edge, lane_v);
+                u32x4 v[16 - kG0];
+                sweep<16 - kG0>(p, rs_gx, base, kG0 * 64, 1024, ep, v, 0x200u + edge, lane_v);
                 float2 sx = {0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 10; ++k) {
-                    *(u64*)(xs + (size_t)(384 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                for (int k = 0; k < 16 - kG0; ++k) {
+                    *(u64*)(xs + (size_t)(kG0 * 64 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
                     pair_sums(sx, v[k][0], v[k][2]);
                 }
                 put_sums(sx);
