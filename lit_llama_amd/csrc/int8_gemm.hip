@@ -50,7 +50,15 @@ struct I8GemmParams {
     int64_t ldy;
     int M, N, K, Kp, units, n_tiles, n_blocks, per_xcd, total_blocks;
     int y_dtype;
+    // split-K for short prompts (a 128-token prompt is ONE token block: 16 workgroups for N = 4096): MODE 1 launches
+    // total_blocks x ksplit workgroups that store their int32 partial tiles to part[ks][M][ldp]; MODE 2 (total_blocks
+    // workgroups) sums them — integer sums: exact in any order — and runs the epilogue
+    int ksplit;
+    int64_t ldp;
+    int* part;
 };
+constexpr size_t kSplitBudget = (size_t)32 << 20;
+constexpr int kMaxSplit = 8;
 
 // ---- 1. rows: f16 operand, absmax over the sub-threshold entries, outlier column mask
 __global__ __launch_bounds__(256) void i8_stage_kernel(const void* x, int x_dtype, int64_t ldx, const void* norm_scale,
@@ -120,17 +128,25 @@ __global__ __launch_bounds__(256) void i8_quant_kernel(const f16_t* xh, const fl
 }
 
 // ---- 3. the product
-template <int EPI, bool PAIR>
+// MODE 0: product + epilogue; 1: product of one K-slice -> partial tiles; 2: sum of the partial tiles + epilogue
+template <int EPI, bool PAIR, int MODE>
 __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3;
-    const int L = xcd * p.per_xcd + j0;
-    if (j0 >= p.per_xcd || L >= p.total_blocks) return;
+    const int L2 = xcd * p.per_xcd + j0;
+    // MODE 1: a workgroup per (block, K-slice); MODE 2: a workgroup per (block, 16-token tile) — 8 x the workgroups of the
+    // product launch, so that summing the slices and the epilogue are not left to a dozen workgroups
+    const int nsplit = MODE == 1 ? p.ksplit : MODE == 2 ? 8 : 1;
+    if (j0 >= p.per_xcd || L2 >= p.total_blocks * nsplit) return;
+    const int L = L2 / nsplit, ks = L2 - L * nsplit;
+    const int tt_lo = MODE == 2 ? ks : 0, tt_hi = MODE == 2 ? ks + 1 : 8;  // token tiles this workgroup finishes
     const int mb = L / p.n_blocks, nb = L - mb * p.n_blocks;
     const int m0 = mb * kBM;
+    const int u_lo = MODE == 1 ? (int)((int64_t)ks * p.units / p.ksplit) : 0;
+    const int u_hi = MODE == 1 ? (int)((int64_t)(ks + 1) * p.units / p.ksplit) : p.units;
     constexpr int R = PAIR ? 2 : 1;
 
     int tile[kTPW], rr[kTPW];
@@ -150,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
         __builtin_amdgcn_make_buffer_rsrc((void*)p.ca, 0, (int)((int64_t)p.M * p.Kp), 0x00020000);
     const unsigned lane_off = lane * 16;
     auto wload = [&](int t, int u, u32x4 (&dst)[2]) {
-        const bool ok = tile[t] < p.n_tiles && u < p.units;
+        const bool ok = tile[t] < p.n_tiles && u < u_hi;
         const unsigned off = (unsigned)((tile[t] * p.units + u) * R + rr[t]) * 2048u;
 #pragma unroll
         for (int e = 0; e < 2; ++e)
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
             const int tok = ch >> 3, col = ch & 7;
             const unsigned off = (unsigned)((int64_t)(m0 + tok) * p.Kp) + (unsigned)u * 128u + (unsigned)col * 16u;
             stage[i] = __builtin_bit_cast(
-                u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ((m0 + tok) < p.M && u < p.units) ? off : 0xFFFFFFF0u, 0, 0));
+                u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ((m0 + tok) < p.M && u < u_hi) ? off : 0xFFFFFFF0u, 0, 0));
         }
     };
     auto xstore = [&](int buf) {
@@ -183,36 +199,67 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
 #pragma unroll
         for (int tt = 0; tt < 8; ++tt) acc[t][tt] = i32x4{0, 0, 0, 0};
 
-    u32x4 wcur[kTPW][2], wnext[kTPW][2];
+    if constexpr (MODE != 2) {
+        u32x4 wcur[kTPW][2], wnext[kTPW][2];
 #pragma unroll
-    for (int t = 0; t < kTPW; ++t) wload(t, 0, wcur[t]);
-    xload(0);
-    xstore(0);
-    __syncthreads();
-    for (int u = 0; u < p.units; ++u) {
-        const int buf = u & 1;
-        xload(u + 1);  // unconditional: past the last unit the offsets are out of the descriptor (zeros, no traffic)
+        for (int t = 0; t < kTPW; ++t) wload(t, u_lo, wcur[t]);
+        xload(u_lo);
+        xstore(u_lo & 1);
+        __syncthreads();
+        for (int u = u_lo; u < u_hi; ++u) {
+            const int buf = u & 1;
+            xload(u + 1);  // unconditional: past the last unit the offsets are out of the descriptor (zeros, no traffic)
 #pragma unroll
-        for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
-        const char* xs = smem + buf * kXTile;
+            for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
+            const char* xs = smem + buf * kXTile;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < 2; ++e) {
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                const int tok = tt * 16 + c;
-                const i32x4 b = *(const i32x4*)(xs + tok * 128 + (((4 * e + g) ^ swz8(tok)) << 4));
+                for (int tt = 0; tt < 8; ++tt) {
+                    const int tok = tt * 16 + c;
+                    const i32x4 b = *(const i32x4*)(xs + tok * 128 + (((4 * e + g) ^ swz8(tok)) << 4));
 #pragma unroll
-                for (int t = 0; t < kTPW; ++t)
-                    acc[t][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wcur[t][e]), b, acc[t][tt], 0, 0, 0);
+                    for (int t = 0; t < kTPW; ++t)
+                        acc[t][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wcur[t][e]), b, acc[t][tt], 0, 0, 0);
+                }
+            }
+            xstore(buf ^ 1);
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) {
+                wcur[t][0] = wnext[t][0];
+                wcur[t][1] = wnext[t][1];
+            }
+            __syncthreads();
+        }
+    }
+    // partial tiles of a K-slice: column n of c_fc2 sits at N + n
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            const int m = m0 + tt * 16 + c;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) {
+                const int n = tile[t] * 16 + 4 * g;
+                if (tile[t] < p.n_tiles && n < p.N)
+                    *(i32x4*)(p.part + ((int64_t)ks * p.M + m) * p.ldp + (PAIR && rr[t] == 1 ? p.N : 0) + n) = acc[t][tt];
             }
         }
-        xstore(buf ^ 1);
+        return;
+    }
+    if constexpr (MODE == 2) {
 #pragma unroll
-        for (int t = 0; t < kTPW; ++t) {
-            wcur[t][0] = wnext[t][0];
-            wcur[t][1] = wnext[t][1];
+        for (int tt = 0; tt < 8; ++tt) {
+            const int m = m0 + tt * 16 + c;
+            if (m >= p.M || tt < tt_lo || tt >= tt_hi) continue;
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) {
+                const int n = tile[t] * 16 + 4 * g;
+                if (tile[t] < p.n_tiles && n < p.N)
+                    for (int s2 = 0; s2 < p.ksplit; ++s2)
+                        acc[t][tt] += *(const i32x4*)(p.part + ((int64_t)s2 * p.M + m) * p.ldp + (PAIR && rr[t] == 1 ? p.N : 0) + n);
+            }
         }
-        __syncthreads();
     }
 
     // ---- epilogue.  lane (g, c) holds rows 4 g .. 4 g + 3 of its tiles for token tt * 16 + c
@@ -305,52 +352,88 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
 #pragma unroll
     for (int tt = 0; tt < 8; ++tt) {
         const int m = m0 + tt * 16 + c;
-        if (m >= p.M) continue;
+        if (m >= p.M || tt < tt_lo || tt >= tt_hi) continue;
+        // four consecutive output columns per lane and tile: one 16-B (f32) / 8-B (bf16, f16) access when the row allows it
+        const bool vec = (p.N & 3) == 0 && (p.ldy & 3) == 0 && ((uintptr_t)p.y & 15) == 0;
         if constexpr (EPI == MI355_EPI_SWIGLU) {
 #pragma unroll
             for (int t = 0; t < kTPW; t += 2) {
                 const int n = tile[t] * 16 + 4 * g;
-                if (tile[t] < p.n_tiles && n < p.N) {
+                if (tile[t] >= p.n_tiles || n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = swiglu_f32(d[t][tt][r], d[t + 1][tt][r]);
+                if (vec && p.y_dtype == MI355_BF16) {
+                    u32x2 pk;
+                    pk[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *(u32x2*)((bf16_t*)p.y + (int64_t)m * p.ldy + n) = pk;
+                } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (n + r < p.N)
-                            st_from_f32(p.y, (int64_t)m * p.ldy + n + r, p.y_dtype, swiglu_f32(d[t][tt][r], d[t + 1][tt][r]));
+                        if (n + r < p.N) st_from_f32(p.y, (int64_t)m * p.ldy + n + r, p.y_dtype, v[r]);
                 }
             }
         } else {
 #pragma unroll
             for (int t = 0; t < kTPW; ++t) {
                 const int n = tile[t] * 16 + 4 * g;
-                if (tile[t] >= p.n_tiles) continue;
+                if (tile[t] >= p.n_tiles || n >= p.N) continue;
+                const int64_t yi = (int64_t)m * p.ldy + n;
+                if (vec && p.y_dtype == MI355_F32) {
+                    f32x4 o = {d[t][tt][0], d[t][tt][1], d[t][tt][2], d[t][tt][3]};
+                    if constexpr (EPI == MI355_EPI_ACCUM) o += *(const f32x4*)((const float*)p.y + yi);
+                    *(f32x4*)((float*)p.y + yi) = o;
+                } else if (vec && p.y_dtype == MI355_BF16) {
+                    float o[4] = {d[t][tt][0], d[t][tt][1], d[t][tt][2], d[t][tt][3]};
+                    if constexpr (EPI == MI355_EPI_ACCUM) {
+                        const u32x2 old = *(const u32x2*)((const bf16_t*)p.y + yi);
+                        o[0] += __uint_as_float(old[0] << 16);
+                        o[1] += __uint_as_float(old[0] & 0xffff0000u);
+                        o[2] += __uint_as_float(old[1] << 16);
+                        o[3] += __uint_as_float(old[1] & 0xffff0000u);
+                    }
+                    u32x2 pk;
+                    pk[0] = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                    pk[1] = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    *(u32x2*)((bf16_t*)p.y + yi) = pk;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r >= p.N) continue;
-                    const int64_t yi = (int64_t)m * p.ldy + n + r;
-                    float v = d[t][tt][r];
-                    if constexpr (EPI == MI355_EPI_ACCUM) v += ld_as_f32(p.y, yi, p.y_dtype);
-                    st_from_f32(p.y, yi, p.y_dtype, v);
+                    for (int r = 0; r < 4; ++r) {
+                        if (n + r >= p.N) continue;
+                        float v = d[t][tt][r];
+                        if constexpr (EPI == MI355_EPI_ACCUM) v += ld_as_f32(p.y, yi + r, p.y_dtype);
+                        st_from_f32(p.y, yi + r, p.y_dtype, v);
+                    }
                 }
             }
         }
     }
 }
 
-template <int EPI, bool PAIR>
-int launch_i8_gemm(const I8GemmParams& p, hipStream_t s) {
+template <int EPI, bool PAIR, int MODE>
+int launch_i8_mode(const I8GemmParams& q, hipStream_t s) {
     static hipError_t attr_err =
-        hipFuncSetAttribute((const void*)i8_gemm_kernel<EPI, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        hipFuncSetAttribute((const void*)i8_gemm_kernel<EPI, PAIR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute(i8_gemm) failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
     }
+    I8GemmParams r = q;
+    r.per_xcd = (q.total_blocks * (MODE == 1 ? q.ksplit : MODE == 2 ? 8 : 1) + 7) / 8;
+    hipLaunchKernelGGL((i8_gemm_kernel<EPI, PAIR, MODE>), dim3(8 * r.per_xcd), dim3(kThreads), kLds, s, r);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+template <int EPI, bool PAIR>
+int launch_i8_gemm(const I8GemmParams& p, hipStream_t s) {
     const int per_block = PAIR ? kSlots / 2 : kSlots;
     I8GemmParams q = p;
     q.n_blocks = (p.n_tiles + per_block - 1) / per_block;
     q.total_blocks = q.n_blocks * ((p.M + kBM - 1) / kBM);
-    q.per_xcd = (q.total_blocks + 7) / 8;
-    hipLaunchKernelGGL((i8_gemm_kernel<EPI, PAIR>), dim3(8 * q.per_xcd), dim3(kThreads), kLds, s, q);
-    MI355_LAUNCH_CHECK();
-    return 0;
+    if (q.ksplit <= 1) return launch_i8_mode<EPI, PAIR, 0>(q, s);
+    if (int rc = launch_i8_mode<EPI, PAIR, 1>(q, s)) return rc;
+    return launch_i8_mode<EPI, PAIR, 2>(q, s);
 }
 
 size_t pad16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -361,7 +444,8 @@ extern "C" size_t mi355_linear_int8_gemm_workspace_bytes(int M, int K) {
     if (M <= 0 || K <= 0) return 0;
     const size_t kp = ((size_t)K + 127) / 128 * 128;
     // xh f16 [M, Kp], CA int8 [M, Kp], absmax [M], column mask [Kp / 32], outlier list [1 + Kp]
-    return pad16((size_t)M * kp * 2) + pad16((size_t)M * kp) + pad16((size_t)M * 4) + pad16(kp / 8) + pad16((1 + kp) * 4) + 256;
+    return pad16((size_t)M * kp * 2) + pad16((size_t)M * kp) + pad16((size_t)M * 4) + pad16(kp / 8) + pad16((1 + kp) * 4) + 256 +
+           kSplitBudget;  // int32 partial tiles of the split-K launches (short prompts)
 }
 
 extern "C" int mi355_linear_int8_gemm(const mi355_int8_args* a, void* workspace, size_t workspace_bytes, mi355_stream_t stream) {
@@ -392,6 +476,18 @@ extern "C" int mi355_linear_int8_gemm(const mi355_int8_args* a, void* workspace,
     unsigned* mask = (unsigned*)ws;
     ws += pad16((size_t)kp / 8);
     int* olist = (int*)ws;
+    ws += pad16((size_t)(1 + kp) * 4);
+    int* part = (int*)ws;
+    // split-K: launches of fewer than 96 blocks are cut into up to 8 K-slices (as many as fit the partial buffer)
+    int ksplit = 1;
+    const int64_t ldp = (int64_t)a->N * (swiglu ? 2 : 1);
+    {
+        const int rows_per_block = swiglu ? 16 * kSlots / 2 : 16 * kSlots;
+        const int blocks = ((a->N + rows_per_block - 1) / rows_per_block) * ((a->M + kBM - 1) / kBM);
+        while (ksplit < kMaxSplit && blocks * ksplit < 96 && units >= 8 * ksplit &&
+               (size_t)2 * ksplit * a->M * ldp * 4 <= kSplitBudget)
+            ksplit *= 2;
+    }
     MI355_HIP(hipMemsetAsync(mask, 0, (size_t)kp / 8, s));
     hipLaunchKernelGGL(i8_stage_kernel, dim3(a->M), dim3(256), 0, s, a->x, a->x_dtype, a->ldx, a->norm_scale, a->norm_dtype, a->eps,
                        a->threshold, a->K, kp, xh, sca, mask);
@@ -421,6 +517,9 @@ extern "C" int mi355_linear_int8_gemm(const mi355_int8_args* a, void* workspace,
     p.units = units;
     p.n_tiles = (a->N + 15) / 16;
     p.y_dtype = a->y_dtype;
+    p.ksplit = ksplit;
+    p.ldp = ldp;
+    p.part = part;
     if (swiglu) return launch_i8_gemm<MI355_EPI_SWIGLU, true>(p, s);
     if (a->epi == MI355_EPI_ACCUM) return launch_i8_gemm<MI355_EPI_ACCUM, false>(p, s);
     return launch_i8_gemm<MI355_EPI_STORE, false>(p, s);

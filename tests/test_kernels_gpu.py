@@ -629,7 +629,9 @@ def test_linear_gemm_over_the_bf16_stream(dev, M, N, K, epi):
 # ---------------------------------------------------------------------------------------------- wide LLM.int8 GEMM (prefill)
 @pytest.mark.parametrize("N,K,M,epi,outliers", [(64, 128, 32, "store", 0), (512, 1024, 100, "store", 5), (4096, 4096, 160, "accum", 9),
                                                  (11008, 4096, 130, "swiglu", 7), (4096, 11008, 96, "store", 70),
-                                                 (72, 200, 40, "store", 3)])
+                                                 (72, 200, 40, "store", 3),
+                                                 # one token block against N = 4096 / 11008: split-K (8 / 2 slices of int32 partials)
+                                                 (4096, 4096, 128, "accum", 6), (11008, 4096, 128, "swiglu", 4), (4096, 11008, 64, "store", 0)])
 def test_int8_gemm_matches_oracle(dev, N, K, M, epi, outliers):
     """mi355_linear_int8_gemm against oracle.llm_int8_linear (the restated MatMul8bitLt forward: outlier columns over ALL rows,
     row absmax over sub-threshold entries, int32 accumulation, f16 roundings) — integer work exact, one f16 ulp on rows with
