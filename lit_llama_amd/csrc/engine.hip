@@ -82,9 +82,9 @@ int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x
                const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy, hipStream_t s,
                const float* attn_partials = nullptr) {
     // wide inputs (prompt chunks of >= 32 tokens) of an int4 model: the LDS-tiled MFMA GEMM over the same stream
-    // (grouped scales: the streaming kernel only, in sub-chunks of rows)
-    if (((w.fmt == MI355_W_Q4 && w.group_cols == 0) || w.fmt == MI355_W_BF16) && M >= 32 && m->gemm_ws != nullptr &&
-        attn_partials == nullptr && w.N % 4 == 0 && ldy % 4 == 0) {
+    // (per-row or grouped scales)
+    if ((w.fmt == MI355_W_Q4 || w.fmt == MI355_W_BF16) && M >= 32 && m->gemm_ws != nullptr &&
+        attn_partials == nullptr && w.N % 4 == 0 && ldy % 4 == 0 && (w.group_cols == 0 || w.K % 128 == 0)) {
         mi355_linear_args a;
         memset(&a, 0, sizeof(a));
         a.fmt = w.fmt;
@@ -104,6 +104,7 @@ int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x
         a.scales2 = w.scales2;
         a.zeros2 = w.zeros2;
         a.sz_dtype = w.sz_dtype;
+        a.group_cols = w.group_cols;
         a.epi = epi;
         a.y = y;
         a.y_dtype = y_dtype;

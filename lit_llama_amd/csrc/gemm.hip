@@ -56,6 +56,11 @@ struct GemmParams {
     // by splitk_reduce_kernel; sx then holds [M][ksplit] per-slice operand sums
     int ksplit;
     float* part;
+    // grouped scales (GRP kernels): gtab[group 0..n_groups][r][tab_ld rows] = bf16 scale | bf16 zero << 16 (row n_groups
+    // is all zero), sxt[group][M] = operand sums per group; upg = 128-column units per group (groups of >= 128 columns)
+    const uint32_t* gtab;
+    const float* sxt;
+    int n_groups, gq_shift, upg, tab_ld;
 };
 
 constexpr size_t kSplitBudget = (size_t)32 << 20;  // bytes of split-K partials a workspace holds
@@ -106,6 +111,59 @@ __global__ __launch_bounds__(256) void stage_rows_kernel(const void* x, int x_dt
     if (threadIdx.x == 0) rinv[m] = norm_scale != nullptr ? rsqrtf(tss / (float)K + eps) : 1.0f;
 }
 
+// grouped scales: as stage_rows_kernel, but sxt[grp][m] = sum of xb over the group's input columns.  A wave per group
+// (wave reductions only); one row per workgroup
+__global__ __launch_bounds__(256) void stage_rows_grouped_kernel(const void* x, int x_dtype, int64_t ldx, const void* norm_scale,
+                                                                 int norm_dtype, float eps, int K, int Kp, bf16_t* xb,
+                                                                 int64_t ldxb, float* rinv, float* sxt, int M, int group_cols,
+                                                                 int n_groups) {
+    __shared__ float red[32];
+    const int m = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ss = 0.f;
+    for (int grp = wave; grp < n_groups; grp += 4) {
+        const int k_lo = grp * group_cols;
+        const int k_hi = k_lo + group_cols < Kp ? k_lo + group_cols : Kp;
+        float sum = 0.f;
+        for (int k = k_lo + lane; k < k_hi; k += 64) {
+            bf16_t o = 0;
+            if (k < K) {
+                float v = ld_as_f32(x, (int64_t)m * ldx + k, x_dtype);
+                if (norm_scale != nullptr) {
+                    ss += v * v;
+                    v *= ld_as_f32(norm_scale, k, norm_dtype);
+                }
+                o = f32_to_bf16(v);
+                sum += bf16_to_f32(o);
+            }
+            xb[(int64_t)m * ldxb + k] = o;
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) sxt[(int64_t)grp * M + m] = sum;
+    }
+    for (int k = n_groups * group_cols + (int)threadIdx.x; k < Kp; k += 256) xb[(int64_t)m * ldxb + k] = 0;
+    const float tss = block_sum(ss, red);
+    if (threadIdx.x == 0) rinv[m] = norm_scale != nullptr ? rsqrtf(tss / (float)K + eps) : 1.0f;
+}
+
+// the reference's [N, n_groups] bf16 scale / zero tables -> gtab[grp][r][n] dwords (n fastest: the four rows a lane holds
+// are one 16-B load); row n_groups and the rows past N are zero
+__global__ __launch_bounds__(256) void group_table_kernel(const bf16_t* s0, const bf16_t* z0, const bf16_t* s1, const bf16_t* z1,
+                                                          int N, int tab_ld, int n_groups, int R, uint32_t* gtab) {
+    const int64_t total = (int64_t)(n_groups + 1) * R * tab_ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % tab_ld);
+        const int64_t gr = i / tab_ld;
+        const int r = (int)(gr % R), grp = (int)(gr / R);
+        uint32_t v = 0;
+        if (n < N && grp < n_groups) {
+            const int64_t src = (int64_t)n * n_groups + grp;
+            v = (uint32_t)(r == 1 ? s1 : s0)[src] | ((uint32_t)(r == 1 ? z1 : z0)[src] << 16);
+        }
+        gtab[i] = v;
+    }
+}
+
 // y[m][n] (+)= sum over the K-slices, in slice order (deterministic)
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, int ksplit, int M, int N, void* y, int y_dtype,
@@ -149,8 +207,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
 // FMT = MI355_W_Q4: int4 stream, one 1-KiB piece per (tile, unit), converted below; MI355_W_BF16: unquantised weights
 // (BASELINE configs[1]), four 1-KiB pieces per (tile, unit) whose piece d IS the A fragment of k-quarter d — same k
 // order as the int4 conversion produces, no conversion, scale 1 / zero-point 0 in the epilogue
-template <int EPI, bool PAIR, int FMT, int kWaves, int BM>
+// GRP (Q4): 0 one (scale, zero) pair per output row; 1 / 2: one pair per row and group of input columns (GPTQ "groupsize",
+// /root/reference lit_llama/quantization.py:284-333 with tile_cols > 0), groups of whole 128-column units (1) or of 32 / 64
+// columns (2).  The MFMA accumulators keep running over K (cum_g = columns up to the end of group g) and at every group
+// end     accf += (s_g - s_{g+1}) cum_g - s_g (128 + z_g) X_g      (Abel summation of sum_g s_g (A_g - (128 + z_g) X_g),
+// s past the last group = 0; X_g = the group's operand sum from stage_rows_grouped_kernel): two FMAs per output element
+// and group, no accumulator reset.  The k columns of ONE MFMA are spread over the unit (lane group g holds columns
+// 32 g + 8 d ..), so sub-unit groups take one pass per group with the other lane groups' activations zeroed, as in gemv.hip.
+template <int EPI, bool PAIR, int FMT, int kWaves, int BM, int GRP = 0>
 __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p) {
+    static_assert(GRP == 0 || FMT == MI355_W_Q4, "grouped scales are a Q4 feature");
     constexpr int kTT = BM / 16;                   // 16-token tiles per block
     constexpr int kSlots = kWaves * kTPW;          // tile slots per block
     constexpr int kThreads = 64 * kWaves;
@@ -169,7 +235,10 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
     const int L = L2 / p.ksplit, ks = L2 - L * p.ksplit;  // (ksplit = 1: ks = 0, all units)
     const int mb = L / n_blocks, nb = L - mb * n_blocks;
     const int m0 = mb * BM;
-    const int u_lo = slice_lo(ks, p.units, p.ksplit), u_hi = slice_lo(ks + 1, p.units, p.ksplit);
+    // K-slice: units [u_lo, u_hi); GRP 1 cuts at group boundaries (groups [g_lo, g_hi) of upg units each)
+    const int g_lo = GRP == 1 ? slice_lo(ks, p.n_groups, p.ksplit) : 0, g_hi = GRP == 1 ? slice_lo(ks + 1, p.n_groups, p.ksplit) : 0;
+    const int u_lo = GRP == 1 ? g_lo * p.upg : slice_lo(ks, p.units, p.ksplit);
+    const int u_hi = GRP == 1 ? (g_hi * p.upg < p.units ? g_hi * p.upg : p.units) : slice_lo(ks + 1, p.units, p.ksplit);
 
     // this wave's row tiles
     int tile[kTPW], rr[kTPW];
@@ -231,17 +300,20 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
     xstore(u_lo & 1);
     __syncthreads();
 
-    for (int u = u_lo; u < u_hi; ++u) {
-        const int buf = u & 1;
-        // next unit's operands, requested UNCONDITIONALLY (a load inside `if (more)` makes hipcc drain vmcnt at the join,
-        // i.e. wait for these very loads before the first MFMA): past the last unit the offsets fall into the next row /
-        // tile or out of the descriptors (zeros) and the values are never used
+    // next unit's operands, requested UNCONDITIONALLY (a load inside `if (more)` makes hipcc drain vmcnt at the join,
+    // i.e. wait for these very loads before the first MFMA): past the last unit the offsets fall into the next row /
+    // tile or out of the descriptors (zeros) and the values are never used
+    auto prefetch = [&](int u) {
         xload(u + 1);
 #pragma unroll
         for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
+    };
+    // the 4 x kTT x kTPW MFMAs of a unit; sub >= 0 (GRP 2): only the lane groups of sub-group `sub` contribute
+    // (explicitly software-pipelined B-fragment reads — 16 fragments in registers, pinned with sched_barrier —
+    // measured SLOWER, 600-670 vs 760-800 TFLOP/s: with 4 waves per SIMD the hardware hides the LDS latency itself)
+    auto mfmas = [&](int buf, int sub, int sub_shift) {
         const char* xs = smem + buf * (BM * 256);
-        // (explicitly software-pipelined B-fragment reads — 16 fragments in registers, pinned with sched_barrier —
-        // measured SLOWER, 600-670 vs 760-800 TFLOP/s: with 4 waves per SIMD the hardware hides the LDS latency itself)
+        const bool mine = GRP != 2 || (g >> sub_shift) == sub;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             // int4 -> bf16 MFMA A fragments of k-quarter d: (w >> 4i) & 0x000F000F | 0x43004300 = (128 + q_2i, 128 + q_2i+1)
@@ -263,17 +335,114 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
 #pragma unroll
             for (int tt = 0; tt < kTT; ++tt) {
                 const int tok = tt * 16 + c;
-                const bf16x8 b = *(const bf16x8*)(xs + tok * 256 + (((4 * g + d) ^ swz(tok)) << 4));
+                u32x4 braw = *(const u32x4*)(xs + tok * 256 + (((4 * g + d) ^ swz(tok)) << 4));
+                if constexpr (GRP == 2) braw = mine ? braw : u32x4{0u, 0u, 0u, 0u};
+                const bf16x8 b = __builtin_bit_cast(bf16x8, braw);
 #pragma unroll
                 for (int t = 0; t < kTPW; ++t) acc[t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[t][tt], 0, 0, 0);
             }
         }
+    };
+    auto rotate = [&](int buf) {
         xstore(buf ^ 1);
 #pragma unroll
         for (int t = 0; t < kTPW; ++t)
 #pragma unroll
             for (int d = 0; d < kWP; ++d) wcur[t][d] = wnext[t][d];
         __syncthreads();
+    };
+
+    f32x4 accf[GRP ? kTPW : 1][GRP ? kTT : 1];
+    if constexpr (GRP == 0) {
+        for (int u = u_lo; u < u_hi; ++u) {
+            prefetch(u);
+            mfmas(u & 1, 0, 0);
+            rotate(u & 1);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < kTPW; ++t)
+#pragma unroll
+            for (int tt = 0; tt < kTT; ++tt) accf[t][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 tabc[kTPW], tabn[kTPW];
+        float sxv[kTT];
+        auto tload = [&](int grp, u32x4 (&dst)[kTPW]) {  // rows 4 g .. 4 g + 3 of this wave's tiles: one 16-B load each
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) {
+                const int tl = tile[t] < p.n_tiles ? tile[t] : 0;
+                dst[t] = *(const u32x4*)(p.gtab + ((int64_t)grp * (PAIR ? 2 : 1) + rr[t]) * p.tab_ld + tl * 16 + 4 * g);
+            }
+        };
+        auto sxload = [&](int grp) {
+#pragma unroll
+            for (int tt = 0; tt < kTT; ++tt) {
+                const int m = m0 + tt * 16 + c;
+                sxv[tt] = p.sxt[(int64_t)grp * p.M + (m < p.M ? m : 0)];
+            }
+        };
+        auto apply = [&]() {  // end of a group: tabc = this group's pairs, tabn = the next group's
+            // two FMAs per output element, issued as v_pk_fma_f32 on register pairs (the VALU, not the matrix pipe, bounds
+            // the grouped kernel: 64-token blocks halve the MFMAs a weight conversion is amortised over)
+            f32x2 ds[kTPW][2], szp[kTPW][2];
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s_c = __uint_as_float(tabc[t][r] << 16), z_c = __uint_as_float(tabc[t][r] & 0xffff0000u);
+                    const float s_n = __uint_as_float(tabn[t][r] << 16);
+                    ds[t][r >> 1][r & 1] = s_c - s_n;
+                    szp[t][r >> 1][r & 1] = -(s_c * (128.f + z_c));
+                }
+#pragma unroll
+            for (int tt = 0; tt < kTT; ++tt) {
+                const f32x2 sx2 = {sxv[tt], sxv[tt]};
+#pragma unroll
+                for (int t = 0; t < kTPW; ++t)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2 a2 = {acc[t][tt][2 * h], acc[t][tt][2 * h + 1]};
+                        f32x2 f2 = {accf[t][tt][2 * h], accf[t][tt][2 * h + 1]};
+                        f2 = __builtin_elementwise_fma(ds[t][h], a2, f2);
+                        f2 = __builtin_elementwise_fma(szp[t][h], sx2, f2);
+                        accf[t][tt][2 * h] = f2[0];
+                        accf[t][tt][2 * h + 1] = f2[1];
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) tabc[t] = tabn[t];
+        };
+        // (a K-slice is a sum of its own: past its last group the scale is 0 — table row n_groups)
+        if constexpr (GRP == 1) {
+            tload(g_lo, tabc);
+            int u = u_lo;
+            for (int grp = g_lo; grp < g_hi; ++grp) {
+                tload(grp + 1 < g_hi ? grp + 1 : p.n_groups, tabn);
+                sxload(grp);
+                const int u_end = (grp + 1) * p.upg < u_hi ? (grp + 1) * p.upg : u_hi;
+                for (; u < u_end; ++u) {
+                    prefetch(u);
+                    mfmas(u & 1, 0, 0);
+                    rotate(u & 1);
+                }
+                apply();
+            }
+        } else {
+            const int sub_shift = p.gq_shift;  // lane groups per sub-group = 1 << gq_shift (0: 32 columns, 1: 64)
+            const int nsub = 4 >> sub_shift;
+            tload(u_lo * nsub, tabc);
+            for (int u = u_lo; u < u_hi; ++u) {
+                prefetch(u);
+#pragma unroll 1
+                for (int sub = 0; sub < nsub; ++sub) {
+                    const int grp = u * nsub + sub < p.n_groups ? u * nsub + sub : p.n_groups - 1;
+                    tload((u == u_hi - 1 && sub == nsub - 1) ? p.n_groups : grp + 1, tabn);
+                    sxload(grp);
+                    mfmas(u & 1, sub, sub_shift);
+                    apply();
+                }
+                rotate(u & 1);
+            }
+        }
     }
 
     // ---- epilogue: lane (g, c) holds rows 4 g .. 4 g + 3 of its tiles for token tt * 16 + c
@@ -286,7 +455,7 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
             const bool ok = n < p.N;
             const void* sp = (PAIR && rr[t] == 1) ? p.scales2 : p.scales;
             const void* zq = (PAIR && rr[t] == 1) ? p.zeros2 : p.zeros;
-            if constexpr (FMT == MI355_W_BF16) {
+            if constexpr (FMT == MI355_W_BF16 || GRP != 0) {
                 sc[t][r] = ok ? 1.f : 0.f;
                 zp[t][r] = 0.f;
             } else {
@@ -298,12 +467,17 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
     for (int tt = 0; tt < kTT; ++tt) {
         const int m = m0 + tt * 16 + c;
         if (m >= p.M) continue;
-        const float sxm = p.sx[(int64_t)m * p.ksplit + ks], ri = p.rinv[m];
+        const float sxm = GRP ? 0.f : p.sx[(int64_t)m * p.ksplit + ks], ri = p.rinv[m];
         float v[kTPW][4];
 #pragma unroll
         for (int t = 0; t < kTPW; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[t][r] = sc[t][r] * (acc[t][tt][r] - zp[t][r] * sxm) * ri;
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (GRP != 0)
+                    v[t][r] = accf[t][tt][r] * ri;
+                else
+                    v[t][r] = sc[t][r] * (acc[t][tt][r] - zp[t][r] * sxm) * ri;
+            }
         if (p.ksplit > 1) {  // partial sums of this K-slice; the SwiGLU pair keeps c_fc1 at column n, c_fc2 at N + n
             const int64_t ldp = PAIR ? 2 * (int64_t)p.N : (int64_t)p.N;
 #pragma unroll
@@ -356,9 +530,9 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
     }
 }
 
-template <int EPI, bool PAIR, int FMT, int kWaves, int BM>
+template <int EPI, bool PAIR, int FMT, int kWaves, int BM, int GRP = 0>
 int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row tiles (pair tiles for the SwiGLU stream)
-    static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR, FMT, kWaves, BM>,
+    static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR, FMT, kWaves, BM, GRP>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * 256);
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute(gemm) failed: %s", hipGetErrorString(attr_err));
@@ -370,7 +544,7 @@ int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row ti
     q.n_blocks = (p.n_tiles + per_block - 1) / per_block;
     q.total_blocks = q.n_blocks * ((p.M + BM - 1) / BM);
     q.per_xcd = (q.total_blocks * q.ksplit + 7) / 8;
-    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR, FMT, kWaves, BM>), dim3(8 * q.per_xcd), dim3(64 * kWaves), 2 * BM * 256, s, q);
+    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR, FMT, kWaves, BM, GRP>), dim3(8 * q.per_xcd), dim3(64 * kWaves), 2 * BM * 256, s, q);
     MI355_LAUNCH_CHECK();
     if (q.ksplit > 1) {
         const int64_t n = (int64_t)p.M * (p.N >> 2);
@@ -398,6 +572,27 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     if (blocks8 * 4 >= 128) return launch_gemm_w<EPI, PAIR, FMT, 2, kBM>(p, s);
     return launch_gemm_w<EPI, PAIR, FMT, 1, kBM>(p, s);
 }
+// grouped scales: blocks of kGrpBM tokens x 4 waves (the second accumulator set costs the registers of more tokens or
+// waves)
+#ifndef MI355_GEMM_GRP_BM
+#define MI355_GEMM_GRP_BM 64
+#endif
+constexpr int kGrpBM = MI355_GEMM_GRP_BM;
+template <int EPI, bool PAIR, int GRP>
+int launch_gemm_grouped(const GemmParams& p, hipStream_t s) {
+    const int per_block8 = PAIR ? 8 * kTPW / 2 : 8 * kTPW;
+    const int blocks8 = ((p.n_tiles + per_block8 - 1) / per_block8) * ((p.M + kGrpBM - 1) / kGrpBM);
+    if (p.ksplit > 1) return launch_gemm_w<EPI, PAIR, MI355_W_Q4, 4, 64, GRP>(p, s);
+    if (blocks8 >= 128) return launch_gemm_w<EPI, PAIR, MI355_W_Q4, 4, kGrpBM, GRP>(p, s);
+    if (blocks8 * 4 >= 128) return launch_gemm_w<EPI, PAIR, MI355_W_Q4, 2, 64, GRP>(p, s);
+    return launch_gemm_w<EPI, PAIR, MI355_W_Q4, 1, 64, GRP>(p, s);
+}
+template <int GRP>
+int launch_gemm_grouped_epi(const GemmParams& p, int epi, hipStream_t s) {
+    if (epi == MI355_EPI_SWIGLU) return launch_gemm_grouped<MI355_EPI_SWIGLU, true, GRP>(p, s);
+    if (epi == MI355_EPI_ACCUM) return launch_gemm_grouped<MI355_EPI_ACCUM, false, GRP>(p, s);
+    return launch_gemm_grouped<MI355_EPI_STORE, false, GRP>(p, s);
+}
 template <int FMT>
 int launch_gemm_epi(const GemmParams& p, int epi, hipStream_t s) {
     if (epi == MI355_EPI_SWIGLU) return launch_gemm<MI355_EPI_SWIGLU, true, FMT>(p, s);
@@ -421,8 +616,15 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
                     "linear_gemm: the wide path handles the Q4 and BF16 streams (fmt %d)", a->fmt);
     const bool q4 = a->fmt == MI355_W_Q4;
     MI355_CHECK_ARG(a->w && a->x && a->y && (!q4 || (a->scales && a->zeros)), MI355_E_ARG, "linear_gemm: null w/x/y/scales/zeros");
-    MI355_CHECK_ARG(!q4 || a->group_cols == 0 || a->group_cols >= a->K, MI355_E_ARG,
-                    "linear_gemm: grouped scales take the streaming kernel (mi355_linear_fast)");
+    // grouped scales: group_cols = input columns per (scale, zero) pair; 0 or >= K: one pair per output row
+    const bool grouped = q4 && a->group_cols > 0 && a->group_cols < a->K;
+    int gq_shift = 0;
+    if (grouped) {
+        while ((32 << gq_shift) < a->group_cols) ++gq_shift;
+        MI355_CHECK_ARG((32 << gq_shift) == a->group_cols && a->K % 128 == 0, MI355_E_SHAPE,
+                        "linear_gemm: group size %d is not 32 * 2^n or K %% 128 != 0 (use the generic kernel)", a->group_cols);
+        MI355_CHECK_ARG(a->sz_dtype == MI355_BF16, MI355_E_DTYPE, "linear_gemm: grouped scales / zeros must be bf16");
+    }
     MI355_CHECK_ARG(a->M >= 1 && a->N > 0 && a->K > 0, MI355_E_SHAPE, "linear_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     MI355_CHECK_ARG(a->attn_partials == nullptr && a->bias == nullptr, MI355_E_ARG, "linear_gemm: no bias / attention prologue");
     const bool swiglu = a->epi == MI355_EPI_SWIGLU;
@@ -444,7 +646,25 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
     // split-K: launches of fewer than 96 blocks (a 128-token prompt against N = 4096 is 16) cut K into up to 8
     // slices, as many as bring the launch to ~128 workgroups and fit the partial buffer
     int ksplit = 1;
-    {
+    size_t tab_bytes = 0, sxt_bytes = 0;
+    int n_groups = 0, tab_ld = 0;
+    if (grouped) {
+        n_groups = (a->K + a->group_cols - 1) / a->group_cols;
+        tab_ld = (a->N + 15) / 16 * 16;
+        tab_bytes = ((size_t)(n_groups + 1) * a->R * tab_ld * 4 + 15) & ~(size_t)15;
+        sxt_bytes = (size_t)n_groups * a->M * 4;
+        MI355_CHECK_ARG(tab_bytes + sxt_bytes <= kSplitBudget, MI355_E_SHAPE,
+                        "linear_gemm: group tables of %zu B exceed the workspace region (%zu B)", tab_bytes + sxt_bytes, kSplitBudget);
+        // blocks of 8 row tiles x 64 tokens; slices of whole groups (>= 4 per slice), partials in the first half of the
+        // region, the tables in the second
+        const int rows_per_block = swiglu ? 16 * 4 * kTPW / 2 : 16 * 4 * kTPW;
+        const int blocks = ((a->N + rows_per_block - 1) / rows_per_block) * ((a->M + 63) / 64);
+        const size_t row_floats = (size_t)a->N * (swiglu ? 2 : 1);
+        const int cuts = a->group_cols >= 128 ? n_groups : units;
+        while (ksplit < kMaxSplit && blocks * ksplit < 256 && cuts >= 8 * ksplit && tab_bytes + sxt_bytes <= kSplitBudget / 2 &&
+               (size_t)2 * ksplit * a->M * row_floats * 4 <= kSplitBudget / 2)
+            ksplit *= 2;
+    } else {
         const int rows_per_block = swiglu ? 16 * 8 * kTPW / 2 : 16 * 8 * kTPW;
         const int blocks8 = ((a->N + rows_per_block - 1) / rows_per_block) * ((a->M + kBM - 1) / kBM);
         const size_t row_floats = (size_t)a->N * (swiglu ? 2 : 1);
@@ -454,11 +674,33 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
     }
     float* part = (float*)((char*)workspace + (size_t)a->M * kp * 2 + (size_t)a->M * 4 * (1 + kMaxSplit) + 256);
     part = (float*)(((uintptr_t)part + 15) & ~(uintptr_t)15);
-    hipLaunchKernelGGL(stage_rows_kernel, dim3(a->M), dim3(256), 0, s, a->x, a->x_dtype, a->ldx, a->norm_scale, a->norm_dtype,
-                       a->eps, a->K, kp, xb, (int64_t)kp, rinv, sx, ksplit);
-    MI355_LAUNCH_CHECK();
     GemmParams p;
     memset(&p, 0, sizeof(p));
+    if (grouped) {
+        // the group tables live in the split-K region of the workspace (its second half when the launch is split)
+        uint32_t* gtab = (uint32_t*)((char*)part + (ksplit > 1 ? kSplitBudget / 2 : 0));
+        float* sxt = (float*)((char*)gtab + tab_bytes);
+        {
+            const int64_t total = (int64_t)(n_groups + 1) * a->R * tab_ld;
+            const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+            hipLaunchKernelGGL(group_table_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)a->scales, (const bf16_t*)a->zeros,
+                               (const bf16_t*)a->scales2, (const bf16_t*)a->zeros2, a->N, tab_ld, n_groups, a->R, gtab);
+            MI355_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(stage_rows_grouped_kernel, dim3(a->M), dim3(256), 0, s, a->x, a->x_dtype, a->ldx, a->norm_scale,
+                           a->norm_dtype, a->eps, a->K, kp, xb, (int64_t)kp, rinv, sxt, a->M, a->group_cols, n_groups);
+        MI355_LAUNCH_CHECK();
+        p.gtab = gtab;
+        p.sxt = sxt;
+        p.n_groups = n_groups;
+        p.gq_shift = gq_shift;
+        p.upg = a->group_cols >= 128 ? a->group_cols / 128 : 1;
+        p.tab_ld = tab_ld;
+    } else {
+        hipLaunchKernelGGL(stage_rows_kernel, dim3(a->M), dim3(256), 0, s, a->x, a->x_dtype, a->ldx, a->norm_scale, a->norm_dtype,
+                           a->eps, a->K, kp, xb, (int64_t)kp, rinv, sx, ksplit);
+        MI355_LAUNCH_CHECK();
+    }
     p.w = (const uint8_t*)a->w;
     {
         const size_t wb = mi355_packed_bytes(a->fmt, a->N, a->K, a->R, swiglu ? 1 : 0);
@@ -485,6 +727,7 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
     p.y_dtype = a->y_dtype;
     p.ksplit = ksplit;
     p.part = part;
+    if (grouped) return a->group_cols >= 128 ? launch_gemm_grouped_epi<1>(p, a->epi, s) : launch_gemm_grouped_epi<2>(p, a->epi, s);
     if (q4) return launch_gemm_epi<MI355_W_Q4>(p, a->epi, s);
     return launch_gemm_epi<MI355_W_BF16>(p, a->epi, s);
 }

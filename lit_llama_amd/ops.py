@@ -180,10 +180,12 @@ _GEMM_WS = {}  # device -> scratch tensor of the wide linear (staged bf16 operan
 def linear_gemm(x2d: torch.Tensor, stream: torch.Tensor, R: int, N: int, K: int, *, scales: Optional[torch.Tensor] = None,
                 zeros: Optional[torch.Tensor] = None, scales2: Optional[torch.Tensor] = None, zeros2: Optional[torch.Tensor] = None,
                 norm_scale: Optional[torch.Tensor] = None, eps: float = 1e-5, epi: int = EPI_STORE,
-                out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, fmt: int = W_Q4) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, fmt: int = W_Q4,
+                group_cols: int = 0) -> torch.Tensor:
     """y[M, N] = epi(x2d[M, K] . W^T) for WIDE inputs through the LDS-tiled MFMA GEMM over the Q4 stream (scales / zeros
-    per output row) or the BF16 stream (`fmt=W_BF16`, unquantised weights) — mi355_linear_gemm, csrc/gemm.hip: prompt
-    prefill / no-cache evaluation (evaluate/full.py:120-129)."""
+    per output row, or [N, ceil(K / group_cols)] bf16 tables with `group_cols`) or the BF16 stream (`fmt=W_BF16`,
+    unquantised weights) — mi355_linear_gemm, csrc/gemm.hip: prompt prefill / no-cache evaluation
+    (evaluate/full.py:120-129)."""
     assert fmt in (W_Q4, W_BF16) and (fmt == W_BF16 or (scales is not None and zeros is not None))
     require_gpu(x2d, "linear_gemm")
     assert x2d.dim() == 2 and x2d.shape[1] == K and x2d.stride(1) == 1
@@ -205,6 +207,7 @@ def linear_gemm(x2d: torch.Tensor, stream: torch.Tensor, R: int, N: int, K: int,
     a.eps = eps
     a.scales, a.zeros, a.scales2, a.zeros2 = ptr(scales), ptr(zeros), ptr(scales2), ptr(zeros2)
     a.sz_dtype = dtype_code(scales.dtype) if scales is not None else BF16
+    a.group_cols = group_cols if (fmt == W_Q4 and 0 < group_cols < K) else 0
     a.epi = epi
     a.y, a.y_dtype, a.ldy = ptr(out), dtype_code(out.dtype), out.stride(0)
     check(lib().mi355_linear_gemm(C.byref(a), ptr(ws), ws.numel(), stream_ptr()), "mi355_linear_gemm")

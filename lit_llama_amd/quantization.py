@@ -165,11 +165,12 @@ class ColBlockQuantizedLinear(torch.nn.Module):
         if x2d.stride(-1) != 1:
             x2d = x2d.contiguous()
         grouped = self.scales.shape[1] > 1
-        if (self.fast_eligible(inp.dtype) and not grouped and x2d.shape[0] >= 32 and self.out_features % 4 == 0
-                and self.bias is None):
+        if (self.fast_eligible(inp.dtype) and x2d.shape[0] >= 32 and self.out_features % 4 == 0 and self.bias is None
+                and (not grouped or self.in_features % 128 == 0)):
             # wide input (prompt / no-cache evaluation, evaluate/full.py:120-129): LDS-tiled MFMA GEMM over the stream
             y = ops.linear_gemm(x2d, self.weight_stream(1), 1, self.out_features, self.in_features,
-                                scales=self.scales.reshape(-1), zeros=self.zeros.reshape(-1), out_dtype=inp.dtype)
+                                scales=self.scales.reshape(-1), zeros=self.zeros.reshape(-1), out_dtype=inp.dtype,
+                                group_cols=self.tile_cols if grouped else 0)
         elif self.fast_eligible(inp.dtype):
             R = 2 if self.out_features % 32 == 0 and self.out_features >= 16384 else 1
             y = ops.linear_fast(

@@ -1,5 +1,5 @@
 """Timing of the wide int4 linear (mi355_linear_gemm) on the 7B prefill shapes, T = 2048: TFLOP/s vs the 2.5 PFLOP/s
-dense bf16 MFMA peak.    python scripts/bench_gemm.py [--M 2048]"""
+dense bf16 MFMA peak.    python scripts/bench_gemm.py [--M 2048] [--group 128]"""
 import argparse
 import sys
 from pathlib import Path
@@ -14,6 +14,7 @@ from lit_llama_amd import ops  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--M", type=int, default=2048)
+    ap.add_argument("--group", type=int, default=0, help="grouped scales: input columns per (scale, zero) pair")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M = a.M
@@ -22,13 +23,14 @@ def main():
                                ("fc pair", 11008, 4096, 2, nat.EPI_SWIGLU), ("mlp.c_proj", 4096, 11008, 1, nat.EPI_ACCUM)]:
         nbytes = ops.packed_bytes(nat.W_Q4, N, K, R, R == 2)
         stream = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device=dev)
-        sc = (torch.rand(N, device=dev) * 0.01 + 0.005).to(torch.bfloat16)
-        z = torch.full((N,), 8.0, device=dev, dtype=torch.bfloat16)
+        ng = -(-K // a.group) if a.group else 1
+        sc = (torch.rand(N * ng, device=dev) * 0.01 + 0.005).to(torch.bfloat16)
+        z = torch.full((N * ng,), 8.0, device=dev, dtype=torch.bfloat16)
         norm = R == 2 or name == "c_attn"
         x = torch.randn((M, K), device=dev, dtype=torch.float32 if norm else torch.bfloat16)
         g = torch.ones(K, device=dev, dtype=torch.bfloat16) if norm else None
         out = torch.zeros((M, N), device=dev, dtype=torch.bfloat16 if R == 2 else torch.float32)
-        kw = dict(scales=sc, zeros=z, norm_scale=g, epi=epi, out=out)
+        kw = dict(scales=sc, zeros=z, norm_scale=g, epi=epi, out=out, group_cols=a.group)
         if R == 2:
             kw.update(scales2=sc, zeros2=z)
         for _ in range(3):

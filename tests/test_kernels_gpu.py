@@ -592,6 +592,67 @@ def test_linear_gemm_with_fused_rmsnorm_matches_the_skinny_kernel(dev):
     assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
 
 
+GROUPED_GEMM_SHAPES = [
+    # M, N, K, group, epi
+    (512, 4096, 4096, 128, "store"),     # 8-tile blocks of 4 waves; one group per unit
+    (128, 4096, 4096, 128, "accum"),     # short prompt: 4 K-slices of 8 groups
+    (40, 96, 1024, 64, "store"),         # 1-wave blocks; two groups per unit (masked passes)
+    (200, 512, 4096, 32, "accum"),       # a group per MFMA k-block
+    (96, 4096, 11008, 256, "store"),     # a group spans two units, 43 groups
+    (257, 4096, 11008, 512, "store"),    # last group short (21.5 groups of 4 units)
+    (257, 11008, 4096, 128, "swiglu"),   # c_fc1 / c_fc2 pair with two tables, fused RMSNorm
+    (130, 1000, 512, 128, "store"),      # N not a multiple of 16
+    (128, 11008, 4096, 128, "swiglu"),   # short prompt: K-slices of whole groups (deterministic split-K) on the pair stream
+    (64, 12288, 4096, 64, "store"),      # split-K over units with sub-unit groups
+]
+
+
+@pytest.mark.parametrize("M,N,K,g,epi", GROUPED_GEMM_SHAPES)
+def test_linear_gemm_with_grouped_scales_matches_oracle(dev, M, N, K, g, epi):
+    """Wide GEMM over the Q4 stream with one (scale, zero) pair per row and group of `g` input columns (GPTQ groupsize,
+    /root/reference lit_llama/quantization.py:284-333, :404-410 with tile_cols > 0): against exact arithmetic on the
+    bf16-rounded operands, the CPU oracle's colblock_linear, and the skinny streaming kernel."""
+    a = _q4_grouped_problem(N, K, M, g, seed=M + N + K + g, dev=dev)
+    bf = lambda t: t.to(torch.bfloat16).to(dev).reshape(-1).contiguous()  # noqa: E731
+    gen = torch.Generator().manual_seed(g + M)
+    if epi == "swiglu":
+        b = _q4_grouped_problem(N, K, M, g, seed=M + N + K + g + 1, dev=dev)
+        x = torch.randn((M, K), generator=gen) * 3
+        nscale = (1 + 0.1 * torch.randn(K, generator=gen)).to(torch.bfloat16)
+        xnb = (x * nscale.float()).to(torch.bfloat16)
+        rinv = torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5).double()
+        stream = ops.repack_q4(a["packed"], b["packed"], N, K, 2)
+        kw = dict(scales=bf(a["scale"]), zeros=bf(a["zero"]), scales2=bf(b["scale"]), zeros2=bf(b["zero"]),
+                  norm_scale=nscale.to(dev), eps=1e-5, epi=nat.EPI_SWIGLU, out_dtype=torch.bfloat16, group_cols=g)
+        y = ops.linear_gemm(x.to(dev), stream, 2, N, K, **kw).float().cpu()
+        h1 = (xnb.double() @ a["wdq"].double().t()) * rinv
+        h2 = (xnb.double() @ b["wdq"].double().t()) * rinv
+        ref = torch.nn.functional.silu(h1) * h2
+        assert (y.double() - ref).abs().max().item() <= 8e-3 * ref.abs().max().item()  # bf16 output
+        ys = torch.cat([ops.linear_fast(x[i:i + 4].to(dev), stream, nat.W_Q4, 2, N, K, **kw).float().cpu()
+                        for i in range(0, 16, 4)])
+        assert (y[:16] - ys).abs().max().item() <= 8e-3 * ref.abs().max().item()
+        return
+    xb = a["x"].to(torch.bfloat16)
+    stream = ops.repack_q4(a["packed"], None, N, K, 1)
+    kw = dict(scales=bf(a["scale"]), zeros=bf(a["zero"]), group_cols=g)
+    ref64 = xb.double() @ a["wdq"].double().t()
+    if epi == "accum":
+        base = torch.randn((M, N), generator=gen)
+        out = base.clone().to(dev)
+        y = ops.linear_gemm(xb.to(dev), stream, 1, N, K, epi=nat.EPI_ACCUM, out=out, **kw).cpu()
+        ref64 = ref64 + base.double()
+    else:
+        y = ops.linear_gemm(xb.to(dev), stream, 1, N, K, out_dtype=torch.float32, **kw).cpu()
+        yo = oracle.colblock_linear(xb.float(), synth.pack_colblock(a["q"]).contiguous(), a["scale"], a["zero"], 4, g)
+        assert (y - yo).abs().max().item() <= 1e-3 * _rms(ref64)
+        rows = slice(0, 8)   # the skinny kernel (exact per-group sums) on the first rows
+        ysk = ops.linear_fast(xb[rows].to(dev), stream, nat.W_Q4, 1, N, K, out_dtype=torch.float32, **kw).cpu()
+        assert (y[rows] - ysk).abs().max().item() <= 1e-3 * _rms(ref64)
+    err = (y.double() - ref64).abs().max().item()
+    assert err <= 1e-3 * _rms(ref64), f"max err {err:.3e} vs rms {_rms(ref64):.3e}"
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(32, 64, 128, "store"), (200, 4096, 4096, "accum"), (257, 11008, 4096, "swiglu"),
                                         (96, 4096, 11008, "store"), (40, 72, 200, "store"), (128, 4096, 4096, "accum")])
 def test_linear_gemm_over_the_bf16_stream(dev, M, N, K, epi):

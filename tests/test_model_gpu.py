@@ -468,8 +468,8 @@ def test_full_7b_int4_model_size_independent_properties(dev):
 
 def test_grouped_int4_model_streams_through_the_engine_and_matches_oracle(dev):
     """gptq.int4 with a group size (ColBlockQuantizedLinear tile_cols = 128: scales / zeros [out, in / 128],
-    lit_llama/quantization.py:350-374): every linear goes through the grouped MFMA streaming kernel — module by module
-    (ColBlockQuantizedLinear.forward) and inside the native engine (prefill in row chunks, decode under a hipGraph) —
+    lit_llama/quantization.py:350-374): every linear goes through the grouped MFMA kernels — module by module
+    (ColBlockQuantizedLinear.forward) and inside the native engine (prompt: wide GEMM, decode: streaming kernel under a hipGraph) —
     and follows the CPU oracle's dequantise-then-F.linear arithmetic."""
     from lit_llama_amd.quantization import ColBlockQuantizedLinear
 
@@ -491,7 +491,7 @@ def test_grouped_int4_model_streams_through_the_engine_and_matches_oracle(dev):
     eng = model.engine()
     assert eng is not None, model._engine_failed
     assert eng.fused is None  # the persistent step is written for one pair per row
-    T, n_new = 40, 6  # a prompt wider than 32 rows: the engine must NOT take the per-row GEMM path
+    T, n_new = 40, 6  # a prompt wider than 32 rows: the wide GEMM with the group tables (csrc/gemm.hip GRP kernels)
     prompt = synth.make_prompt(T)
     om = oracle.Model(oracle.Config(**kw), sd, mode="gptq.int4")
     ref = oracle.generate(om, prompt, n_new, top_k=1)
