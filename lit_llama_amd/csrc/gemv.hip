@@ -304,7 +304,7 @@ __device__ __forceinline__ float cvt2(uint32_t raw, int dtype) {
     return dtype == MI355_F32 ? __uint_as_float(raw) : __uint_as_float(raw << 16);
 }
 
-template <int FMT, int R, int EPI, bool GRP = false>
+template <int FMT, int R, int EPI, int GRP = 0>
 __device__ __forceinline__ void load_epi(const GemvParams& p, const EpiRsrc& er, int tile, int e_row, int e_col,
                                          bool e_owner, EpiOps<R>& o) {
     constexpr bool sw = EPI == MI355_EPI_SWIGLU;
@@ -333,7 +333,7 @@ __device__ __forceinline__ void load_epi(const GemvParams& p, const EpiRsrc& er,
 // Combine the W partial 16x16 tiles of `buf` in wave order and write the tile's outputs (stores only).
 // RS = partial tiles per wave: R weight tiles (+ the all-ones tile carrying sum_k x_k for Q4).
 // GRP: the partial tiles are already dequantised (grouped scales are applied inside the k loop).
-template <int FMT, int R, int EPI, bool MULTI, bool GRP = false>
+template <int FMT, int R, int EPI, bool MULTI, int GRP = 0>
 __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* part, int buf, int W, int tile,
                                               int e_row, int e_col, const EpiOps<R>& o, float rinv) {
     constexpr bool kDeq = FMT == MI355_W_Q4 && !GRP;
@@ -399,7 +399,7 @@ __device__ __forceinline__ void tile_epilogue(const GemvParams& p, const char* p
 // step) is its own symbol in profiles, and the epilogue carries no runtime switch.
 // Up to 16 waves (1024 threads) per workgroup for the lean Q4 P=4 variants (<= 128 VGPRs); the register-hungrier
 // ones (deep ring, bf16 weights: 4 pieces per unit) stay at 8 waves.
-template <int FMT, int P, bool GRP = false>
+template <int FMT, int P, int GRP = 0>
 constexpr int kMaxThreads = (FMT == MI355_W_Q4 && P <= 4 && !GRP) ? 1024 : 512;
 
 // MULTI = false is the decode step (M == 1): no row loop, no per-row branches — the loop around the row-staging
@@ -410,9 +410,10 @@ constexpr int kMaxThreads = (FMT == MI355_W_Q4 && P <= 4 && !GRP) ? 1024 : 512;
 // in LDS at the tile switch; inside the k loop every wave applies  accf += s (acc - (128 + z) sum_x)  at each group
 // boundary of its unit range (sum_x from the all-ones MFMA of the same columns) and restarts acc / sum_x.  The partial
 // tiles that reach the epilogue are then plain sums.
-constexpr int kGrpLoads = 4;  // (scale, zero) pairs per thread, matrix and tile: 16 n_groups <= kGrpLoads x threads
+constexpr int kGrpLoadsMax = 4;  // GRP = (scale, zero) pairs per thread, matrix and tile: 16 n_groups <= GRP x threads (1 or 4;
+                                 // every pair is an issued buffer load whether it fetches or not: 32 groups over 512 threads need one)
 
-template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI, bool GRP = false>
+template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI, int GRP = 0>
 __global__ __launch_bounds__((kMaxThreads<FMT, P, GRP>)) void gemv_kernel(const GemvParams p) {
     static_assert(!GRP || FMT == MI355_W_Q4, "grouped scales are a Q4 feature");
     const int M = MULTI ? p.M : 1;
@@ -489,6 +490,7 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P, GRP>)) void gemv_kernel(const 
     const EpiRsrc er = make_epi_rsrc(p, M);
     load_epi<FMT, R, EPI, GRP>(p, er, bid, e_row, e_col, e_owner, eo);
     // GRP: the (scale, zero) pairs of a tile, element e = thread + k * threads of the [16][n_groups] block of matrix r
+    constexpr int kGrpLoads = GRP ? GRP : 1;
     uint32_t gs[GRP ? R : 1][kGrpLoads], gz[GRP ? R : 1][kGrpLoads];
     auto grp_load = [&](int t) {
         if constexpr (GRP) {
@@ -580,6 +582,26 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P, GRP>)) void gemv_kernel(const 
     const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // 8 x bf16 1.0
     int uu = 0;
 
+    // GRP decode step (see consume): first group of the 16-group column window of this wave, and the end of a window
+    int gbase = GRP ? (u0 >> (p.gq_shift >= 2 ? p.gq_shift - 2 : 0)) : 0;
+    auto apply_window = [&]() {
+        if constexpr (GRP && !MULTI) {
+            int grp = gbase + c;
+            grp = grp < p.n_groups ? grp : p.n_groups - 1;  // (columns past the wave's range hold zeros)
+            const uint32_t* sz = szl + ((buf * R) * 16 + 4 * g) * p.n_groups + grp;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const uint32_t w = sz[(r * 16 + rr) * p.n_groups];
+                    const float sc = __uint_as_float(w << 16), zp = __uint_as_float(w & 0xffff0000u);
+                    accf[r][rr] += sc * (acc[r][rr] - (128.f + zp) * acc1[rr]);
+                }
+                acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
     // one k-unit: operands from LDS, int4 -> bf16, MFMAs
     auto consume = [&](int j) {
         const char* xb = xl + (uu < nu ? u0 + uu : units) * (kUnitK * 2);  // idle step: the all-zero unit
@@ -587,6 +609,42 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P, GRP>)) void gemv_kernel(const 
 #pragma unroll
         for (int d = 0; d < 4; ++d) b[d] = *(const bf16x8*)(xb + 16 * d);
 
+        if constexpr (GRP && !MULTI) {
+            if (p.gq_shift >= 2) {
+                // Decode step, groups of whole units: the MFMA's 16 token columns are idle (M = 1), so the activations
+                // of group g go to COLUMN (g - gbase) & 15 (every other column reads the all-zero unit) and ONE running
+                // accumulator holds the sums of 16 groups side by side — no per-group work in the k loop at all; the
+                // scales are applied once per tile (or every 16 groups of a wave's range) in apply_window().
+                const int grp = (u0 + uu) >> (p.gq_shift - 2);
+                if (uu < nu && grp - gbase >= 16) {  // (wave-uniform) the window is full
+                    apply_window();
+                    gbase += 16;
+                }
+                const bool mine = uu < nu && c == ((grp - gbase) & 15);
+                const char* xc = xs + g * 64 + (mine ? u0 + uu : units) * (kUnitK * 2);
+                bf16x8 bc[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) bc[d] = *(const bf16x8*)(xc + 16 * d);
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ones), bc[d], acc1, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const u32x4 q = ring[j][r];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const uint32_t v = q[d];
+                        u32x4 a;
+                        a[0] = (v & 0x000F000Fu) | 0x43004300u;
+                        a[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
+                        a[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
+                        a[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), bc[d], acc[r], 0, 0, 0);
+                    }
+                }
+                return;
+            }
+        }
         if constexpr (GRP) {
             // The k dimension of ONE MFMA is spread over the unit (lane group g holds columns 32 g + 8 d .. + 7 of
             // MFMA d), so the four MFMAs of a unit always add up whole 128-column units.  Groups of >= 128 columns
@@ -668,6 +726,16 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P, GRP>)) void gemv_kernel(const 
     };
     // tile done for this wave: publish the partial 16x16 tiles, combine, epilogue
     auto flush = [&]() {
+        if constexpr (GRP && !MULTI) {
+            if (p.gq_shift >= 2) {  // the window's groups lie side by side in the 16 columns: scale them, add them up
+                apply_window();
+                gbase = u0 >> (p.gq_shift - 2);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) accf[r][rr] = group_sum(accf[r][rr], 16);
+            }
+        }
         f32x4* pp = (f32x4*)(part + (size_t)((buf * W + wave) * RS) * 1024) + lane;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -840,7 +908,7 @@ __global__ void i8_repack_kernel(const int8_t* c0, const int8_t* c1, int N, int 
 }
 
 
-template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI, bool GRP>
+template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI, int GRP>
 int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -870,7 +938,7 @@ int launch_gemv_m(const GemvParams& p, int grid, int waves, size_t lds, hipStrea
     return 0;
 }
 
-template <int FMT, int R, int P, int EPI, int VMODE, bool GRP>
+template <int FMT, int R, int P, int EPI, int VMODE, int GRP>
 int launch_gemv_v(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     if constexpr (VMODE == 3) {  // split-attention input exists for M = 1 only (host check)
         return launch_gemv_m<FMT, R, P, EPI, VMODE, false, GRP>(p, grid, waves, lds, stream);
@@ -880,7 +948,7 @@ int launch_gemv_v(const GemvParams& p, int grid, int waves, size_t lds, hipStrea
     }
 }
 
-template <int FMT, int R, int P, int EPI, bool GRP>
+template <int FMT, int R, int P, int EPI, int GRP>
 int launch_gemv_epi(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     switch (p.vec_mode) {
         case 1:
@@ -904,7 +972,7 @@ int launch_gemv_epi(const GemvParams& p, int grid, int waves, size_t lds, hipStr
     return launch_gemv_v<FMT, R, P, EPI, 0, GRP>(p, grid, waves, lds, stream);
 }
 
-template <int FMT, int R, int P, bool GRP>
+template <int FMT, int R, int P, int GRP>
 int launch_gemv(const GemvParams& p, int grid, int waves, size_t lds, hipStream_t stream) {
     switch (p.epi) {
         case MI355_EPI_STORE: return launch_gemv_epi<FMT, R, P, MI355_EPI_STORE, GRP>(p, grid, waves, lds, stream);
@@ -924,7 +992,9 @@ int dispatch_p(const GemvParams& p, int /*prefetch*/, int grid, int waves, size_
     // ignored.
     constexpr int PA = FMT == MI355_W_Q4 ? 4 : 2;
     if constexpr (FMT == MI355_W_Q4) {
-        if (p.n_groups > 0) return launch_gemv<FMT, R, PA, true>(p, grid, waves, lds, s);
+        if (p.n_groups > 0)
+            return 16 * p.n_groups <= waves * 64 ? launch_gemv<FMT, R, PA, 1>(p, grid, waves, lds, s)
+                                                 : launch_gemv<FMT, R, PA, kGrpLoadsMax>(p, grid, waves, lds, s);
     }
     return launch_gemv<FMT, R, PA, false>(p, grid, waves, lds, s);
 }
@@ -1110,9 +1180,9 @@ extern "C" int mi355_linear_fast(const mi355_linear_args* a, mi355_stream_t stre
         p.n_groups = (a->K + group_cols - 1) / group_cols;
         p.gq_shift = sh;
         p.inv_ng = 1.0f / (float)p.n_groups;
-        MI355_CHECK_ARG(16 * p.n_groups <= kGrpLoads * waves * 64, MI355_E_SHAPE,
+        MI355_CHECK_ARG(16 * p.n_groups <= kGrpLoadsMax * waves * 64, MI355_E_SHAPE,
                         "linear_fast: %d groups per row exceed what %d waves prefetch per tile (%d)", p.n_groups, waves,
-                        kGrpLoads * waves * 4);
+                        kGrpLoadsMax * waves * 4);
         MI355_CHECK_ARG((int64_t)a->N * p.n_groups * 2 < 0x7FFFFFF0ll, MI355_E_SHAPE, "linear_fast: scale table too large");
     }
     const int RS = a->R + ((a->fmt == MI355_W_Q4 && p.n_groups == 0) ? 1 : 0);

@@ -23,16 +23,20 @@ def main():
     ap.add_argument("--waves", type=int, default=8)
     ap.add_argument("--prefetch", type=int, default=4)
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--group", type=int, default=0, help="grouped scales: input columns per (scale, zero) pair")
+    ap.add_argument("--shapes", default=",".join(SHAPES_7B))
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev).manual_seed(0)
-    for name, (N, K, R, epi) in SHAPES_7B.items():
+    for name in args.shapes.split(","):
+        N, K, R, epi = SHAPES_7B[name]
         pair = epi == nat.EPI_SWIGLU
         nbytes = ops.packed_bytes(nat.W_Q4, N, K, R, pair)
         n_buf = max(2, int(600e6 // nbytes) + 1)
         streams = [torch.randint(0, 256, (nbytes,), generator=gen, device=dev, dtype=torch.uint8) for _ in range(n_buf)]
-        sc = (0.005 + 0.005 * torch.rand(N, generator=gen, device=dev)).to(torch.bfloat16)
-        ze = torch.full((N,), 8.0, device=dev, dtype=torch.bfloat16)
+        ng = -(-K // args.group) if args.group else 1
+        sc = (0.005 + 0.005 * torch.rand(N * ng, generator=gen, device=dev)).to(torch.bfloat16)
+        ze = torch.full((N * ng,), 8.0, device=dev, dtype=torch.bfloat16)
         x = torch.randn((1, K), generator=gen, device=dev).to(torch.bfloat16 if epi == nat.EPI_ACCUM else torch.float32)
         norm = None if epi == nat.EPI_ACCUM else (1 + 0.1 * torch.randn(K, generator=gen, device=dev)).to(torch.bfloat16)
         out = torch.zeros((1, N), device=dev, dtype=torch.float32 if epi != nat.EPI_SWIGLU else torch.bfloat16)
@@ -50,6 +54,7 @@ def main():
             if pair:
                 a.scales2, a.zeros2 = sc.data_ptr(), ze.data_ptr()
             a.sz_dtype, a.epi = nat.BF16, epi
+            a.group_cols = args.group
             a.y, a.y_dtype, a.ldy = out.data_ptr(), nat.dtype_code(out.dtype), N
             a.waves, a.grid, a.prefetch, a.flags = args.waves, grid, args.prefetch, args.flags
             a.debug_stamps = stamps.data_ptr() if dbg else None

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--shapes", default="attn,proj,fc,mproj,lm_head")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--group", type=int, default=0, help="grouped scales: input columns per (scale, zero) pair")
     ap.add_argument("--bufs", type=int, default=0, help="distinct weight buffers in rotation (0: enough to defeat "
                     "the 256 MiB Infinity Cache; 1: one buffer, i.e. cache-resident weights)")
     args = ap.parse_args()
@@ -52,8 +53,9 @@ def main():
         nbytes = ops.packed_bytes(nat.W_Q4, N, K, R, pair)
         n_buf = args.bufs if args.bufs > 0 else max(2, int(600e6 // nbytes) + 1)  # > 2x the Infinity Cache
         streams = [torch.randint(0, 256, (nbytes,), generator=gen, device=dev, dtype=torch.uint8) for _ in range(n_buf)]
-        sc = (0.005 + 0.005 * torch.rand(N, generator=gen, device=dev)).to(torch.bfloat16)
-        ze = torch.full((N,), 8.0, device=dev, dtype=torch.bfloat16)
+        ng = -(-K // args.group) if args.group else 1
+        sc = (0.005 + 0.005 * torch.rand(N * ng, generator=gen, device=dev)).to(torch.bfloat16)
+        ze = torch.full((N * ng,), 8.0, device=dev, dtype=torch.bfloat16)
         x = torch.randn((1, K), generator=gen, device=dev).to(torch.bfloat16 if epi == nat.EPI_ACCUM else torch.float32)
         norm = None if epi == nat.EPI_ACCUM else (1 + 0.1 * torch.randn(K, generator=gen, device=dev)).to(torch.bfloat16)
         out = torch.zeros((1, N), device=dev, dtype=torch.float32 if epi != nat.EPI_SWIGLU else torch.bfloat16)
@@ -75,6 +77,7 @@ def main():
             if pair:
                 a.scales2, a.zeros2 = sc.data_ptr(), ze.data_ptr()
             a.sz_dtype, a.epi = nat.BF16, epi
+            a.group_cols = args.group
             a.y, a.y_dtype, a.ldy = out.data_ptr(), nat.dtype_code(out.dtype), N
             a.waves, a.grid, a.prefetch, a.flags = waves, grid, pf, flags
             return a
