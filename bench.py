@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tp-timeout", type=float, default=180.0, help="seconds after which a hanging TP leg is abandoned")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--adapter", action="store_true", help="LLaMA-Adapter variant (generate/adapter.py): prefix attention "
+                    "with random adaption prompts / gates in every block from adapter_start_layer on (not a BASELINE config)")
     ap.add_argument("--dry-run", action="store_true", help="check the launch contract only (ranks, world size); no GPU work")
     ap.add_argument("--no-tp", action="store_true", help="skip the tensor-parallel leg (65B gptq.int4, TP = --gpus)")
     ap.add_argument("--tp-model", default="65B")
@@ -84,9 +86,23 @@ def build_model(args, dev):
 
     cfg = LLaMAConfig.from_name(args.model)
     mode = None if args.quantize == "none" else args.quantize
+    if args.adapter:
+        from lit_llama_amd import adapter as A
+
+        cfg = A.LLaMAConfig.from_name(args.model)
+        cfg.vocab_size = cfg.padded_vocab_size  # (the reference's adapter model sizes its head by vocab_size)
+        LLaMA = A.LLaMA
     with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode=mode):
         model = LLaMA(cfg)
     model.eval()
+    if args.adapter:
+        gen_a = torch.Generator(device=dev).manual_seed(7)
+        with torch.no_grad():
+            for blk in model.transformer.h:
+                if hasattr(blk.attn, "adapter_wte"):
+                    w = blk.attn.adapter_wte.weight
+                    w.copy_(torch.randn(w.shape, generator=gen_a, device=dev).to(w.dtype))
+                    blk.attn.gating_factor.fill_(0.5)
     if mode == "gptq.int4":
         synth.fill_model_random_int4(model, seed=0)
     else:
@@ -532,11 +548,12 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    default_cfg = args.model == "7B" and args.quantize == "gptq.int4"
-    cfg_idx = {"none": 1, "gptq.int4": 2, "llm.int8": 3}[args.quantize] if args.model == "7B" else None
+    default_cfg = args.model == "7B" and args.quantize == "gptq.int4" and not args.adapter
+    cfg_idx = {"none": 1, "gptq.int4": 2, "llm.int8": 3}[args.quantize] if args.model == "7B" and not args.adapter else None
     wname = {"gptq.int4": "int4", "llm.int8": "int8", "none": "bf16"}[args.quantize]
     out = {
-        "metric": METRIC if default_cfg else f"decode tokens/sec/GPU LLaMA-{args.model} {args.quantize} bs=1; % HBM roofline",
+        "metric": METRIC if default_cfg else f"decode tokens/sec/GPU LLaMA-{args.model}{' + LLaMA-Adapter' if args.adapter else ''} "
+                                             f"{args.quantize} bs=1; % HBM roofline",
         "value": round(tok_s_gpu * world, 2),
         "unit": "tokens/s",
         "n_gpus": world,

@@ -242,6 +242,33 @@ int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream);
 int mi355_attn_combine(const float* partials, int n_split, int rows, int n_head, int hs, void* y, int y_dtype,
                        int64_t ldy, mi355_stream_t stream);
 
+/* LLaMA-Adapter prefix term — CausalSelfAttention.forward of lit_llama/adapter.py:134-151 after the causal attention:
+ *     y[row, h, :] += gate[h] * softmax(rope(q[row, h]) . ak[h]^T / sqrt(hs)) av[h]
+ * q is read from the same qkv rows as mi355_attention (column h * hs) and RoPE'd the same way; ak / av are the k / v
+ * projections of the adapter_prompt_length prefix rows (no RoPE, adapter.py:136-141), f32 [n_head, aT, hs]; gate is
+ * gating_factor, f32 [n_head]; y ([B*T, ldy] of y_dtype) is updated in place. */
+typedef struct mi355_adapter_args {
+    const void* qkv;
+    int32_t qkv_dtype;
+    int32_t B;
+    int64_t ld_qkv;
+    const float* rope;     /* as mi355_attn_args.rope */
+    const int32_t* pos;    /* device [T] or NULL (positions 0 .. T - 1) */
+    int32_t rope_gathered; /* as mi355_attn_args.rope_gathered */
+    int32_t T;
+    int32_t n_head;
+    int32_t hs;
+    int32_t aT;            /* prefix rows (adapter_prompt_length) */
+    int32_t y_dtype;
+    const float* ak;
+    const float* av;
+    const float* gate;
+    void* y;
+    int64_t ldy;
+} mi355_adapter_args;
+
+int mi355_adapter_prefix(const mi355_adapter_args* a, mi355_stream_t stream);
+
 /* torch.roll(cache, -1, dims=2) of lit_llama/model.py:217-218, in place, for both caches */
 int mi355_kv_roll(void* kcache, void* vcache, int cache_dtype, int B, int n_head, int S, int hs,
                   mi355_stream_t stream);
@@ -350,6 +377,13 @@ typedef struct mi355_layer {
     mi355_weight mproj;  /* mlp.c_proj [C, n_hidden] */
     void* kcache;
     void* vcache;
+    /* LLaMA-Adapter (lit_llama/adapter.py:62-171): prefix keys / values / gate of this block as mi355_adapter_args takes
+     * them, adapter_len = adapter_prompt_length; 0 / NULL for a block without adapter (and for every plain model) */
+    const float* adapter_k;
+    const float* adapter_v;
+    const float* adapter_gate;
+    int32_t adapter_len;
+    int32_t reserved0;
 } mi355_layer;
 
 typedef struct mi355_model {

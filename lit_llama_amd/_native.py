@@ -53,6 +53,15 @@ class AttnArgs(C.Structure):
     ]
 
 
+class AdapterArgs(C.Structure):
+    _fields_ = [
+        ("qkv", c_void_p), ("qkv_dtype", c_int32), ("B", c_int32), ("ld_qkv", c_int64),
+        ("rope", c_void_p), ("pos", c_void_p), ("rope_gathered", c_int32), ("T", c_int32),
+        ("n_head", c_int32), ("hs", c_int32), ("aT", c_int32), ("y_dtype", c_int32),
+        ("ak", c_void_p), ("av", c_void_p), ("gate", c_void_p), ("y", c_void_p), ("ldy", c_int64),
+    ]
+
+
 class Int8Args(C.Structure):
     _fields_ = [
         ("w", c_void_p), ("scb", c_void_p), ("N", c_int32), ("K", c_int32),
@@ -82,6 +91,8 @@ class Layer(C.Structure):
         ("rms1", c_void_p), ("rms2", c_void_p),
         ("attn", Weight), ("proj", Weight), ("fc", Weight), ("mproj", Weight),
         ("kcache", c_void_p), ("vcache", c_void_p),
+        ("adapter_k", c_void_p), ("adapter_v", c_void_p), ("adapter_gate", c_void_p),
+        ("adapter_len", c_int32), ("reserved0", c_int32),
     ]
 
 
@@ -151,6 +162,7 @@ PROTOTYPES = {
     "mi355_embedding": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mi355_argmax": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mi355_attention": (c_int, [C.POINTER(AttnArgs), c_void_p]),
+    "mi355_adapter_prefix": (c_int, [C.POINTER(AdapterArgs), c_void_p]),
     "mi355_attn_combine": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "mi355_kv_roll": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mi355_int8_quant_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

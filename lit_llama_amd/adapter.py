@@ -10,13 +10,13 @@ the `adapter_kv_cache`) and q the RoPE'd query of the token.  Class names, const
 (`transformer.h.{i}.attn.adapter_wte.weight`, `...attn.gating_factor`) and the forward / cache contract follow the
 reference so that generate/adapter.py:67-95 runs unchanged.
 
-The linears, RMSNorm, RoPE, the KV cache and the causal attention are the native kernels of the launch-per-operator path
-(lit_llama_amd/ops.py); the prefix term — ten rows per head — is a few tensor operations on the device.  The whole-forward
-engine and the fused decode step do not know the prefix term: an adapter model runs op by op (`engine()` is None).
+The linears, RMSNorm, RoPE, the KV cache and the causal attention are the native kernels (lit_llama_amd/ops.py); the prefix
+term — ten rows per head, own softmax, gate — is `mi355_adapter_prefix` (csrc/attention.hip), which the whole-forward engine
+runs right after the causal attention of an adapter block (csrc/engine.hip), so an adapter model decodes under the same
+hipGraph as a plain one (not through the persistent fused step, which does not know the prefix term).
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -72,17 +72,22 @@ class CausalSelfAttention(llama.CausalSelfAttention):
             y = ops.attention(qkv, rope_f, nh, rope_gathered=True)
         if self.block_idx >= self.adapter_start_layer:
             if adapter_kv_cache is None:
-                prefix = self.adapter_wte.weight.detach().reshape(1, self.adapter_prompt_length, C)
-                akv = _linear(self.c_attn, prefix.to(x.dtype))                      # [1, aT, 3 C]
-                ak = akv[0, :, C:2 * C].reshape(-1, nh, hs).transpose(0, 1).float()  # [nh, aT, hs]
-                av = akv[0, :, 2 * C:].reshape(-1, nh, hs).transpose(0, 1).float()
-                adapter_kv_cache = (ak, av)
+                adapter_kv_cache = self.adapter_prefix_kv(x.dtype)[:2]
             ak, av = adapter_kv_cache
-            q = ops.apply_rope(qkv[..., :C].reshape(B, T, nh, hs).contiguous(), rope_f)  # RoPE'd queries (model.py:306-323)
-            att = torch.einsum("bthd,hsd->bhts", q.float(), ak) * (1.0 / math.sqrt(hs))
-            ay = torch.einsum("bhts,hsd->bthd", torch.softmax(att, dim=-1), av)          # [B, T, nh, hs]
-            y = y + (self.gating_factor.detach().float().view(1, 1, nh, 1) * ay).reshape(B, T, C).to(y.dtype)
+            gate = self.gating_factor.detach().float().reshape(-1).contiguous()
+            ops.adapter_prefix(qkv, rope_f, nh, ak, av, gate, y)  # y += gate * softmax(rope(q) ak^T / sqrt(hs)) av
         return _linear(self.c_proj, y), kv_cache, adapter_kv_cache
+
+    def adapter_prefix_kv(self, dtype: torch.dtype):
+        """(ak, av, gate): the k / v projections of the adaption prompt through this block's c_attn, f32 [n_head, aT, hs]
+        (no RoPE, adapter.py:136-141), and the per-head gate, f32 [n_head]."""
+        C, nh = self.n_embd, self.n_head
+        hs = C // nh
+        prefix = self.adapter_wte.weight.detach().reshape(1, self.adapter_prompt_length, C)
+        akv = _linear(self.c_attn, prefix.to(dtype))                                     # [1, aT, 3 C]
+        ak = akv[0, :, C:2 * C].reshape(-1, nh, hs).transpose(0, 1).float().contiguous()  # [nh, aT, hs]
+        av = akv[0, :, 2 * C:].reshape(-1, nh, hs).transpose(0, 1).float().contiguous()
+        return ak, av, self.gating_factor.detach().float().reshape(-1).contiguous()
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         """Old checkpoints hold ONE gating value for all heads (adapter.py:173-183)."""
@@ -135,19 +140,13 @@ class LLaMA(llama.LLaMA):
         self.kv_caches: List[KVCache] = []
         self.adapter_kv_caches: List[Optional[KVCache]] = []
         self._engine = None
-        self._engine_failed = self._NO_ENGINE
+        self._engine_failed = None
         self._engine_failed_fp = None
-        self.use_engine = False
+        self.use_engine = True
 
     @classmethod
     def from_name(cls, name: str):
         return cls(LLaMAConfig.from_name(name))
-
-    _NO_ENGINE = "LLaMA-Adapter models run op by op: the prefix attention is not part of the native engine"
-
-    def engine(self, check: bool = True):
-        self._engine_failed = self._NO_ENGINE
-        return None
 
     def reset_cache(self) -> None:
         super().reset_cache()
@@ -167,6 +166,12 @@ class LLaMA(llama.LLaMA):
             self.rope_cache = self.build_rope_cache(idx)
         if self.mask_cache is None:
             self.mask_cache = self.build_mask_cache(idx)
+        if input_pos is not None and B == 1 and self.use_engine:
+            eng = self.engine(check=False)  # (None for LLaMA-Adapter v2 linears: op by op below)
+            if eng is not None:
+                out = eng.forward(idx, max_seq_length, input_pos)
+                if out is not None:
+                    return out
         rope = self.rope_cache.index_select(0, input_pos) if input_pos is not None else self.rope_cache[:T]
         x = ops.embedding(idx, self.transformer.wte.weight.detach())
         if input_pos is None:  # no cache (adapter.py:277-279)

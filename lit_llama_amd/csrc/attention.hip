@@ -590,6 +590,115 @@ extern "C" int mi355_attn_combine(const float* partials, int n_split, int rows, 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------ LLaMA-Adapter prefix term
+// y[row, h, :] += gate[h] * softmax(rope(q[row, h]) . ak[h]^T / sqrt(hs)) av[h]      (/root/reference lit_llama/adapter.py:134-151:
+// the adaption prompt's keys / values carry no RoPE and no mask, the softmax is its own, the gate is per head).
+// One wave per (row, head): a lane holds the interleaved pairs lane, lane + 64 of the query (RoPE is lane-local), the
+// aT (ten) prefix rows are walked with a running (max, sum, weighted values) — f32 throughout.
+struct AdapterParams {
+    const void* qkv;
+    int qkv_dtype;
+    int64_t ld_qkv;
+    const float* rope;
+    const int* pos;
+    int rope_gathered, T, rows, n_head, hs, aT;
+    const float* ak;    // [n_head, aT, hs]
+    const float* av;
+    const float* gate;  // [n_head]
+    void* y;
+    int y_dtype;
+    int64_t ldy;
+};
+
+__global__ __launch_bounds__(256) void adapter_prefix_kernel(const AdapterParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.x, row = blockIdx.y * 4 + wave;
+    if (row >= p.rows) return;
+    const int hs = p.hs, half = hs >> 1;
+    const int t = row % p.T;
+    const int rrow = p.rope_gathered ? t : (p.pos ? p.pos[t] : t);
+    float qa[2], qb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pi = lane + 64 * j;
+        qa[j] = qb[j] = 0.f;
+        if (pi < half) {
+            const float a = ld_as_f32(p.qkv, (int64_t)row * p.ld_qkv + h * hs + 2 * pi, p.qkv_dtype);
+            const float b = ld_as_f32(p.qkv, (int64_t)row * p.ld_qkv + h * hs + 2 * pi + 1, p.qkv_dtype);
+            rope_pair(p.rope, rrow, half, pi, a, b, qa[j], qb[j]);
+        }
+    }
+    const float scale = rsqrtf((float)hs);
+    float m = -INFINITY, l = 0.f, oa[2] = {0.f, 0.f}, ob[2] = {0.f, 0.f};
+    for (int s = 0; s < p.aT; ++s) {
+        const float* kr = p.ak + ((int64_t)h * p.aT + s) * hs;
+        const float* vr = p.av + ((int64_t)h * p.aT + s) * hs;
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pi = lane + 64 * j;
+            if (pi < half) dot += qa[j] * kr[2 * pi] + qb[j] * kr[2 * pi + 1];
+        }
+        dot = wave_sum(dot) * scale;
+        const float mn = fmaxf(m, dot);
+        const float corr = __expf(m - mn), pw = __expf(dot - mn);
+        l = l * corr + pw;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pi = lane + 64 * j;
+            if (pi < half) {
+                oa[j] = oa[j] * corr + pw * vr[2 * pi];
+                ob[j] = ob[j] * corr + pw * vr[2 * pi + 1];
+            }
+        }
+        m = mn;
+    }
+    const float gl = p.gate[h] / l;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pi = lane + 64 * j;
+        if (pi < half) {
+            const int64_t yi = (int64_t)row * p.ldy + h * hs + 2 * pi;
+            st_from_f32(p.y, yi, p.y_dtype, ld_as_f32(p.y, yi, p.y_dtype) + gl * oa[j]);
+            st_from_f32(p.y, yi + 1, p.y_dtype, ld_as_f32(p.y, yi + 1, p.y_dtype) + gl * ob[j]);
+        }
+    }
+}
+
+extern "C" int mi355_adapter_prefix(const mi355_adapter_args* a, mi355_stream_t stream) {
+    MI355_CHECK_ARG(a != nullptr && a->qkv && a->rope && a->ak && a->av && a->gate && a->y, MI355_E_ARG,
+                    "adapter_prefix: null argument");
+    MI355_CHECK_ARG(a->B > 0 && a->T > 0 && a->n_head > 0 && a->hs > 0 && a->hs % 2 == 0 && a->hs <= 256 && a->aT > 0,
+                    MI355_E_SHAPE, "adapter_prefix: bad shape (B=%d T=%d heads=%d hs=%d prefix rows=%d)", a->B, a->T, a->n_head,
+                    a->hs, a->aT);
+    auto three = [](int d) { return d == MI355_F32 || d == MI355_BF16 || d == MI355_F16; };
+    MI355_CHECK_ARG(three(a->qkv_dtype) && three(a->y_dtype), MI355_E_DTYPE, "adapter_prefix: qkv / y dtype");
+    MI355_CHECK_ARG(a->rope_gathered || a->pos != nullptr || a->T > 0, MI355_E_ARG, "adapter_prefix: no positions");
+    const int64_t rows = (int64_t)a->B * a->T;
+    MI355_CHECK_ARG((rows + 3) / 4 <= 65535, MI355_E_SHAPE, "adapter_prefix: too many rows for the grid");
+    AdapterParams p;
+    p.qkv = a->qkv;
+    p.qkv_dtype = a->qkv_dtype;
+    p.ld_qkv = a->ld_qkv;
+    p.rope = a->rope;
+    p.pos = a->pos;
+    p.rope_gathered = a->rope_gathered;
+    p.T = a->T;
+    p.rows = (int)rows;
+    p.n_head = a->n_head;
+    p.hs = a->hs;
+    p.aT = a->aT;
+    p.ak = a->ak;
+    p.av = a->av;
+    p.gate = a->gate;
+    p.y = a->y;
+    p.y_dtype = a->y_dtype;
+    p.ldy = a->ldy;
+    hipLaunchKernelGGL(adapter_prefix_kernel, dim3(a->n_head, (unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int mi355_kv_roll(void* kcache, void* vcache, int cache_dtype, int B, int n_head, int S, int hs,
                              mi355_stream_t stream) {
     MI355_CHECK_ARG(kcache && vcache, MI355_E_ARG, "kv_roll: null cache");

@@ -146,6 +146,8 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
     not one the persistent launch handles (then every linear keeps its own stream tensor)."""
     if _env_int("MI355_FUSED", 1) == 0 or kinds != {"q4"}:
         return None
+    if any(hasattr(blk.attn, "adapter_wte") for blk in model.transformer.h):
+        return None  # LLaMA-Adapter blocks: the prefix term lives in the launch-per-operator step
     if not lib().mi355_fused_step_supported(C_, nh, hs, H, V, 1):
         return None
     first = model.transformer.h[0]
@@ -222,6 +224,14 @@ class DecodeEngine:
                 o = i * plan["layer_bytes"] + plan["offs"][j]
                 return self.w_arena[o:o + plan["sizes"][j]]
 
+            # LLaMA-Adapter: the k / v projections of the prefix rows through the block's own c_attn, once (the reference
+            # keeps them as adapter_kv_cache, adapter.py:136-141) — through the module's forward, before its weights are repacked
+            adapter_kv = {}
+            for i, blk in enumerate(model.transformer.h):
+                if hasattr(blk.attn, "adapter_wte"):
+                    if tp_world != 1:
+                        raise EngineUnavailable("LLaMA-Adapter blocks in a tensor-parallel shard")
+                    adapter_kv[i] = blk.attn.adapter_prefix_kv(wte.dtype)
             for i, blk in enumerate(model.transformer.h):
                 attn = pack_linear(blk.attn.c_attn, 1, tune=dflt("attn"), out=slot(i, 0))
                 proj = pack_linear(blk.attn.c_proj, 1, tune=dflt("proj"), out=slot(i, 1))
@@ -231,6 +241,10 @@ class DecodeEngine:
                 L = layers[i]
                 L.rms1, L.rms2 = ptr(blk.rms_1.scale.detach()), ptr(blk.rms_2.scale.detach())
                 L.attn, L.proj, L.fc, L.mproj = attn.desc, proj.desc, fc.desc, mproj.desc
+                if i in adapter_kv:  # LLaMA-Adapter: prefix keys / values / gate of this block (adapter.py:134-151)
+                    ak, av, gate = adapter_kv[i]
+                    L.adapter_k, L.adapter_v, L.adapter_gate, L.adapter_len = ptr(ak), ptr(av), ptr(gate), ak.shape[1]
+                    self._keep += [ak, av, gate]
             head = pack_linear(model.lm_head, 1, tune=dflt("lm_head"))
             self.packed.append(head)
             self.layers = layers

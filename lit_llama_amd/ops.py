@@ -505,6 +505,32 @@ def attention(
     return y
 
 
+def adapter_prefix(qkv: torch.Tensor, rope: torch.Tensor, n_head: int, ak: torch.Tensor, av: torch.Tensor,
+                   gate: torch.Tensor, y: torch.Tensor, pos: Optional[torch.Tensor] = None,
+                   rope_gathered: bool = True) -> torch.Tensor:
+    """In place: y[b, t, h, :] += gate[h] * softmax(rope(q[b, t, h]) . ak[h]^T / sqrt(hs)) av[h] — the LLaMA-Adapter
+    prefix term of lit_llama/adapter.py:134-151 (mi355_adapter_prefix, csrc/attention.hip).  qkv [B, T, 3 C] as
+    `attention` takes it, ak / av f32 [n_head, aT, hs], gate f32 [n_head], y [B, T, C]."""
+    require_gpu(qkv, "adapter_prefix")
+    B, T, C3 = qkv.shape
+    hs = C3 // 3 // n_head
+    assert qkv.stride(-1) == 1 and qkv.stride(0) == T * qkv.stride(1) and y.shape == (B, T, n_head * hs) and y.is_contiguous()
+    assert ak.dtype == av.dtype == gate.dtype == torch.float32 and ak.shape == av.shape == (n_head, ak.shape[1], hs)
+    assert ak.is_contiguous() and av.is_contiguous() and gate.is_contiguous() and gate.numel() == n_head
+    assert rope.dtype == torch.float32 and rope.is_contiguous()
+    a = nat.AdapterArgs()
+    a.qkv, a.qkv_dtype, a.B, a.ld_qkv = ptr(qkv), dtype_code(qkv.dtype), B, qkv.stride(1)
+    a.rope, a.rope_gathered, a.T = ptr(rope), 1 if rope_gathered else 0, T
+    if pos is not None:
+        pos32 = pos.to(torch.int32).contiguous()
+        a.pos = ptr(pos32)
+    a.n_head, a.hs, a.aT = n_head, hs, ak.shape[1]
+    a.ak, a.av, a.gate = ptr(ak), ptr(av), ptr(gate)
+    a.y, a.y_dtype, a.ldy = ptr(y), dtype_code(y.dtype), y.stride(1)
+    check(lib().mi355_adapter_prefix(C.byref(a), stream_ptr()), "mi355_adapter_prefix")
+    return y
+
+
 def kv_roll(k: torch.Tensor, v: torch.Tensor) -> None:
     require_gpu(k, "kv_roll")
     B, nh, S, hs = k.shape

@@ -45,7 +45,7 @@ def test_adapter_module_layout_and_cache_contract():
     model.load_state_dict(sd)
     assert not hasattr(model.transformer.h[1].attn, "adapter_wte") and hasattr(model.transformer.h[2].attn, "adapter_wte")
     assert model.transformer.h[2].attn.gating_factor.shape == (1, 4, 1, 1)
-    assert model.engine() is None and "Adapter" in model._engine_failed
+    assert model.engine() is None and "cpu" in model._engine_failed  # (on a GPU, bf16: the native engine runs the prefix term)
     assert set(A.adapter_state_from_state_dict(sd)) == {k for k in sd if "adapter_wte" in k or "gating_factor" in k}
     A.mark_only_adapter_as_trainable(model)
     assert {n for n, p_ in model.named_parameters() if p_.requires_grad} == set(A.adapter_state_from_state_dict(sd))

@@ -1,6 +1,7 @@
-"""generate/adapter.py:67-95 through the native kernels: lit_llama_amd.adapter.LLaMA (op by op: native linears, RMSNorm,
-RoPE + KV cache + causal attention; the ten-row prefix attention as tensor ops) against the reference's own run
-(tests/golden/adapter.npz) in f32 and against the oracle in bf16."""
+"""generate/adapter.py:67-95 through the native kernels: lit_llama_amd.adapter.LLaMA — op by op (native linears, RMSNorm,
+RoPE + KV cache + causal attention, the ten-row gated prefix attention as mi355_adapter_prefix) in f32, and through the
+whole-forward engine (prefix term right after the causal attention, decode under a hipGraph) in bf16 — against the
+reference's own run (tests/golden/adapter.npz)."""
 import numpy as np
 import pytest
 import torch
@@ -35,15 +36,57 @@ def test_adapter_model_follows_the_reference(dev, golden, dtype, tol):
         model = A.LLaMA(A.LLaMAConfig(**CFG))
     model.load_state_dict(adapter_state_dict())
     model.eval()
-    got = _teacher_forced(model, toks, T, S, dev)
-    err = (got - ref_logits).abs().max().item()
-    assert err <= tol * std, f"{dtype}: adapter logits off by {err:.5f} (std {std:.3f})"
-    assert model.adapter_kv_caches == [] and len(model.kv_caches) == 0
-    out = lit_llama_amd.generate(model, toks[:T], toks.numel() - T, top_k=1).cpu()
+    on_engine = dtype == torch.bfloat16
+    eng = model.engine()
+    assert (eng is not None) == on_engine, model._engine_failed  # f32 models run op by op through the exact kernels
+    if on_engine:
+        assert eng.fused is None and eng.layers[2].adapter_len == 10 and eng.layers[0].adapter_len == 0
     margins = g["margin"]
     n = T + 1 + next((i for i, m in enumerate(margins.tolist()) if m <= 2 * tol * std), len(margins))
-    assert torch.equal(out[:n].long(), toks[:n].cpu().long()), f"{out.tolist()} vs {toks.tolist()}"
-    assert model.adapter_kv_caches[2] is not None and model.adapter_kv_caches[0] is None  # prefix k / v computed once
+    for use_engine in ((True, False) if on_engine else (False,)):
+        model.use_engine = use_engine
+        got = _teacher_forced(model, toks, T, S, dev)
+        err = (got - ref_logits).abs().max().item()
+        assert err <= tol * std, f"{dtype} engine={use_engine}: adapter logits off by {err:.5f} (std {std:.3f})"
+        assert model.adapter_kv_caches == [] and len(model.kv_caches) == 0
+        out = lit_llama_amd.generate(model, toks[:T], toks.numel() - T, top_k=1).cpu()
+        assert torch.equal(out[:n].long(), toks[:n].cpu().long()), f"engine={use_engine}: {out.tolist()} vs {toks.tolist()}"
+        if not use_engine:  # op by op: prefix k / v computed once and kept (adapter.py:136-141)
+            assert model.adapter_kv_caches[2] is not None and model.adapter_kv_caches[0] is None
+
+
+@pytest.mark.parametrize("qdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hs,nh,B,T", [(128, 32, 1, 1), (128, 4, 2, 5), (16, 4, 1, 7), (256, 2, 1, 3)])
+def test_adapter_prefix_kernel_matches_the_reference_arithmetic(dev, qdtype, hs, nh, B, T):
+    """mi355_adapter_prefix against adapter.py:134-151 spelled in torch: softmax(rope(q) ak^T / sqrt(hs)) av, gated, added."""
+    import math
+
+    from lit_llama_amd import ops
+    from lit_llama_amd.model import build_rope_cache
+
+    gen = torch.Generator().manual_seed(hs + T)
+    C, aT = nh * hs, 10
+    qkv = torch.randn((B, T, 3 * C), generator=gen).to(qdtype)
+    ak, av = torch.randn((nh, aT, hs), generator=gen), torch.randn((nh, aT, hs), generator=gen)
+    gate = torch.randn((nh,), generator=gen)
+    y0 = torch.randn((B, T, C), generator=gen).to(qdtype)
+    pos = torch.arange(3, 3 + T)
+    table = build_rope_cache(64, hs, torch.int64, torch.device("cpu")).float()
+    rope = table.index_select(0, pos)
+    q = qkv[..., :C].float().reshape(B, T, nh, hs)
+    qs = q.reshape(B, T, nh, hs // 2, 2)
+    rc = rope.view(1, T, 1, hs // 2, 2)
+    qr = torch.stack([qs[..., 0] * rc[..., 0] - qs[..., 1] * rc[..., 1],
+                      qs[..., 1] * rc[..., 0] + qs[..., 0] * rc[..., 1]], -1).flatten(3)
+    att = torch.einsum("bthd,hsd->bhts", qr, ak) / math.sqrt(hs)
+    ay = torch.einsum("bhts,hsd->bthd", torch.softmax(att, -1), av)
+    ref = y0.float() + (gate.view(1, 1, nh, 1) * ay).reshape(B, T, C)
+    for gathered in (True, False):
+        y = y0.clone().to(dev)
+        ops.adapter_prefix(qkv.to(dev), (rope if gathered else table).contiguous().to(dev), nh, ak.to(dev), av.to(dev),
+                           gate.to(dev), y, pos=None if gathered else pos.to(dev), rope_gathered=gathered)
+        err = (y.float().cpu() - ref).abs().max().item()
+        assert err <= (1e-5 if qdtype == torch.float32 else 2e-2) * ref.abs().max().item(), (gathered, err)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 0.05)])
