@@ -234,6 +234,15 @@ typedef struct mi355_attn_args {
     float* partials;
     uint64_t* debug_stamps; /* optional: uint64 [workgroups][8] wall-clock stamps (100 MHz): 0 entry, 1 K/V loads
                                issued, 2 q staged, 3 rows done, 4 exit */
+    /* LLaMA-Adapter (lit_llama/adapter.py:134-151), adapter_len > 0: y (or, with n_split > 1, every partial record, so
+     * that the combined result is the same) additionally receives gate[h] * softmax(q ak[h]^T / sqrt(hs)) av[h] — operands as
+     * mi355_adapter_args takes them, at most 64 prefix rows.  The decode kernel computes the term itself; behind the
+     * many-token flash kernel it is a mi355_adapter_prefix launch. */
+    const float* adapter_k;
+    const float* adapter_v;
+    const float* adapter_gate;
+    int32_t adapter_len;
+    int32_t reserved0;
 } mi355_attn_args;
 
 int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream);

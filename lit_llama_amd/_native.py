@@ -50,6 +50,8 @@ class AttnArgs(C.Structure):
         ("S", c_int32), ("y_dtype", c_int32), ("y", c_void_p), ("ldy", c_int64),
         ("kv_tmp", c_void_p), ("rope_gathered", c_int32), ("n_split", c_int32), ("partials", c_void_p),
         ("debug_stamps", c_void_p),
+        ("adapter_k", c_void_p), ("adapter_v", c_void_p), ("adapter_gate", c_void_p),
+        ("adapter_len", c_int32), ("reserved0", c_int32),
     ]
 
 

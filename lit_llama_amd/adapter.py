@@ -11,9 +11,10 @@ the `adapter_kv_cache`) and q the RoPE'd query of the token.  Class names, const
 reference so that generate/adapter.py:67-95 runs unchanged.
 
 The linears, RMSNorm, RoPE, the KV cache and the causal attention are the native kernels (lit_llama_amd/ops.py); the prefix
-term — ten rows per head, own softmax, gate — is `mi355_adapter_prefix` (csrc/attention.hip), which the whole-forward engine
-runs right after the causal attention of an adapter block (csrc/engine.hip), so an adapter model decodes under the same
-hipGraph as a plain one (not through the persistent fused step, which does not know the prefix term).
+term — ten rows per head, own softmax, gate — is computed inside the decode attention kernel (every flash-decoding split
+adds its share to its partial record; `mi355_attn_args.adapter_*`, csrc/attention.hip) and by `mi355_adapter_prefix` behind the
+many-token flash kernel, in the op-by-op path and in the whole-forward engine alike (csrc/engine.hip), so an adapter model
+decodes under the same hipGraph as a plain one (not through the persistent fused step, which does not know the prefix term).
 """
 from __future__ import annotations
 
@@ -62,20 +63,20 @@ class CausalSelfAttention(llama.CausalSelfAttention):
         nh, hs = self.n_head, C // self.n_head
         qkv = _linear(self.c_attn, x)
         rope_f = rope.float().contiguous()
+        adapter = None
+        if self.block_idx >= self.adapter_start_layer:
+            if adapter_kv_cache is None:
+                adapter_kv_cache = self.adapter_prefix_kv(x.dtype)[:2]
+            # y += gate * softmax(rope(q) ak^T / sqrt(hs)) av, inside the attention op (csrc/attention.hip)
+            adapter = (*adapter_kv_cache, self.gating_factor.detach().float().reshape(-1).contiguous())
         if kv_cache is not None:
             assert input_pos is not None
             k, v = kv_cache
             if int(input_pos[-1]) >= max_seq_length:  # the reference's host decision (adapter.py:119)
                 ops.kv_roll(k, v)
-            y = ops.attention(qkv, rope_f, nh, pos=input_pos, kv_cache=(k, v), rope_gathered=True)
+            y = ops.attention(qkv, rope_f, nh, pos=input_pos, kv_cache=(k, v), rope_gathered=True, adapter=adapter)
         else:
-            y = ops.attention(qkv, rope_f, nh, rope_gathered=True)
-        if self.block_idx >= self.adapter_start_layer:
-            if adapter_kv_cache is None:
-                adapter_kv_cache = self.adapter_prefix_kv(x.dtype)[:2]
-            ak, av = adapter_kv_cache
-            gate = self.gating_factor.detach().float().reshape(-1).contiguous()
-            ops.adapter_prefix(qkv, rope_f, nh, ak, av, gate, y)  # y += gate * softmax(rope(q) ak^T / sqrt(hs)) av
+            y = ops.attention(qkv, rope_f, nh, rope_gathered=True, adapter=adapter)
         return _linear(self.c_proj, y), kv_cache, adapter_kv_cache
 
     def adapter_prefix_kv(self, dtype: torch.dtype):

@@ -39,7 +39,14 @@ struct AttnParams {
     float* part;
     unsigned long long* dbg;
     float scale;
+    // LLaMA-Adapter prefix term folded into the decode kernel (aT > 0): see the tail of attn_kernel
+    const float* ak;
+    const float* av;
+    const float* gate;
+    int aT;
 };
+
+constexpr int kMaxPrefix = 64;  // prefix rows the folded adapter term handles (adapter_prompt_length is 10)
 
 template <typename CT>
 __device__ __forceinline__ float ct_to_f32(CT v);
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     float* wl = wm + nw;          // [nw] running sum per wave
     float* scur = wl + nw;        // [4] score of the current position (fused)
     float* opart = scur + 4;      // [nw][hs]
+    float* pdot = opart + nw * hs;  // [kMaxPrefix] scores of the adapter prefix rows (aT > 0)
     const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 #define MI355_STAMP(i)                                                                  \
     do {                                                                                \
@@ -422,6 +430,31 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
     }
     const float p_cur = own_cur ? __expf(s_cur - m_all) : 0.f;
     l_all += p_cur;
+    // LLaMA-Adapter (adapter.py:134-151): y += P,  P = gate[h] * softmax(q . ak[h]^T * scale) av[h]  over the aT prefix rows
+    // (no RoPE on them, no mask, a softmax of their own).  With the rows split over ns workgroups every split adds
+    // l_split * P to its un-normalised record: sum_s w_s (o_s + l_s P) / sum_s w_s l_s = y + P, so the consumers of the
+    // records (mi355_attn_combine, the c_proj prologue) need not know about the prefix.
+    float pfx_scale = 0.f, pfx_max = 0.f;  // gate / sum of the prefix softmax weights, their maximum (aT == 0: no adapter)
+    if (p.aT > 0) {
+        for (int s2 = wave; s2 < p.aT; s2 += nw) {
+            const float* kr = p.ak + ((int64_t)h * p.aT + s2) * hs;
+            float dot = 0.f;
+            for (int d = lane; d < hs; d += 64) dot += qs[d] * kr[d];
+            dot = group_sum(dot, 64);
+            if (lane == 0) pdot[s2] = dot * p.scale;
+        }
+        __syncthreads();
+        pfx_max = kNegBig;
+        for (int s2 = 0; s2 < p.aT; ++s2) pfx_max = fmaxf(pfx_max, pdot[s2]);
+        float pl = 0.f;
+        for (int s2 = 0; s2 < p.aT; ++s2) pl += __expf(pdot[s2] - pfx_max);
+        pfx_scale = p.gate[h] / pl;
+    }
+    auto prefix = [&](int d) {  // P[d]
+        float acc = 0.f;
+        for (int s2 = 0; s2 < p.aT; ++s2) acc += __expf(pdot[s2] - pfx_max) * p.av[((int64_t)h * p.aT + s2) * hs + d];
+        return acc * pfx_scale;
+    };
     if (ns == 1) {
         const float inv = 1.0f / l_all;
         for (int d = tid; d < hs; d += blockDim.x) {
@@ -430,7 +463,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
             for (int w = 0; w < 8; ++w)
                 if (w < nw) o += opart[w * hs + d] * wgt[w];
             if (own_cur) o += p_cur * vcur[d];
-            st_from_f32(p.y, ((int64_t)b * p.T + t) * p.ldy + h * hs + d, p.y_dtype, o * inv);
+            st_from_f32(p.y, ((int64_t)b * p.T + t) * p.ldy + h * hs + d, p.y_dtype, o * inv + prefix(d));
         }
     } else {
         // partial record: [m, l, 0, 0, o[hs]] (un-normalised), one per (token row, head, split)
@@ -447,7 +480,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const AttnParams p) {
             for (int w = 0; w < 8; ++w)
                 if (w < nw) o += opart[w * hs + d] * wgt[w];
             if (own_cur) o += p_cur * vcur[d];
-            rec[4 + d] = o;
+            rec[4 + d] = o + l_all * prefix(d);
         }
     }
     MI355_STAMP(4);
@@ -522,6 +555,14 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
     }
     p.fused = (has_cache && a->T == 1) ? 1 : 0;
     p.rope_gathered = a->rope_gathered;
+    // LLaMA-Adapter: the gated prefix term rides in the decode kernel; behind the flash kernel it is its own launch
+    const bool adapter = a->adapter_len > 0;
+    MI355_CHECK_ARG(!adapter || (a->adapter_k && a->adapter_v && a->adapter_gate && a->adapter_len <= kMaxPrefix), MI355_E_ARG,
+                    "attention: adapter prefix of %d rows (at most %d) needs keys, values and gates", a->adapter_len, kMaxPrefix);
+    p.ak = a->adapter_k;
+    p.av = a->adapter_v;
+    p.gate = a->adapter_gate;
+    p.aT = adapter ? a->adapter_len : 0;
 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(a->n_head, a->T, a->B);
@@ -537,9 +578,32 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
     // (with a cache: rows [0, pos[t]]; without: the T tokens themselves, K / V in kv_tmp, token t at position t)
     if (a->T >= 32 && a->B == 1 && esz == 2 && a->hs == 128 && (a->qkv_dtype == MI355_F32 || a->qkv_dtype == MI355_BF16) &&
         a->y_dtype == MI355_BF16 && a->n_split <= 1 && a->ld_qkv % 8 == 0 && a->ldy % 4 == 0 &&
-        (int64_t)p.S * 256 < 0x7fffffffLL)
-        return mi355_flash_prefill(a->qkv, a->qkv_dtype, a->ld_qkv, a->rope, a->rope_gathered, p.pos, p.kcache, p.vcache,
-                                   a->T, a->n_head, p.S, a->y, a->ldy, p.scale, s);
+        (int64_t)p.S * 256 < 0x7fffffffLL) {
+        if (int rc = mi355_flash_prefill(a->qkv, a->qkv_dtype, a->ld_qkv, a->rope, a->rope_gathered, p.pos, p.kcache, p.vcache,
+                                         a->T, a->n_head, p.S, a->y, a->ldy, p.scale, s))
+            return rc;
+        if (!adapter) return 0;
+        mi355_adapter_args b;
+        memset(&b, 0, sizeof(b));
+        b.qkv = a->qkv;
+        b.qkv_dtype = a->qkv_dtype;
+        b.B = a->B;
+        b.ld_qkv = a->ld_qkv;
+        b.rope = a->rope;
+        b.pos = p.pos;
+        b.rope_gathered = a->rope_gathered;
+        b.T = a->T;
+        b.n_head = a->n_head;
+        b.hs = a->hs;
+        b.aT = a->adapter_len;
+        b.y_dtype = a->y_dtype;
+        b.ak = a->adapter_k;
+        b.av = a->adapter_v;
+        b.gate = a->adapter_gate;
+        b.y = a->y;
+        b.ldy = a->ldy;
+        return mi355_adapter_prefix(&b, stream);
+    }
     int ns = a->n_split > 1 ? a->n_split : 1;
     MI355_CHECK_ARG(ns == 1 || a->partials != nullptr, MI355_E_ARG, "attention: n_split > 1 needs a partials buffer");
     MI355_CHECK_ARG(ns <= 64 && (int64_t)a->B * ns <= 65535, MI355_E_SHAPE, "attention: n_split too large");
@@ -554,7 +618,7 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
     p.part = (float*)a->partials;
     p.dbg = (unsigned long long*)a->debug_stamps;
     const int threads = ns > 1 ? 256 : 512, nw = threads / 64;
-    const size_t lds = (size_t)(3 * a->hs + 2 * nw + 4 + nw * a->hs) * sizeof(float) + 16;
+    const size_t lds = (size_t)(3 * a->hs + 2 * nw + 4 + nw * a->hs + kMaxPrefix) * sizeof(float) + 16;
     MI355_CHECK_ARG(a->hs <= 256 || (a->hs * esz) % 16 == 0, MI355_E_SHAPE, "attention: head size %d unsupported", a->hs);
     MI355_CHECK_ARG(lds <= 160 * 1024, MI355_E_SHAPE, "attention: hs=%d needs %zu B of LDS", a->hs, lds);
     static bool attr_done = false;

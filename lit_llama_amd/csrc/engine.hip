@@ -258,7 +258,7 @@ extern "C" int mi355_forward_segment(const mi355_model* m, int T, int layer, int
     const int Cl = m->n_head * m->hs;  // local attention width (== C unless tensor parallel)
     const bool tp = m->tp_world > 1;
     // decode steps spread each head's K/V over attn_splits workgroups; the c_proj prologue combines the partials
-    const bool split = T == 1 && m->attn_splits > 1 && m->attn_part != nullptr && L.adapter_len == 0;
+    const bool split = T == 1 && m->attn_splits > 1 && m->attn_part != nullptr;
     for (int seg = seg_begin; seg < seg_end; ++seg) {
         switch (seg) {
             case 0: {
@@ -287,28 +287,13 @@ extern "C" int mi355_forward_segment(const mi355_model* m, int T, int layer, int
                     a.n_split = m->attn_splits;
                     a.partials = m->attn_part;
                 }
-                if (int rc = mi355_attention(&a, s)) return rc;
-                if (L.adapter_len > 0) {  // LLaMA-Adapter: the gated prefix term on top of the attention output
-                    mi355_adapter_args b;
-                    memset(&b, 0, sizeof(b));
-                    b.qkv = m->qkv;
-                    b.qkv_dtype = MI355_F32;
-                    b.B = 1;
-                    b.ld_qkv = 3 * Cl;
-                    b.rope = m->rope;
-                    b.pos = m->pos;
-                    b.T = T;
-                    b.n_head = m->n_head;
-                    b.hs = m->hs;
-                    b.aT = L.adapter_len;
-                    b.ak = L.adapter_k;
-                    b.av = L.adapter_v;
-                    b.gate = L.adapter_gate;
-                    b.y = m->att;
-                    b.y_dtype = MI355_BF16;
-                    b.ldy = Cl;
-                    if (int rc = mi355_adapter_prefix(&b, s)) return rc;
+                if (L.adapter_len > 0) {  // LLaMA-Adapter: the gated prefix term rides along (partial records included)
+                    a.adapter_k = L.adapter_k;
+                    a.adapter_v = L.adapter_v;
+                    a.adapter_gate = L.adapter_gate;
+                    a.adapter_len = L.adapter_len;
                 }
+                if (int rc = mi355_attention(&a, s)) return rc;
                 break;
             }
             case 1: {

@@ -461,10 +461,12 @@ def attention(
     out_dtype: Optional[torch.dtype] = None,
     n_split: int = 1,
     return_partials: bool = False,
+    adapter: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None,
 ) -> torch.Tensor:
     """qkv [B, T, 3C] -> y [B, T, C]; RoPE + (in-place) cache write + causal attention.  n_split > 1 spreads each
     head over n_split workgroups (flash-decoding) and combines the partial records with mi355_attn_combine, or
-    returns them ([B*T, heads, n_split, hs + 4]) for a consumer that combines on the fly."""
+    returns them ([B*T, heads, n_split, hs + 4]) for a consumer that combines on the fly.  `adapter` = (ak, av, gate):
+    the LLaMA-Adapter prefix term of lit_llama/adapter.py:134-151 is added (operands as `adapter_prefix` takes them)."""
     require_gpu(qkv, "attention")
     B, T, C3 = qkv.shape
     Cw = C3 // 3
@@ -496,6 +498,11 @@ def attention(
     if n_split > 1:
         parts = torch.empty((B * T, n_head, n_split, hs + 4), dtype=torch.float32, device=qkv.device)
         a.n_split, a.partials = n_split, ptr(parts)
+    if adapter is not None:
+        ak, av, gate = adapter
+        assert ak.dtype == av.dtype == gate.dtype == torch.float32 and ak.shape == av.shape == (n_head, ak.shape[1], hs)
+        assert ak.is_contiguous() and av.is_contiguous() and gate.is_contiguous() and gate.numel() == n_head
+        a.adapter_k, a.adapter_v, a.adapter_gate, a.adapter_len = ptr(ak), ptr(av), ptr(gate), ak.shape[1]
     check(lib().mi355_attention(C.byref(a), stream_ptr()), "mi355_attention")
     if parts is not None:
         if return_partials:

@@ -89,6 +89,44 @@ def test_adapter_prefix_kernel_matches_the_reference_arithmetic(dev, qdtype, hs,
         assert err <= (1e-5 if qdtype == torch.float32 else 2e-2) * ref.abs().max().item(), (gathered, err)
 
 
+@pytest.mark.parametrize("case", ["decode", "decode_split4", "no_cache_T5", "prefill_T40"])
+def test_attention_with_the_prefix_term_folded_in_equals_attention_plus_the_prefix_kernel(dev, case):
+    """mi355_attn_args.adapter_*: the decode kernel adds the prefix term itself — every flash-decoding split adds
+    l_split * P to its un-normalised record, so the combined result is y + P — and the many-token path runs the prefix
+    kernel behind the flash kernel.  Checked against attention() followed by the stand-alone adapter_prefix()."""
+    from lit_llama_amd import ops
+    from lit_llama_amd.model import build_rope_cache
+
+    nh, hs, aT, S = 8, 128, 10, 64
+    C = nh * hs
+    gen = torch.Generator().manual_seed(len(case))
+    T = {"decode": 1, "decode_split4": 1, "no_cache_T5": 5, "prefill_T40": 40}[case]
+    ns = 4 if case == "decode_split4" else 1
+    dt = torch.float32 if case == "no_cache_T5" else torch.bfloat16
+    qkv = torch.randn((1, T, 3 * C), generator=gen).to(dt).to(dev)
+    ak, av = torch.randn((nh, aT, hs), generator=gen).to(dev), torch.randn((nh, aT, hs), generator=gen).to(dev)
+    gate = torch.randn((nh,), generator=gen).to(dev)
+    table = build_rope_cache(S, hs, torch.int64, dev).float().contiguous()
+    if case == "no_cache_T5":
+        kw = dict(rope_gathered=True)
+        rope = table[:T].contiguous()
+        y0 = ops.attention(qkv, rope, nh, **kw)
+        y1 = ops.attention(qkv, rope, nh, adapter=(ak, av, gate), **kw)
+        ref = ops.adapter_prefix(qkv, rope, nh, ak, av, gate, y0.clone(), rope_gathered=True)
+    else:
+        start = 20 if T == 1 else 0
+        pos = torch.arange(start, start + T, device=dev)
+        k0 = torch.randn((1, nh, S, hs), generator=gen).to(torch.bfloat16).to(dev)
+        v0 = torch.randn((1, nh, S, hs), generator=gen).to(torch.bfloat16).to(dev)
+        kw = dict(pos=pos, n_split=ns)
+        y0 = ops.attention(qkv, table, nh, kv_cache=(k0.clone(), v0.clone()), **kw)
+        y1 = ops.attention(qkv, table, nh, kv_cache=(k0.clone(), v0.clone()), adapter=(ak, av, gate), **kw)
+        ref = ops.adapter_prefix(qkv, table, nh, ak, av, gate, y0.clone(), pos=pos, rope_gathered=False)
+    assert (ref.float() - y0.float()).abs().max().item() > 0.05          # the prefix term is not a rounding error
+    tol = 1e-5 if dt == torch.float32 else 2e-2                          # bf16 y: one rounding (folded) vs two
+    assert (y1.float() - ref.float()).abs().max().item() <= tol * ref.float().abs().max().item()
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 0.05)])
 def test_adapter_v2_model_follows_the_reference(dev, golden, dtype, tol):
     """generate/adapter_v2.py:63-78: the adapter model with a learned scale / bias on every linear."""
