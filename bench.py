@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tp-timeout", type=float, default=180.0, help="seconds after which a hanging TP leg is abandoned")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--group-cols", type=int, default=0, help="gptq.int4 with one (scale, zero) pair per row and group of this "
+                    "many input columns (GPTQ groupsize, e.g. 128) instead of one pair per row (not a BASELINE config)")
     ap.add_argument("--adapter", action="store_true", help="LLaMA-Adapter variant (generate/adapter.py): prefix attention "
                     "with random adaption prompts / gates in every block from adapter_start_layer on (not a BASELINE config)")
     ap.add_argument("--dry-run", action="store_true", help="check the launch contract only (ranks, world size); no GPU work")
@@ -95,6 +97,15 @@ def build_model(args, dev):
     with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode=mode):
         model = LLaMA(cfg)
     model.eval()
+    if args.group_cols:
+        assert mode == "gptq.int4", "--group-cols is a gptq.int4 option"
+        from lit_llama_amd.quantization import ColBlockQuantizedLinear
+
+        for _, mod in list(model.named_modules()):
+            for cname, child in list(mod.named_children()):
+                if isinstance(child, ColBlockQuantizedLinear):
+                    q = ColBlockQuantizedLinear(child.in_features, child.out_features, bias=False, bits=4, tile_cols=args.group_cols)
+                    setattr(mod, cname, q.to(device=dev, dtype=torch.bfloat16))
     if args.adapter:
         gen_a = torch.Generator(device=dev).manual_seed(7)
         with torch.no_grad():
@@ -548,12 +559,13 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    default_cfg = args.model == "7B" and args.quantize == "gptq.int4" and not args.adapter
-    cfg_idx = {"none": 1, "gptq.int4": 2, "llm.int8": 3}[args.quantize] if args.model == "7B" and not args.adapter else None
+    variant = args.adapter or args.group_cols > 0
+    default_cfg = args.model == "7B" and args.quantize == "gptq.int4" and not variant
+    cfg_idx = {"none": 1, "gptq.int4": 2, "llm.int8": 3}[args.quantize] if args.model == "7B" and not variant else None
     wname = {"gptq.int4": "int4", "llm.int8": "int8", "none": "bf16"}[args.quantize]
     out = {
         "metric": METRIC if default_cfg else f"decode tokens/sec/GPU LLaMA-{args.model}{' + LLaMA-Adapter' if args.adapter else ''} "
-                                             f"{args.quantize} bs=1; % HBM roofline",
+                                             f"{args.quantize}{' groupsize %d' % args.group_cols if args.group_cols else ''} bs=1; % HBM roofline",
         "value": round(tok_s_gpu * world, 2),
         "unit": "tokens/s",
         "n_gpus": world,

@@ -522,6 +522,16 @@ typedef struct mi355_fused_step_args {
     int32_t n_layer, n_head, n_embd, hs, n_hidden, vocab, S, mode;
     float eps;
     int32_t reserved0;      /* layer to stamp when debug_stamps is given, else 0 */
+    /* Grouped scales (GPTQ "groupsize", quantization.py:284-333 with tile_cols > 0): group_cols = 128 * 2^n input columns
+     * per (scale, zero) pair, dividing n_embd and n_hidden (0: one pair per output row, `sz` / `sz_head` above).  Then `sz` and
+     * `sz_head` are not read; `gt` holds per layer (stride gt_layer_stride bytes) the tables of c_attn, attn.c_proj, c_fc1,
+     * c_fc2, mlp.c_proj in this order, `gt_head` lm_head's, each [N / 16 tiles][K / group_cols groups][16 rows] uint32 =
+     * bf16 scale | bf16 zero << 16.  Register-ring implementation only. */
+    int32_t group_cols;
+    int32_t reserved1;
+    const void* gt;
+    const void* gt_head;
+    uint64_t gt_layer_stride;
 } mi355_fused_step_args;
 
 size_t mi355_fused_step_workspace_bytes(int n_hidden);

@@ -1280,9 +1280,21 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
                     "S <= %d (got %d CUs, C=%d, heads=%d x %d, H=%d, V=%d, S=%d)",
                     kG, kC, kHeads, kHs, kMaxFcTiles * kG * 16, kMaxHeadTiles * kG * 16, kMaxS, mi355_num_cus(), a->n_embd,
                     a->n_head, a->hs, a->n_hidden, a->vocab, a->S);
-    MI355_CHECK_ARG(a->w && a->w_head && a->sz && a->sz_head && a->norms && a->wte && a->rope && a->kv && a->tokens &&
+    const bool grouped = a->group_cols > 0;
+    MI355_CHECK_ARG(a->w && a->w_head && (grouped || (a->sz && a->sz_head)) && a->norms && a->wte && a->rope && a->kv && a->tokens &&
                         a->pos && a->logits && a->workspace,
                     MI355_E_ARG, "fused_step: null pointer");
+    int gsh = 0;
+    if (grouped) {
+        while ((128 << gsh) < a->group_cols) ++gsh;
+        MI355_CHECK_ARG((128 << gsh) == a->group_cols && a->n_embd % a->group_cols == 0 && a->n_hidden % a->group_cols == 0 &&
+                            a->n_hidden % 256 == 0,
+                        MI355_E_SHAPE, "fused_step: group size %d must be 128 * 2^n and divide n_embd and n_hidden", a->group_cols);
+        MI355_CHECK_ARG(a->gt && a->gt_head && ((uintptr_t)a->gt | (uintptr_t)a->gt_head | a->gt_layer_stride) % 16 == 0, MI355_E_ARG,
+                        "fused_step: grouped scales need the 16-B aligned group tables gt / gt_head");
+        // a streamer wave keeps its groups side by side in the 16 MFMA token columns
+        MI355_CHECK_ARG(((a->n_hidden / 128 + 7) / 8 >> gsh) + 1 <= 16, MI355_E_SHAPE, "fused_step: too many groups per wave");
+    }
     MI355_CHECK_ARG(a->n_layer >= 1 && a->n_layer * 6 + 8 < 1024, MI355_E_SHAPE, "fused_step: n_layer %d", a->n_layer);
     MI355_CHECK_ARG(!(a->mode & 1) || a->next_token != nullptr, MI355_E_ARG, "fused_step: arg-max without next_token");
     MI355_CHECK_ARG(a->mode >= 0 && a->mode <= 3 && a->mode != 2, MI355_E_ARG, "fused_step: mode must be 0, 1 or 3");
@@ -1300,7 +1312,8 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     });
     MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "fused_step: hipFuncSetAttribute failed: %s",
                     hipGetErrorString(attr_err));
-    MI355_CHECK_ARG(use_ring ? fused_step_ring_occupancy_ok() : occupancy_ok(), MI355_E_STATE,
+    MI355_CHECK_ARG(!grouped || use_ring, MI355_E_ARG, "fused_step: grouped scales are implemented by the register-ring kernel only");
+    MI355_CHECK_ARG(use_ring ? (fused_step_ring_occupancy_ok() & (grouped ? 2 : 1)) != 0 : occupancy_ok(), MI355_E_STATE,
                     "fused_step: the device does not admit one %d-thread workgroup with %d B of LDS per CU", kThreads, kLdsBytes);
     FusedParams p;
     memset(&p, 0, sizeof(p));
@@ -1349,6 +1362,21 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     p.mode = a->mode;
     p.eps = a->eps;
     p.scale = 1.0f / sqrtf((float)kHs);
+    if (grouped) {
+        p.grouped = 1;
+        p.gsh = gsh;
+        p.ngc = a->n_embd / a->group_cols;
+        p.ngh = a->n_hidden / a->group_cols;
+        p.gt = (const uint8_t*)a->gt;
+        p.gt_head = (const uint8_t*)a->gt_head;
+        p.gt_layer_stride = a->gt_layer_stride;
+        const size_t lb = ((size_t)(3 * kC / 16 + kC / 16 + 2 * (a->n_hidden / 16)) * p.ngc + (size_t)(kC / 16) * p.ngh) * 64;
+        const size_t hb = (size_t)p.head_tiles * p.ngc * 64;
+        MI355_CHECK_ARG(lb < 0x7FFFFFF0ull && hb < 0x7FFFFFF0ull && a->gt_layer_stride >= lb, MI355_E_SHAPE,
+                        "fused_step: group tables of %zu / %zu B (layer stride %llu)", lb, hb, (unsigned long long)a->gt_layer_stride);
+        p.gt_layer_bytes = (unsigned)lb;
+        p.gt_head_bytes = (unsigned)hb;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (t_time_start != nullptr) {  // measurement hook: see gemv.hip launch_gemv_m
         e0 = t_time_start;

@@ -35,6 +35,14 @@ struct FusedParams {
     int mode;                // bit 0: greedy arg-max, bit 1: chained (advance tokens[0] / pos[0])
     int dbg_layer;           // layer whose phases are stamped into dbg
     float eps, scale;
+    // grouped scales (register-ring kernel, GRP instantiation): gsh = log2(units of 128 columns per group), ngc / ngh = groups per
+    // row for K = n_embd / K = n_hidden; gt: per layer the tables [tile][group][16 rows] of (bf16 scale | bf16 zero << 16) of
+    // c_attn, attn.c_proj, c_fc1, c_fc2, mlp.c_proj in this order; gt_head: lm_head's
+    const uint8_t* gt;
+    const uint8_t* gt_head;
+    u64 gt_layer_stride;
+    unsigned gt_layer_bytes, gt_head_bytes;
+    int grouped, gsh, ngc, ngh;
 };
 
 

@@ -81,7 +81,9 @@ constexpr int kOffQ = kOffStage + 1024;           // q[128] knew[128] vnew[128] 
 constexpr int kOffOpart = kOffQ + 3 * 512;        // [8 waves][16] f32
 constexpr int kMaxS = 32768;                      // cache rows (the attention keeps no per-row state in LDS)
 constexpr int kLdsBytes = kOffOpart + 512;
-static_assert(kLdsBytes <= 160 * 1024, "LDS map exceeds the CU");
+constexpr int kOffUsum = kLdsBytes;               // GRP: [2][96] f32 sums of the even / odd pairs of every 128-value unit
+constexpr int kLdsBytesG = kOffUsum + 2 * 96 * 4;
+static_assert(kLdsBytesG <= 160 * 1024, "LDS map exceeds the CU");
 
 // ------------------------------------------------------------------------------------------------ granules
 __device__ __forceinline__ void gr_store(u64* p, unsigned tag, unsigned val) {
@@ -139,6 +141,10 @@ __device__ __forceinline__ bool sweep(const FusedParams& p, __amdgpu_buffer_rsrc
 struct PhaseW {  // one phase as a streamer wave sees it (all wave-uniform)
     unsigned base;  // byte offset of the stream inside the layer's descriptor
     int tile0, tstride, ntiles, units, u0, nu;
+    // grouped scales (GRP): byte offsets of the phase's [tile][group][16 rows] tables (tab2: c_fc2) inside the layer's table
+    // descriptor, groups per row
+    unsigned tab, tab2;
+    int ng;
 };
 
 // Scalar byte offset of the piece consumed at global step `gstep` of the phase, row group r; ok = false for an idle
@@ -184,8 +190,16 @@ __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_b
 
 }  // namespace
 
+// GRP: one (scale, zero) pair per output row AND group of 128 << gsh input columns (GPTQ "groupsize",
+// /root/reference lit_llama/quantization.py:284-333, :404-410 with tile_cols > 0).  The streamers send group g's activations to MFMA
+// token column (g - first group of the wave) & 15 — at M = 1 the 16 columns are otherwise 16 copies of one dot product — so a
+// wave's accumulator holds its (<= 16) groups side by side, and apply the scales themselves at the end of a tile (tables
+// [tile][group][16 rows] of bf16 scale | bf16 zero << 16, one 16-B load per lane and row group, requested at the tile's first step;
+// per-unit sums of the staged operands from the gatherers); what reaches the gatherers' epilogues is already dequantised.
+template <bool GRP>
 __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    [[maybe_unused]] float* usum = (float*)(smem + kOffUsum);  // [0..95] even pairs, [96..191] odd pairs
     const int bid = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -242,6 +256,23 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             ph_mp = {p.off_mproj, bid, kG, 1, p.units_h, wave * uq + (wave < ur ? wave : ur), uq + (wave < ur ? 1 : 0)};
         }
         ph_head = {0u, bid, kG, n_head_t, kUnitsC, wave * 4, 4};
+        if constexpr (GRP) {
+            const unsigned sz_attn = (unsigned)(3 * kC / 16) * (unsigned)p.ngc * 64u, sz_proj = (unsigned)(kC / 16) * (unsigned)p.ngc * 64u;
+            const unsigned sz_fc = (unsigned)(p.H / 16) * (unsigned)p.ngc * 64u;
+            ph_attn.tab = 0u;
+            ph_proj.tab = sz_attn;
+            ph_fc.tab = sz_attn + sz_proj;
+            ph_fc.tab2 = sz_attn + sz_proj + sz_fc;
+            ph_mp.tab = sz_attn + sz_proj + 2u * sz_fc;
+            ph_head.tab = 0u;
+            ph_attn.ng = ph_proj.ng = ph_fc.ng = ph_head.ng = p.ngc;
+            ph_mp.ng = p.ngh;
+        }
+        // GRP: the layer's group tables / lm_head's (one descriptor per layer, like the weights)
+        [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_t =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(GRP ? p.gt : p.w), 0, GRP ? (int)p.gt_layer_bytes : 0, 0x00020000);
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_th =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(GRP ? p.gt_head : p.w), 0, GRP ? (int)p.gt_head_bytes : 0, 0x00020000);
 
         __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.layer_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_h =
@@ -268,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
     } while (0)
 
         // ---- one phase: BODIES x TURNS ring turns of 12 / R steps; a step = R pieces against one activation unit
-#define FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_)                                             \
+#define FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_)                                       \
     do {                                                                                                             \
         constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
         const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
@@ -280,8 +311,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         /* B operands (activation unit of a step) are read one step ahead: a step otherwise starts with an LDS */     \
         /* round trip (~150 cycles x 12 steps on the hand-off chain)                                           */     \
         f16x8 bn__[4];                                                                                                \
+        /* GRP: this lane's token column, the wave's first group, the (scale | zero) pairs of rows 4 g .. 4 g + 3 */  \
+        [[maybe_unused]] const int cc__ = (int)(lane_off >> 4) & 15;                                                  \
+        [[maybe_unused]] const int gfirst__ = GRP ? ((PH_).u0 >> p.gsh) : 0;                                          \
+        [[maybe_unused]] u32x4 tab__[R__];                                                                            \
         {                                                                                                             \
-            const char* xb0__ = xs + ((PH_).u0) * 256 + g * 64;                                                       \
+            /* (GRP: the unit's group owns ONE column; the other 15 read the all-zero unit) */                        \
+            const char* xb0__ = ((!GRP || cc__ == 0) ? xs + ((PH_).u0) * 256 : smem + kOffZero) + g * 64;             \
             _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const f16x8*)(xb0__ + 16 * d__);       \
         }                                                                                                             \
         for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
@@ -293,8 +329,25 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) b__[d__] = bn__[d__];                         \
                     {                                                                                                 \
                         const int nst__ = (st__ + 1 == SPT__) ? 0 : st__ + 1;                                         \
-                        const char* xbn__ = xs + ((PH_).u0 + (nst__ < (PH_).nu ? nst__ : 0)) * 256 + g * 64;          \
+                        const int nun__ = (PH_).u0 + (nst__ < (PH_).nu ? nst__ : 0);                                  \
+                        const bool mine__ = !GRP || cc__ == (nun__ >> p.gsh) - gfirst__;                              \
+                        const char* xbn__ = (mine__ ? xs + nun__ * 256 : smem + kOffZero) + g * 64;                   \
                         _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const f16x8*)(xbn__ + 16 * d__); \
+                    }                                                                                                 \
+                    if constexpr (GRP) {                                                                              \
+                        /* first step of a tile: request its table entries (consumed at the tile's last step) */      \
+                        if ((t__ * STEPS__ + s__) % SPT__ == 0) {                                                     \
+                            int grp__ = gfirst__ + cc__;                                                              \
+                            grp__ = grp__ < (PH_).ng ? grp__ : (PH_).ng - 1;                                          \
+                            const unsigned voff__ = (unsigned)(grp__ * 16 + 4 * g) * 4u;                              \
+                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                   \
+                                const int tile__ = (QKV_) ? (PH_).tile0 + r__ * (PH_).tstride : (PH_).tile0 + ti__ * (PH_).tstride; \
+                                const bool okt__ = (QKV_) || ti__ < (PH_).ntiles;                                     \
+                                const unsigned tb__ = ((PAIR_) && r__ == 1) ? (PH_).tab2 : (PH_).tab;                 \
+                                tab__[r__] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(         \
+                                    okt__ ? (RST_) : rs_null, voff__, okt__ ? tb__ + (unsigned)(tile__ * (PH_).ng) * 64u : 0u, 0)); \
+                            }                                                                                         \
+                        }                                                                                             \
                     }                                                                                                 \
                     /* idle steps (padding of the ring turn) carry no data: skip their MFMAs (wave-uniform) */        \
                     if (st__ < (PH_).nu && ((QKV_) || ti__ < (PH_).ntiles)) {                                         \
@@ -323,9 +376,38 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         /* tile done: publish this wave's partial 16x16 tiles */                                      \
                         if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
                         f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * 1024) + lane;                \
+                        if constexpr (GRP) {                                                                          \
+                            /* column c holds group gfirst + c: y = s (acc - 1024 (Se + So) - z (Se + 16 So)) with    */ \
+                            /* the group's operand sums (units of the group), then the 16 columns are added up        */ \
+                            const int gl__ = gfirst__ + cc__;                                                         \
+                            const int glast__ = ((PH_).u0 + ((PH_).nu > 0 ? (PH_).nu - 1 : 0)) >> p.gsh;              \
+                            float se__ = 0.f, so__ = 0.f;                                                             \
+                            if (gl__ <= glast__ && (PH_).nu > 0) {                                                    \
+                                for (int j__ = 0; j__ < (1 << p.gsh); ++j__) {                                        \
+                                    const int un__ = (gl__ << p.gsh) + j__;                                           \
+                                    if (un__ >= (PH_).u0 && un__ < (PH_).u0 + (PH_).nu) { /* (this wave's units) */   \
+                                        se__ += usum[un__];                                                           \
+                                        so__ += usum[96 + un__];                                                      \
+                                    }                                                                                 \
+                                }                                                                                     \
+                            }                                                                                         \
+                            const float ga__ = 1024.f * (se__ + so__), gb__ = se__ + 16.f * so__;                     \
+                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                   \
+                                const f32x4 a4__ = acc__[r__][0] + acc__[r__][1];                                     \
+                                f32x4 y4__;                                                                           \
+                                _Pragma("unroll") for (int e__ = 0; e__ < 4; ++e__) {                                 \
+                                    const uint32_t w__ = tab__[r__][e__];                                             \
+                                    const float sc__ = __uint_as_float(w__ << 16), zp__ = __uint_as_float(w__ & 0xffff0000u); \
+                                    y4__[e__] = group_sum(sc__ * (a4__[e__] - ga__ - zp__ * gb__), 16);               \
+                                }                                                                                     \
+                                pp__[r__ * 64] = y4__;                                                                \
+                                acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                            \
+                            }                                                                                         \
+                        } else {                                                                                      \
                         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
                             pp__[r__ * 64] = acc__[r__][0] + acc__[r__][1];                                           \
                             acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                                \
+                        }                                                                                             \
                         }                                                                                             \
                         __syncthreads(); /* Bt */                                                                     \
                         buf ^= 1;                                                                                     \
@@ -350,7 +432,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             dbg_on = p.dbg != nullptr && l == p.dbg_layer;
             asm volatile("" : "+v"(lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
             // ---------------- c_attn (q, k, v tiles of this workgroup's 16 dimensions of its head)
-            FS_RUN(rs_l, 3, 4, false, true, 1, ph_attn, 1, 20);
+            FS_RUN(rs_l, 3, 4, false, true, 1, ph_attn, 1, 20, rs_t);
             // ---------------- attention: scores over the whole context, then this workgroup's 16 output dims
             {
                 const bf16_t* kc = kv_l + (size_t)head * p.S * kHs;
@@ -572,23 +654,26 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }
             // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows)
             FS_BURST(rs_l, 1, 12, false, false, ph_proj);
-            FS_RUN(rs_l, 1, 12, false, false, 1, ph_proj, 1, 26);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_proj, 1, 26, rs_t);
             FS_BURST(rs_l, 2, 4, true, false, ph_fc);
-            FS_RUN(rs_l, 2, 4, true, false, 2, ph_fc, 1, 28);
+            FS_RUN(rs_l, 2, 4, true, false, 2, ph_fc, 1, 28, rs_t);
             FS_BURST(rs_l, 1, 12, false, false, ph_mp);
-            FS_RUN(rs_l, 1, 12, false, false, 1, ph_mp, 1, 30);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_mp, 1, 30, rs_t);
             // next layer (or the head)
             kv_l += (size_t)2 * kHeads * p.S * kHs;
             if (l + 1 < p.n_layer) {
                 rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (size_t)(l + 1) * p.layer_stride), 0,
                                                          (int)p.layer_bytes, 0x00020000);
+                if constexpr (GRP)
+                    rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gt + (size_t)(l + 1) * p.gt_layer_stride), 0,
+                                                             (int)p.gt_layer_bytes, 0x00020000);
                 FS_BURST(rs_l, 3, 4, false, true, ph_attn);
             } else {
                 FS_BURST(rs_h, 1, 4, false, false, ph_head);
             }
         }
         dbg_on = false;
-        FS_RUN(rs_h, 1, 4, false, false, 1, ph_head, p.head_turns, 32);
+        FS_RUN(rs_h, 1, 4, false, false, 1, ph_head, p.head_turns, 32, rs_th);
         if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
 #undef FS_RUN
 #undef FS_BURST
@@ -625,6 +710,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         auto ldpair = [&](const bf16_t* q) {  // two consecutive bf16 (4-byte aligned) as floats
             const unsigned v = *(const unsigned*)q;
             return float2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+        };
+        auto ldsz = [&](const bf16_t* q) {  // per-row scale / zero pair (GRP: the streamers hold the group tables)
+            if constexpr (GRP) return float2{0.f, 0.f};
+            return ldpair(q);
         };
         auto bfpair = [&](float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); };
         // activation pair granule: fp16 (a, b); ODD pairs of a vector carry a / 16, b / 16 (see nib2f16).  pg is the
@@ -665,6 +754,19 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         auto get_sums = [&]() {
             const float se = misc[4] + misc[5], so = misc[6] + misc[7];
             return float2{1024.f * (se + so), se + 16.f * so};
+        };
+        // GRP: the same two sums per 128-value unit (32 consecutive lanes of a sweep load hold a unit), for the streamers' epilogues
+        auto unit_sums = [&](int i, unsigned even, unsigned odd, bool live, int ln) {
+            if constexpr (GRP) {
+                float se = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, even), ones2, 0.f, false);
+                float so = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, odd), ones2, 0.f, false);
+                se = group_sum(live ? se : 0.f, 32);
+                so = group_sum(live ? so : 0.f, 32);
+                if (live && (ln & 31) == 0) {
+                    usum[i >> 5] = se;
+                    usum[96 + (i >> 5)] = so;
+                }
+            }
         };
         bool dbg_on = false;
 #define FS_GSTAMP(i)                                                                              \
@@ -738,6 +840,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 for (int k = 0; k < kG0; ++k) {
                     *(u64*)(xs + (size_t)(k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
                     pair_sums(sx, v[k][0], v[k][2]);
+                    unit_sums(k * 64 + lane_v, v[k][0], v[k][2], true, lane_v);
                 }
                 float ss = ((__uint_as_float(v[kG0][0]) + __uint_as_float(v[kG0][2])) + __uint_as_float(v[kG0 + 1][0])) +
                            __uint_as_float(v[kG0 + 1][2]);
@@ -752,6 +855,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 for (int k = 0; k < 16 - kG0; ++k) {
                     *(u64*)(xs + (size_t)(kG0 * 64 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
                     pair_sums(sx, v[k][0], v[k][2]);
+                    unit_sums(kG0 * 64 + k * 64 + lane_v, v[k][0], v[k][2], true, lane_v);
                 }
                 put_sums(sx);
             }
@@ -759,6 +863,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             ++edge;
         };
         auto deq = [&](float2 t, float2 sc_, float2 z_, float2 sx) {
+            if constexpr (GRP) return t;  // the streamers applied the group scales
             return float2{sc_.x * (t.x - sx.x - z_.x * sx.y), sc_.y * (t.y - sx.x - z_.y * sx.y)};
         };
 
@@ -783,8 +888,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             if (gw == 0) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    sc[r] = ldpair(sz_l + nq + r * kC);
-                    zr[r] = ldpair(sz_l + 3 * kC + nq + r * kC);
+                    sc[r] = ldsz(sz_l + nq + r * kC);
+                    zr[r] = ldsz(sz_l + 3 * kC + nq + r * kC);
                 }
             }
             gather_x();
@@ -933,8 +1038,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             {
                 float2 s1 = {0.f, 0.f}, z1 = {0.f, 0.f}, gn = {0.f, 0.f};
                 if (gw == 0) {
-                    s1 = ldpair(sz_l + 6 * kC + r0);
-                    z1 = ldpair(sz_l + 7 * kC + r0);
+                    s1 = ldsz(sz_l + 6 * kC + r0);
+                    z1 = ldsz(sz_l + 7 * kC + r0);
                     gn = ldpair(norms_l + kC + r0);  // rms_2
                 }
                 const unsigned ep = ebase + edge;
@@ -946,6 +1051,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 for (int k = 0; k < 8; ++k) {
                     *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
                     pair_sums(sxp, v[k][0], v[k][2]);
+                    unit_sums(gw * 512 + k * 64 + lane_v, v[k][0], v[k][2], true, lane_v);
                 }
                 put_sums(sxp);
                 apar ^= 1;
@@ -971,10 +1077,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
 #pragma unroll
                     for (int t = 0; t < kMaxFcTiles; ++t) {
                         const int n = (bid + (t < n_fc ? t : 0) * kG) * 16 + 2 * pg;
-                        fs1[t] = ldpair(s_fc + n);
-                        fz1[t] = ldpair(s_fc + p.H + n);
-                        fs2[t] = ldpair(s_fc + 2 * p.H + n);
-                        fz2[t] = ldpair(s_fc + 3 * p.H + n);
+                        fs1[t] = ldsz(s_fc + n);
+                        fz1[t] = ldsz(s_fc + p.H + n);
+                        fs2[t] = ldsz(s_fc + 2 * p.H + n);
+                        fz2[t] = ldsz(s_fc + 3 * p.H + n);
                     }
                 }
                 gather_x();
@@ -1006,8 +1112,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 float2 s1 = {0.f, 0.f}, z1 = {0.f, 0.f}, gn = {0.f, 0.f};
                 const bf16_t* s_mp = sz_l + 8 * kC + 4 * p.H;
                 if (gw == 0) {
-                    s1 = ldpair(s_mp + r0);
-                    z1 = ldpair(s_mp + kC + r0);
+                    s1 = ldsz(s_mp + r0);
+                    z1 = ldsz(s_mp + kC + r0);
                     gn = ldpair(norms_l + 2 * kC + r0);  // rms_1 of the next layer, or ln_f after the last
                 }
                 const unsigned ep = ebase + edge;
@@ -1032,6 +1138,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                                 *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
                                 pair_sums(sxp, v[k][0], v[k][2]);
                             }
+                            unit_sums(i, v[k][0], v[k][2], i < end, lh);
                         }
                     };
                     const int c1 = first + 512, c2 = first + 1024;
@@ -1057,6 +1164,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                                 *(u64*)(xs + (size_t)i * 8) = ((u64)va[k][2] << 32) | va[k][0];
                                 pair_sums(sxp, va[k][0], va[k][2]);
                             }
+                            unit_sums(i, va[k][0], va[k][2], i < end, lh);
                         }
                     };
                     auto stage_b = [&](int c0) {
@@ -1067,6 +1175,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                                 *(u64*)(xs + (size_t)i * 8) = ((u64)vb[k][2] << 32) | vb[k][0];
                                 pair_sums(sxp, vb[k][0], vb[k][2]);
                             }
+                            unit_sums(i, vb[k][0], vb[k][2], i < end, lh);
                         }
                     };
                     const int c1 = first + 512, c2 = first + 768, c3 = first + 1280;
@@ -1112,8 +1221,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             auto head_sz = [&](int t, float2& sc_, float2& z_) {
                 const int n = (bid + t * kG) * 16 + 2 * pg;
                 const bool ok = t < n_head_t && n + 1 < p.V;
-                sc_ = ok ? ldpair(p.sz_head + n) : float2{0.f, 0.f};
-                z_ = ok ? ldpair(p.sz_head + p.V + n) : float2{0.f, 0.f};
+                sc_ = ok ? ldsz(p.sz_head + n) : float2{0.f, 0.f};
+                z_ = ok ? ldsz(p.sz_head + p.V + n) : float2{0.f, 0.f};
             };
             float2 sct = {0.f, 0.f}, zt = {0.f, 0.f};
             if (gw == 0) head_sz(0, sct, zt);
@@ -1221,12 +1330,14 @@ int fused_step_ring_occupancy_ok() {
     static int ok = -1;
     static std::once_flag once;
     std::call_once(once, [] {
-        int per_cu = 0;
-        (void)hipFuncSetAttribute((const void*)fused_step_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fused_step_ring_kernel, kThreads, kLdsBytes);
-        ok = (e == hipSuccess && per_cu >= 1) ? 1 : 0;
+        int per_cu = 0, per_cu_g = 0;
+        (void)hipFuncSetAttribute((const void*)fused_step_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        (void)hipFuncSetAttribute((const void*)fused_step_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesG);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fused_step_ring_kernel<false>, kThreads, kLdsBytes);
+        hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_g, (const void*)fused_step_ring_kernel<true>, kThreads, kLdsBytesG);
+        ok = (e == hipSuccess && per_cu >= 1 ? 1 : 0) | (e2 == hipSuccess && per_cu_g >= 1 ? 2 : 0);
     });
-    return ok;
+    return ok;  // bit 0: the per-row kernel fits one workgroup per CU, bit 1: the grouped-scale kernel
 }
 
 // launched by mi355_fused_step (fused_step.hip)
@@ -1234,14 +1345,22 @@ int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t 
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)fused_step_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        attr_err = hipFuncSetAttribute((const void*)fused_step_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (attr_err == hipSuccess)
+            attr_err = hipFuncSetAttribute((const void*)fused_step_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesG);
     });
     MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "fused_step: hipFuncSetAttribute failed: %s",
                     hipGetErrorString(attr_err));
-    if (e0 != nullptr) {
-        hipExtLaunchKernelGGL(fused_step_ring_kernel, dim3(kG), dim3(kThreads), (uint32_t)kLdsBytes, stream, e0, e1, 0, p);
+    if (p.grouped) {
+        if (e0 != nullptr) {
+            hipExtLaunchKernelGGL(fused_step_ring_kernel<true>, dim3(kG), dim3(kThreads), (uint32_t)kLdsBytesG, stream, e0, e1, 0, p);
+        } else {
+            hipLaunchKernelGGL(fused_step_ring_kernel<true>, dim3(kG), dim3(kThreads), kLdsBytesG, stream, p);
+        }
+    } else if (e0 != nullptr) {
+        hipExtLaunchKernelGGL(fused_step_ring_kernel<false>, dim3(kG), dim3(kThreads), (uint32_t)kLdsBytes, stream, e0, e1, 0, p);
     } else {
-        hipLaunchKernelGGL(fused_step_ring_kernel, dim3(kG), dim3(kThreads), kLdsBytes, stream, p);
+        hipLaunchKernelGGL(fused_step_ring_kernel<false>, dim3(kG), dim3(kThreads), kLdsBytes, stream, p);
     }
     MI355_LAUNCH_CHECK();
     return 0;

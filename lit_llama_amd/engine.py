@@ -151,16 +151,29 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
     if not lib().mi355_fused_step_supported(C_, nh, hs, H, V, 1):
         return None
     first = model.transformer.h[0]
-    for mod in (first.attn.c_attn, first.attn.c_proj, first.mlp.c_fc1, first.mlp.c_fc2, first.mlp.c_proj, model.lm_head):
-        if not mod.fast_eligible(torch.bfloat16) or mod.scales.dtype != torch.bfloat16 or mod.scales.shape[1] != 1:
-            return None  # (grouped scales: launch-per-operator engine)
+    group_cols = 0
+    mods = [m_ for blk in model.transformer.h
+            for m_ in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj)] + [model.lm_head]
+    if all(m_.scales.shape[1] > 1 for m_ in mods):
+        # grouped scales ("groupsize" checkpoints): the GRP instantiation of the register-ring kernel — one group size of
+        # 128 * 2^n columns throughout, dividing n_embd and n_hidden, bf16 tables
+        group_cols = first.attn.c_attn.tile_cols
+        ok = (_env_int("MI355_FUSED_GROUPED", 1) != 0 and group_cols >= 128 and (group_cols & (group_cols - 1)) == 0
+              and C_ % group_cols == 0 and H % group_cols == 0 and os.environ.get("MI355_FUSED_IMPL", "") != "lds"
+              and all(m_.tile_cols == group_cols and m_.grouped_fast() for m_ in mods))
+        if not ok:
+            return None
+    else:
+        for mod in (first.attn.c_attn, first.attn.c_proj, first.mlp.c_fc1, first.mlp.c_fc2, first.mlp.c_proj, model.lm_head):
+            if not mod.fast_eligible(torch.bfloat16) or mod.scales.dtype != torch.bfloat16 or mod.scales.shape[1] != 1:
+                return None  # (mixed per-row / grouped layouts: launch-per-operator engine)
     sizes = [ops.packed_bytes(W_Q4, 3 * C_, C_, 1, False), ops.packed_bytes(W_Q4, C_, C_, 1, False),
              ops.packed_bytes(W_Q4, H, C_, 2, True), ops.packed_bytes(W_Q4, C_, H, 1, False)]
     offs = [0, sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2]]
     layer_bytes = sum(sizes)
     if layer_bytes >= 1 << 32 or any(o % 16 for o in offs) or layer_bytes % 16:
         return None
-    return {"sizes": sizes, "offs": offs, "layer_bytes": layer_bytes}
+    return {"sizes": sizes, "offs": offs, "layer_bytes": layer_bytes, "group_cols": group_cols}
 
 
 class DecodeEngine:
@@ -339,18 +352,39 @@ class DecodeEngine:
         """Side arenas of the persistent decode launch: scales / zeros, norm scales, hand-off workspace."""
         cfg, plan, dev = self.cfg, self.fused_plan, self.device
         C_, H, V = cfg.n_embd, self.n_hidden, model.lm_head.out_features
+        gc = plan.get("group_cols", 0)
+
+        def group_table(mod):
+            """[N, groups] bf16 scales / zeros -> [N / 16 tiles][group][16 rows] int32 = scale bits | zero bits << 16 (what a
+            streamer lane of the GRP kernel reads with one 16-B load: rows 4 g .. 4 g + 3 of a tile for its group)"""
+            N, G = mod.scales.shape
+            assert N % 16 == 0 and mod.scales.dtype == torch.bfloat16 and mod.zeros.dtype == torch.bfloat16
+            word = (mod.scales.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF) | \
+                   (mod.zeros.contiguous().view(torch.int16).to(torch.int32) << 16)
+            return word.view(N // 16, 16, G).permute(0, 2, 1).contiguous().reshape(-1)
+
         with torch.cuda.device(dev):
-            sz = torch.empty((cfg.n_layer, 10 * C_ + 4 * H), dtype=torch.bfloat16, device=dev)
+            sz = sz_head = gt = gt_head = None
             norms = torch.empty((2 * cfg.n_layer + 1, C_), dtype=torch.bfloat16, device=dev)
+            if gc:
+                rows = []
+                for blk in model.transformer.h:
+                    rows.append(torch.cat([group_table(mod) for mod in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1,
+                                                                        blk.mlp.c_fc2, blk.mlp.c_proj)]))
+                gt = torch.stack(rows).contiguous()      # [n_layer, dwords per layer]
+                gt_head = group_table(model.lm_head)
+            else:
+                sz = torch.empty((cfg.n_layer, 10 * C_ + 4 * H), dtype=torch.bfloat16, device=dev)
+                sz_head = torch.cat([model.lm_head.scales.reshape(-1), model.lm_head.zeros.reshape(-1)]).contiguous()
             for i, blk in enumerate(model.transformer.h):
-                parts = []
-                for mod in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj):
-                    parts += [mod.scales.reshape(-1), mod.zeros.reshape(-1)]
-                sz[i].copy_(torch.cat(parts))
+                if not gc:
+                    parts = []
+                    for mod in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj):
+                        parts += [mod.scales.reshape(-1), mod.zeros.reshape(-1)]
+                    sz[i].copy_(torch.cat(parts))
                 norms[2 * i].copy_(blk.rms_1.scale.detach())
                 norms[2 * i + 1].copy_(blk.rms_2.scale.detach())
             norms[2 * cfg.n_layer].copy_(model.transformer.ln_f.scale.detach())
-            sz_head = torch.cat([model.lm_head.scales.reshape(-1), model.lm_head.zeros.reshape(-1)]).contiguous()
             ws = torch.zeros(int(lib().mi355_fused_step_workspace_bytes(H)), dtype=torch.uint8, device=dev)
         a = nat.FusedStepArgs()
         a.w, a.layer_stride = ptr(self.w_arena), plan["layer_bytes"]
@@ -358,13 +392,15 @@ class DecodeEngine:
         a.layer_bytes, a.head_bytes = plan["layer_bytes"], head.stream_bytes
         a.w_head = head.desc.w
         a.sz, a.sz_head, a.norms = ptr(sz), ptr(sz_head), ptr(norms)
+        if gc:
+            a.group_cols, a.gt, a.gt_head, a.gt_layer_stride = gc, ptr(gt), ptr(gt_head), gt.shape[1] * 4
         a.wte, a.rope = self.m.wte, self.m.rope
         a.tokens, a.pos, a.next_token, a.out_tokens = self.m.tokens, self.m.pos, self.m.next_token, self.m.out_tokens
         a.logits, a.workspace = self.m.logits, ptr(ws)
         a.n_layer, a.n_head, a.n_embd, a.hs = cfg.n_layer, self.local_heads, C_, C_ // cfg.n_head
         a.n_hidden, a.vocab, a.eps = H, V, self.m.eps
         self.fused = a
-        self._fused_keep = [sz, sz_head, norms, ws]
+        self._fused_keep = [sz, sz_head, norms, ws, gt, gt_head]
         self._fused_ws = ws
         self._fused_warm = False
         self.fused_clipped = 0  # fp16 granules clipped by the persistent step so far (check_status)

@@ -112,6 +112,55 @@ def test_fused_step_against_oracle_at_7b_width(dev):
     assert torch.equal(got.argmax(-1)[decisive], ref.argmax(-1)[decisive])
 
 
+def build_grouped(n_layer, dev, g, seed=0):
+    """A 7B-width gptq.int4 model whose scales / zeros are per row AND group of g input columns (GPTQ groupsize)."""
+    from lit_llama_amd.quantization import ColBlockQuantizedLinear
+
+    cfg = LLaMAConfig(n_layer=n_layer, **W7B)
+    sd = synth.make_state_dict(cfg, seed=seed, mode="gptq.int4", group_cols=g)
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
+        model = LLaMA(cfg)
+    for _, mod in list(model.named_modules()):
+        for cname, child in list(mod.named_children()):
+            if isinstance(child, ColBlockQuantizedLinear):
+                q = ColBlockQuantizedLinear(child.in_features, child.out_features, bias=False, bits=4, tile_cols=g)
+                setattr(mod, cname, q.to(device=dev, dtype=torch.bfloat16))
+    model.load_state_dict(sd)
+    model.eval()
+    return model, sd, cfg
+
+
+@pytest.mark.parametrize("g", [128, 256])
+def test_fused_step_with_grouped_scales(dev, g):
+    """GPTQ groupsize checkpoints on the persistent step (GRP instantiation of the register-ring kernel: 16 groups side by
+    side in the MFMA token columns, scales applied by the streamers): against the launch-per-operator engine on the same
+    weights (tokens equal up to the first near tie, logits within 0.03 std) and against the CPU oracle (0.05 std)."""
+    model, sd, cfg = build_grouped(2, dev, g)
+    eng = need_fused(model)
+    assert eng.fused.group_cols == g
+    prompt = synth.make_prompt(12, seed=3).to(dev)
+    outs, logits = {}, {}
+    for fused in (False, True):
+        eng.fused_enabled = fused
+        model.reset_cache()
+        outs[fused] = lit_llama_amd.generate(model, prompt, 12, top_k=1, max_seq_length=32).cpu()
+        logits[fused] = teacher_forced(model, outs[False].to(dev), 12, 32, dev)
+        eng.check_status()
+    eng.fused_enabled = True
+    std = float(logits[False].std(-1).mean())
+    err = (logits[True] - logits[False]).abs().max().item()
+    assert err <= 0.03 * std, f"grouped fused vs unfused logits: {err:.4f} (std {std:.3f})"
+    top2 = torch.topk(logits[False], 2, dim=-1).values
+    margins = (top2[:, 0] - top2[:, 1]).tolist()
+    first_tie = next((i for i, m_ in enumerate(margins) if m_ <= 2 * 0.03 * std), len(margins))
+    n = 12 + first_tie + 1
+    assert torch.equal(outs[True][:n], outs[False][:n]), f"{outs[True].tolist()} vs {outs[False].tolist()}"
+    om = oracle.Model(oracle.Config(n_layer=2, **W7B), {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()},
+                      mode="gptq.int4")
+    ref = oracle.teacher_forced_logits(om, outs[False], 12)
+    assert (logits[True] - ref).abs().max().item() <= 0.05 * float(ref.std(-1).mean())
+
+
 def test_fused_step_is_reproducible_and_modes_agree(dev):
     model, _, cfg = build(2, dev, seed=1)
     eng = need_fused(model)
