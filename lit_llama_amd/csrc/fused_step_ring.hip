@@ -81,9 +81,7 @@ constexpr int kOffQ = kOffStage + 1024;           // q[128] knew[128] vnew[128] 
 constexpr int kOffOpart = kOffQ + 3 * 512;        // [8 waves][16] f32
 constexpr int kMaxS = 32768;                      // cache rows (the attention keeps no per-row state in LDS)
 constexpr int kLdsBytes = kOffOpart + 512;
-constexpr int kOffUsum = kLdsBytes;               // GRP: [2][96] f32 sums of the even / odd pairs of every 128-value unit
-constexpr int kLdsBytesG = kOffUsum + 2 * 96 * 4;
-static_assert(kLdsBytesG <= 160 * 1024, "LDS map exceeds the CU");
+constexpr int kLdsBytesG = kLdsBytes;             // (the GRP instantiation needs no LDS of its own)
 
 // ------------------------------------------------------------------------------------------------ granules
 __device__ __forceinline__ void gr_store(u64* p, unsigned tag, unsigned val) {
@@ -195,11 +193,11 @@ __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_b
 // token column (g - first group of the wave) & 15 — at M = 1 the 16 columns are otherwise 16 copies of one dot product — so a
 // wave's accumulator holds its (<= 16) groups side by side, and apply the scales themselves at the end of a tile (tables
 // [tile][group][16 rows] of bf16 scale | bf16 zero << 16, one 16-B load per lane and row group, requested at the tile's first step;
-// per-unit sums of the staged operands from the gatherers); what reaches the gatherers' epilogues is already dequantised.
+// the operand sums of its groups taken by the wave itself from the staged vector); what reaches the gatherers' epilogues is
+// already dequantised.
 template <bool GRP>
 __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    [[maybe_unused]] float* usum = (float*)(smem + kOffUsum);  // [0..95] even pairs, [96..191] odd pairs
     const int bid = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -320,6 +318,32 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             const char* xb0__ = ((!GRP || cc__ == 0) ? xs + ((PH_).u0) * 256 : smem + kOffZero) + g * 64;             \
             _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const f16x8*)(xb0__ + 16 * d__);       \
         }                                                                                                             \
+        /* GRP: sums of the even / odd pairs of the staged operands of THIS column's group, over this wave's units   */ \
+        /* of it (a wave's range may start or end inside a group): the four lanes of a column take 16 pairs of a     */ \
+        /* unit each.  Once per phase, off the gatherers' hand-off path.                                              */ \
+        [[maybe_unused]] float gse__ = 0.f, gso__ = 0.f;                                                              \
+        if constexpr (GRP) {                                                                                          \
+            const f16x2 one2__ = {(_Float16)1.0f, (_Float16)1.0f};                                                    \
+            for (int j__ = 0; j__ < (1 << p.gsh); ++j__) {                                                            \
+                const int un__ = ((gfirst__ + cc__) << p.gsh) + j__;                                                  \
+                if (un__ >= (PH_).u0 && un__ < (PH_).u0 + (PH_).nu) {                                                 \
+                    const u32x4* q4__ = (const u32x4*)(xs + un__ * 256 + g * 64);                                     \
+                    _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                             \
+                        const u32x4 w4__ = q4__[d__];                                                                 \
+                        /* (scalars first: __builtin_bit_cast of an ext-vector ELEMENT reads element 0, hipcc 7.2) */ \
+                        const unsigned e0__ = w4__[0], e1__ = w4__[1], e2__ = w4__[2], e3__ = w4__[3];                \
+                        gse__ = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, e0__), one2__, gse__, false);        \
+                        gso__ = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, e1__), one2__, gso__, false);        \
+                        gse__ = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, e2__), one2__, gse__, false);        \
+                        gso__ = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, e3__), one2__, gso__, false);        \
+                    }                                                                                                 \
+                }                                                                                                     \
+            }                                                                                                         \
+            gse__ += lane_xor16(gse__);                                                                               \
+            gse__ += lane_xor32(gse__);                                                                               \
+            gso__ += lane_xor16(gso__);                                                                               \
+            gso__ += lane_xor32(gso__);                                                                               \
+        }                                                                                                             \
         for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
             _Pragma("unroll") for (int t__ = 0; t__ < (TURNS_); ++t__) {                                              \
                 _Pragma("unroll") for (int s__ = 0; s__ < STEPS__; ++s__) {                                           \
@@ -379,18 +403,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         if constexpr (GRP) {                                                                          \
                             /* column c holds group gfirst + c: y = s (acc - 1024 (Se + So) - z (Se + 16 So)) with    */ \
                             /* the group's operand sums (units of the group), then the 16 columns are added up        */ \
-                            const int gl__ = gfirst__ + cc__;                                                         \
-                            const int glast__ = ((PH_).u0 + ((PH_).nu > 0 ? (PH_).nu - 1 : 0)) >> p.gsh;              \
-                            float se__ = 0.f, so__ = 0.f;                                                             \
-                            if (gl__ <= glast__ && (PH_).nu > 0) {                                                    \
-                                for (int j__ = 0; j__ < (1 << p.gsh); ++j__) {                                        \
-                                    const int un__ = (gl__ << p.gsh) + j__;                                           \
-                                    if (un__ >= (PH_).u0 && un__ < (PH_).u0 + (PH_).nu) { /* (this wave's units) */   \
-                                        se__ += usum[un__];                                                           \
-                                        so__ += usum[96 + un__];                                                      \
-                                    }                                                                                 \
-                                }                                                                                     \
-                            }                                                                                         \
+                            const float se__ = gse__, so__ = gso__; /* (0 in the columns past the wave's groups) */   \
                             const float ga__ = 1024.f * (se__ + so__), gb__ = se__ + 16.f * so__;                     \
                             _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                   \
                                 const f32x4 a4__ = acc__[r__][0] + acc__[r__][1];                                     \
@@ -755,19 +768,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             const float se = misc[4] + misc[5], so = misc[6] + misc[7];
             return float2{1024.f * (se + so), se + 16.f * so};
         };
-        // GRP: the same two sums per 128-value unit (32 consecutive lanes of a sweep load hold a unit), for the streamers' epilogues
-        auto unit_sums = [&](int i, unsigned even, unsigned odd, bool live, int ln) {
-            if constexpr (GRP) {
-                float se = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, even), ones2, 0.f, false);
-                float so = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, odd), ones2, 0.f, false);
-                se = group_sum(live ? se : 0.f, 32);
-                so = group_sum(live ? so : 0.f, 32);
-                if (live && (ln & 31) == 0) {
-                    usum[i >> 5] = se;
-                    usum[96 + (i >> 5)] = so;
-                }
-            }
-        };
         bool dbg_on = false;
 #define FS_GSTAMP(i)                                                                              \
     do {                                                                                          \
@@ -840,7 +840,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 for (int k = 0; k < kG0; ++k) {
                     *(u64*)(xs + (size_t)(k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
                     pair_sums(sx, v[k][0], v[k][2]);
-                    unit_sums(k * 64 + lane_v, v[k][0], v[k][2], true, lane_v);
                 }
                 float ss = ((__uint_as_float(v[kG0][0]) + __uint_as_float(v[kG0][2])) + __uint_as_float(v[kG0 + 1][0])) +
                            __uint_as_float(v[kG0 + 1][2]);
@@ -855,7 +854,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 for (int k = 0; k < 16 - kG0; ++k) {
                     *(u64*)(xs + (size_t)(kG0 * 64 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
                     pair_sums(sx, v[k][0], v[k][2]);
-                    unit_sums(kG0 * 64 + k * 64 + lane_v, v[k][0], v[k][2], true, lane_v);
                 }
                 put_sums(sx);
             }
@@ -1051,7 +1049,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 for (int k = 0; k < 8; ++k) {
                     *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
                     pair_sums(sxp, v[k][0], v[k][2]);
-                    unit_sums(gw * 512 + k * 64 + lane_v, v[k][0], v[k][2], true, lane_v);
                 }
                 put_sums(sxp);
                 apar ^= 1;
@@ -1138,7 +1135,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                                 *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
                                 pair_sums(sxp, v[k][0], v[k][2]);
                             }
-                            unit_sums(i, v[k][0], v[k][2], i < end, lh);
                         }
                     };
                     const int c1 = first + 512, c2 = first + 1024;
@@ -1164,7 +1160,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                                 *(u64*)(xs + (size_t)i * 8) = ((u64)va[k][2] << 32) | va[k][0];
                                 pair_sums(sxp, va[k][0], va[k][2]);
                             }
-                            unit_sums(i, va[k][0], va[k][2], i < end, lh);
                         }
                     };
                     auto stage_b = [&](int c0) {
@@ -1175,7 +1170,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                                 *(u64*)(xs + (size_t)i * 8) = ((u64)vb[k][2] << 32) | vb[k][0];
                                 pair_sums(sxp, vb[k][0], vb[k][2]);
                             }
-                            unit_sums(i, vb[k][0], vb[k][2], i < end, lh);
                         }
                     };
                     const int c1 = first + 512, c2 = first + 768, c3 = first + 1280;

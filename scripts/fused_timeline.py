@@ -26,11 +26,20 @@ def main():
     ap.add_argument("--layer", type=int, default=10)
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--group-cols", type=int, default=0, help="GPTQ groupsize model (GRP instantiation of the kernel)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = LLaMAConfig(n_layer=a.layers, n_head=32, n_embd=4096)
     with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
         model = LLaMA(cfg)
+    if a.group_cols:
+        from lit_llama_amd.quantization import ColBlockQuantizedLinear
+
+        for _, mod in list(model.named_modules()):
+            for cname, child in list(mod.named_children()):
+                if isinstance(child, ColBlockQuantizedLinear):
+                    q = ColBlockQuantizedLinear(child.in_features, child.out_features, bias=False, bits=4, tile_cols=a.group_cols)
+                    setattr(mod, cname, q.to(device=dev, dtype=torch.bfloat16))
     synth.fill_model_random_int4(model, seed=0)
     eng = model.engine()
     assert eng is not None and eng.fused is not None, model._engine_failed
