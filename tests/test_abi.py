@@ -37,6 +37,35 @@ def test_struct_layouts_match():
     assert lib.mi355_version() == 1
 
 
+def test_every_field_of_every_struct_sits_where_the_header_puts_it(tmp_path):
+    """The ctypes mirrors (lit_llama_amd/_native.py) against include/mi355_llama.h compiled as C99 by gcc: same field names,
+    same offsets, same sizes — mi355_sizeof only covers the sizes, and a drop-in binding lives or dies by the offsets."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = [("mi355_linear_args", nat.LinearArgs), ("mi355_attn_args", nat.AttnArgs), ("mi355_adapter_args", nat.AdapterArgs),
+             ("mi355_int8_args", nat.Int8Args), ("mi355_weight", nat.Weight), ("mi355_layer", nat.Layer),
+             ("mi355_model", nat.Model), ("mi355_fused_step_args", nat.FusedStepArgs), ("mi355_tp_comm", nat.TpComm)]
+    src = ["#include <stdio.h>", "#include <stddef.h>", '#include "mi355_llama.h"', "int main(void) {"]
+    for cname, st in pairs:
+        src.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f, _ in st._fields_:
+            src.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    src.append("return 0; }")
+    (tmp_path / "o.c").write_text("\n".join(src))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", f"-I{HEADER.parent}", str(tmp_path / "o.c"), "-o", str(tmp_path / "o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr  # (also: the header is plain C and every ctypes field name exists in it)
+    got = dict(line.split() for line in subprocess.run([str(tmp_path / "o")], capture_output=True, text=True).stdout.splitlines())
+    for cname, st in pairs:
+        assert int(got[cname]) == C.sizeof(st), cname
+        for f, _ in st._fields_:
+            assert int(got[f"{cname}.{f}"]) == getattr(st, f).offset, f"{cname}.{f}"
+    assert len(got) > 200
+
+
 def test_packed_bytes_accounting():
     lib = nat.lib()
     # 7B shapes: one byte per two int4 weights, no padding
