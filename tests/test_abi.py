@@ -66,6 +66,18 @@ def test_every_field_of_every_struct_sits_where_the_header_puts_it(tmp_path):
     assert len(got) > 200
 
 
+def test_the_binding_stubs_in_integration_md_follow_the_structs():
+    """INTEGRATION.md shows the ctypes stubs a lit-llama maintainer would paste; a struct that grew must grow there too."""
+    text = (HEADER.parents[1] / "INTEGRATION.md").read_text()
+    blk = text[text.index("class _LinearArgs"):text.index("def _check(rc)")]
+    assert re.findall(r'\("(\w+)", C\.c_', blk) == [f for f, _ in nat.LinearArgs._fields_]
+    blk = text[text.index("class _FusedArgs"):text.index("# once per model")]
+    names = re.findall(r'\("(\w+)", C\.c_', blk)
+    ints = [x.strip().strip('"') for x in re.search(r"\(n, C\.c_int32\) for n in\s*\(([^)]*)\)", blk).group(1).split(",")]
+    k = names.index("eps")
+    assert names[:k] + ints + names[k:] == [f for f, _ in nat.FusedStepArgs._fields_]
+
+
 def test_packed_bytes_accounting():
     lib = nat.lib()
     # 7B shapes: one byte per two int4 weights, no padding
