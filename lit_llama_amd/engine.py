@@ -176,6 +176,16 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
     return {"sizes": sizes, "offs": offs, "layer_bytes": layer_bytes, "group_cols": group_cols}
 
 
+def group_table(scales: torch.Tensor, zeros: torch.Tensor) -> torch.Tensor:
+    """[N, groups] bf16 scales / zeros of a grouped ColBlockQuantizedLinear -> the table the GRP instantiation of the fused
+    step reads (`mi355_fused_step_args.gt`): int32 [N / 16 tiles][group][16 rows] = scale bits | zero bits << 16, flattened —
+    a streamer lane fetches rows 4 g .. 4 g + 3 of a tile for its group with one 16-B load."""
+    N, G = scales.shape
+    assert N % 16 == 0 and scales.dtype == torch.bfloat16 and zeros.dtype == torch.bfloat16 and zeros.shape == scales.shape
+    word = (scales.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF) | (zeros.contiguous().view(torch.int16).to(torch.int32) << 16)
+    return word.view(N // 16, 16, G).permute(0, 2, 1).contiguous().reshape(-1)
+
+
 class DecodeEngine:
     """Owns everything `mi355_forward` / `mi355_fused_step` need for one `LLaMA` instance."""
 
@@ -354,25 +364,16 @@ class DecodeEngine:
         C_, H, V = cfg.n_embd, self.n_hidden, model.lm_head.out_features
         gc = plan.get("group_cols", 0)
 
-        def group_table(mod):
-            """[N, groups] bf16 scales / zeros -> [N / 16 tiles][group][16 rows] int32 = scale bits | zero bits << 16 (what a
-            streamer lane of the GRP kernel reads with one 16-B load: rows 4 g .. 4 g + 3 of a tile for its group)"""
-            N, G = mod.scales.shape
-            assert N % 16 == 0 and mod.scales.dtype == torch.bfloat16 and mod.zeros.dtype == torch.bfloat16
-            word = (mod.scales.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF) | \
-                   (mod.zeros.contiguous().view(torch.int16).to(torch.int32) << 16)
-            return word.view(N // 16, 16, G).permute(0, 2, 1).contiguous().reshape(-1)
-
         with torch.cuda.device(dev):
             sz = sz_head = gt = gt_head = None
             norms = torch.empty((2 * cfg.n_layer + 1, C_), dtype=torch.bfloat16, device=dev)
             if gc:
                 rows = []
                 for blk in model.transformer.h:
-                    rows.append(torch.cat([group_table(mod) for mod in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1,
+                    rows.append(torch.cat([group_table(mod.scales, mod.zeros) for mod in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1,
                                                                         blk.mlp.c_fc2, blk.mlp.c_proj)]))
                 gt = torch.stack(rows).contiguous()      # [n_layer, dwords per layer]
-                gt_head = group_table(model.lm_head)
+                gt_head = group_table(model.lm_head.scales, model.lm_head.zeros)
             else:
                 sz = torch.empty((cfg.n_layer, 10 * C_ + 4 * H), dtype=torch.bfloat16, device=dev)
                 sz_head = torch.cat([model.lm_head.scales.reshape(-1), model.lm_head.zeros.reshape(-1)]).contiguous()

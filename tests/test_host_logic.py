@@ -277,3 +277,21 @@ def test_bench_gpus_n_starts_n_ranks():
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_group_table_layout_of_the_grouped_fused_step():
+    """engine.group_table: dword ((tile * groups + g) * 16 + row) holds bf16 scale | bf16 zero << 16 of output row tile * 16 + row,
+    group g (what a streamer lane of fused_step_ring_kernel<true> loads as rows 4 g4 .. 4 g4 + 3 with one 16-B read)."""
+    from lit_llama_amd.engine import group_table
+
+    gen = torch.Generator().manual_seed(0)
+    N, G = 48, 5
+    scales = (torch.rand((N, G), generator=gen) * 0.1 + 0.01).to(torch.bfloat16)
+    zeros = torch.randint(0, 16, (N, G), generator=gen).to(torch.bfloat16) - 3   # (negative values: the sign bit must not smear)
+    t = group_table(scales, zeros)
+    assert t.dtype == torch.int32 and t.numel() == N * G
+    sb = scales.view(torch.int16).to(torch.int64) & 0xFFFF
+    zb = zeros.view(torch.int16).to(torch.int64) & 0xFFFF
+    for n, g in [(0, 0), (17, 3), (47, 4), (16, 0), (31, 2)]:
+        w = int(t[((n // 16) * G + g) * 16 + n % 16]) & 0xFFFFFFFF
+        assert w & 0xFFFF == int(sb[n, g]) and w >> 16 == int(zb[n, g])
