@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import pickle
 import struct
+import sys
 import warnings
 import zipfile
 from collections import OrderedDict
@@ -52,6 +53,7 @@ class LazyTensor:
         self._storage, self._offset = storage, int(offset)
         self._size, self._stride = tuple(int(s) for s in size), tuple(int(s) for s in stride)
         self._requires_grad, self._parameter = bool(requires_grad), parameter
+        self._subclass = None  # (Tensor subclass, its pickled state) when the checkpoint stored one (_rebuild_from_type)
 
     # ---- metadata without I/O
     @property
@@ -113,8 +115,10 @@ class LazyTensor:
             raise IndexError(f"narrow({dim}, {start}, {length}) out of range for {tuple(self._size)}")
         size = list(self._size)
         size[dim] = length
-        return LazyTensor(self._storage, self._offset + start * self._stride[dim], tuple(size), self._stride,
-                          self._requires_grad, self._parameter)
+        out = LazyTensor(self._storage, self._offset + start * self._stride[dim], tuple(size), self._stride,
+                         self._requires_grad, self._parameter)
+        out._subclass = self._subclass
+        return out
 
     # ---- I/O
     def _extent(self) -> Tuple[int, int]:
@@ -136,9 +140,17 @@ class LazyTensor:
         else:
             flat = torch.empty((0,), dtype=self.dtype)
         t = torch.as_strided(flat, self._size, self._stride, 0)
+        if self._subclass is not None:  # as the reference does it (lit_llama/utils.py:176-186)
+            plain = t
+            t = torch._tensor._rebuild_from_type_v2(lambda: plain, self._subclass[0], (), self._subclass[1])
         if self._parameter:
             t = torch.nn.Parameter(t, requires_grad=self._requires_grad)
         return t
+
+    def _load_tensor(self) -> torch.Tensor:
+        """The reference's spelling (`NotYetLoadedTensor._load_tensor`, lit_llama/utils.py:166-330): its callers test for
+        this attribute and call it (lit_llama/adapter.py:182, scripts/convert_hf_checkpoint.py:65, tests/test_utils.py:49)."""
+        return self.materialize()
 
     def to(self, *args, **kwargs) -> torch.Tensor:
         return self.materialize().to(*args, **kwargs)
@@ -197,6 +209,11 @@ class _Unpickler(pickle.Unpickler):
             return getattr(torch, name)
         if module == "builtins" and name in _SAFE_BUILTINS:
             return super().find_class(module, name)
+        # a torch.Tensor SUBCLASS of a module the process has already imported (the reference's tests/test_utils.py:32-49 save
+        # one): looked up, never imported — nothing the pickle names gets to run
+        obj = getattr(sys.modules.get(module), name, None)
+        if isinstance(obj, type) and issubclass(obj, torch.Tensor):
+            return obj
         raise pickle.UnpicklingError(f"checkpoint pickle refers to {module}.{name}; only plain state dicts are read")
 
     def persistent_load(self, pid):
@@ -213,12 +230,17 @@ def _rebuild_tensor(storage, storage_offset, size, stride, requires_grad=False, 
 
 def _rebuild_parameter(data, requires_grad, backward_hooks):
     if isinstance(data, LazyTensor):
-        return LazyTensor(data._storage, data._offset, data._size, data._stride, requires_grad, parameter=True)
+        out = LazyTensor(data._storage, data._offset, data._size, data._stride, requires_grad, parameter=True)
+        out._subclass = data._subclass
+        return out
     return torch.nn.Parameter(data, requires_grad=requires_grad)
 
 
 def _rebuild_from_type(func, new_type, args, state):
-    return func(*args)  # tensor subclasses in a checkpoint decay to plain (lazy) tensors
+    ret = func(*args)
+    if isinstance(ret, LazyTensor) and isinstance(new_type, type) and issubclass(new_type, torch.Tensor):
+        ret._subclass = (new_type, state)  # restored at materialize()
+    return ret
 
 
 class lazy_load:

@@ -338,8 +338,49 @@ def big_bf16_case(name="cfg2_7b_int4"):
           "argmax equal:", bool((out["argmax"] == fx["argmax"]).all()))
 
 
+def lazy_load_case():
+    """f2: the reference's `lazy_load` (lit_llama/utils.py:166-344) on a small committed checkpoint — keys, dtypes, shapes,
+    strides, Parameter-ness and values of what it hands out; tests/test_checkpoint.py holds lit_llama_amd.utils.lazy_load to it."""
+    from lit_llama.utils import lazy_load as ref_lazy_load
+
+    gen = torch.Generator().manual_seed(11)
+    base = torch.arange(64, dtype=torch.float32).reshape(8, 8)
+    sd = {
+        "a.weight": torch.randn((5, 7), generator=gen),
+        "b.bf16": torch.randn((4, 6), generator=gen).to(torch.bfloat16),
+        # the transposed view ColBlockQuantizedLinear registers (lit_llama/quantization.py:350-358)
+        "c.quant_weight": torch.randint(0, 255, (6, 10), generator=gen, dtype=torch.uint8).t(),
+        "d.view1": base[2:5],      # two views of ONE storage, one of them strided
+        "d.view2": base[:, 3],
+        "e.scalar": torch.tensor(3.5),
+        "f.param": torch.nn.Parameter(torch.randn((3, 3), generator=gen)),
+        "g.int": torch.arange(10, dtype=torch.int64),
+        "h.half": torch.randn((2, 2, 2), generator=gen).half(),
+    }
+    ckpt = OUT / "lazy_ckpt.pth"
+    torch.save(sd, ckpt)
+    out = {"keys": np.array(list(sd))}
+    with ref_lazy_load(ckpt) as lz:
+        assert list(lz) == list(sd)
+        for k, v in lz.items():
+            assert type(v).__name__ == "NotYetLoadedTensor", (k, type(v))
+            t = v._load_tensor()
+            assert torch.equal(t, sd[k])
+            raw = t.detach().contiguous()
+            raw = raw.view(torch.int16) if raw.dtype in (torch.bfloat16, torch.float16) else raw
+            out[k + "/values"] = raw.numpy()
+            out[k + "/meta"] = np.array([str(t.dtype), str(tuple(t.shape)), str(tuple(t.stride())),
+                                         str(isinstance(t, torch.nn.Parameter))])
+    np.savez(OUT / "lazy_load.npz", **out)
+    print("lazy_load fixture:", len(sd), "tensors ->", ckpt)
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--lazy-load" in sys.argv:
+        print("generating the lazy_load fixture from", REF)
+        lazy_load_case()
+        return
     if "--big-long" in sys.argv:
         print("generating the long full-depth 7B fixture from", REF)
         big_long_case()

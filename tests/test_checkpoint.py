@@ -54,6 +54,59 @@ def test_lazy_load_reads_nothing_until_asked_and_matches_torch_load(tmp_path):
     assert reader is ck
 
 
+def test_lazy_load_hands_out_what_the_reference_lazy_load_hands_out(golden):
+    """tests/golden/lazy_ckpt.pth read by the REFERENCE's lazy_load (lit_llama/utils.py:166-344; recorded by
+    `python oracle/gen_golden.py --lazy-load` in tests/golden/lazy_load.npz): same keys in the same order, every entry a
+    not-yet-loaded tensor with `_load_tensor()`, same dtype / shape / stride / Parameter-ness / values — including the
+    transposed quant_weight view and two views of one storage."""
+    import numpy as np
+    from pathlib import Path
+
+    g = golden("lazy_load")
+    ckpt = Path(__file__).resolve().parent / "golden" / "lazy_ckpt.pth"
+    with lazy_load(ckpt) as ck:
+        assert list(ck) == [str(k) for k in g["keys"]]
+        for k, v in ck.items():
+            assert hasattr(v, "_load_tensor"), k      # the attribute the reference's callers test for (quantization.py, adapter.py:177)
+            dtype_s, shape_s, stride_s, is_param = (str(x) for x in g[k + "/meta"])
+            assert str(v.dtype) == dtype_s and str(tuple(v.shape)) == shape_s, k
+            t = v._load_tensor()
+            assert str(t.dtype) == dtype_s and str(tuple(t.shape)) == shape_s and str(tuple(t.stride())) == stride_s, k
+            assert str(isinstance(t, torch.nn.Parameter)) == is_param, k
+            raw = t.detach().contiguous()
+            raw = raw.view(torch.int16) if raw.dtype in (torch.bfloat16, torch.float16) else raw
+            assert np.array_equal(raw.numpy(), g[k + "/values"]), k
+
+
+class ATensor(torch.Tensor):  # (module level: the pickle of the checkpoint names the class)
+    pass
+
+
+def test_the_reference_s_own_lazy_load_tests_hold(tmp_path):
+    """/root/reference tests/test_utils.py:12-49 restated for lit_llama_amd.utils.lazy_load: a module's state dict loads
+    through `load_state_dict(lazy dict)` and computes the same; plain tensors, Parameters and Tensor SUBCLASSES come back
+    equal from `_load_tensor()`."""
+    m = torch.nn.Linear(5, 3)
+    fn = tmp_path / "test.pt"
+    torch.save(m.state_dict(), fn)
+    with lazy_load_from_utils(fn) as sd_lazy:
+        assert "LazyTensor" in str(next(iter(sd_lazy.values())))   # (the reference prints NotYetLoadedTensor here)
+        m2 = torch.nn.Linear(5, 3)
+        m2.load_state_dict(sd_lazy)
+    x = torch.randn(2, 5)
+    torch.testing.assert_close(m2(x), m(x))
+
+    t = torch.randn(2, 3)[:, 1:]
+    sd = {1: t, 2: torch.nn.Parameter(t), 3: torch.Tensor._make_subclass(ATensor, t)}
+    fn2 = tmp_path / "sub.pt"
+    torch.save(sd, fn2)
+    with lazy_load_from_utils(fn2) as sd_lazy:
+        for k in sd:
+            torch.testing.assert_close(sd_lazy[k]._load_tensor(), sd[k])
+        assert isinstance(sd_lazy[2]._load_tensor(), torch.nn.Parameter)
+        assert type(sd_lazy[3]._load_tensor()) is ATensor
+
+
 def test_lazy_row_shards_read_only_their_byte_range(tmp_path):
     w = torch.arange(64 * 16, dtype=torch.float32).view(64, 16)
     path = tmp_path / "w.pth"
