@@ -27,6 +27,14 @@ def adapter_v2_state_from_state_dict(state_dict: dict) -> dict:
     return {name: param for name, param in state_dict.items() if any(s in name for s in get_adapter_substrings())}
 
 
+def adapter_v2_new_forward(self, input: torch.Tensor) -> torch.Tensor:
+    """`adapter_scale * (W x + bias + adapter_bias)` (adapter_v2.py:29-32) as a function of the layer: the native linear plus
+    the elementwise epilogue of `lit_llama_amd.model._linear`."""
+    from .model import _linear
+
+    return _linear(self, input)
+
+
 def adapter_v2_linear_with_bias_and_scale(layer: nn.Linear) -> nn.Linear:
     """Identity at initialisation: bias 0, scale 1 (adapter_v2.py:35-40)."""
     w = layer.weight

@@ -262,3 +262,26 @@ class Linear8bitLt(torch.nn.Linear):
             threshold=self.threshold, bias=self.bias, out_dtype=x.dtype,
         )
         return y.view(*x.shape[:-1], self.out_features)
+
+
+def qlinear_4bit_weight(inp: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor) -> torch.Tensor:
+    """Module-level entry of the reference's Triton kernel (lit_llama/quantization.py:284-333): inp [..., K] times the 4-bit
+    ColBlock weight `weight` ([N, K / 2] uint8, the `quant_weight` buffer) with one (scale, zero) pair per output row
+    (`scales`, `zeros` of shape [N, 1]).  Here: the exact generic kernel on the reference layout, no repack
+    (`ColBlockQuantizedLinear.forward` streams the repacked weights through the MFMA kernels instead)."""
+    nat.require_gpu(inp, "qlinear_4bit_weight")
+    N, K = weight.shape[0], inp.shape[-1]
+    assert weight.shape[1] * 2 == K, "incompatible dimensions"
+    assert scales.shape == (N, 1) and zeros.shape == (N, 1)
+    y = ops.linear_colblock(inp.reshape(-1, K), weight, scales, zeros, 4, K, None, K)
+    return y.view(*inp.shape[:-1], N)
+
+
+def __getattr__(name: str):
+    # `from lit_llama.quantization import GPTQQuantizer` (quantize/gptq.py:17): the quantiser lives in lit_llama_amd/gptq.py,
+    # which imports this module — resolved on first use
+    if name == "GPTQQuantizer":
+        from .gptq import GPTQQuantizer
+
+        return GPTQQuantizer
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -17,6 +17,7 @@ from contextlib import contextmanager
 import torch
 import torch.utils._device
 
+from .checkpoint import LazyTensor as NotYetLoadedTensor  # noqa: F401  (the reference's name for a lazy checkpoint entry)
 from .checkpoint import lazy_load  # noqa: F401  (same name and use as lit_llama.utils.lazy_load)
 
 llama_model_sizes = {

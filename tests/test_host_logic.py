@@ -295,3 +295,19 @@ def test_group_table_layout_of_the_grouped_fused_step():
     for n, g in [(0, 0), (17, 3), (47, 4), (16, 0), (31, 2)]:
         w = int(t[((n // 16) * G + g) * 16 + n % 16]) & 0xFFFFFFFF
         assert w & 0xFFFF == int(sb[n, g]) and w >> 16 == int(zb[n, g])
+
+
+def test_import_paths_of_the_reference_resolve():
+    """Names a script written against lit_llama imports from the same module paths: the quantiser from `quantization`
+    (quantize/gptq.py:17), the lazy tensor class from `utils`, the Triton wrapper's name, adapter v2's forward."""
+    from lit_llama_amd import _native as nat
+    from lit_llama_amd import adapter_v2, checkpoint, gptq
+    from lit_llama_amd.quantization import GPTQQuantizer, qlinear_4bit_weight
+    from lit_llama_amd.utils import NotYetLoadedTensor
+
+    assert GPTQQuantizer is gptq.GPTQQuantizer and NotYetLoadedTensor is checkpoint.LazyTensor
+    assert callable(adapter_v2.adapter_v2_new_forward)
+    x = torch.zeros((2, 64), dtype=torch.bfloat16)
+    w = torch.zeros((8, 32), dtype=torch.uint8)
+    with pytest.raises(nat.NativeError):  # no CPU fallback: the product path needs the GPU
+        qlinear_4bit_weight(x, w, torch.ones((8, 1), dtype=torch.bfloat16), torch.zeros((8, 1), dtype=torch.bfloat16))

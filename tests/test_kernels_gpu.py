@@ -329,6 +329,23 @@ def test_colblock_generic_kernels_match_reference_golden(dev, golden):
         assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_qlinear_4bit_weight_entry_matches_reference_golden(dev, golden):
+    """`lit_llama_amd.quantization.qlinear_4bit_weight` — the module-level name of the reference's Triton wrapper
+    (lit_llama/quantization.py:284-333) — on the reference module's own data and output (tests/golden/colblock.npz, b4_row)."""
+    from lit_llama_amd.quantization import qlinear_4bit_weight
+
+    g = golden("colblock")
+    N, K, bits, tc = (int(v) for v in g["b4_row_meta"])
+    assert bits == 4
+    q = _t(g["b4_row_q"]).t().contiguous().t().to(dev)
+    scales, zeros, x = _t(g["b4_row_scales"]).to(dev), _t(g["b4_row_zeros"]).to(dev), _t(g["b4_row_x"]).to(dev)
+    assert scales.shape == (N, 1)
+    y = qlinear_4bit_weight(x.view(1, *x.shape), q, scales, zeros).cpu()
+    ref = _t(g["b4_row_y"])
+    assert y.shape == (1, *ref.shape)
+    assert (y[0] - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_dense_rmsnorm_rope_swiglu_add_embedding_argmax(dev, golden):
     g = golden("blocks")
     # RMSNorm / RoPE against the reference's own outputs
