@@ -575,7 +575,13 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16",
+        # what the timed kernels compute with (not a precision claim): the persistent int4 step feeds fp16 MFMA operands (int4
+        # weights -> fp16, fp16 activation granules), the launch-per-operator paths bf16 operands, LLM.int8 int8 x int8 -> int32
+        # plus f16 outlier columns; f32 accumulation and a bf16 KV cache throughout (>= the reference's bf16-true run)
+        "dtype": ("fp16" if fused else "int8" if args.quantize == "llm.int8" else "bf16"),
+        "dtype_detail": ("int4 weights -> fp16 MFMA operands x fp16 activations, f32 accumulate, bf16 KV cache" if fused else
+                         "int8 x int8 -> int32 MFMA + f16 outlier columns, bf16 KV cache" if args.quantize == "llm.int8" else
+                         "bf16 MFMA operands, f32 accumulate, bf16 KV cache"),
         "data": "synthetic",
         "config": {
             "workload": f"LLaMA-{args.model} {args.quantize} bs=1 greedy decode "

@@ -153,6 +153,15 @@ class LLaMA(llama.LLaMA):
         super().reset_cache()
         self.adapter_kv_caches.clear()
 
+    def _adapter_fingerprint(self) -> tuple:
+        out = []
+        for blk in self.transformer.h:
+            attn = blk.attn
+            if hasattr(attn, "adapter_wte"):
+                for t in (attn.adapter_wte.weight, attn.gating_factor):
+                    out.append((t.data_ptr(), t._version))
+        return tuple(out)
+
     def forward(self, idx: torch.Tensor, max_seq_length: Optional[int] = None,
                 input_pos: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, T = idx.size()
@@ -168,8 +177,15 @@ class LLaMA(llama.LLaMA):
         if self.mask_cache is None:
             self.mask_cache = self.build_mask_cache(idx)
         if input_pos is not None and B == 1 and self.use_engine:
+            # the engine snapshots the prefix k / v (and the gates) of every adapter block when it is built; the per-token path
+            # skips the full fingerprint walk (check=False), so at least an in-place edit of the adapter's own parameters
+            # (adapter_wte.weight.copy_(...), gating_factor.fill_(...)) is caught here: ~60 (data_ptr, version) pairs
+            afp = self._adapter_fingerprint()
+            if self._engine is not None and getattr(self._engine, "_adapter_fp", afp) != afp:
+                self._drop_engine()
             eng = self.engine(check=False)  # (None for LLaMA-Adapter v2 linears: op by op below)
             if eng is not None:
+                eng._adapter_fp = afp
                 out = eng.forward(idx, max_seq_length, input_pos)
                 if out is not None:
                     return out

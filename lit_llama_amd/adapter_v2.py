@@ -32,7 +32,13 @@ def adapter_v2_new_forward(self, input: torch.Tensor) -> torch.Tensor:
     the elementwise epilogue of `lit_llama_amd.model._linear`."""
     from .model import _linear
 
-    return _linear(self, input)
+    if type(self) is nn.Linear or getattr(self, "_mi355_plain_weight", False):
+        return _linear(self, input)  # native linear + epilogue
+    # a plug-in linear (Linear8bitLt, an unmerged LoRA layer) BOUND to this function the way the reference binds it
+    # (adapter_v2.py:39, `adapter_v2_new_forward.__get__(layer, layer.__class__)`): `_linear` would call `self(input)`, i.e. this
+    # function again.  Call the class's own forward, then the epilogue.
+    y = type(self).forward(self, input)
+    return self.adapter_scale.detach().to(y.dtype) * (y + self.adapter_bias.detach().to(y.dtype))
 
 
 def adapter_v2_linear_with_bias_and_scale(layer: nn.Linear) -> nn.Linear:

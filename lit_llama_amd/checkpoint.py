@@ -211,9 +211,11 @@ class _Unpickler(pickle.Unpickler):
             return super().find_class(module, name)
         # a torch.Tensor SUBCLASS of a module the process has already imported (the reference's tests/test_utils.py:32-49 save
         # one): looked up, never imported — nothing the pickle names gets to run
+        # Handed out as an inert marker, NOT as the class: a pickle could otherwise REDUCE-call the class with arguments of its
+        # choosing; the marker is only accepted as the `new_type` argument of _rebuild_from_type_v2 (advisor r3)
         obj = getattr(sys.modules.get(module), name, None)
         if isinstance(obj, type) and issubclass(obj, torch.Tensor):
-            return obj
+            return _SubclassRef(obj)
         raise pickle.UnpicklingError(f"checkpoint pickle refers to {module}.{name}; only plain state dicts are read")
 
     def persistent_load(self, pid):
@@ -236,10 +238,21 @@ def _rebuild_parameter(data, requires_grad, backward_hooks):
     return torch.nn.Parameter(data, requires_grad=requires_grad)
 
 
+class _SubclassRef:
+    """Stands for a torch.Tensor subclass named by a checkpoint pickle; not callable, so the pickle cannot construct it."""
+
+    __slots__ = ("cls",)
+
+    def __init__(self, cls):
+        self.cls = cls
+
+
 def _rebuild_from_type(func, new_type, args, state):
+    if isinstance(func, _SubclassRef):
+        raise pickle.UnpicklingError("checkpoint pickle calls a Tensor subclass; only plain state dicts are read")
     ret = func(*args)
-    if isinstance(ret, LazyTensor) and isinstance(new_type, type) and issubclass(new_type, torch.Tensor):
-        ret._subclass = (new_type, state)  # restored at materialize()
+    if isinstance(ret, LazyTensor) and isinstance(new_type, _SubclassRef):
+        ret._subclass = (new_type.cls, state)  # restored at materialize()
     return ret
 
 

@@ -44,12 +44,14 @@ class _PackedWeight:
 def _kind(mod: nn.Module) -> str:
     from .quantization import ColBlockQuantizedLinear, Linear8bitLt
 
+    # FIRST: LLaMA-Adapter v2 attaches adapter_scale / adapter_bias to every nn.Linear — Linear8bitLt subclasses nn.Linear, so a
+    # quantised v2 model carries the pair too; the engine's streams have no such epilogue (advisor r3: the i8 check used to win)
+    if getattr(mod, "adapter_scale", None) is not None:
+        raise EngineUnavailable("LLaMA-Adapter v2 scale / bias on a linear: such models run op by op")
     if isinstance(mod, ColBlockQuantizedLinear):
         return "q4"
     if isinstance(mod, Linear8bitLt):
         return "i8"
-    if getattr(mod, "adapter_scale", None) is not None:
-        raise EngineUnavailable("LLaMA-Adapter v2 scale / bias on a linear: such models run op by op")
     if type(mod) is nn.Linear or getattr(mod, "_mi355_plain_weight", False):
         return "bf16"
     if hasattr(mod, "lora_A"):
@@ -161,8 +163,8 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
         ok = (_env_int("MI355_FUSED_GROUPED", 1) != 0 and group_cols >= 128 and (group_cols & (group_cols - 1)) == 0
               and C_ % group_cols == 0 and H % group_cols == 0 and os.environ.get("MI355_FUSED_IMPL", "") != "lds"
               and all(m_.tile_cols == group_cols and m_.grouped_fast() for m_ in mods))
-        if not ok:
-            return None
+        if not ok or any(m_.out_features % 16 for m_ in mods):
+            return None  # (group_table packs whole 16-row tiles: other row counts stay on the launch-per-operator engine)
     else:
         for mod in (first.attn.c_attn, first.attn.c_proj, first.mlp.c_fc1, first.mlp.c_fc2, first.mlp.c_proj, model.lm_head):
             if not mod.fast_eligible(torch.bfloat16) or mod.scales.dtype != torch.bfloat16 or mod.scales.shape[1] != 1:

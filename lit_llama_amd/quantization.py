@@ -101,35 +101,39 @@ class ColBlockQuantizedLinear(torch.nn.Module):
                 self._materialize()
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    # ---- format utilities (device agnostic tensor reshuffling; not on the hot path) -----------------
+    # ---- format utilities (checkpoint tooling: tensor reshuffling on whatever device the buffers live on; NOT compute entry
+    # points — `forward` and every kernel-backed op refuse CPU tensors, DESIGN.md section 1) ---------------------------------
+    def _grouped(self, t: torch.Tensor) -> torch.Tensor:
+        """[N, K] -> a [N, groups, tile_cols] view (one scale / zero per row and group)."""
+        return t.view(t.shape[0], self.scales.size(1), -1)
+
     def pack_weight(self, weight):
-        """Quantise `weight` with the current scales / zeros and pack it (lit_llama/quantization.py:376-390),
-        including the reference's truncating float -> uint8 conversion."""
-        weight = weight.to(device=self.quant_weight.device, copy=True)
-        for j in range(self.scales.size(1)):
-            sl = slice(j * self.tile_cols, (j + 1) * self.tile_cols)
-            weight[:, sl] /= self.scales[:, j : j + 1]
-            weight[:, sl] += self.zeros[:, j : j + 1]
-        weight = weight.clamp_(min=0, max=2**self.bits - 1).to(dtype=torch.uint8)
-        self.quant_weight.zero_()
-        for nr in range(self.entries_per_byte):
-            self.quant_weight += weight[:, nr :: self.entries_per_byte] << (nr * self.bits)
+        """Quantise `weight` with the current scales / zeros and pack it: levels = clamp(w / scale + zero) with the reference's
+        truncating float -> uint8 conversion, `entries_per_byte` consecutive columns per byte, low bits first
+        (lit_llama/quantization.py:376-390).  All groups at once, in place in the weight's own dtype as the reference's per-slice
+        `/=` and `+=` are."""
+        dev = self.quant_weight.device
+        w = weight.to(device=dev, copy=True).contiguous()
+        g = self._grouped(w)
+        g.div_(self.scales.unsqueeze(-1)).add_(self.zeros.unsqueeze(-1))
+        levels = w.clamp_(min=0, max=2**self.bits - 1).to(dtype=torch.uint8)
+        epb = self.entries_per_byte
+        shifts = torch.arange(epb, device=dev, dtype=torch.int32) * self.bits
+        packed = (levels.view(levels.shape[0], -1, epb).to(torch.int32) << shifts).sum(-1).to(torch.uint8)
+        self.quant_weight.copy_(packed)  # (keeps the buffer's column-major strides)
         self._stream = None
 
     def get_weight(self, dtype=torch.float):
-        """Dequantised [out, in] weight (lit_llama/quantization.py:392-411)."""
+        """Dequantised [out, in] weight, (level - zero) * scale (lit_llama/quantization.py:392-411)."""
         if self.quant_weight.device.type == "cuda":
             return ops.colblock_dequant(self.quant_weight, self.scales, self.zeros, self.bits, self.tile_cols,
                                         self.in_features, dtype)
-        # host-side format utility (checkpoint tooling); same arithmetic as the reference
-        weight = torch.empty((self.out_features, self.in_features), device=self.quant_weight.device, dtype=dtype)
-        mask = (1 << self.bits) - 1
-        for nr in range(self.entries_per_byte):
-            weight[:, nr :: self.entries_per_byte] = ((self.quant_weight >> (nr * self.bits)) & mask).float()
-        for j in range(self.scales.size(1)):
-            sl = slice(j * self.tile_cols, (j + 1) * self.tile_cols)
-            weight[:, sl] -= self.zeros[:, j : j + 1]
-            weight[:, sl] *= self.scales[:, j : j + 1]
+        # off the GPU: checkpoint inspection only; unpack all entries of a byte at once, then the reference's in-place - / *
+        epb = self.entries_per_byte
+        shifts = torch.arange(epb, dtype=torch.int32) * self.bits
+        levels = (self.quant_weight.to(torch.int32).unsqueeze(-1) >> shifts) & ((1 << self.bits) - 1)
+        weight = levels.reshape(self.out_features, self.in_features).to(dtype)
+        self._grouped(weight).sub_(self.zeros.unsqueeze(-1)).mul_(self.scales.unsqueeze(-1))
         return weight
 
     # ---- hot path -----------------------------------------------------------------------------------

@@ -305,6 +305,15 @@ def big_long_case():
                nocache=False)
 
 
+def big_p400_case():
+    """The same checkpoint with a 400-token prompt and 16 greedy tokens: decode runs at positions
+    400..415, i.e. past the fused step's row-split threshold (position 384) at FULL depth — where the reference's own
+    usage lives (generate.py:94-155 with real prompts, evaluate/full.py:120-129)."""
+    torch.set_num_threads(max(8, (torch.get_num_threads() or 8)))
+    model_case("cfg2_7b_int4_p400", dict(n_layer=32, n_head=32, n_embd=4096), "gptq.int4", prompt_len=400, new_tokens=16,
+               nocache=False)
+
+
 def big_bf16_case(name="cfg2_7b_int4"):
     """Calibrates the engine's parity bar: the REFERENCE ITSELF in bf16 on the CPU (what `--precision bf16-true` makes
     of it: parameters, scales / zeros and activations in bf16, generate.py:123-134) on the tokens of the f32 fixture,
@@ -381,13 +390,18 @@ def main():
         print("generating the lazy_load fixture from", REF)
         lazy_load_case()
         return
+    if "--big-p400" in sys.argv:
+        print("generating the 400-token-prompt full-depth 7B fixture from", REF)
+        big_p400_case()
+        return
     if "--big-long" in sys.argv:
         print("generating the long full-depth 7B fixture from", REF)
         big_long_case()
         return
     if "--big-bf16" in sys.argv:
         print("running the reference in bf16 on the full-depth fixture from", REF)
-        big_bf16_case("cfg2_7b_int4_long" if "--long" in sys.argv else "cfg2_7b_int4")
+        big_bf16_case("cfg2_7b_int4_p400" if "--p400" in sys.argv else
+                      "cfg2_7b_int4_long" if "--long" in sys.argv else "cfg2_7b_int4")
         return
     if "--adapter-v2" in sys.argv:
         print("generating the LLaMA-Adapter v2 fixture from", REF)

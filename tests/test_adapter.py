@@ -94,3 +94,25 @@ def test_oracle_reproduces_adapter_v2_and_module_layout(golden):
     import pytest
     with pytest.raises(EngineUnavailable, match="Adapter v2"):
         _kind(lin)
+
+
+def test_adapter_v2_new_forward_bound_to_a_plugin_linear_does_not_recurse():
+    """The reference binds the function as the layer's forward (adapter_v2.py:39); on a linear with a forward of its own
+    (Linear8bitLt, LoRA) going back through `mod(x)` would never return (advisor r3)."""
+    import torch
+    import torch.nn as nn
+
+    from lit_llama_amd import adapter_v2 as V2
+
+    class Doubling(nn.Linear):
+        def forward(self, x):
+            return 2.0 * nn.functional.linear(x, self.weight, self.bias)
+
+    layer = Doubling(4, 3, bias=False)
+    V2.adapter_v2_linear_with_bias_and_scale(layer)
+    layer.adapter_scale.data.fill_(0.5)
+    layer.adapter_bias.data.fill_(1.0)
+    x = torch.randn(2, 4)
+    want = 0.5 * (2.0 * nn.functional.linear(x, layer.weight) + 1.0)
+    layer.forward = V2.adapter_v2_new_forward.__get__(layer, layer.__class__)
+    assert torch.allclose(layer(x), want)

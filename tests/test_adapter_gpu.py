@@ -149,3 +149,59 @@ def test_adapter_v2_model_follows_the_reference(dev, golden, dtype, tol):
     margins = g["margin"]
     n = T + 1 + next((i for i, m in enumerate(margins.tolist()) if m <= 2 * tol * std), len(margins))
     assert torch.equal(out[:n].long(), toks[:n].cpu().long()), f"{out.tolist()} vs {toks.tolist()}"
+
+
+def test_adapter_v2_on_llm_int8_linears_stays_off_the_engine_and_keeps_its_epilogue(dev):
+    """generate/adapter_v2.py accepts --quantize llm.int8: Linear8bitLt subclasses nn.Linear, so every quantised linear carries
+    adapter_scale / adapter_bias too.  The engine's streams have no such epilogue: the model must decode op by op (advisor r3:
+    engine._kind used to answer "i8" before it looked at adapter_scale, and the pair was silently dropped)."""
+    from lit_llama_amd import adapter_v2 as V2
+    from lit_llama_amd.engine import EngineUnavailable, _kind
+
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="llm.int8"):
+        model = A.LLaMA(A.LLaMAConfig(**CFG))
+        V2.add_adapter_v2_parameters_to_linear_layers(model)
+    sd = {k: v for k, v in adapter_v2_state_dict().items()}
+    model.load_state_dict(sd)
+    model.eval()
+    lin = model.transformer.h[0].attn.c_attn
+    assert type(lin).__name__ == "Linear8bitLt" and lin.adapter_scale is not None
+    with pytest.raises(EngineUnavailable):
+        _kind(lin)
+    assert model.engine() is None and "Adapter v2" in model._engine_failed
+    toks = torch.arange(3, 3 + 6, device=dev, dtype=torch.int32)
+    S = 12
+    got = _teacher_forced(model, torch.cat([toks, toks]), 6, S, dev)
+    # the same model with the scale / bias pairs at their identity values must differ: the epilogue is applied
+    for mod in model.modules():
+        if getattr(mod, "adapter_scale", None) is not None:
+            mod.adapter_scale.data.fill_(1.0)
+            mod.adapter_bias.data.zero_()
+    plain = _teacher_forced(model, torch.cat([toks, toks]), 6, S, dev)
+    assert torch.isfinite(got).all() and (got - plain).abs().max().item() > 1e-3 * float(plain.std())
+
+
+def test_adapter_parameter_edit_in_place_rebuilds_the_engine_on_the_token_path(dev):
+    """The engine snapshots the prefix k / v at build time; `forward` (check=False on the per-token path) must still notice an
+    in-place edit of adapter_wte / gating_factor (advisor r3)."""
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16):
+        model = A.LLaMA(A.LLaMAConfig(**CFG))
+    model.load_state_dict(adapter_state_dict())
+    model.eval()
+    toks = torch.arange(3, 3 + 6, device=dev, dtype=torch.int32)
+    pos = torch.arange(0, 6, device=dev)
+    a = model(toks.view(1, -1), 16, pos)[0, -1].float().cpu()
+    assert model._engine is not None
+    eng0 = model._engine
+    for blk in model.transformer.h:
+        if hasattr(blk.attn, "gating_factor"):
+            with torch.no_grad():
+                blk.attn.gating_factor.mul_(-3.0)  # in place: same storage, new version
+    model.reset_cache()
+    b = model(toks.view(1, -1), 16, pos)[0, -1].float().cpu()
+    assert model._engine is not eng0, "stale engine kept after an in-place edit of the gates"
+    model.use_engine = False
+    model.reset_cache()
+    c = model(toks.view(1, -1), 16, pos)[0, -1].float().cpu()
+    std = float(c.std())
+    assert (b - c).abs().max().item() <= 0.05 * std and (a - b).abs().max().item() > 0.01 * std
