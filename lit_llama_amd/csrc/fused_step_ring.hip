@@ -68,24 +68,18 @@ constexpr unsigned kSpinLimit = 400000u;
 #ifndef MI355_FUSED_SPLIT_POS
 #define MI355_FUSED_SPLIT_POS 384
 #endif
-#ifndef MI355_FUSED_PRED_RESWEEP
-#define MI355_FUSED_PRED_RESWEEP 0  // retries of a sweep re-request only the granules that were stale
+// MEASUREMENT ONLY (results are wrong): 1 = the streamers skip the int4 -> fp16 conversion, 2 = they issue every second MFMA only.
+// Together they say which pipe bounds a compute phase (profiles/r04_ab4_compute_proxies.txt).
+#ifndef MI355_FUSED_PROXY
+#define MI355_FUSED_PROXY 0
 #endif
-// s_sleep units (64 cycles each) before the FIRST sweep of the head-local q edge / the attention-out edge / the hidden edge
-#ifndef MI355_FUSED_DELAY_Q
-#define MI355_FUSED_DELAY_Q 0
+#if MI355_FUSED_PROXY == 2
+#define FS_PROXY_MFMA(d_) if (((d_) & 1) == 0)
+#else
+#define FS_PROXY_MFMA(d_)
 #endif
-#ifndef MI355_FUSED_DELAY_A
-#define MI355_FUSED_DELAY_A 0
-#endif
-#ifndef MI355_FUSED_DELAY_H
-#define MI355_FUSED_DELAY_H 0
-#endif
-#ifndef MI355_FUSED_FCP
-#define MI355_FUSED_FCP 1  // c_fc1 / c_fc2 prefetch: shared ring with attn.c_proj + an LDS extension filled by LDS-DMA (per-row kernel)
-#endif
-#ifndef MI355_FUSED_BALANCED
-#define MI355_FUSED_BALANCED 1  // c_fc1 / c_fc2: the leftover pair tiles (n_hidden / 16 mod 256) are split by ROWS over all workgroups
+#ifndef MI355_FUSED_PRE
+#define MI355_FUSED_PRE 0  // pieces per wave and phase converted ahead of the hand-off into LDS (0: off — measured neutral; 4 = all of the 128 KiB of LDS left)
 #endif
 constexpr int kSplitPos = MI355_FUSED_SPLIT_POS;  // from this position on the attention splits rows, not dimensions
 constexpr int kPartStride = 136;  // granules per workgroup partial of the row-split attention: 128 values, max, sum, pad
@@ -99,15 +93,14 @@ constexpr int kOffXs = 512;                       // activation vector, fp16, <=
 // attention parks its per-wave partial outputs here ([8 waves][128] f32: the same 4 KiB).
 constexpr int kPartBytes = 2 * kSW * 4 * 64;
 constexpr int kOffPart = kOffXs + 96 * 256;
-constexpr int kOffStage = kOffPart + kPartBytes;  // (1 KiB, unused since the register epilogues)
-constexpr int kOffQ = kOffStage + 1024;           // q[128] knew[128] vnew[128] f32
+constexpr int kOffQ = kOffPart + kPartBytes;      // q[128] knew[128] vnew[128] f32
 constexpr int kOffOpart = kOffQ + 3 * 512;        // [8 waves][16] f32
-// FCP: [8 waves][12 pieces][1 KiB] — the second half of a workgroup's c_fc1 / c_fc2 weights, landed by LDS-DMA during the hand-off
-// into the phase (the first half waits in the register ring)
-constexpr int kPreSlots = 12;
+// PRE-CONVERTED OPERANDS (round 4): [8 waves][kPre pieces][4 MFMA A operands][64 lanes][16 B] — the first kPre pieces of a phase's
+// ring turn, converted int4 -> fp16 by the streamer waves WHILE the phase's activations are still being gathered
+constexpr int kPre = MI355_FUSED_PRE;
 constexpr int kOffPre = 32 * 1024;
 [[maybe_unused]] constexpr int kMaxS = 32768;     // cache rows (the attention keeps no per-row state in LDS)
-constexpr int kLdsBytes = kOffPre + kSW * kPreSlots * 1024;
+constexpr int kLdsBytes = kOffPre + kSW * kPre * 4096;
 constexpr int kLdsBytesG = kLdsBytes;             // (the GRP instantiation uses the same map)
 static_assert(kOffOpart + 512 <= kOffPre && kLdsBytes <= 160 * 1024 && kPartBytes >= kSW * 128 * 4, "LDS map");
 
@@ -137,49 +130,22 @@ __device__ __forceinline__ void sweep_issue(__amdgpu_buffer_rsrc_t rs, unsigned 
     }
 }
 // `preissued`: the caller has requested v already (sweep_issue) — several chunks of one edge in flight at once
-template <int NL, bool PRED = false>
+template <int NL>
 __device__ __forceinline__ bool sweep(const FusedParams& p, __amdgpu_buffer_rsrc_t rs, unsigned base, int first, int end,
                                       unsigned epoch, u32x4 (&v)[NL], unsigned code, int lane, unsigned* iters = nullptr,
                                       bool preissued = false) {
     // (lane: the caller's per-layer opaque copy of the lane id — from threadIdx the offsets of every sweep site are
     // loop invariants, which hipcc computes once in the kernel prologue and then spills)
-    [[maybe_unused]] unsigned pend = 0xFFFFFFFFu;  // PRED_RESWEEP: bit k = load k of this lane has not shown both tags yet
     for (unsigned spins = 0;; ++spins) {
 #ifdef MI355_FUSED_COUNT_SWEEPS
         if (iters != nullptr) *iters = spins + 1;
 #endif
         bool ok = true;
-        if (!(preissued && spins == 0)) {
-#if MI355_FUSED_PRED_RESWEEP
-            if (!PRED || spins == 0) {
-                sweep_issue<NL>(rs, base, first, end, v, lane);
-            } else {
-                // a retry re-requests only the loads whose tags were stale: the lanes that passed send an out-of-range
-                // offset (no memory request) and keep their registers — the retry's traffic through the CU's miss queue
-                // is the stale part of the edge, not the whole chunk again
-                u32x4 t[NL];
-#pragma unroll
-                for (int k = 0; k < NL; ++k) {
-                    const int i = first + k * 64 + lane;
-                    const unsigned off = (i < end && ((pend >> k) & 1u)) ? base + (unsigned)i * 16u : 0xFFFFFFF0u;
-                    t[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
-                }
-#pragma unroll
-                for (int k = 0; k < NL; ++k)
-                    if ((pend >> k) & 1u) v[k] = t[k];
-            }
-#else
-            sweep_issue<NL>(rs, base, first, end, v, lane);
-#endif
-        }
+        if (!(preissued && spins == 0)) sweep_issue<NL>(rs, base, first, end, v, lane);
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             const int i = first + k * 64 + lane;
-            const bool okk = i >= end || (v[k][1] == epoch && v[k][3] == epoch);
-            ok &= okk;
-#if MI355_FUSED_PRED_RESWEEP
-            if (okk) pend &= ~(1u << k);
-#endif
+            ok &= i >= end || (v[k][1] == epoch && v[k][3] == epoch);
         }
         if (__all(ok)) return true;
         if (spins > kSpinLimit || aborted(p)) {
@@ -198,9 +164,6 @@ struct PhaseW {  // one phase as a streamer wave sees it (all wave-uniform)
     // descriptor, groups per row
     unsigned tab, tab2;
     int ng;
-    // balanced c_fc1 / c_fc2 (per-row kernel): tile index `split_ti` of this workgroup is its share of ROWS of the leftover
-    // pair tiles, starting in stream tile `split_tile` (the lanes select their rows, FS lane_off3); -1: none
-    int split_ti, split_tile;
 };
 
 // Scalar byte offset of the piece consumed at global step `gstep` of the phase, row group r; ok = false for an idle
@@ -215,7 +178,7 @@ __device__ __forceinline__ unsigned piece_off(const PhaseW& ph, int gstep, int r
         tile = ph.tile0 + r * ph.tstride;  // the q, k and v tiles of this workgroup share the activation operand
         ok = ti == 0 && st < ph.nu;
     } else {
-        tile = (PAIR && ti == ph.split_ti) ? ph.split_tile : ph.tile0 + ti * ph.tstride;
+        tile = ph.tile0 + ti * ph.tstride;
         ok = ti < ph.ntiles && st < ph.nu;
     }
     return ph.base + (unsigned)((tile * ph.units + ph.u0 + st) * (PAIR ? 2 : 1) + (PAIR ? r : 0)) * 1024u;
@@ -277,17 +240,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
     const int token = p.tokens[0];
     const unsigned step_id = p.state[1];
     const unsigned ebase = step_id * 1024u + 1u;
-    // c_fc1 / c_fc2 pair tiles: n_hidden / 16 tiles over 256 workgroups = fc_full each + fc_left leftover tiles (7B: 2 + 176).
-    // Dealt out whole, 176 workgroups carry a third tile and the hidden edge waits ~3 us for them; BALANCED: the leftover
-    // tiles are split by ROW PAIRS over all workgroups (7B: 10 or 12 rows each) — workgroup b takes leftover rows
-    // bal_r0 .. bal_r0 + bal_rows - 1, which sit in one or two stream tiles; a lane of the 16-row MFMA tile loads its row from
-    // the tile that holds it (or nothing), so the stream layout and every other kernel stay as they are.
-    const int fc_full = p.fc_tiles / kG, fc_left = p.fc_tiles - fc_full * kG;
-    const bool balanced = MI355_FUSED_BALANCED && !GRP && fc_left > 0;
-    const int bal_p0 = (8 * fc_left * bid) >> 8, bal_p1 = (8 * fc_left * (bid + 1)) >> 8;
-    const int bal_r0 = 2 * bal_p0, bal_rows = 2 * (bal_p1 - bal_p0);       // even start, even count: whole row pairs
-    const int bal_tile = fc_full * kG + (bal_r0 >> 4);                       // stream tile of the first leftover row
-    const int n_fc = balanced ? fc_full + 1 : (p.fc_tiles - bid + kG - 1) / kG;  // this workgroup's pair tiles (7B: 3, or 2 / 3)
+    const int n_fc = (p.fc_tiles - bid + kG - 1) / kG;       // this workgroup's pair tiles (2 or 3 for 7B)
     const int n_head_t = (p.head_tiles - bid + kG - 1) / kG;  // lm_head tiles (7 or 8)
     const bool split = pos >= kSplitPos;  // long context: the head group splits the cache rows (attention phase)
 
@@ -311,23 +264,16 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         asm volatile("" : "+s"(nmask16));
         u32x4 ring[kRing];
         int buf = 0;
-        unsigned lane_off3 = lane_off;  // balanced c_fc1 / c_fc2: this lane's offset inside the row-split tile (set per layer)
 
         PhaseW ph_attn, ph_proj, ph_fc, ph_mp, ph_head;
         ph_attn = {p.off_attn, head * 8 + hj, kC / 16, 1, kUnitsC, wave * 4, 4};
         ph_proj = {p.off_proj, bid, kG, 1, kUnitsC, wave * 4, 4};
         ph_fc = {p.off_fc, bid, kG, n_fc, kUnitsC, wave * 4, 4};
-        ph_attn.split_ti = ph_proj.split_ti = ph_fc.split_ti = -1;
-        if (balanced) {
-            ph_fc.split_ti = fc_full;
-            ph_fc.split_tile = bal_tile;
-        }
         {
             const int uq = p.units_h / kSW, ur = p.units_h % kSW;
             ph_mp = {p.off_mproj, bid, kG, 1, p.units_h, wave * uq + (wave < ur ? wave : ur), uq + (wave < ur ? 1 : 0)};
         }
         ph_head = {0u, bid, kG, n_head_t, kUnitsC, wave * 4, 4};
-        ph_mp.split_ti = ph_head.split_ti = -1;
         if constexpr (GRP) {
             const unsigned sz_attn = (unsigned)(3 * kC / 16) * (unsigned)p.ngc * 64u, sz_proj = (unsigned)(kC / 16) * (unsigned)p.ngc * 64u;
             const unsigned sz_fc = (unsigned)(p.H / 16) * (unsigned)p.ngc * 64u;
@@ -352,14 +298,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
 
         // ---- first ring turn of a phase (12 pieces), requested right after the previous phase's publish
-#define FS_BURST(RS_, R_, SPT_, PAIR_, QKV_, PH_)                                                             \
+#define FS_BURST(RS_, R_, SPT_, PAIR_, QKV_, PH_, PRE_)                                                       \
     do {                                                                                                     \
         _Pragma("unroll") for (int pc__ = 0; pc__ < kRing; ++pc__) {                                         \
             bool ok__;                                                                                       \
             const unsigned so__ = piece_off<SPT_, PAIR_, QKV_>(PH_, pc__ / (R_), pc__ % (R_), ok__);          \
-            /* (the row-split tile of a balanced c_fc1 / c_fc2: per-lane tile choice, lane_off3) */          \
-            const unsigned lo__ = ((PAIR_) && (pc__ / (R_)) / (SPT_) == (PH_).split_ti) ? lane_off3 : lane_off; \
-            ring[pc__] = ring_load(RS_, rs_null, ok__, lo__, so__);                                          \
+            ring[pc__] = ring_load(RS_, rs_null, ok__, lane_off, so__);                                      \
             __builtin_amdgcn_sched_barrier(0); /* issue order = consumption order (VMEM returns in order) */ \
             /* sliding window: at most kWin pieces per wave (8 kWin KiB per CU) are in flight; a deeper     */ \
             /* queue only stands in front of the gatherers' sweep in the CU's in-order memory pipeline (the */ \
@@ -368,12 +312,30 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             if (pc__ + 1 >= kWin && pc__ + 1 < kRing) {                                                      \
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWin - 1) : "memory");                               \
                 __builtin_amdgcn_sched_barrier(0);                                                           \
+                /* piece pc - (kWin - 1) has landed: convert it NOW, while the phase's activations are still */ \
+                /* being gathered (the wave would only wait for the next piece), and park the four MFMA A    */ \
+                /* operands in LDS; FS_RUN then feeds these pieces to the MFMA with ds_read_b128 instead of   */ \
+                /* 20 VALU instructions on the chain behind B1                                                */ \
+                if ((PRE_) && pc__ - (kWin - 1) < kPre) {                                                    \
+                    char* pd__ = smem + kOffPre + wave * (kPre * 4096) + (pc__ - (kWin - 1)) * 4096 + lane_off; \
+                    _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                    \
+                        const uint32_t v__ = ring[pc__ - (kWin - 1)][d__];                                   \
+                        const uint32_t v8__ = v__ >> 8;                                                      \
+                        u32x4 a__;                                                                           \
+                        a__[0] = nib2f16(v__, nmask, magic);                                                 \
+                        a__[1] = nib2f16(v__, nmask16, magic);                                               \
+                        a__[2] = nib2f16(v8__, nmask, magic);                                                \
+                        a__[3] = nib2f16(v8__, nmask16, magic);                                              \
+                        *(u32x4*)(pd__ + d__ * 1024) = a__;                                                  \
+                    }                                                                                        \
+                    __builtin_amdgcn_sched_barrier(0);                                                       \
+                }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
     } while (0)
 
         // ---- one phase: BODIES x TURNS ring turns of 12 / R steps; a step = R pieces against one activation unit
-#define FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_)                                       \
+#define FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_, PRE_)                                 \
     do {                                                                                                             \
         constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
         const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
@@ -453,13 +415,24 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if (st__ < (PH_).nu && ((QKV_) || ti__ < (PH_).ntiles)) {                                         \
                         _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                         \
                             _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                   \
-                                const uint32_t v__ = ring[s__ * R__ + r__][d__];                                      \
-                                const uint32_t v8__ = v__ >> 8;                                                       \
                                 u32x4 a__;                                                                            \
-                                a__[0] = nib2f16(v__, nmask, magic);                                                  \
-                                a__[1] = nib2f16(v__, nmask16, magic);                                                \
-                                a__[2] = nib2f16(v8__, nmask, magic);                                                 \
-                                a__[3] = nib2f16(v8__, nmask16, magic);                                               \
+                                if ((PRE_) && t__ == 0 && s__ * R__ + r__ < kPre) {                                   \
+                                    /* converted during the hand-off (FS_BURST) */                                    \
+                                    a__ = *(const u32x4*)(smem + kOffPre + wave * (kPre * 4096) +                     \
+                                                          ((s__ * R__ + r__) * 4 + d__) * 1024 + lane_off);           \
+                                } else if (MI355_FUSED_PROXY == 1) {                                                  \
+                                    /* PROXY 1 (wrong numerics): no conversion, raw dwords as operands */             \
+                                    const uint32_t v__ = ring[s__ * R__ + r__][d__];                                  \
+                                    a__[0] = a__[1] = a__[2] = a__[3] = v__;                                          \
+                                } else {                                                                              \
+                                    const uint32_t v__ = ring[s__ * R__ + r__][d__];                                  \
+                                    const uint32_t v8__ = v__ >> 8;                                                   \
+                                    a__[0] = nib2f16(v__, nmask, magic);                                              \
+                                    a__[1] = nib2f16(v__, nmask16, magic);                                            \
+                                    a__[2] = nib2f16(v8__, nmask, magic);                                             \
+                                    a__[3] = nib2f16(v8__, nmask16, magic);                                           \
+                                }                                                                                     \
+                                FS_PROXY_MFMA(d__)                                                                    \
                                 acc__[r__][d__ & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                         \
                                     __builtin_bit_cast(f16x8, a__), b__[d__], acc__[r__][d__ & 1], 0, 0, 0);          \
                             }                                                                                         \
@@ -470,8 +443,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         const int nstep__ = gstep__ + STEPS__;                                                        \
                         bool ok__;                                                                                    \
                         const unsigned so__ = piece_off<SPT__, PAIR_, QKV_>(PH_, nstep__, r__, ok__);                 \
-                        const unsigned lo__ = ((PAIR_) && nstep__ / SPT__ == (PH_).split_ti) ? lane_off3 : lane_off;  \
-                        ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lo__, so__);       \
+                        ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
                     }                                                                                                 \
                     if ((t__ * STEPS__ + s__ + 1) % SPT__ == 0) {                                                     \
                         /* tile done: publish this wave's partial 16x16 tiles */                                      \
@@ -513,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
     } while (0)
 
-        FS_BURST(rs_l, 3, 4, false, true, ph_attn);
+        FS_BURST(rs_l, 3, 4, false, true, ph_attn, true);
         const bf16_t* kv_l = (const bf16_t*)p.kv;
         bool dbg_on = false;
 #define FS_SSTAMP(i)                                                                      \
@@ -523,16 +495,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         for (int l = 0; l < p.n_layer; ++l) {
             dbg_on = p.dbg != nullptr && l == p.dbg_layer;
             asm volatile("" : "+v"(lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
-            if (balanced) {
-                // MFMA row slot s = lane & 15 carries leftover row bal_r0 + ((s - bal_r0) & 15) if that is one of this
-                // workgroup's bal_rows rows: the row keeps its slot of the stream tile that holds it (bal_tile or the next
-                // one, 64 KiB further on: kUnitsC units x 2 x 1 KiB); the other lanes request nothing (offset out of range)
-                const unsigned rel = ((lane_off >> 4) - (unsigned)bal_r0) & 15u;
-                const bool second = ((unsigned)bal_r0 & 15u) + rel >= 16u;
-                lane_off3 = rel < (unsigned)bal_rows ? lane_off + (second ? (unsigned)kUnitsC * 2048u : 0u) : 0x80000000u;
-            }
             // ---------------- c_attn (q, k, v tiles of this workgroup's 16 dimensions of its head)
-            FS_RUN(rs_l, 3, 4, false, true, 1, ph_attn, 1, 20, rs_t);
+            FS_RUN(rs_l, 3, 4, false, true, 1, ph_attn, 1, 20, rs_t, true);
             // ---------------- attention: scores over the whole context, then this workgroup's 16 output dims
             {
                 const bf16_t* kc = kv_l + (size_t)head * p.S * kHs;
@@ -753,153 +717,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 __syncthreads();  // Ba4: the attention output is published
             }
             // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows)
-            if constexpr (!GRP && MI355_FUSED_FCP) {
-                // ---- c_fc1 / c_fc2 PREFETCH (round 4).  The pair is the one phase that streams in-phase (24 pieces per wave against
-                // a 12-piece ring): its second ring turn was only requested as the first was consumed, so the phase ran at the
-                // chip's fair share of HBM per CU (~25 GB/s: 3.9 us for the turn) while the memory system had idled through the
-                // attention and attn.c_proj before it.  Now: (1) attn.c_proj needs 4 ring slots, so the other 8 take the first 8
-                // pieces of the pair at the SAME request (behind the attention-out publish); (2) behind the c_proj publish the ring
-                // slots c_proj has freed take pieces 8..11 and pieces 12..23 go to an LDS extension by LDS-DMA
-                // (`buffer_load_dwordx4 ... lds`: no registers, counted in vmcnt like any load); (3) the phase itself requests
-                // nothing: 12 pieces from registers, one `vmcnt(0)`, 12 pieces from LDS.
-                auto pf_slot = [&](int q) { return q < 8 ? q + 4 : q - 8; };  // ring slot of pair piece q < 12
-                // this wave's LDS accesses have completed, then the workgroup barrier — without the fence of __syncthreads()
-                auto wg_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-                // one 1-KiB piece against the step's four B operands (k-quarters of the activation unit)
-                auto piece_mfma = [&](const u32x4& v, const f16x8 (&b)[4], f32x4 (&acc)[2]) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const uint32_t w = v[d], w8 = w >> 8;
-                        u32x4 a;
-                        a[0] = nib2f16(w, nmask, magic);
-                        a[1] = nib2f16(w, nmask16, magic);
-                        a[2] = nib2f16(w8, nmask, magic);
-                        a[3] = nib2f16(w8, nmask16, magic);
-                        acc[d & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), b[d], acc[d & 1], 0, 0, 0);
-                    }
-                };
-                auto load_b = [&](int unit, f16x8 (&b)[4]) __attribute__((always_inline)) {
-                    const char* xb = xs + unit * 256 + g * 64;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) b[d] = *(const f16x8*)(xb + 16 * d);
-                };
-                auto store_part = [&](int r, const f32x4& y) __attribute__((always_inline)) {
-                    if ((lane_off & 0xF0u) == 0u)
-                        ((f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * 64) + (lane_off >> 8))[r * 4] = y;
-                };
-#define FS_WINDOW(issued_, total_)                                              \
-    do {                                                                        \
-        if ((issued_) >= kWin && (issued_) < (total_)) {                        \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWin - 1) : "memory");     \
-            __builtin_amdgcn_sched_barrier(0);                                  \
-        }                                                                       \
-    } while (0)
-                // (1) behind the attention-out publish: c_proj's 4 pieces, then pieces 0..7 of the pair
-#pragma unroll
-                for (int pc = 0; pc < kRing; ++pc) {
-                    bool ok;
-                    unsigned so;
-                    if (pc < 4) so = piece_off<12, false, false>(ph_proj, pc, 0, ok);
-                    else so = piece_off<4, true, false>(ph_fc, (pc - 4) >> 1, (pc - 4) & 1, ok);
-                    ring[pc] = ring_load(rs_l, rs_null, ok, lane_off, so);
-                    __builtin_amdgcn_sched_barrier(0);
-                    FS_WINDOW(pc + 1, kRing);
-                }
-                // ---------------- attn.c_proj: ring slots 0..3
-                {
-                    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-                    __syncthreads();  // B1
-                    FS_SSTAMP(26);
-                    f16x8 bn[4];
-                    load_b(ph_proj.u0, bn);
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        f16x8 b[4];
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) b[d] = bn[d];
-                        if (st < 3) load_b(ph_proj.u0 + st + 1, bn);
-                        piece_mfma(ring[st], b, acc);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    FS_SSTAMP(27);
-                    store_part(0, acc[0] + acc[1]);
-                    __syncthreads();  // Bt
-                    buf ^= 1;
-                    __syncthreads();  // B3
-                }
-                // (2) behind the c_proj publish: pieces 8..11 into the freed ring slots, 12..23 into LDS
-                {
-                    const unsigned pre_w = (unsigned)kOffPre + (unsigned)wave * (kPreSlots * 1024u);
-#pragma unroll
-                    for (int q = 8; q < 24; ++q) {
-                        const int gs = q >> 1;
-                        bool ok;
-                        const unsigned so = piece_off<4, true, false>(ph_fc, gs, q & 1, ok);
-                        const unsigned lo = (gs >> 2) == ph_fc.split_ti ? lane_off3 : lane_off;
-                        if (q < 12) {
-                            ring[q - 8] = ring_load(rs_l, rs_null, ok, lo, so);
-                        } else {
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                                ok ? rs_l : rs_null, (__attribute__((address_space(3))) void*)(smem + pre_w + (unsigned)(q - 12) * 1024u), 16,
-                                lo, ok ? so : 0u, 0, 2);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        FS_WINDOW(q - 7, 16);
-                    }
-                }
-#undef FS_WINDOW
-                // ---------------- c_fc1 / c_fc2: 12 steps of a pair of pieces, nothing requested
-                {
-                    f32x4 acc[2][2];
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) acc[r][0] = acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    // (a bare s_barrier: `__syncthreads()` carries a workgroup-scope fence, and hipcc — which counts the LDS-DMA pieces
-                    // as LDS stores in flight — then waits with vmcnt(0) in front of it: B1 would wait for the whole extension)
-                    wg_barrier();  // B1
-                    FS_SSTAMP(28);
-                    const char* pre = smem + kOffPre + wave * (kPreSlots * 1024) + lane_off;
-                    f16x8 bn[4];
-                    load_b(ph_fc.u0, bn);
-#pragma unroll
-                    for (int gs = 0; gs < 12; ++gs) {
-                        const int ti = gs >> 2, st = gs & 3;
-                        f16x8 b[4];
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) b[d] = bn[d];
-                        load_b(ph_fc.u0 + ((st + 1) & 3), bn);
-                        if (gs == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA pieces have landed
-                        if (ti < ph_fc.ntiles) {
-#pragma unroll
-                            for (int r = 0; r < 2; ++r) {
-                                const int q = gs * 2 + r;
-                                u32x4 v;
-                                if (q < 12) v = ring[pf_slot(q)];
-                                else v = *(const u32x4*)(pre + (q - 12) * 1024);
-                                piece_mfma(v, b, acc[r]);
-                            }
-                        }
-                        if (st == 3) {
-                            if (gs == 11) FS_SSTAMP(29);
-#pragma unroll
-                            for (int r = 0; r < 2; ++r) {
-                                store_part(r, acc[r][0] + acc[r][1]);
-                                acc[r][0] = acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            }
-                            wg_barrier();  // Bt
-                            buf ^= 1;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    __syncthreads();  // B3
-                }
-            } else {
-                FS_BURST(rs_l, 1, 12, false, false, ph_proj);
-                FS_RUN(rs_l, 1, 12, false, false, 1, ph_proj, 1, 26, rs_t);
-                FS_BURST(rs_l, 2, 4, true, false, ph_fc);
-                FS_RUN(rs_l, 2, 4, true, false, 2, ph_fc, 1, 28, rs_t);
-            }
-            FS_BURST(rs_l, 1, 12, false, false, ph_mp);
-            FS_RUN(rs_l, 1, 12, false, false, 1, ph_mp, 1, 30, rs_t);
+            FS_BURST(rs_l, 1, 12, false, false, ph_proj, true);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_proj, 1, 26, rs_t, true);
+            FS_BURST(rs_l, 2, 4, true, false, ph_fc, true);
+            FS_RUN(rs_l, 2, 4, true, false, 2, ph_fc, 1, 28, rs_t, true);
+            FS_BURST(rs_l, 1, 12, false, false, ph_mp, true);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_mp, 1, 30, rs_t, true);
             // next layer (or the head)
             kv_l += (size_t)2 * kHeads * p.S * kHs;
             if (l + 1 < p.n_layer) {
@@ -908,13 +731,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if constexpr (GRP)
                     rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gt + (size_t)(l + 1) * p.gt_layer_stride), 0,
                                                              (int)p.gt_layer_bytes, 0x00020000);
-                FS_BURST(rs_l, 3, 4, false, true, ph_attn);
+                FS_BURST(rs_l, 3, 4, false, true, ph_attn, true);
             } else {
-                FS_BURST(rs_h, 1, 4, false, false, ph_head);
+                FS_BURST(rs_h, 1, 4, false, false, ph_head, false);
             }
         }
         dbg_on = false;
-        FS_RUN(rs_h, 1, 4, false, false, 1, ph_head, p.head_turns, 32, rs_th);
+        FS_RUN(rs_h, 1, 4, false, false, 1, ph_head, p.head_turns, 32, rs_th, false);
         if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
 #undef FS_RUN
 #undef FS_BURST
@@ -1157,7 +980,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 const unsigned ep = ebase + edge;
                 if (gw == 0) {
                     u32x4 v[2];
-                    if (MI355_FUSED_DELAY_Q > 0) __builtin_amdgcn_s_sleep(MI355_FUSED_DELAY_Q);
                     sweep<2>(p, rs_gq, (unsigned)((qpar * kHeads + head) * 256) * 8u, 0, 128, ep, v, 0x300u + edge, lane_v, &n_sweeps);
                     FS_GCOUNT(41);
 #pragma unroll
@@ -1271,7 +1093,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 }
                 const unsigned ep = ebase + edge;
                 u32x4 v[8];
-                if (MI355_FUSED_DELAY_A > 0) __builtin_amdgcn_s_sleep(MI355_FUSED_DELAY_A);
                 sweep<8>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, ep, v, 0x400u + edge, lane_v, &n_sweeps);
                 FS_GCOUNT(42);
                 float2 sxp = {0.f, 0.f};
@@ -1298,19 +1119,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }
             // ================= c_fc1 / c_fc2 + SwiGLU
             {
-                // hidden tile of this lane's row pair in the workgroup's t-th pair tile (balanced: the row-split tile's rows
-                // keep their slot in the stream tile that holds them; a pair outside the workgroup's rows is not published)
-                auto fc_tile = [&](int t) {
-                    if (balanced && t == fc_full) return bal_tile + (((bal_r0 & 15) + ((2 * pg - bal_r0) & 15)) >> 4);
-                    return bid + t * kG;
-                };
-                auto fc_mine = [&](int t) { return !(balanced && t == fc_full) || ((2 * pg - bal_r0) & 15) < bal_rows; };
                 const bf16_t* s_fc = sz_l + 8 * kC;
                 float2 fs1[kMaxFcTiles], fz1[kMaxFcTiles], fs2[kMaxFcTiles], fz2[kMaxFcTiles];
                 if (gw == 0) {
 #pragma unroll
                     for (int t = 0; t < kMaxFcTiles; ++t) {
-                        const int n = fc_tile(t < n_fc ? t : 0) * 16 + 2 * pg;
+                        const int n = (bid + (t < n_fc ? t : 0) * kG) * 16 + 2 * pg;
                         fs1[t] = ldsz(s_fc + n);
                         fz1[t] = ldsz(s_fc + p.H + n);
                         fs2[t] = ldsz(s_fc + 2 * p.H + n);
@@ -1332,8 +1146,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if (gw == 0 && t < n_fc) {
                         const float2 a = deq(tile_pair(0), fs1[t], fz1[t], sx);
                         const float2 b = deq(tile_pair(1), fs2[t], fz2[t], sx);
-                        if (w8 == 0 && fc_mine(t))
-                            gr_store(dst + fc_tile(t) * 8 + pg, ep,
+                        if (w8 == 0)
+                            gr_store(dst + (bid + t * kG) * 8 + pg, ep,
                                      hpair(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv)));
                     }
                     buf ^= 1;
@@ -1410,10 +1224,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         }
                     };
                     const int c1 = first + 512, c2 = first + 768, c3 = first + 1280;
-                    if (MI355_FUSED_DELAY_H > 0) __builtin_amdgcn_s_sleep(MI355_FUSED_DELAY_H);
                     sweep_issue<8>(rs_gh, hbase, first, end, va, lh);
                     sweep_issue<4>(rs_gh, hbase, c1, end, vb, lh);
-                    sweep<8, true>(p, rs_gh, hbase, first, end, ep, va, 0x500u + edge, lh, &n_sweeps, true);
+                    sweep<8>(p, rs_gh, hbase, first, end, ep, va, 0x500u + edge, lh, &n_sweeps, true);
                     FS_GCOUNT(44);
                     stage_a(first);
                     sweep_issue<8>(rs_gh, hbase, c2, end, va, lh);

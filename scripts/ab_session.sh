@@ -27,7 +27,7 @@ for r in $(seq 1 $ROUNDS); do
     [ -e "$f" ] || continue
     t=$(basename $f .so); t=${t#libmi355llama_}
     echo "== $t (round $r)" | tee -a $OUT/ab.log
-    tl=""; [ "$t" = base ] && tl=$TL
+    tl=""; [ "$t" = pre0 ] && tl=$TL
     MI355_LLAMA_LIB=$PWD/$f timeout 300 python scripts/ab_fused.py --tag $t $tl $( [ $r -gt 1 ] && echo --no-parity ) 2>&1 | grep -E "^AB|timeline|^  [GS] |Error|error|abort" | tee -a $OUT/ab.log
   done
 done

@@ -6,7 +6,9 @@ max |dlogit| = 0).  Here the same checkpoint goes through the engine: prefill on
 the fused persistent step.
 
 A second fixture of the same checkpoint, cfg2_7b_int4_long.npz (--big-long), has a 128-token prompt (the wide path of the
-engine at full depth: GEMM + flash attention) and 16 decode steps starting at position 128.
+engine at full depth: GEMM + flash attention) and 16 decode steps starting at position 128.  A third, cfg2_7b_int4_p400.npz
+(--big-p400, round 4), has a 400-token prompt: its 16 decode steps run at positions 400..415, past the fused step's row-split
+threshold (position 384) — the regime of the reference's own usage (generate.py:94-155 with real prompts) at FULL depth.
 
 The bar is CALIBRATED on the reference itself: tests/golden/cfg2_7b_int4*_bf16ref.npz (oracle/gen_golden.py --big-bf16)
 hold the reference's OWN bf16 run (parameters, scales and activations in bf16, what `--precision bf16-true` makes of
@@ -47,7 +49,7 @@ def test_full_depth_7b_int4_against_the_reference_golden_run(dev, golden):
     model.eval()
     eng = model.engine()
     assert eng is not None, model._engine_failed
-    for name, regression_bar in (("cfg2_7b_int4", 0.03), ("cfg2_7b_int4_long", None)):
+    for name, regression_bar in (("cfg2_7b_int4", 0.03), ("cfg2_7b_int4_long", None), ("cfg2_7b_int4_p400", None)):
         g, ref_bf16 = golden(name), golden(name + "_bf16ref")
         assert int(g["seed"]) == int(g0["seed"])
         T, S = int(g["prompt_len"]), int(g["max_seq_length"])
