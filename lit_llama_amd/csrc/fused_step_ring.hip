@@ -68,26 +68,13 @@ constexpr unsigned kSpinLimit = 400000u;
 #ifndef MI355_FUSED_SPLIT_POS
 #define MI355_FUSED_SPLIT_POS 384
 #endif
-// MEASUREMENT ONLY (results are wrong): 1 = the streamers skip the int4 -> fp16 conversion, 2 = they issue every second MFMA only.
-// Together they say which pipe bounds a compute phase (profiles/r04_ab4_compute_proxies.txt).
-#ifndef MI355_FUSED_PROXY
-#define MI355_FUSED_PROXY 0
-#endif
-#if MI355_FUSED_PROXY == 2
-#define FS_PROXY_MFMA(d_) if (((d_) & 1) == 0)
-#else
-#define FS_PROXY_MFMA(d_)
-#endif
-#ifndef MI355_FUSED_PRE
-#define MI355_FUSED_PRE 0  // pieces per wave and phase converted ahead of the hand-off into LDS (0: off — measured neutral; 4 = all of the 128 KiB of LDS left)
-#endif
 constexpr int kSplitPos = MI355_FUSED_SPLIT_POS;  // from this position on the attention splits rows, not dimensions
 constexpr int kPartStride = 136;  // granules per workgroup partial of the row-split attention: 128 values, max, sum, pad
 
 // LDS map (bytes)
 constexpr int kOffMisc = 0;                       // [0] 1/rms, [4..7] operand sums, [16..23] / [24..31] per-wave softmax max / sum
 constexpr int kOffZero = 256;                     // one all-zero unit (idle ring steps read it)
-constexpr int kOffXs = 512;                       // activation vector, fp16, <= 96 units
+constexpr int kOffXs = 512;                       // activation vector, 16-bit values, <= 96 units
 // [2][8 waves][4 row tiles][4 row groups] f32x4: COLUMN 0 of a wave's 16 x 16 partial tiles (at M = 1 the 16 token columns are copies;
 // the GRP kernel has added its columns up before the store): 4 KiB.  (Round 3 kept the whole tiles: 64 KiB.)  The row-split
 // attention parks its per-wave partial outputs here ([8 waves][128] f32: the same 4 KiB).
@@ -95,14 +82,10 @@ constexpr int kPartBytes = 2 * kSW * 4 * 64;
 constexpr int kOffPart = kOffXs + 96 * 256;
 constexpr int kOffQ = kOffPart + kPartBytes;      // q[128] knew[128] vnew[128] f32
 constexpr int kOffOpart = kOffQ + 3 * 512;        // [8 waves][16] f32
-// PRE-CONVERTED OPERANDS (round 4): [8 waves][kPre pieces][4 MFMA A operands][64 lanes][16 B] — the first kPre pieces of a phase's
-// ring turn, converted int4 -> fp16 by the streamer waves WHILE the phase's activations are still being gathered
-constexpr int kPre = MI355_FUSED_PRE;
-constexpr int kOffPre = 32 * 1024;
 [[maybe_unused]] constexpr int kMaxS = 32768;     // cache rows (the attention keeps no per-row state in LDS)
-constexpr int kLdsBytes = kOffPre + kSW * kPre * 4096;
+constexpr int kLdsBytes = kOffOpart + 512;
 constexpr int kLdsBytesG = kLdsBytes;             // (the GRP instantiation uses the same map)
-static_assert(kOffOpart + 512 <= kOffPre && kLdsBytes <= 160 * 1024 && kPartBytes >= kSW * 128 * 4, "LDS map");
+static_assert(kLdsBytes <= 160 * 1024 && kPartBytes >= kSW * 128 * 4, "LDS map");
 
 // ------------------------------------------------------------------------------------------------ granules
 __device__ __forceinline__ void gr_store(u64* p, unsigned tag, unsigned val) {
@@ -298,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
 
         // ---- first ring turn of a phase (12 pieces), requested right after the previous phase's publish
-#define FS_BURST(RS_, R_, SPT_, PAIR_, QKV_, PH_, PRE_)                                                       \
+#define FS_BURST(RS_, R_, SPT_, PAIR_, QKV_, PH_)                                                             \
     do {                                                                                                     \
         _Pragma("unroll") for (int pc__ = 0; pc__ < kRing; ++pc__) {                                         \
             bool ok__;                                                                                       \
@@ -312,30 +295,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             if (pc__ + 1 >= kWin && pc__ + 1 < kRing) {                                                      \
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWin - 1) : "memory");                               \
                 __builtin_amdgcn_sched_barrier(0);                                                           \
-                /* piece pc - (kWin - 1) has landed: convert it NOW, while the phase's activations are still */ \
-                /* being gathered (the wave would only wait for the next piece), and park the four MFMA A    */ \
-                /* operands in LDS; FS_RUN then feeds these pieces to the MFMA with ds_read_b128 instead of   */ \
-                /* 20 VALU instructions on the chain behind B1                                                */ \
-                if ((PRE_) && pc__ - (kWin - 1) < kPre) {                                                    \
-                    char* pd__ = smem + kOffPre + wave * (kPre * 4096) + (pc__ - (kWin - 1)) * 4096 + lane_off; \
-                    _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                    \
-                        const uint32_t v__ = ring[pc__ - (kWin - 1)][d__];                                   \
-                        const uint32_t v8__ = v__ >> 8;                                                      \
-                        u32x4 a__;                                                                           \
-                        a__[0] = nib2f16(v__, nmask, magic);                                                 \
-                        a__[1] = nib2f16(v__, nmask16, magic);                                               \
-                        a__[2] = nib2f16(v8__, nmask, magic);                                                \
-                        a__[3] = nib2f16(v8__, nmask16, magic);                                              \
-                        *(u32x4*)(pd__ + d__ * 1024) = a__;                                                  \
-                    }                                                                                        \
-                    __builtin_amdgcn_sched_barrier(0);                                                       \
-                }                                                                                            \
             }                                                                                                \
         }                                                                                                    \
     } while (0)
 
         // ---- one phase: BODIES x TURNS ring turns of 12 / R steps; a step = R pieces against one activation unit
-#define FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_, PRE_)                                 \
+#define FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_)                                       \
     do {                                                                                                             \
         constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
         const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
@@ -415,24 +380,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if (st__ < (PH_).nu && ((QKV_) || ti__ < (PH_).ntiles)) {                                         \
                         _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                         \
                             _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                   \
+                                const uint32_t v__ = ring[s__ * R__ + r__][d__];                                      \
+                                const uint32_t v8__ = v__ >> 8;                                                       \
                                 u32x4 a__;                                                                            \
-                                if ((PRE_) && t__ == 0 && s__ * R__ + r__ < kPre) {                                   \
-                                    /* converted during the hand-off (FS_BURST) */                                    \
-                                    a__ = *(const u32x4*)(smem + kOffPre + wave * (kPre * 4096) +                     \
-                                                          ((s__ * R__ + r__) * 4 + d__) * 1024 + lane_off);           \
-                                } else if (MI355_FUSED_PROXY == 1) {                                                  \
-                                    /* PROXY 1 (wrong numerics): no conversion, raw dwords as operands */             \
-                                    const uint32_t v__ = ring[s__ * R__ + r__][d__];                                  \
-                                    a__[0] = a__[1] = a__[2] = a__[3] = v__;                                          \
-                                } else {                                                                              \
-                                    const uint32_t v__ = ring[s__ * R__ + r__][d__];                                  \
-                                    const uint32_t v8__ = v__ >> 8;                                                   \
-                                    a__[0] = nib2f16(v__, nmask, magic);                                              \
-                                    a__[1] = nib2f16(v__, nmask16, magic);                                            \
-                                    a__[2] = nib2f16(v8__, nmask, magic);                                             \
-                                    a__[3] = nib2f16(v8__, nmask16, magic);                                           \
-                                }                                                                                     \
-                                FS_PROXY_MFMA(d__)                                                                    \
+                                a__[0] = nib2f16(v__, nmask, magic);                                                  \
+                                a__[1] = nib2f16(v__, nmask16, magic);                                                \
+                                a__[2] = nib2f16(v8__, nmask, magic);                                                 \
+                                a__[3] = nib2f16(v8__, nmask16, magic);                                               \
                                 acc__[r__][d__ & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                         \
                                     __builtin_bit_cast(f16x8, a__), b__[d__], acc__[r__][d__ & 1], 0, 0, 0);          \
                             }                                                                                         \
@@ -485,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
     } while (0)
 
-        FS_BURST(rs_l, 3, 4, false, true, ph_attn, true);
+        FS_BURST(rs_l, 3, 4, false, true, ph_attn);
         const bf16_t* kv_l = (const bf16_t*)p.kv;
         bool dbg_on = false;
 #define FS_SSTAMP(i)                                                                      \
@@ -496,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             dbg_on = p.dbg != nullptr && l == p.dbg_layer;
             asm volatile("" : "+v"(lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
             // ---------------- c_attn (q, k, v tiles of this workgroup's 16 dimensions of its head)
-            FS_RUN(rs_l, 3, 4, false, true, 1, ph_attn, 1, 20, rs_t, true);
+            FS_RUN(rs_l, 3, 4, false, true, 1, ph_attn, 1, 20, rs_t);
             // ---------------- attention: scores over the whole context, then this workgroup's 16 output dims
             {
                 const bf16_t* kc = kv_l + (size_t)head * p.S * kHs;
@@ -717,12 +671,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 __syncthreads();  // Ba4: the attention output is published
             }
             // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows)
-            FS_BURST(rs_l, 1, 12, false, false, ph_proj, true);
-            FS_RUN(rs_l, 1, 12, false, false, 1, ph_proj, 1, 26, rs_t, true);
-            FS_BURST(rs_l, 2, 4, true, false, ph_fc, true);
-            FS_RUN(rs_l, 2, 4, true, false, 2, ph_fc, 1, 28, rs_t, true);
-            FS_BURST(rs_l, 1, 12, false, false, ph_mp, true);
-            FS_RUN(rs_l, 1, 12, false, false, 1, ph_mp, 1, 30, rs_t, true);
+            FS_BURST(rs_l, 1, 12, false, false, ph_proj);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_proj, 1, 26, rs_t);
+            FS_BURST(rs_l, 2, 4, true, false, ph_fc);
+            FS_RUN(rs_l, 2, 4, true, false, 2, ph_fc, 1, 28, rs_t);
+            FS_BURST(rs_l, 1, 12, false, false, ph_mp);
+            FS_RUN(rs_l, 1, 12, false, false, 1, ph_mp, 1, 30, rs_t);
             // next layer (or the head)
             kv_l += (size_t)2 * kHeads * p.S * kHs;
             if (l + 1 < p.n_layer) {
@@ -731,13 +685,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if constexpr (GRP)
                     rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gt + (size_t)(l + 1) * p.gt_layer_stride), 0,
                                                              (int)p.gt_layer_bytes, 0x00020000);
-                FS_BURST(rs_l, 3, 4, false, true, ph_attn, true);
+                FS_BURST(rs_l, 3, 4, false, true, ph_attn);
             } else {
-                FS_BURST(rs_h, 1, 4, false, false, ph_head, false);
+                FS_BURST(rs_h, 1, 4, false, false, ph_head);
             }
         }
         dbg_on = false;
-        FS_RUN(rs_h, 1, 4, false, false, 1, ph_head, p.head_turns, 32, rs_th, false);
+        FS_RUN(rs_h, 1, 4, false, false, 1, ph_head, p.head_turns, 32, rs_th);
         if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
 #undef FS_RUN
 #undef FS_BURST
