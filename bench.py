@@ -477,8 +477,8 @@ def main():
         else:
             avg_s, med_s = measure_dominant_kernel(eng)
             key = "fc_swiglu_bytes_per_launch"
-        if pmc.exists():
-            try:
+        if pmc.exists() and args.model == "7B" and args.quantize == "gptq.int4" and not args.group_cols and not args.adapter:
+            try:  # (the committed PMC pass is of the headline configuration)
                 traffic = json.loads(pmc.read_text()).get(key)
                 traffic_source = ("profiles/pmc_traffic.json: committed rocprofv3 --pmc FETCH_SIZE pass over this command "
                                   "(x2 gfx950 wide-read correction); static, not measured in this run") if traffic else None
@@ -539,11 +539,31 @@ def main():
         box = {}
 
         def _run_tp():
+            import copy
+
+            torch.cuda.set_device(dev)
+            err = None
             try:
-                torch.cuda.set_device(dev)
                 box["res"] = tp_leg(args, dev, rank, world, dist)
             except BaseException as e:  # noqa: BLE001
-                box["res"] = {"error": repr(e)}
+                err = repr(e)
+                box["res"] = {"error": err}
+            # The native collective (peer writes over HIP IPC) has never run across devices: if it fails on ANY
+            # rank — its spins are bounded, a peer that never delivers raises — every rank repeats the leg over RCCL
+            # (`--tp-comm rccl`, torch.distributed), so that a multi-GPU run always yields a curve.  The ranks agree on the retry
+            # through one all-reduce; a rank that died takes that all-reduce down with it, and the watchdog below takes over.
+            if args.tp_comm == "native" and world > 1 and dist is not None:
+                try:
+                    bad = torch.tensor([1.0 if err is not None else 0.0], device=dev)
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                    if float(bad.item()) > 0:
+                        a2 = copy.copy(args)
+                        a2.tp_comm = "rccl"
+                        res = tp_leg(a2, dev, rank, world, dist)
+                        res["fallback_from_native"] = err or "the native leg failed on another rank"
+                        box["res"] = res
+                except BaseException as e:  # noqa: BLE001
+                    box["res"] = {"error": f"native leg: {err}; RCCL fallback: {e!r}"}
 
         th = threading.Thread(target=_run_tp, daemon=True)
         th.start()
@@ -578,8 +598,9 @@ def main():
         # what the timed kernels compute with (not a precision claim): the persistent int4 step feeds fp16 MFMA operands (int4
         # weights -> fp16, fp16 activation granules), the launch-per-operator paths bf16 operands, LLM.int8 int8 x int8 -> int32
         # plus f16 outlier columns; f32 accumulation and a bf16 KV cache throughout (>= the reference's bf16-true run)
-        "dtype": ("fp16" if fused else "int8" if args.quantize == "llm.int8" else "bf16"),
-        "dtype_detail": ("int4 weights -> fp16 MFMA operands x fp16 activations, f32 accumulate, bf16 KV cache" if fused else
+        "dtype": ("fp16" if fused and args.quantize == "gptq.int4" else "int8" if args.quantize == "llm.int8" else "bf16"),
+        "dtype_detail": ("int4 weights -> fp16 MFMA operands x fp16 activations, f32 accumulate, bf16 KV cache"
+                         if fused and args.quantize == "gptq.int4" else
                          "int8 x int8 -> int32 MFMA + f16 outlier columns, bf16 KV cache" if args.quantize == "llm.int8" else
                          "bf16 MFMA operands, f32 accumulate, bf16 KV cache"),
         "data": "synthetic",

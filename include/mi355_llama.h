@@ -528,7 +528,14 @@ typedef struct mi355_fused_step_args {
      * c_fc2, mlp.c_proj in this order, `gt_head` lm_head's, each [N / 16 tiles][K / group_cols groups][16 rows] uint32 =
      * bf16 scale | bf16 zero << 16.  Register-ring implementation only. */
     int32_t group_cols;
-    int32_t reserved1;
+    /* 0: `w` / `w_head` hold int4 streams (mi355_q4_repack) as described above; 1 (round 4): BF16 streams of an unquantised model
+     * (mi355_bf16_repack, same R / pair arguments: lit_llama/model.py with plain nn.Linear, BASELINE configs[1]) — `sz`, `sz_head`
+     * and the group tables are not read, the hand-offs carry bf16 pairs; 2 (round 4): LLM.int8 streams (mi355_i8_repack) of a
+     * Linear8bitLt model (lit_llama/quantization.py:38-77, BASELINE configs[3], threshold 6.0) — `sz` then holds per layer (stride
+     * 5 C + 2 H floats) the f32 row scales SCB of c_attn[3C] attn.c_proj[C] c_fc1[H] c_fc2[H] mlp.c_proj[C], `sz_head` lm_head's [V];
+     * at most 1024 outlier columns per gathered vector (more raise the abort word: such a step belongs on mi355_forward).
+     * Register-ring implementation only. */
+    int32_t weight_fmt;
     const void* gt;
     const void* gt_head;
     uint64_t gt_layer_stride;

@@ -126,7 +126,7 @@ class FusedStepArgs(C.Structure):
         ("n_layer", c_int32), ("n_head", c_int32), ("n_embd", c_int32), ("hs", c_int32),
         ("n_hidden", c_int32), ("vocab", c_int32), ("S", c_int32), ("mode", c_int32),
         ("eps", c_float), ("reserved0", c_int32),
-        ("group_cols", c_int32), ("reserved1", c_int32), ("gt", c_void_p), ("gt_head", c_void_p),
+        ("group_cols", c_int32), ("weight_fmt", c_int32), ("gt", c_void_p), ("gt_head", c_void_p),
         ("gt_layer_stride", C.c_uint64),
     ]
 

@@ -1281,7 +1281,10 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
                     kG, kC, kHeads, kHs, kMaxFcTiles * kG * 16, kMaxHeadTiles * kG * 16, kMaxS, mi355_num_cus(), a->n_embd,
                     a->n_head, a->hs, a->n_hidden, a->vocab, a->S);
     const bool grouped = a->group_cols > 0;
-    MI355_CHECK_ARG(a->w && a->w_head && (grouped || (a->sz && a->sz_head)) && a->norms && a->wte && a->rope && a->kv && a->tokens &&
+    const int fmt = a->weight_fmt;
+    MI355_CHECK_ARG(fmt >= 0 && fmt <= 2, MI355_E_ARG, "fused_step: weight_fmt %d (0 = int4 streams, 1 = BF16, 2 = LLM.int8)", fmt);
+    MI355_CHECK_ARG(!(grouped && fmt != 0), MI355_E_ARG, "fused_step: grouped scales exist for int4 streams only");
+    MI355_CHECK_ARG(a->w && a->w_head && (grouped || fmt == 1 || (a->sz && a->sz_head)) && a->norms && a->wte && a->rope && a->kv && a->tokens &&
                         a->pos && a->logits && a->workspace,
                     MI355_E_ARG, "fused_step: null pointer");
     int gsh = 0;
@@ -1312,8 +1315,9 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     });
     MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "fused_step: hipFuncSetAttribute failed: %s",
                     hipGetErrorString(attr_err));
-    MI355_CHECK_ARG(!grouped || use_ring, MI355_E_ARG, "fused_step: grouped scales are implemented by the register-ring kernel only");
-    MI355_CHECK_ARG(use_ring ? (fused_step_ring_occupancy_ok() & (grouped ? 2 : 1)) != 0 : occupancy_ok(), MI355_E_STATE,
+    MI355_CHECK_ARG((!grouped && fmt == 0) || use_ring, MI355_E_ARG,
+                    "fused_step: grouped scales and BF16 streams are implemented by the register-ring kernel only");
+    MI355_CHECK_ARG(use_ring ? (fused_step_ring_occupancy_ok() & (fmt == 2 ? 8 : fmt == 1 ? 4 : grouped ? 2 : 1)) != 0 : occupancy_ok(), MI355_E_STATE,
                     "fused_step: the device does not admit one %d-thread workgroup with %d B of LDS per CU", kThreads, kLdsBytes);
     FusedParams p;
     memset(&p, 0, sizeof(p));
@@ -1347,7 +1351,8 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     p.gh = (u64*)(ws + kFsWsGh);
     p.dbg = (u64*)a->debug_stamps;
     p.dbg_layer = a->reserved0;  // with debug_stamps: the layer whose phases are stamped
-    p.sz_layer_stride = (unsigned)(10 * kC + 4 * a->n_hidden);
+    // elements of `sz` per layer: bf16 scales + zeros of the int4 streams, or (weight_fmt 2) the f32 row scales SCB of the int8 ones
+    p.sz_layer_stride = fmt == 2 ? (unsigned)(5 * kC + 2 * a->n_hidden) : (unsigned)(10 * kC + 4 * a->n_hidden);
     p.n_layer = a->n_layer;
     p.H = a->n_hidden;
     p.V = a->vocab;
@@ -1355,9 +1360,11 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     p.units_h = a->n_hidden / 128;
     p.fc_tiles = a->n_hidden / 16;
     p.head_tiles = (a->vocab + 15) / 16;
+    p.fmt = fmt;
     {
-        const int per_wg = (p.head_tiles + kG - 1) / kG;  // tiles of the busiest workgroup, 4 steps each (ring version)
-        p.head_turns = (per_wg * 4 + 12 - 1) / 12;
+        const int per_wg = (p.head_tiles + kG - 1) / kG;  // tiles of the busiest workgroup (ring version)
+        const int steps = per_wg * 4 * (fmt == 1 ? 4 : fmt == 2 ? 2 : 1);  // ring steps per tile and wave: 4 (int4), 16 (BF16), 8 (int8)
+        p.head_turns = (steps + 12 - 1) / 12;
     }
     p.mode = a->mode;
     p.eps = a->eps;

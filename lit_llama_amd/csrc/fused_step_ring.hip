@@ -82,9 +82,15 @@ constexpr int kPartBytes = 2 * kSW * 4 * 64;
 constexpr int kOffPart = kOffXs + 96 * 256;
 constexpr int kOffQ = kOffPart + kPartBytes;      // q[128] knew[128] vnew[128] f32
 constexpr int kOffOpart = kOffQ + 3 * 512;        // [8 waves][16] f32
+// LLM.int8 streams (FMT 2): the quantised activation vector (int8, natural k order, <= 96 units of 128) and the ascending list of
+// its outlier columns; misc[1] = 1/rms over x_scale of the x edge gathered last, misc[8 + w] = streamer wave w's sub-threshold
+// absmax
+constexpr int kOffXq = kOffOpart + 512;
+constexpr int kMaxOut = 1024;
+constexpr int kOffObits = kOffXq + 96 * 128;      // u32 [96 * 4]: outlier columns as a bit set (atomic OR by whichever lane stages the column)
+constexpr int kOffOlist = kOffObits + 96 * 16;    // u16 [kMaxOut]: the same columns in ascending order (gatherer 0, behind B1b)
 [[maybe_unused]] constexpr int kMaxS = 32768;     // cache rows (the attention keeps no per-row state in LDS)
-constexpr int kLdsBytes = kOffOpart + 512;
-constexpr int kLdsBytesG = kLdsBytes;             // (the GRP instantiation uses the same map)
+constexpr int kLdsBytes = kOffOlist + kMaxOut * 2;
 static_assert(kLdsBytes <= 160 * 1024 && kPartBytes >= kSW * 128 * 4, "LDS map");
 
 // ------------------------------------------------------------------------------------------------ granules
@@ -153,18 +159,22 @@ struct PhaseW {  // one phase as a streamer wave sees it (all wave-uniform)
 // piece (padding of the ring turn: the load then goes through a zero-sized descriptor = zeros, no memory request).
 // The offset travels in the load's SGPR operand and the lane's 16 B in ONE shared VGPR: per-piece address VGPRs are
 // loop-invariant over the layers, get hoisted and spill.
-template <int SPT, bool PAIR, bool QKV>
+// SUB: ring steps per unit of 128 input columns — 1 for the int4 stream (a 1-KiB piece is 16 rows x 128 columns), 4 for the BF16
+// stream (16 rows x 32 columns: [tile][unit][r][piece d][lane], a piece IS an MFMA A operand), 2 for int8 (16 rows x 64 columns);
+// ph.u0 / ph.nu count units, SPT counts steps.
+template <int SPT, bool PAIR, bool QKV, int SUB = 1>
 __device__ __forceinline__ unsigned piece_off(const PhaseW& ph, int gstep, int r, bool& ok) {
     const int ti = gstep / SPT, st = gstep - ti * SPT;
     int tile;
     if constexpr (QKV) {
         tile = ph.tile0 + r * ph.tstride;  // the q, k and v tiles of this workgroup share the activation operand
-        ok = ti == 0 && st < ph.nu;
+        ok = ti == 0 && st < ph.nu * SUB;
     } else {
         tile = ph.tile0 + ti * ph.tstride;
-        ok = ti < ph.ntiles && st < ph.nu;
+        ok = ti < ph.ntiles && st < ph.nu * SUB;
     }
-    return ph.base + (unsigned)((tile * ph.units + ph.u0 + st) * (PAIR ? 2 : 1) + (PAIR ? r : 0)) * 1024u;
+    return ph.base +
+           (unsigned)(((tile * ph.units + ph.u0 + st / SUB) * (PAIR ? 2 : 1) + (PAIR ? r : 0)) * SUB + st % SUB) * 1024u;
 }
 // int4 -> MFMA operand, 5 VALU ops per 8 weights.  The conversion is what bounds a compute phase of the fused step, so
 // the operands are fp16, whose 10-bit mantissa holds TWO nibble positions under one exponent pattern:
@@ -199,8 +209,17 @@ __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_b
 // [tile][group][16 rows] of bf16 scale | bf16 zero << 16, one 16-B load per lane and row group, requested at the tile's first step;
 // the operand sums of its groups taken by the wave itself from the staged vector); what reaches the gatherers' epilogues is
 // already dequantised.
-template <bool GRP>
+// FMT: 0 = the int4 streams described above; 1 = BF16 streams of an unquantised model (BASELINE configs[1], round 4): the same
+// ring, hand-offs and epilogues — a 1-KiB piece is one MFMA A operand (16 rows x 32 columns), four ring steps per unit, no
+// conversion, no scales; the activations travel as bf16 pairs.  2 = LLM.int8 streams (BASELINE configs[3], Linear8bitLt,
+// /root/reference lit_llama/quantization.py:38-77): a piece is the A operand of v_mfma_i32_16x16x64_i8 (16 rows x 64 columns), two ring
+// steps per unit; the streamer waves quantise the gathered vector themselves — f16 cast, outlier columns |x| >= 6, absmax of the rest,
+// rint(x 127 / absmax), the arithmetic of csrc/int8.hip (bitsandbytes' MatMul8bitLt as oracle/oracle.py restates it: PARITY
+// UNPINNED) — and the gatherers' epilogue dequantises and adds the f16 outlier side product.
+template <bool GRP, int FMT>
 __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedParams p) {
+    static_assert(!(GRP && FMT != 0), "grouped scales exist for int4 only");
+    constexpr int kSub = FMT == 1 ? 4 : FMT == 2 ? 2 : 1;  // ring steps per 128-column unit
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -285,7 +304,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
     do {                                                                                                     \
         _Pragma("unroll") for (int pc__ = 0; pc__ < kRing; ++pc__) {                                         \
             bool ok__;                                                                                       \
-            const unsigned so__ = piece_off<SPT_, PAIR_, QKV_>(PH_, pc__ / (R_), pc__ % (R_), ok__);          \
+            const unsigned so__ = piece_off<SPT_, PAIR_, QKV_, kSub>(PH_, pc__ / (R_), pc__ % (R_), ok__);    \
             ring[pc__] = ring_load(RS_, rs_null, ok__, lane_off, so__);                                      \
             __builtin_amdgcn_sched_barrier(0); /* issue order = consumption order (VMEM returns in order) */ \
             /* sliding window: at most kWin pieces per wave (8 kWin KiB per CU) are in flight; a deeper     */ \
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                           \
                         const int nstep__ = gstep__ + STEPS__;                                                        \
                         bool ok__;                                                                                    \
-                        const unsigned so__ = piece_off<SPT__, PAIR_, QKV_>(PH_, nstep__, r__, ok__);                 \
+                        const unsigned so__ = piece_off<SPT__, PAIR_, QKV_, kSub>(PH_, nstep__, r__, ok__);           \
                         ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
                     }                                                                                                 \
                     if ((t__ * STEPS__ + s__ + 1) % SPT__ == 0) {                                                     \
@@ -439,7 +458,197 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
     } while (0)
 
-        FS_BURST(rs_l, 3, 4, false, true, ph_attn);
+        // ---- one phase over a BF16 stream: FS_RUN's ring discipline (turns, refills, barriers), ONE MFMA per piece against 16 B of
+        // the staged vector (k quarter d of the unit: piece d of lane (g, row) holds k = 128 u + 32 g + 8 d + 0..7, the layout of the
+        // int4 kernel's d-th MFMA)
+#define FS_RUN_W(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_)                                           \
+    do {                                                                                                             \
+        constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
+        const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
+        f32x4 acc__[R__][2];                                                                                          \
+        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+        __syncthreads(); /* B1: the activation vector is staged */                                                   \
+        FS_SSTAMP(STAMP_);                                                                                            \
+        const int nsub__ = (PH_).nu * kSub;                                                                           \
+        bf16x8 bn__ = *(const bf16x8*)(xs + (PH_).u0 * 256 + g * 64); /* read one step ahead */                       \
+        for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
+            _Pragma("unroll") for (int t__ = 0; t__ < (TURNS_); ++t__) {                                              \
+                _Pragma("unroll") for (int s__ = 0; s__ < STEPS__; ++s__) {                                           \
+                    const int gstep__ = (body__ * (TURNS_) + t__) * STEPS__ + s__;                                    \
+                    const int ti__ = gstep__ / SPT__, st__ = gstep__ - ti__ * SPT__;                                  \
+                    const bf16x8 b__ = bn__;                                                                          \
+                    {                                                                                                 \
+                        int nst__ = (st__ + 1 == SPT__) ? 0 : st__ + 1;                                               \
+                        nst__ = nst__ < nsub__ ? nst__ : 0;                                                           \
+                        bn__ = *(const bf16x8*)(xs + ((PH_).u0 + nst__ / kSub) * 256 + g * 64 + (nst__ % kSub) * 16); \
+                    }                                                                                                 \
+                    if (st__ < nsub__ && ((QKV_) || ti__ < (PH_).ntiles)) {                                           \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__)                                         \
+                            acc__[r__][s__ & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                            \
+                                __builtin_bit_cast(bf16x8, ring[s__ * R__ + r__]), b__, acc__[r__][s__ & 1], 0, 0, 0); \
+                    }                                                                                                 \
+                    _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                           \
+                        const int nstep__ = gstep__ + STEPS__;                                                        \
+                        bool ok__;                                                                                    \
+                        const unsigned so__ = piece_off<SPT__, PAIR_, QKV_, kSub>(PH_, nstep__, r__, ok__);           \
+                        ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
+                    }                                                                                                 \
+                    if ((gstep__ + 1) % SPT__ == 0) { /* (bodies of 12 steps need not hold whole tiles) */         \
+                        if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
+                        f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * 64) + (lane_off >> 8);       \
+                        if ((lane_off & 0xF0u) == 0u) {                                                               \
+                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * 4] = acc__[r__][0] + acc__[r__][1]; \
+                        }                                                                                             \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+                        __syncthreads(); /* Bt */                                                                     \
+                        buf ^= 1;                                                                                     \
+                    }                                                                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                                \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+        __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
+    } while (0)
+        // ---- LLM.int8 streams: the streamer waves quantise the gathered vector, each its own units (lane <-> octet of 8 columns).
+        // Pass 1: xh = f16 of the staged value (x edges: times 1/rms over x_scale, misc[1] — the launch path's `sc * (x * rinv)`
+        // -> f16, csrc/int8.hip emit()), written back for the outlier side product; columns with |xh| >= 6 go to the outlier list,
+        // the others into the wave's absmax.  One workgroup barrier.  Pass 2: CA = rint(xh * (127 / absmax)), outlier columns 0.
+        [[maybe_unused]] u32x4 q8v[3];
+        [[maybe_unused]] unsigned q8o[3];
+        [[maybe_unused]] auto q8_pass1 = [&](int u0, int nu, bool xedge) __attribute__((always_inline)) {
+            const int noct = nu * 16;
+            const float rn = xedge ? misc[1] : 1.0f;
+            float amax = 0.f;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                q8v[it] = u32x4{0u, 0u, 0u, 0u};
+                q8o[it] = 0u;
+                if (it * 64 >= noct) continue;  // (wave-uniform)
+                const int o = it * 64 + (int)(lane_off >> 4);
+                if (o < noct) {
+                    u32x4 v = *(const u32x4*)(xs + (size_t)u0 * 256 + (size_t)o * 16);
+                    unsigned om = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f16x2 h2 = __builtin_bit_cast(f16x2, (unsigned)v[e]);
+                        const f16x2 r2 = {(_Float16)((float)h2[0] * rn), (_Float16)((float)h2[1] * rn)};
+                        v[e] = __builtin_bit_cast(unsigned, r2);
+                        const float a0 = fabsf((float)r2[0]), a1 = fabsf((float)r2[1]);
+                        if (a0 >= 6.0f) om |= 1u << (2 * e); else amax = fmaxf(amax, a0);
+                        if (a1 >= 6.0f) om |= 2u << (2 * e); else amax = fmaxf(amax, a1);
+                    }
+                    if (xedge) *(u32x4*)(xs + (size_t)u0 * 256 + (size_t)o * 16) = v;
+                    q8v[it] = v;
+                    q8o[it] = om;
+                    if (om != 0u) {  // rare: a handful of columns per vector (four octets share a word of the bit set)
+                        const int k0 = (u0 + (o >> 4)) * 128 + (o & 15) * 8;
+                        atomicOr((unsigned*)(smem + kOffObits) + (k0 >> 5), om << (k0 & 31));
+                    }
+                }
+            }
+            amax = MI355_DPP_MAX(amax, 0xB1);
+            amax = MI355_DPP_MAX(amax, 0x4E);
+            amax = MI355_DPP_MAX(amax, 0x141);
+            amax = MI355_DPP_MAX(amax, 0x140);
+            amax = fmaxf(amax, lane_xor16(amax));
+            amax = fmaxf(amax, lane_xor32(amax));
+            if ((lane_off >> 4) == 0u) misc[8 + wave] = amax;
+        };
+        [[maybe_unused]] auto q8_pass2 = [&](int u0, int nu) __attribute__((always_inline)) {
+            const int noct = nu * 16;
+            const f32x4 ma = *(const f32x4*)(misc + 8), mb = *(const f32x4*)(misc + 12);
+            const float amax = fmaxf(fmaxf(fmaxf(ma[0], ma[1]), fmaxf(ma[2], ma[3])), fmaxf(fmaxf(mb[0], mb[1]), fmaxf(mb[2], mb[3])));
+            const float inv = amax > 0.f ? __fdiv_rn(127.0f, amax) : 0.f;  // IEEE division, as int8.hip and the oracle
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                if (it * 64 >= noct) continue;
+                const int o = it * 64 + (int)(lane_off >> 4);
+                if (o < noct) {
+                    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f16x2 h2 = __builtin_bit_cast(f16x2, (unsigned)q8v[it][e]);
+                        const int qa = ((q8o[it] >> (2 * e)) & 1u) ? 0 : (int)rintf((float)h2[0] * inv);
+                        const int qb = ((q8o[it] >> (2 * e + 1)) & 1u) ? 0 : (int)rintf((float)h2[1] * inv);
+                        const unsigned two = ((unsigned)qa & 0xffu) | (((unsigned)qb & 0xffu) << 8);
+                        if (e < 2) lo |= two << (16 * e); else hi |= two << (16 * (e - 2));
+                    }
+                    *(u32x2*)(smem + kOffXq + (size_t)u0 * 128 + (size_t)o * 8) = u32x2{lo, hi};
+                }
+            }
+        };
+#define FS_RUN_8(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, XEDGE_)                                    \
+    do {                                                                                                             \
+        constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
+        const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
+        i32x4 acc__[R__][2];                                                                                          \
+        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = i32x4{0, 0, 0, 0};      \
+        __syncthreads(); /* B1: the activation vector is staged (f16) */                                             \
+        FS_SSTAMP(STAMP_);                                                                                            \
+        q8_pass1((PH_).u0, (PH_).nu, (XEDGE_));                                                                       \
+        __syncthreads(); /* B1b: every wave's absmax and outlier columns are known */                                \
+        q8_pass2((PH_).u0, (PH_).nu);                                                                                 \
+        const int nsub__ = (PH_).nu * kSub;                                                                           \
+        i32x4 bn__ = *(const i32x4*)(smem + kOffXq + (PH_).u0 * 128 + g * 16);                                        \
+        for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
+            _Pragma("unroll") for (int t__ = 0; t__ < (TURNS_); ++t__) {                                              \
+                _Pragma("unroll") for (int s__ = 0; s__ < STEPS__; ++s__) {                                           \
+                    const int gstep__ = (body__ * (TURNS_) + t__) * STEPS__ + s__;                                    \
+                    const int ti__ = gstep__ / SPT__, st__ = gstep__ - ti__ * SPT__;                                  \
+                    const i32x4 b__ = bn__;                                                                           \
+                    {                                                                                                 \
+                        int nst__ = (st__ + 1 == SPT__) ? 0 : st__ + 1;                                               \
+                        nst__ = nst__ < nsub__ ? nst__ : 0;                                                           \
+                        bn__ = *(const i32x4*)(smem + kOffXq + ((PH_).u0 + nst__ / kSub) * 128 + (nst__ % kSub) * 64 + g * 16); \
+                    }                                                                                                 \
+                    if (st__ < nsub__ && ((QKV_) || ti__ < (PH_).ntiles)) {                                           \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__)                                         \
+                            acc__[r__][s__ & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(                              \
+                                __builtin_bit_cast(i32x4, ring[s__ * R__ + r__]), b__, acc__[r__][s__ & 1], 0, 0, 0); \
+                    }                                                                                                 \
+                    _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                           \
+                        const int nstep__ = gstep__ + STEPS__;                                                        \
+                        bool ok__;                                                                                    \
+                        const unsigned so__ = piece_off<SPT__, PAIR_, QKV_, kSub>(PH_, nstep__, r__, ok__);           \
+                        ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
+                    }                                                                                                 \
+                    if ((gstep__ + 1) % SPT__ == 0) { /* (bodies of 12 steps need not hold whole tiles) */         \
+                        if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
+                        i32x4* pp__ = (i32x4*)(part + (size_t)((buf * kSW + wave) * 4) * 64) + (lane_off >> 8);       \
+                        if ((lane_off & 0xF0u) == 0u) {                                                               \
+                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * 4] = acc__[r__][0] + acc__[r__][1]; \
+                        }                                                                                             \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = i32x4{0, 0, 0, 0}; \
+                        __syncthreads(); /* Bt */                                                                     \
+                        buf ^= 1;                                                                                     \
+                    }                                                                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                                \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+        __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
+    } while (0)
+        // a phase: (int4 SPT / TURNS, wide-format SPT / TURNS) — steps per tile and ring turns differ with the piece width
+#define FS_PHASE(RS_, R_, SPT_, TURNS_, SPTW_, TURNSW_, PAIR_, QKV_, PH_, NBODIES_, STAMP_, RST_, XEDGE_)             \
+    do {                                                                                                             \
+        if constexpr (FMT == 0) {                                                                                    \
+            FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_);                                  \
+        } else if constexpr (FMT == 1) {                                                                             \
+            FS_RUN_W(RS_, R_, SPTW_, PAIR_, QKV_, TURNSW_, PH_, NBODIES_, STAMP_);                                    \
+        } else {                                                                                                     \
+            FS_RUN_8(RS_, R_, SPTW_, PAIR_, QKV_, TURNSW_, PH_, NBODIES_, STAMP_, XEDGE_);                            \
+        }                                                                                                            \
+    } while (0)
+#define FS_PBURST(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_)                                                             \
+    do {                                                                                                             \
+        if constexpr (FMT == 0) {                                                                                    \
+            FS_BURST(RS_, R_, SPT_, PAIR_, QKV_, PH_);                                                                \
+        } else {                                                                                                     \
+            FS_BURST(RS_, R_, SPTW_, PAIR_, QKV_, PH_);                                                               \
+        }                                                                                                            \
+    } while (0)
+
+        FS_PBURST(rs_l, 3, 4, 4 * kSub, false, true, ph_attn);
         const bf16_t* kv_l = (const bf16_t*)p.kv;
         bool dbg_on = false;
 #define FS_SSTAMP(i)                                                                      \
@@ -450,7 +659,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             dbg_on = p.dbg != nullptr && l == p.dbg_layer;
             asm volatile("" : "+v"(lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
             // ---------------- c_attn (q, k, v tiles of this workgroup's 16 dimensions of its head)
-            FS_RUN(rs_l, 3, 4, false, true, 1, ph_attn, 1, 20, rs_t);
+            FS_PHASE(rs_l, 3, 4, 1, 4 * kSub, kSub, false, true, ph_attn, 1, 20, rs_t, true);
             // ---------------- attention: scores over the whole context, then this workgroup's 16 output dims
             {
                 const bf16_t* kc = kv_l + (size_t)head * p.S * kHs;
@@ -671,12 +880,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 __syncthreads();  // Ba4: the attention output is published
             }
             // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows)
-            FS_BURST(rs_l, 1, 12, false, false, ph_proj);
-            FS_RUN(rs_l, 1, 12, false, false, 1, ph_proj, 1, 26, rs_t);
-            FS_BURST(rs_l, 2, 4, true, false, ph_fc);
-            FS_RUN(rs_l, 2, 4, true, false, 2, ph_fc, 1, 28, rs_t);
-            FS_BURST(rs_l, 1, 12, false, false, ph_mp);
-            FS_RUN(rs_l, 1, 12, false, false, 1, ph_mp, 1, 30, rs_t);
+            FS_PBURST(rs_l, 1, 12, 4 * kSub, false, false, ph_proj);
+            FS_PHASE(rs_l, 1, 12, 1, 4 * kSub, (4 * kSub + 11) / 12, false, false, ph_proj, 1, 26, rs_t, false);
+            FS_PBURST(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
+            FS_PHASE(rs_l, 2, 4, 2, 4 * kSub, 2 * kSub, true, false, ph_fc, 1, 28, rs_t, true);
+            FS_PBURST(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
+            FS_PHASE(rs_l, 1, 12, 1, 12 * kSub, kSub, false, false, ph_mp, 1, 30, rs_t, false);
             // next layer (or the head)
             kv_l += (size_t)2 * kHeads * p.S * kHs;
             if (l + 1 < p.n_layer) {
@@ -685,14 +894,18 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if constexpr (GRP)
                     rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gt + (size_t)(l + 1) * p.gt_layer_stride), 0,
                                                              (int)p.gt_layer_bytes, 0x00020000);
-                FS_BURST(rs_l, 3, 4, false, true, ph_attn);
+                FS_PBURST(rs_l, 3, 4, 4 * kSub, false, true, ph_attn);
             } else {
-                FS_BURST(rs_h, 1, 4, false, false, ph_head);
+                FS_PBURST(rs_h, 1, 4, 4 * kSub, false, false, ph_head);
             }
         }
         dbg_on = false;
-        FS_RUN(rs_h, 1, 4, false, false, 1, ph_head, p.head_turns, 32, rs_th);
+        FS_PHASE(rs_h, 1, 4, 1, 4 * kSub, 1, false, false, ph_head, p.head_turns, 32, rs_th, true);
         if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
+#undef FS_PBURST
+#undef FS_PHASE
+#undef FS_RUN_8
+#undef FS_RUN_W
 #undef FS_RUN
 #undef FS_BURST
 #undef FS_SSTAMP
@@ -729,8 +942,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             const unsigned v = *(const unsigned*)q;
             return float2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
         };
-        auto ldsz = [&](const bf16_t* q) {  // per-row scale / zero pair (GRP: the streamers hold the group tables)
-            if constexpr (GRP) return float2{0.f, 0.f};
+        auto ldsz = [&](const bf16_t* q) {  // per-row scale / zero pair (GRP: the streamers hold the group tables; BF16: none)
+            if constexpr (GRP || FMT != 0) return float2{0.f, 0.f};
             return ldpair(q);
         };
         auto bfpair = [&](float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); };
@@ -742,12 +955,19 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         // Every clip is COUNTED in state[2] (mi355_fused_step_status / DecodeEngine.check_status report it): the step's
         // outputs then differ from the unclipped arithmetic of the reference.
         auto hpair = [&](float a, float b) {
-            const float k = (pg & 1) ? 0.0625f : 1.0f;
+            if constexpr (FMT == 1) return bfpair(a, b);  // BF16 streams: the operands of the launch-per-operator path, no range to guard
+            const float k = (FMT == 0 && (pg & 1)) ? 0.0625f : 1.0f;
             const float ak = a * k, bk = b * k;
             if (fmaxf(fabsf(ak), fabsf(bk)) > 65504.f) atomicAdd(p.state + 2, 1u);
             const f16x2 h = {(_Float16)__builtin_amdgcn_fmed3f(ak, -65504.f, 65504.f),
                              (_Float16)__builtin_amdgcn_fmed3f(bk, -65504.f, 65504.f)};
             return __builtin_bit_cast(unsigned, h);
+        };
+        // int8 streams: the attention output and the MLP hidden vector are bf16 in the launch-per-operator path (its att / hbuf buffers),
+        // which the LLM.int8 kernel then casts to f16 (exact): same values here
+        auto hpair_b = [&](float a, float b) {
+            if constexpr (FMT == 2) return hpair(bf16_to_f32(f32_to_bf16(a)), bf16_to_f32(f32_to_bf16(b)));
+            return hpair(a, b);
         };
         // sums of the staged operands, even pairs in .x and odd pairs in .y (one v_dot2_f32_f16 per dword).  They undo
         // the +1024 / zero-point offsets of the int4 operands:
@@ -756,12 +976,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         // MFMAs in every streamer wave.
         const f16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
         auto pair_sums = [&](float2& sx, unsigned even, unsigned odd) {
+            if constexpr (FMT != 0) return;  // (no operand offsets to undo)
             sx.x = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, even), ones2, sx.x, false);
             sx.y = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, odd), ones2, sx.y, false);
         };
         // misc[4 + gw] / misc[6 + gw]: this gatherer wave's S_even / S_odd; the epilogue form {A, B}:
         // y = scale (acc - A - zero B)
         auto put_sums = [&](float2 sx) {
+            if constexpr (FMT != 0) return;
             sx.x = group_sum(sx.x, 64);
             sx.y = group_sum(sx.y, 64);
             if (lane == 0) {
@@ -811,6 +1033,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
 #else
 #define FS_GCOUNT(i) do { } while (0)
 #endif
+        [[maybe_unused]] auto zero_obits = [&]() {  // (one gatherer wave; the streamers set bits behind the next B1)
+#pragma unroll
+            for (int i = 0; i < 96 * 4; i += 64) ((unsigned*)(smem + kOffObits))[i + lane_v] = 0u;
+        };
         auto gather_x = [&]() {
             const unsigned ep = ebase + edge;
             const unsigned base = (unsigned)xpar * 2304u * 8u;
@@ -850,8 +1076,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                            __uint_as_float(v[kG0 + 1][2]);
                 ss = group_sum(ss, 64);
                 put_sums(sx);
-                if (lane == 0) misc[0] = rsqrtf(ss / (float)kC + p.eps);
+                if (lane == 0) {
+                    const float rv = rsqrtf(ss / (float)kC + p.eps);
+                    misc[0] = rv;
+                    if constexpr (FMT == 2) misc[1] = rv / x_scale;  // what the streamers multiply the staged values by before their f16 cast
+                }
             } else {
+                if constexpr (FMT == 2) zero_obits();
                 u32x4 v[16 - kG0];
                 sweep<16 - kG0>(p, rs_gx, base, kG0 * 64, 1024, ep, v, 0x200u + edge, lane_v);
                 float2 sx = {0.f, 0.f};
@@ -866,9 +1097,83 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             ++edge;
         };
         auto deq = [&](float2 t, float2 sc_, float2 z_, float2 sx) {
-            if constexpr (GRP) return t;  // the streamers applied the group scales
+            if constexpr (GRP || FMT != 0) return t;  // the streamers applied the group scales / unquantised weights
             return float2{sc_.x * (t.x - sx.x - z_.x * sx.y), sc_.y * (t.y - sx.x - z_.y * sx.y)};
         };
+
+        // ---- LLM.int8 streams (FMT 2): what the gatherers add to the protocol.  After B1 the streamers quantise (FS_RUN_8): one more
+        // workgroup barrier (B1b), behind which gatherer 0 reads the vector's absmax SCA (max of the waves') and puts the outlier columns
+        // in ascending order.  The epilogue is csrc/int8.hip's: f16(((acc * 1/127^2) * SCA) * SCB[n]), plus, when there are outlier
+        // columns, f16(sum_k xh[k] * f16(CB[n,k] * SCB[n] / 127)) added in f16 (the sum split over the 8 lanes of a row pair).
+        [[maybe_unused]] float sca8 = 0.f;
+        [[maybe_unused]] int n_out8 = 0;
+        [[maybe_unused]] auto f16r = [](float v) { return (float)(_Float16)v; };
+        [[maybe_unused]] auto post_b1 = [&]() {
+            if constexpr (FMT == 2) {
+                __syncthreads();  // B1b
+                if (gw == 0) {
+                    const f32x4 ma = *(const f32x4*)(misc + 8), mb = *(const f32x4*)(misc + 12);
+                    sca8 = fmaxf(fmaxf(fmaxf(ma[0], ma[1]), fmaxf(ma[2], ma[3])), fmaxf(fmaxf(mb[0], mb[1]), fmaxf(mb[2], mb[3])));
+                    // the ascending list of outlier columns from the bit set, as csrc/int8.hip's wave 0 writes it
+                    const unsigned* obits = (const unsigned*)(smem + kOffObits);
+                    uint16_t* ol = (uint16_t*)(smem + kOffOlist);
+                    int oc = 0;
+                    for (int w0 = 0; w0 < 96 * 4; w0 += 64) {
+                        const unsigned word = obits[w0 + lane_v];
+                        unsigned long long live = __ballot(word != 0u);
+                        while (live != 0ull) {
+                            const int src = __builtin_ctzll(live);
+                            live &= live - 1ull;
+                            unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)word, src);
+                            while (bits != 0u) {
+                                const int b = __builtin_ctz(bits);
+                                bits &= bits - 1u;
+                                if (lane_v == 0 && oc < kMaxOut) ol[oc] = (uint16_t)(((w0 + src) << 5) + b);
+                                ++oc;
+                            }
+                        }
+                    }
+                    if (oc > kMaxOut) {  // (a vector with more than 1024 columns past the threshold: not what LLM.int8 is for)
+                        if (lane == 0) raise_abort(p, 0x700u + edge);
+                        oc = kMaxOut;
+                    }
+                    n_out8 = oc;
+                }
+            }
+        };
+        [[maybe_unused]] auto isum8 = [](int v) {
+            v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+            return v;
+        };
+        // rows n0, n0 + 1 (n0 even) of partial tile r; wb: the phase's I8 stream [tile][unit][RL][2][lane][16 B], rl: which matrix of a pair
+        [[maybe_unused]] auto tile_deq8 = [&](int r, float2 scb, const uint8_t* wb, int units, int RL, int rl, int n0) {
+            const int* pi = (const int*)(part + (size_t)((buf * kSW + w8) * 4 + r) * 64) + psrc;
+            const int tx = isum8(pi[0]), ty = isum8(pi[1]);
+            float dx = f16r((((float)tx * 6.200012e-05f) * sca8) * scb.x), dy = f16r((((float)ty * 6.200012e-05f) * sca8) * scb.y);
+            if (n_out8 > 0) {
+                const uint16_t* ol = (const uint16_t*)(smem + kOffOlist);
+                float ox = 0.f, oy = 0.f;
+                for (int i = w8; i < n_out8; i += 8) {
+                    const int k = ol[i];
+                    const float xv = (float)*(const _Float16*)(xs + (size_t)k * 2);
+                    const size_t o0 = ((((size_t)(n0 >> 4) * units + (k >> 7)) * RL + rl) * 2 + ((k >> 6) & 1)) * 1024 +
+                                      (size_t)(((k >> 4) & 3) * 16 + (n0 & 15)) * 16 + (k & 15);
+                    const float c0 = (float)(int8_t)wb[o0], c1 = (float)(int8_t)wb[o0 + 16];
+                    ox += xv * f16r(__fdiv_rn(c0 * scb.x, 127.0f));
+                    oy += xv * f16r(__fdiv_rn(c1 * scb.y, 127.0f));
+                }
+                ox = group_sum(ox, 8);
+                oy = group_sum(oy, 8);
+                dx = f16r(dx + f16r(ox));
+                dy = f16r(dy + f16r(oy));
+            }
+            return float2{dx, dy};
+        };
+        [[maybe_unused]] auto ldscb = [&](const float* q) { return float2{q[0], q[1]}; };
+        [[maybe_unused]] const float* scb_l = (const float*)p.sz;  // FMT 2: per layer SCB of c_attn[3C] attn.c_proj[C] c_fc1[H] c_fc2[H] mlp.c_proj[C]
+        [[maybe_unused]] const uint8_t* wl8 = p.w;
 
         // ---- the residual rows of this workgroup: embedding of the step's token (model.py:102)
         int r0 = bid * 16 + 2 * pg;  // first row of this lane's pair among the n_embd residual rows
@@ -891,23 +1196,30 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             if (gw == 0) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    sc[r] = ldsz(sz_l + nq + r * kC);
-                    zr[r] = ldsz(sz_l + 3 * kC + nq + r * kC);
+                    if constexpr (FMT == 2) {
+                        sc[r] = ldscb(scb_l + nq + r * kC);
+                        zr[r] = float2{0.f, 0.f};
+                    } else {
+                        sc[r] = ldsz(sz_l + nq + r * kC);
+                        zr[r] = ldsz(sz_l + 3 * kC + nq + r * kC);
+                    }
                 }
             }
             gather_x();
             FS_GSTAMP(2);
             FS_GCOUNT(40);
             __syncthreads();  // B1
+            post_b1();
             __syncthreads();  // Bt (one virtual tile)
             if (gw == 0) {
                 rinv_seen = misc[0];
-                const float rinv = rinv_seen / x_scale;
+                const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;  // (int8 streams: 1/rms is inside the quantised operand)
                 const float2 sx = get_sums();
                 float2 y[3];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    y[r] = deq(tile_pair(r), sc[r], zr[r], sx);
+                    if constexpr (FMT == 2) y[r] = tile_deq8(r, sc[r], wl8 + p.off_attn, kUnitsC, 1, 0, nq + r * kC);
+                    else y[r] = deq(tile_pair(r), sc[r], zr[r], sx);
                     y[r].x *= rinv;
                     y[r].y *= rinv;
                 }
@@ -974,7 +1286,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     const float inv = 1.0f / group_sum(misc[24 + w8] * wsc, 8);
                     // attention output elements head * 128 + hj * 16 + 2 pg, + 1 -> one pair granule
                     if (w8 == 0)
-                        gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair(o.x * inv, o.y * inv));
+                        gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair_b(o.x * inv, o.y * inv));
                 }
                 if (split) {
                     // row-split attention: this workgroup's partial over ITS rows (all 128 dimensions) goes to the head
@@ -1030,7 +1342,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         const float oy = group_sum(__uint_as_float(v1[2]) * wsc, 8);
                         const float inv = 1.0f / group_sum(lj * wsc, 8);
                         if (w8 == 0)
-                            gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair(ox * inv, oy * inv));
+                            gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair_b(ox * inv, oy * inv));
                     }
                     ppar ^= 1;
                 }
@@ -1041,11 +1353,18 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             {
                 float2 s1 = {0.f, 0.f}, z1 = {0.f, 0.f}, gn = {0.f, 0.f};
                 if (gw == 0) {
-                    s1 = ldsz(sz_l + 6 * kC + r0);
-                    z1 = ldsz(sz_l + 7 * kC + r0);
+                    if constexpr (FMT == 2) {
+                        s1 = ldscb(scb_l + 3 * kC + r0);
+                    } else {
+                        s1 = ldsz(sz_l + 6 * kC + r0);
+                        z1 = ldsz(sz_l + 7 * kC + r0);
+                    }
                     gn = ldpair(norms_l + kC + r0);  // rms_2
                 }
                 const unsigned ep = ebase + edge;
+                if constexpr (FMT == 2) {
+                    if (gw == 1) zero_obits();
+                }
                 u32x4 v[8];
                 sweep<8>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, ep, v, 0x400u + edge, lane_v, &n_sweeps);
                 FS_GCOUNT(42);
@@ -1060,9 +1379,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 ++edge;
                 FS_GSTAMP(7);
                 __syncthreads();  // B1
+                post_b1();
                 __syncthreads();  // Bt
                 if (gw == 0) {
-                    const float2 d = deq(tile_pair(0), s1, z1, get_sums());
+                    float2 d;
+                    if constexpr (FMT == 2) d = tile_deq8(0, s1, wl8 + p.off_proj, kUnitsC, 1, 0, r0);
+                    else d = deq(tile_pair(0), s1, z1, get_sums());
                     xres.x += d.x;
                     xres.y += d.y;
                     publish_x(xres, gn);
@@ -1079,30 +1401,44 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
 #pragma unroll
                     for (int t = 0; t < kMaxFcTiles; ++t) {
                         const int n = (bid + (t < n_fc ? t : 0) * kG) * 16 + 2 * pg;
-                        fs1[t] = ldsz(s_fc + n);
-                        fz1[t] = ldsz(s_fc + p.H + n);
-                        fs2[t] = ldsz(s_fc + 2 * p.H + n);
-                        fz2[t] = ldsz(s_fc + 3 * p.H + n);
+                        if constexpr (FMT == 2) {
+                            fs1[t] = ldscb(scb_l + 4 * kC + n);
+                            fs2[t] = ldscb(scb_l + 4 * kC + p.H + n);
+                            fz1[t] = fz2[t] = float2{0.f, 0.f};
+                        } else {
+                            fs1[t] = ldsz(s_fc + n);
+                            fz1[t] = ldsz(s_fc + p.H + n);
+                            fs2[t] = ldsz(s_fc + 2 * p.H + n);
+                            fz2[t] = ldsz(s_fc + 3 * p.H + n);
+                        }
                     }
                 }
                 gather_x();
                 FS_GSTAMP(9);
                 FS_GCOUNT(43);
                 __syncthreads();  // B1
+                post_b1();
                 const unsigned ep = ebase + edge;
                 u64* dst = p.gh + (size_t)hpar * (p.H / 2);
                 rinv_seen = misc[0];
-                const float rinv = rinv_seen / x_scale;
+                const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;
                 const float2 sx = get_sums();
 #pragma unroll
                 for (int t = 0; t < kMaxFcTiles; ++t) {
                     __syncthreads();  // Bt
                     if (gw == 0 && t < n_fc) {
-                        const float2 a = deq(tile_pair(0), fs1[t], fz1[t], sx);
-                        const float2 b = deq(tile_pair(1), fs2[t], fz2[t], sx);
+                        float2 a, b;
+                        if constexpr (FMT == 2) {
+                            const int n = (bid + t * kG) * 16 + 2 * pg;
+                            a = tile_deq8(0, fs1[t], wl8 + p.off_fc, kUnitsC, 2, 0, n);
+                            b = tile_deq8(1, fs2[t], wl8 + p.off_fc, kUnitsC, 2, 1, n);
+                        } else {
+                            a = deq(tile_pair(0), fs1[t], fz1[t], sx);
+                            b = deq(tile_pair(1), fs2[t], fz2[t], sx);
+                        }
                         if (w8 == 0)
                             gr_store(dst + (bid + t * kG) * 8 + pg, ep,
-                                     hpair(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv)));
+                                     hpair_b(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv)));
                     }
                     buf ^= 1;
                 }
@@ -1114,11 +1450,18 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 float2 s1 = {0.f, 0.f}, z1 = {0.f, 0.f}, gn = {0.f, 0.f};
                 const bf16_t* s_mp = sz_l + 8 * kC + 4 * p.H;
                 if (gw == 0) {
-                    s1 = ldsz(s_mp + r0);
-                    z1 = ldsz(s_mp + kC + r0);
+                    if constexpr (FMT == 2) {
+                        s1 = ldscb(scb_l + 4 * kC + 2 * p.H + r0);
+                    } else {
+                        s1 = ldsz(s_mp + r0);
+                        z1 = ldsz(s_mp + kC + r0);
+                    }
                     gn = ldpair(norms_l + 2 * kC + r0);  // rms_1 of the next layer, or ln_f after the last
                 }
                 const unsigned ep = ebase + edge;
+                if constexpr (FMT == 2) {
+                    if (gw == 1) zero_obits();
+                }
                 const int n_loads = p.H / 4, half_l = (n_loads + 1) / 2;
                 const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
                 float2 sxp = {0.f, 0.f};
@@ -1198,9 +1541,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 ++edge;
                 FS_GSTAMP(11);
                 __syncthreads();  // B1
+                post_b1();
                 __syncthreads();  // Bt
                 if (gw == 0) {
-                    const float2 d = deq(tile_pair(0), s1, z1, get_sums());
+                    float2 d;
+                    if constexpr (FMT == 2) d = tile_deq8(0, s1, wl8 + p.off_mproj, p.units_h, 1, 0, r0);
+                    else d = deq(tile_pair(0), s1, z1, get_sums());
                     xres.x += d.x;
                     xres.y += d.y;
                     publish_x(xres, gn);
@@ -1211,6 +1557,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }
             norms_l += 2 * kC;
             sz_l += p.sz_layer_stride;
+            if constexpr (FMT == 2) {
+                scb_l += p.sz_layer_stride;  // (floats: 5 C + 2 H)
+                wl8 += p.layer_stride;
+            }
             kv_l += (size_t)2 * kHeads * p.S * kHs;
         }
         dbg_on = false;
@@ -1220,26 +1570,34 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             auto head_sz = [&](int t, float2& sc_, float2& z_) {
                 const int n = (bid + t * kG) * 16 + 2 * pg;
                 const bool ok = t < n_head_t && n + 1 < p.V;
-                sc_ = ok ? ldsz(p.sz_head + n) : float2{0.f, 0.f};
-                z_ = ok ? ldsz(p.sz_head + p.V + n) : float2{0.f, 0.f};
+                if constexpr (FMT == 2) {
+                    sc_ = ok ? ldscb((const float*)p.sz_head + n) : float2{0.f, 0.f};
+                    z_ = float2{0.f, 0.f};
+                } else {
+                    sc_ = ok ? ldsz(p.sz_head + n) : float2{0.f, 0.f};
+                    z_ = ok ? ldsz(p.sz_head + p.V + n) : float2{0.f, 0.f};
+                }
             };
             float2 sct = {0.f, 0.f}, zt = {0.f, 0.f};
             if (gw == 0) head_sz(0, sct, zt);
             gather_x();
             __syncthreads();  // B1
+            post_b1();
             rinv_seen = misc[0];
-                const float rinv = rinv_seen / x_scale;
+            const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;
             const float2 sx = get_sums();
             float best = -INFINITY;
             int bi = 0x7fffffff;
-            const int tiles_pad = p.head_turns * 3;
+            const int tiles_pad = p.head_turns * 12 / (4 * kSub);  // tile ends the streamers pass (4 kSub ring steps per tile and wave)
             for (int t = 0; t < tiles_pad; ++t) {
                 float2 scn = {0.f, 0.f}, zn = {0.f, 0.f};
                 if (gw == 0) head_sz(t + 1, scn, zn);
                 __syncthreads();  // Bt
                 if (gw == 0 && t < n_head_t) {
                     const int n = (bid + t * kG) * 16 + 2 * pg;
-                    float2 y = deq(tile_pair(0), sct, zt, sx);
+                    float2 y;
+                    if constexpr (FMT == 2) y = tile_deq8(0, sct, p.w_head, kUnitsC, 1, 0, n);
+                    else y = deq(tile_pair(0), sct, zt, sx);
                     y.x *= rinv;
                     y.y *= rinv;
                     if (n + 1 < p.V) {  // vocab sizes are even (host check): a pair is inside or outside
@@ -1329,14 +1687,17 @@ int fused_step_ring_occupancy_ok() {
     static int ok = -1;
     static std::once_flag once;
     std::call_once(once, [] {
-        int per_cu = 0, per_cu_g = 0;
-        (void)hipFuncSetAttribute((const void*)fused_step_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void)hipFuncSetAttribute((const void*)fused_step_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesG);
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fused_step_ring_kernel<false>, kThreads, kLdsBytes);
-        hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_g, (const void*)fused_step_ring_kernel<true>, kThreads, kLdsBytesG);
-        ok = (e == hipSuccess && per_cu >= 1 ? 1 : 0) | (e2 == hipSuccess && per_cu_g >= 1 ? 2 : 0);
+        const void* fn[4] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
+                             (const void*)fused_step_ring_kernel<false, 1>, (const void*)fused_step_ring_kernel<false, 2>};
+        ok = 0;
+        for (int i = 0; i < 4; ++i) {
+            int per_cu = 0;
+            (void)hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn[i], kThreads, kLdsBytes) == hipSuccess && per_cu >= 1)
+                ok |= 1 << i;
+        }
     });
-    return ok;  // bit 0: the per-row kernel fits one workgroup per CU, bit 1: the grouped-scale kernel
+    return ok;  // bit 0: the per-row int4 kernel fits one workgroup per CU, bit 1: the grouped-scale kernel, bit 2: BF16, bit 3: LLM.int8
 }
 
 // launched by mi355_fused_step (fused_step.hip)
@@ -1344,23 +1705,31 @@ int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t 
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute((const void*)fused_step_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        if (attr_err == hipSuccess)
-            attr_err = hipFuncSetAttribute((const void*)fused_step_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesG);
+        const void* fn[4] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
+                             (const void*)fused_step_ring_kernel<false, 1>, (const void*)fused_step_ring_kernel<false, 2>};
+        for (int i = 0; i < 4 && attr_err == hipSuccess; ++i)
+            attr_err = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     });
     MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "fused_step: hipFuncSetAttribute failed: %s",
                     hipGetErrorString(attr_err));
-    if (p.grouped) {
-        if (e0 != nullptr) {
-            hipExtLaunchKernelGGL(fused_step_ring_kernel<true>, dim3(kG), dim3(kThreads), (uint32_t)kLdsBytesG, stream, e0, e1, 0, p);
-        } else {
-            hipLaunchKernelGGL(fused_step_ring_kernel<true>, dim3(kG), dim3(kThreads), kLdsBytesG, stream, p);
-        }
-    } else if (e0 != nullptr) {
-        hipExtLaunchKernelGGL(fused_step_ring_kernel<false>, dim3(kG), dim3(kThreads), (uint32_t)kLdsBytes, stream, e0, e1, 0, p);
+#define FS_LAUNCH(K_)                                                                                                  \
+    do {                                                                                                              \
+        if (e0 != nullptr) {                                                                                          \
+            hipExtLaunchKernelGGL((K_), dim3(kG), dim3(kThreads), (uint32_t)kLdsBytes, stream, e0, e1, 0, p);          \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL((K_), dim3(kG), dim3(kThreads), kLdsBytes, stream, p);                                  \
+        }                                                                                                             \
+    } while (0)
+    if (p.fmt == 2) {
+        FS_LAUNCH((fused_step_ring_kernel<false, 2>));
+    } else if (p.fmt == 1) {
+        FS_LAUNCH((fused_step_ring_kernel<false, 1>));
+    } else if (p.grouped) {
+        FS_LAUNCH((fused_step_ring_kernel<true, 0>));
     } else {
-        hipLaunchKernelGGL(fused_step_ring_kernel<false>, dim3(kG), dim3(kThreads), kLdsBytes, stream, p);
+        FS_LAUNCH((fused_step_ring_kernel<false, 0>));
     }
+#undef FS_LAUNCH
     MI355_LAUNCH_CHECK();
     return 0;
 }

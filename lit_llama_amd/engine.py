@@ -106,7 +106,7 @@ def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: 
         if not hasattr(mod.weight, "CB"):
             raise EngineUnavailable("Linear8bitLt weight not quantised yet")
         N, K = mod.out_features, mod.in_features
-        stream = ops.repack_i8(mod.weight.CB, pair.weight.CB if pair is not None else None, d.R)
+        stream = ops.repack_i8(mod.weight.CB, pair.weight.CB if pair is not None else None, d.R, out=out)
         d.fmt, d.w, d.N, d.K = W_I8, ptr(stream), N, K
         d.scb = ptr(mod.weight.SCB)
         pw.keep += [stream, mod.weight.SCB]
@@ -121,7 +121,7 @@ def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: 
         if mod.weight.dtype != torch.bfloat16:
             raise EngineUnavailable(f"dense weights are {mod.weight.dtype}; the MFMA path needs bf16")
         N, K = mod.weight.shape
-        stream = ops.repack_bf16(mod.weight.detach(), pair.weight.detach() if pair is not None else None, d.R)
+        stream = ops.repack_bf16(mod.weight.detach(), pair.weight.detach() if pair is not None else None, d.R, out=out)
         d.fmt, d.w, d.N, d.K = W_BF16, ptr(stream), N, K
         pw.keep.append(stream)
     pw.stream_bytes = pw.keep[0].numel()
@@ -146,13 +146,26 @@ def model_fingerprint(model: "nn.Module") -> tuple:
 def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
     """Byte layout of the weight arena of the fused decode step (csrc/fused_step.hip), or None when the model is
     not one the persistent launch handles (then every linear keeps its own stream tensor)."""
-    if _env_int("MI355_FUSED", 1) == 0 or kinds != {"q4"}:
+    if _env_int("MI355_FUSED", 1) == 0 or kinds not in ({"q4"}, {"bf16"}, {"i8"}):
         return None
     if any(hasattr(blk.attn, "adapter_wte") for blk in model.transformer.h):
         return None  # LLaMA-Adapter blocks: the prefix term lives in the launch-per-operator step
     if not lib().mi355_fused_step_supported(C_, nh, hs, H, V, 1):
         return None
     first = model.transformer.h[0]
+    if kinds in ({"bf16"}, {"i8"}):
+        # unquantised models (BASELINE configs[1]) and LLM.int8 models (configs[3]): the BF16 / int8 instantiations of the
+        # register-ring kernel (round 4) over BF16 / I8 streams
+        wfmt, fmt, env = (W_BF16, 1, "MI355_FUSED_BF16") if kinds == {"bf16"} else (W_I8, 2, "MI355_FUSED_INT8")
+        if _env_int(env, 1) == 0 or os.environ.get("MI355_FUSED_IMPL", "") == "lds":
+            return None
+        sizes = [ops.packed_bytes(wfmt, 3 * C_, C_, 1, False), ops.packed_bytes(wfmt, C_, C_, 1, False),
+                 ops.packed_bytes(wfmt, H, C_, 2, True), ops.packed_bytes(wfmt, C_, H, 1, False)]
+        offs = [0, sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2]]
+        layer_bytes = sum(sizes)
+        if layer_bytes >= 1 << 31 or ops.packed_bytes(wfmt, V, C_, 1, False) >= 1 << 31:
+            return None  # (a layer is addressed through one 32-bit buffer descriptor)
+        return {"sizes": sizes, "offs": offs, "layer_bytes": layer_bytes, "group_cols": 0, "fmt": fmt}
     group_cols = 0
     mods = [m_ for blk in model.transformer.h
             for m_ in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj)] + [model.lm_head]
@@ -366,10 +379,20 @@ class DecodeEngine:
         C_, H, V = cfg.n_embd, self.n_hidden, model.lm_head.out_features
         gc = plan.get("group_cols", 0)
 
+        fmt = plan.get("fmt", 0)
         with torch.cuda.device(dev):
             sz = sz_head = gt = gt_head = None
             norms = torch.empty((2 * cfg.n_layer + 1, C_), dtype=torch.bfloat16, device=dev)
-            if gc:
+            if fmt == 1:
+                pass  # BF16 streams: no scales / zeros
+            elif fmt == 2:
+                # LLM.int8: the f32 row scales SCB per layer, c_attn[3C] attn.c_proj[C] c_fc1[H] c_fc2[H] mlp.c_proj[C]; lm_head's [V]
+                sz = torch.stack([torch.cat([mod.weight.SCB.reshape(-1).float() for mod in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1,
+                                                                                           blk.mlp.c_fc2, blk.mlp.c_proj)])
+                                  for blk in model.transformer.h]).contiguous()
+                assert sz.shape == (cfg.n_layer, 5 * C_ + 2 * H)
+                sz_head = model.lm_head.weight.SCB.reshape(-1).float().contiguous()
+            elif gc:
                 rows = []
                 for blk in model.transformer.h:
                     rows.append(torch.cat([group_table(mod.scales, mod.zeros) for mod in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1,
@@ -380,7 +403,7 @@ class DecodeEngine:
                 sz = torch.empty((cfg.n_layer, 10 * C_ + 4 * H), dtype=torch.bfloat16, device=dev)
                 sz_head = torch.cat([model.lm_head.scales.reshape(-1), model.lm_head.zeros.reshape(-1)]).contiguous()
             for i, blk in enumerate(model.transformer.h):
-                if not gc:
+                if not gc and fmt == 0:
                     parts = []
                     for mod in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj):
                         parts += [mod.scales.reshape(-1), mod.zeros.reshape(-1)]
@@ -395,6 +418,7 @@ class DecodeEngine:
         a.layer_bytes, a.head_bytes = plan["layer_bytes"], head.stream_bytes
         a.w_head = head.desc.w
         a.sz, a.sz_head, a.norms = ptr(sz), ptr(sz_head), ptr(norms)
+        a.weight_fmt = fmt
         if gc:
             a.group_cols, a.gt, a.gt_head, a.gt_layer_stride = gc, ptr(gt), ptr(gt_head), gt.shape[1] * 4
         a.wte, a.rope = self.m.wte, self.m.rope

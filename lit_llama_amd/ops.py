@@ -72,27 +72,36 @@ def unpack_q4_stream(stream: torch.Tensor, N: int, K: int, R: int, pair: bool, w
     return packed.t().contiguous().t()
 
 
-def repack_bf16(w0: torch.Tensor, w1: Optional[torch.Tensor], R: int) -> torch.Tensor:
+def repack_bf16(w0: torch.Tensor, w1: Optional[torch.Tensor], R: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[N, K] f32 / bf16 weights -> BF16 stream (`out`: a slice of a caller's arena, as for `repack_q4`)."""
     require_gpu(w0, "repack_bf16")
     N, K = w0.shape
     w0 = w0.contiguous()
     if w1 is not None:
         w1 = w1.contiguous()
         assert w1.shape == w0.shape and w1.dtype == w0.dtype
-    out = torch.empty(packed_bytes(W_BF16, N, K, R, w1 is not None), dtype=torch.uint8, device=w0.device)
+    nbytes = packed_bytes(W_BF16, N, K, R, w1 is not None)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=w0.device)
+    elif out.dtype != torch.uint8 or out.numel() != nbytes or not out.is_contiguous() or out.device != w0.device:
+        raise nat.NativeError(f"repack_bf16: `out` must be a contiguous uint8 tensor of {nbytes} bytes on {w0.device}")
     check(lib().mi355_bf16_repack(ptr(w0), ptr(w1), dtype_code(w0.dtype), N, K, R, ptr(out), stream_ptr()),
           "mi355_bf16_repack")
     return out
 
 
-def repack_i8(c0: torch.Tensor, c1: Optional[torch.Tensor], R: int) -> torch.Tensor:
+def repack_i8(c0: torch.Tensor, c1: Optional[torch.Tensor], R: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     require_gpu(c0, "repack_i8")
     N, K = c0.shape
     assert c0.dtype == torch.int8
     c0 = c0.contiguous()
     if c1 is not None:
         c1 = c1.contiguous()
-    out = torch.empty(packed_bytes(W_I8, N, K, R, c1 is not None), dtype=torch.uint8, device=c0.device)
+    nbytes = packed_bytes(W_I8, N, K, R, c1 is not None)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=c0.device)
+    elif out.dtype != torch.uint8 or out.numel() != nbytes or not out.is_contiguous() or out.device != c0.device:
+        raise nat.NativeError(f"repack_i8: `out` must be a contiguous uint8 tensor of {nbytes} bytes on {c0.device}")
     check(lib().mi355_i8_repack(ptr(c0), ptr(c1), N, K, R, ptr(out), stream_ptr()), "mi355_i8_repack")
     return out
 
