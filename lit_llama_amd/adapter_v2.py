@@ -44,8 +44,11 @@ def adapter_v2_new_forward(self, input: torch.Tensor) -> torch.Tensor:
 def adapter_v2_linear_with_bias_and_scale(layer: nn.Linear) -> nn.Linear:
     """Identity at initialisation: bias 0, scale 1 (adapter_v2.py:35-40)."""
     w = layer.weight
-    layer.adapter_bias = torch.nn.Parameter(torch.zeros(w.shape[0], device=w.device, dtype=w.dtype), requires_grad=True)
-    layer.adapter_scale = torch.nn.Parameter(torch.ones(w.shape[0], device=w.device, dtype=w.dtype), requires_grad=True)
+    # (a quantised plug-in keeps an integer weight: Linear8bitLt's int8 rows — the pair is float there, in the default dtype as the
+    # reference's `torch.zeros(layer.weight.shape[0])` is; the epilogue casts it to the output's dtype)
+    dt = w.dtype if w.is_floating_point() else torch.get_default_dtype()
+    layer.adapter_bias = torch.nn.Parameter(torch.zeros(w.shape[0], device=w.device, dtype=dt), requires_grad=True)
+    layer.adapter_scale = torch.nn.Parameter(torch.ones(w.shape[0], device=w.device, dtype=dt), requires_grad=True)
     return layer
 
 
