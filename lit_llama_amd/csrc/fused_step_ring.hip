@@ -65,6 +65,12 @@ constexpr unsigned kSpinLimit = 400000u;
 #ifndef MI355_FUSED_G0_PAIRS
 #define MI355_FUSED_G0_PAIRS 6
 #endif
+#ifndef MI355_FUSED_VSPLIT
+#define MI355_FUSED_VSPLIT 0  // c_attn epilogue: gatherer 1 dequantises and publishes the v rows (int4 streams; A / B knob)
+#endif
+#ifndef MI355_FUSED_GPRIO
+#define MI355_FUSED_GPRIO 0
+#endif
 #ifndef MI355_FUSED_SPLIT_POS
 #define MI355_FUSED_SPLIT_POS 384
 #endif
@@ -912,6 +918,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
     } else {
         // =========================================================================================== gatherers
         const int gw = wave - kSW;  // 0: combines / publishes, 1: helps with the sweeps
+#if MI355_FUSED_GPRIO
+        __builtin_amdgcn_s_setprio(MI355_FUSED_GPRIO);  // (A / B knob: the gatherers' instructions issue ahead of the streamers')
+#endif
         unsigned edge = 0;   // edges published so far in this step (the epoch of the next one is ebase + edge)
         int xpar = 0, apar = 0, hpar = 0, qpar = 0, ppar = 0;
         int buf = 0;
@@ -1079,7 +1088,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if (lane == 0) {
                     const float rv = rsqrtf(ss / (float)kC + p.eps);
                     misc[0] = rv;
-                    if constexpr (FMT == 2) misc[1] = rv / x_scale;  // what the streamers multiply the staged values by before their f16 cast
+                    misc[1] = rv / x_scale;  // (int8 streams: what the streamers multiply the staged values by before their f16 cast)
                 }
             } else {
                 if constexpr (FMT == 2) zero_obits();
@@ -1193,7 +1202,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             // ================= c_attn
             const int nq = (head * 8 + hj) * 16 + 2 * pg;  // q rows of this lane's pair; k at + C, v at + 2 C
             float2 sc[3], zr[3];
-            if (gw == 0) {
+            constexpr bool VSPLIT = MI355_FUSED_VSPLIT && FMT == 0;
+            if (gw == 0 || VSPLIT) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     if constexpr (FMT == 2) {
@@ -1211,13 +1221,24 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             __syncthreads();  // B1
             post_b1();
             __syncthreads();  // Bt (one virtual tile)
+            if (VSPLIT && gw == 1) {
+                // the v rows: dequantise, publish to the head group, write the cache row (gatherer 0 keeps q and k)
+                const float rinv1 = misc[1];  // 1/rms over the edge scale (gather_x)
+                const float2 sx = get_sums();
+                float2 yv = deq(tile_pair(2), sc[2], zr[2], sx);
+                const unsigned vp = bfpair(yv.x * rinv1, yv.y * rinv1);
+                u64* dst = p.gq + ((size_t)qpar * kHeads + head) * 256 + hj * 32;
+                bf16_t* vrow = kv_l + ((size_t)head * p.S + pos) * kHs + hj * 16 + (size_t)kHeads * p.S * kHs;
+                if (w8 == 3) gr_store(dst + 24 + pg, ebase + edge, vp);
+                if (w8 == 5) ((unsigned*)vrow)[pg] = vp;
+            }
             if (gw == 0) {
                 rinv_seen = misc[0];
                 const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;  // (int8 streams: 1/rms is inside the quantised operand)
                 const float2 sx = get_sums();
                 float2 y[3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
+                for (int r = 0; r < (VSPLIT ? 2 : 3); ++r) {
                     if constexpr (FMT == 2) y[r] = tile_deq8(r, sc[r], wl8 + p.off_attn, kUnitsC, 1, 0, nq + r * kC);
                     else y[r] = deq(tile_pair(r), sc[r], zr[r], sx);
                     y[r].x *= rinv;
@@ -1230,13 +1251,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 bf16_t* vrow = krow + (size_t)kHeads * p.S * kHs;
                 const float qa = y[0].x * cs.x - y[0].y * cs.y, qb = y[0].y * cs.x + y[0].x * cs.y;
                 const unsigned kp = bfpair(y[1].x * cs.x - y[1].y * cs.y, y[1].y * cs.x + y[1].x * cs.y);
-                const unsigned vp = bfpair(y[2].x, y[2].y);
                 if (w8 == 0) gr_store(dst + 2 * pg, ep, __float_as_uint(qa));
                 if (w8 == 1) gr_store(dst + 2 * pg + 1, ep, __float_as_uint(qb));
                 if (w8 == 2) gr_store(dst + 16 + pg, ep, kp);
-                if (w8 == 3) gr_store(dst + 24 + pg, ep, vp);
                 if (w8 == 4) ((unsigned*)krow)[pg] = kp;
-                if (w8 == 5) ((unsigned*)vrow)[pg] = vp;
+                if constexpr (!VSPLIT) {
+                    const unsigned vp = bfpair(y[2].x, y[2].y);
+                    if (w8 == 3) gr_store(dst + 24 + pg, ep, vp);
+                    if (w8 == 5) ((unsigned*)vrow)[pg] = vp;
+                }
             }
             FS_GSTAMP(3);
             buf ^= 1;

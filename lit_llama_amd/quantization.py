@@ -215,7 +215,10 @@ class Linear8bitLt(torch.nn.Linear):
             return
         weight = state_dict.pop(weight_key)
         self._quantize_weight(weight)
-        if prefix + "bias" in state_dict:
+        # the module's other parameters — the bias, and the adapter_scale / adapter_bias pair LLaMA-Adapter v2 attaches to every
+        # nn.Linear, this class included (generate/adapter_v2.py with --quantize llm.int8) — go through nn.Module's loader, as the
+        # reference's `if local_state_dict: super()._load_from_state_dict(...)` does (round 4: only the bias used to be loaded)
+        if any(k.startswith(prefix) and "." not in k[len(prefix):] for k in state_dict):
             stash = self._parameters.pop("weight")
             try:
                 super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
