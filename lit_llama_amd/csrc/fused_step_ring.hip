@@ -81,10 +81,17 @@ constexpr int kPartStride = 136;  // granules per workgroup partial of the row-s
 constexpr int kOffMisc = 0;                       // [0] 1/rms, [4..7] operand sums, [16..23] / [24..31] per-wave softmax max / sum
 constexpr int kOffZero = 256;                     // one all-zero unit (idle ring steps read it)
 constexpr int kOffXs = 512;                       // activation vector, 16-bit values, <= 96 units
-// [2][8 waves][4 row tiles][4 row groups] f32x4: COLUMN 0 of a wave's 16 x 16 partial tiles (at M = 1 the 16 token columns are copies;
-// the GRP kernel has added its columns up before the store): 4 KiB.  (Round 3 kept the whole tiles: 64 KiB.)  The row-split
-// attention parks its per-wave partial outputs here ([8 waves][128] f32: the same 4 KiB).
-constexpr int kPartBytes = 2 * kSW * 4 * 64;
+// [2][8 waves][4 row tiles] partial 16 x 16 tiles of the streamer waves (f32; int8 streams: int32): whole tiles (1 KiB each), or column 0
+// only (64 B) with MI355_FUSED_PART_FULL = 0.  The row-split attention parks its per-wave partial outputs here ([8 waves][128] f32).
+// 1 (default): a wave parks its whole 16 x 16 partial tiles (64 KiB of LDS in all); 0: COLUMN 0 only (4 KiB; at M = 1 the other
+// columns are copies).  The small form measured SLOWER on the int4 step (profiles/r04_ab6_*.txt, us per step: box A small 934.9 against
+// 918.7 for the round-3 object; box B small 942.2, whole 936.2, round-3 object 933.3) although it moves 1/16 of the LDS bytes — the
+// masked store sits on the tile-end path of every phase — and nothing needs the LDS it frees.
+#ifndef MI355_FUSED_PART_FULL
+#define MI355_FUSED_PART_FULL 1
+#endif
+constexpr int kPartTile = MI355_FUSED_PART_FULL ? 1024 : 64;  // bytes of one partial tile in LDS
+constexpr int kPartBytes = 2 * kSW * 4 * kPartTile;
 constexpr int kOffPart = kOffXs + 96 * 256;
 constexpr int kOffQ = kOffPart + kPartBytes;      // q[128] knew[128] vnew[128] f32
 constexpr int kOffOpart = kOffQ + 3 * 512;        // [8 waves][16] f32
@@ -96,7 +103,10 @@ constexpr int kMaxOut = 1024;
 constexpr int kOffObits = kOffXq + 96 * 128;      // u32 [96 * 4]: outlier columns as a bit set (atomic OR by whichever lane stages the column)
 constexpr int kOffOlist = kOffObits + 96 * 16;    // u16 [kMaxOut]: the same columns in ascending order (gatherer 0, behind B1b)
 [[maybe_unused]] constexpr int kMaxS = 32768;     // cache rows (the attention keeps no per-row state in LDS)
-constexpr int kLdsBytes = kOffOlist + kMaxOut * 2;
+#ifndef MI355_FUSED_LDS_PAD
+#define MI355_FUSED_LDS_PAD 0  // (A / B knob: bytes of LDS requested on top of the map)
+#endif
+constexpr int kLdsBytes = kOffOlist + kMaxOut * 2 + MI355_FUSED_LDS_PAD;
 static_assert(kLdsBytes <= 160 * 1024 && kPartBytes >= kSW * 128 * 4, "LDS map");
 
 // ------------------------------------------------------------------------------------------------ granules
@@ -201,6 +211,11 @@ __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_b
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rs : rs_null, lane_off, ok ? soff : 0u, 2));
 }
 
+#if MI355_FUSED_PART_FULL
+#define FS_PART_LANE (lane_off >> 4)   /* every lane parks its 4 rows x 1 column */
+#else
+#define FS_PART_LANE (lane_off >> 8)   /* column 0 only: lanes 0, 16, 32, 48 = row groups 0..3 */
+#endif
 #define FS_STAMP(i)                                                                   \
     do {                                                                              \
         if (p.dbg != nullptr && (threadIdx.x & 63) == 0) p.dbg[bid * 64 + (i)] = wall_clock64(); \
@@ -428,8 +443,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         /* tile done: publish this wave's partial 16x16 tiles */                                      \
                         if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
                         /* column 0 only: lanes 0, 16, 32, 48 hold rows 4 g .. 4 g + 3 of it */                       \
-                        f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * 64) + (lane_off >> 8);       \
-                        const bool col0__ = (lane_off & 0xF0u) == 0u;                                                 \
+                        f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
+                        const bool col0__ = MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u;                       \
                         if constexpr (GRP) {                                                                          \
                             /* column c holds group gfirst + c: y = s (acc - 1024 (Se + So) - z (Se + 16 So)) with    */ \
                             /* the group's operand sums (units of the group), then the 16 columns are added up        */ \
@@ -443,12 +458,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                                     const float sc__ = __uint_as_float(w__ << 16), zp__ = __uint_as_float(w__ & 0xffff0000u); \
                                     y4__[e__] = group_sum(sc__ * (a4__[e__] - ga__ - zp__ * gb__), 16);               \
                                 }                                                                                     \
-                                if (col0__) pp__[r__ * 4] = y4__;                                                     \
+                                if (col0__) pp__[r__ * (kPartTile / 16)] = y4__;                                                     \
                                 acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                            \
                             }                                                                                         \
                         } else {                                                                                      \
                         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
-                            if (col0__) pp__[r__ * 4] = acc__[r__][0] + acc__[r__][1];                                \
+                            if (col0__) pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1];                                \
                             acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                                \
                         }                                                                                             \
                         }                                                                                             \
@@ -501,9 +516,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     }                                                                                                 \
                     if ((gstep__ + 1) % SPT__ == 0) { /* (bodies of 12 steps need not hold whole tiles) */         \
                         if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
-                        f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * 64) + (lane_off >> 8);       \
-                        if ((lane_off & 0xF0u) == 0u) {                                                               \
-                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * 4] = acc__[r__][0] + acc__[r__][1]; \
+                        f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
+                        if (MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u) {                                      \
+                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1]; \
                         }                                                                                             \
                         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f}; \
                         __syncthreads(); /* Bt */                                                                     \
@@ -620,9 +635,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     }                                                                                                 \
                     if ((gstep__ + 1) % SPT__ == 0) { /* (bodies of 12 steps need not hold whole tiles) */         \
                         if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
-                        i32x4* pp__ = (i32x4*)(part + (size_t)((buf * kSW + wave) * 4) * 64) + (lane_off >> 8);       \
-                        if ((lane_off & 0xF0u) == 0u) {                                                               \
-                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * 4] = acc__[r__][0] + acc__[r__][1]; \
+                        i32x4* pp__ = (i32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
+                        if (MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u) {                                      \
+                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1]; \
                         }                                                                                             \
                         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = i32x4{0, 0, 0, 0}; \
                         __syncthreads(); /* Bt */                                                                     \
@@ -940,9 +955,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         int lane_v = lane;  // made opaque once per layer: per-lane pointers are otherwise hoisted out of the layer loop
                             // (a few dozen 64-bit addresses) and spilled to scratch, i.e. to VMEM on the hand-off path
         int pg = lane >> 3, w8 = lane & 7;
-        int psrc = (pg >> 1) * 4 + ((2 * pg) & 3);  // float index of D[2 pg][0] in column 0 of a wave's partial tile
+        // float index of D[2 pg][0] in a wave's partial tile (column 0 is lane 16 g: 4 floats per row group, or per lane with whole tiles)
+        int psrc = (pg >> 1) * (MI355_FUSED_PART_FULL ? 64 : 4) + ((2 * pg) & 3);
         auto tile_pair = [&](int r) {
-            float2 t = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * 64) + psrc);
+            float2 t = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc);
             t.x = group_sum(t.x, 8);
             t.y = group_sum(t.y, 8);
             return t;
@@ -1088,7 +1104,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if (lane == 0) {
                     const float rv = rsqrtf(ss / (float)kC + p.eps);
                     misc[0] = rv;
+#if !defined(MI355_FUSED_NO_MISC1)
                     misc[1] = rv / x_scale;  // (int8 streams: what the streamers multiply the staged values by before their f16 cast)
+#endif
                 }
             } else {
                 if constexpr (FMT == 2) zero_obits();
@@ -1158,7 +1176,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         };
         // rows n0, n0 + 1 (n0 even) of partial tile r; wb: the phase's I8 stream [tile][unit][RL][2][lane][16 B], rl: which matrix of a pair
         [[maybe_unused]] auto tile_deq8 = [&](int r, float2 scb, const uint8_t* wb, int units, int RL, int rl, int n0) {
-            const int* pi = (const int*)(part + (size_t)((buf * kSW + w8) * 4 + r) * 64) + psrc;
+            const int* pi = (const int*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc;
             const int tx = isum8(pi[0]), ty = isum8(pi[1]);
             float dx = f16r((((float)tx * 6.200012e-05f) * sca8) * scb.x), dy = f16r((((float)ty * 6.200012e-05f) * sca8) * scb.y);
             if (n_out8 > 0) {
@@ -1197,7 +1215,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             asm volatile("" : "+v"(lane_v));
             pg = lane_v >> 3;
             w8 = lane_v & 7;
-            psrc = (pg >> 1) * 4 + ((2 * pg) & 3);
+            psrc = (pg >> 1) * (MI355_FUSED_PART_FULL ? 64 : 4) + ((2 * pg) & 3);
             r0 = bid * 16 + 2 * pg;
             // ================= c_attn
             const int nq = (head * 8 + hj) * 16 + 2 * pg;  // q rows of this lane's pair; k at + C, v at + 2 C
