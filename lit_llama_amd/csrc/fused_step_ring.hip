@@ -515,7 +515,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
                     }                                                                                                 \
                     if ((gstep__ + 1) % SPT__ == 0) { /* (bodies of 12 steps need not hold whole tiles) */         \
-                        if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
+                        FS_SSTAMP((STAMP_) + 1); /* (the last tile end is what stays) */                               \
                         f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
                         if (MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u) {                                      \
                             _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1]; \
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
                     }                                                                                                 \
                     if ((gstep__ + 1) % SPT__ == 0) { /* (bodies of 12 steps need not hold whole tiles) */         \
-                        if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
+                        FS_SSTAMP((STAMP_) + 1); /* (the last tile end is what stays) */                               \
                         i32x4* pp__ = (i32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
                         if (MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u) {                                      \
                             _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1]; \
@@ -1175,7 +1175,21 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             return v;
         };
         // rows n0, n0 + 1 (n0 even) of partial tile r; wb: the phase's I8 stream [tile][unit][RL][2][lane][16 B], rl: which matrix of a pair
-        [[maybe_unused]] auto tile_deq8 = [&](int r, float2 scb, const uint8_t* wb, int units, int RL, int rl, int n0) {
+        // the weight bytes of this lane's FIRST outlier column (outlier w8 of the list: the fast path for up to 8 of them), requested
+        // right behind B1b — the phase streams for microseconds before the epilogue needs them; a load issued in the epilogue itself
+        // sits on the chain (mlp.c_proj published 1.58 us after consumed: the SwiGLU output has an outlier in almost every step)
+        [[maybe_unused]] int pb0[6] = {0, 0, 0, 0, 0, 0}, pb1[6] = {0, 0, 0, 0, 0, 0};
+        [[maybe_unused]] auto pre8 = [&](int& b0, int& b1, const uint8_t* wb, int units, int RL, int rl, int n0) {
+            if (w8 < n_out8) {
+                const int k = ((const uint16_t*)(smem + kOffOlist))[w8];
+                const size_t o0 = ((((size_t)(n0 >> 4) * units + (k >> 7)) * RL + rl) * 2 + ((k >> 6) & 1)) * 1024 +
+                                  (size_t)(((k >> 4) & 3) * 16 + (n0 & 15)) * 16 + (k & 15);
+                b0 = wb[o0];
+                b1 = wb[o0 + 16];
+            }
+        };
+        [[maybe_unused]] auto tile_deq8 = [&](int r, float2 scb, const uint8_t* wb, int units, int RL, int rl, int n0, int q0 = -1,
+                                              int q1 = 0) {
             const int* pi = (const int*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc;
             const int tx = isum8(pi[0]), ty = isum8(pi[1]);
             float dx = f16r((((float)tx * 6.200012e-05f) * sca8) * scb.x), dy = f16r((((float)ty * 6.200012e-05f) * sca8) * scb.y);
@@ -1187,7 +1201,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     const float xv = (float)*(const _Float16*)(xs + (size_t)k * 2);
                     const size_t o0 = ((((size_t)(n0 >> 4) * units + (k >> 7)) * RL + rl) * 2 + ((k >> 6) & 1)) * 1024 +
                                       (size_t)(((k >> 4) & 3) * 16 + (n0 & 15)) * 16 + (k & 15);
-                    const float c0 = (float)(int8_t)wb[o0], c1 = (float)(int8_t)wb[o0 + 16];
+                    float c0, c1;
+                    if (q0 >= 0 && i == w8) {  // prefetched (pre8)
+                        c0 = (float)(int8_t)q0;
+                        c1 = (float)(int8_t)q1;
+                    } else {
+                        c0 = (float)(int8_t)wb[o0];
+                        c1 = (float)(int8_t)wb[o0 + 16];
+                    }
                     ox += xv * f16r(__fdiv_rn(c0 * scb.x, 127.0f));
                     oy += xv * f16r(__fdiv_rn(c1 * scb.y, 127.0f));
                 }
@@ -1238,6 +1259,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             FS_GCOUNT(40);
             __syncthreads();  // B1
             post_b1();
+            if constexpr (FMT == 2) {
+                if (gw == 0) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) pre8(pb0[r], pb1[r], wl8 + p.off_attn, kUnitsC, 1, 0, nq + r * kC);
+                }
+            }
             __syncthreads();  // Bt (one virtual tile)
             if (VSPLIT && gw == 1) {
                 // the v rows: dequantise, publish to the head group, write the cache row (gatherer 0 keeps q and k)
@@ -1257,7 +1284,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 float2 y[3];
 #pragma unroll
                 for (int r = 0; r < (VSPLIT ? 2 : 3); ++r) {
-                    if constexpr (FMT == 2) y[r] = tile_deq8(r, sc[r], wl8 + p.off_attn, kUnitsC, 1, 0, nq + r * kC);
+                    if constexpr (FMT == 2) y[r] = tile_deq8(r, sc[r], wl8 + p.off_attn, kUnitsC, 1, 0, nq + r * kC, pb0[r], pb1[r]);
                     else y[r] = deq(tile_pair(r), sc[r], zr[r], sx);
                     y[r].x *= rinv;
                     y[r].y *= rinv;
@@ -1421,10 +1448,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 FS_GSTAMP(7);
                 __syncthreads();  // B1
                 post_b1();
+                if constexpr (FMT == 2) {
+                    if (gw == 0) pre8(pb0[0], pb1[0], wl8 + p.off_proj, kUnitsC, 1, 0, r0);
+                }
                 __syncthreads();  // Bt
                 if (gw == 0) {
                     float2 d;
-                    if constexpr (FMT == 2) d = tile_deq8(0, s1, wl8 + p.off_proj, kUnitsC, 1, 0, r0);
+                    if constexpr (FMT == 2) d = tile_deq8(0, s1, wl8 + p.off_proj, kUnitsC, 1, 0, r0, pb0[0], pb1[0]);
                     else d = deq(tile_pair(0), s1, z1, get_sums());
                     xres.x += d.x;
                     xres.y += d.y;
@@ -1459,6 +1489,16 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 FS_GCOUNT(43);
                 __syncthreads();  // B1
                 post_b1();
+                if constexpr (FMT == 2) {
+                    if (gw == 0) {
+#pragma unroll
+                        for (int t = 0; t < kMaxFcTiles; ++t) {
+                            const int n = (bid + (t < n_fc ? t : 0) * kG) * 16 + 2 * pg;
+                            pre8(pb0[2 * t], pb1[2 * t], wl8 + p.off_fc, kUnitsC, 2, 0, n);
+                            pre8(pb0[2 * t + 1], pb1[2 * t + 1], wl8 + p.off_fc, kUnitsC, 2, 1, n);
+                        }
+                    }
+                }
                 const unsigned ep = ebase + edge;
                 u64* dst = p.gh + (size_t)hpar * (p.H / 2);
                 rinv_seen = misc[0];
@@ -1471,8 +1511,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         float2 a, b;
                         if constexpr (FMT == 2) {
                             const int n = (bid + t * kG) * 16 + 2 * pg;
-                            a = tile_deq8(0, fs1[t], wl8 + p.off_fc, kUnitsC, 2, 0, n);
-                            b = tile_deq8(1, fs2[t], wl8 + p.off_fc, kUnitsC, 2, 1, n);
+                            a = tile_deq8(0, fs1[t], wl8 + p.off_fc, kUnitsC, 2, 0, n, pb0[2 * t], pb1[2 * t]);
+                            b = tile_deq8(1, fs2[t], wl8 + p.off_fc, kUnitsC, 2, 1, n, pb0[2 * t + 1], pb1[2 * t + 1]);
                         } else {
                             a = deq(tile_pair(0), fs1[t], fz1[t], sx);
                             b = deq(tile_pair(1), fs2[t], fz2[t], sx);
@@ -1583,10 +1623,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 FS_GSTAMP(11);
                 __syncthreads();  // B1
                 post_b1();
+                if constexpr (FMT == 2) {
+                    if (gw == 0) pre8(pb0[0], pb1[0], wl8 + p.off_mproj, p.units_h, 1, 0, r0);
+                }
                 __syncthreads();  // Bt
                 if (gw == 0) {
                     float2 d;
-                    if constexpr (FMT == 2) d = tile_deq8(0, s1, wl8 + p.off_mproj, p.units_h, 1, 0, r0);
+                    if constexpr (FMT == 2) d = tile_deq8(0, s1, wl8 + p.off_mproj, p.units_h, 1, 0, r0, pb0[0], pb1[0]);
                     else d = deq(tile_pair(0), s1, z1, get_sums());
                     xres.x += d.x;
                     xres.y += d.y;

@@ -27,11 +27,22 @@ def main():
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--group-cols", type=int, default=0, help="GPTQ groupsize model (GRP instantiation of the kernel)")
+    ap.add_argument("--quantize", default="gptq.int4", choices=["gptq.int4", "llm.int8", "none"],
+                    help="stream format of the persistent step: int4 (default), LLM.int8 or BF16 (round 4)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = LLaMAConfig(n_layer=a.layers, n_head=32, n_embd=4096)
-    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
-        model = LLaMA(cfg)
+    if a.quantize != "gptq.int4":
+        import types
+
+        import bench  # the bench's random 7B model of that format (32 layers)
+
+        built = bench.build_model(types.SimpleNamespace(model="7B", quantize=a.quantize, adapter=False, group_cols=0, tune=None), dev)
+        model = built[0] if isinstance(built, tuple) else built
+        a.layers = model.config.n_layer
+    else:
+        with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
+            model = LLaMA(cfg)
     if a.group_cols:
         from lit_llama_amd.quantization import ColBlockQuantizedLinear
 
@@ -40,7 +51,8 @@ def main():
                 if isinstance(child, ColBlockQuantizedLinear):
                     q = ColBlockQuantizedLinear(child.in_features, child.out_features, bias=False, bits=4, tile_cols=a.group_cols)
                     setattr(mod, cname, q.to(device=dev, dtype=torch.bfloat16))
-    synth.fill_model_random_int4(model, seed=0)
+    if a.quantize == "gptq.int4":
+        synth.fill_model_random_int4(model, seed=0)
     eng = model.engine()
     assert eng is not None and eng.fused is not None, model._engine_failed
     prompt = synth.make_prompt(a.prompt).to(dev)
