@@ -474,8 +474,7 @@ int mi355_graph_destroy(mi355_graph* g);
 /* ------------------------------------------------------------------------------------------
  * The whole T = 1 decode step (LLaMA.forward for one token + greedy sampling, lit_llama/model.py:76-122,
  * generate.py:68-85) as ONE persistent launch: 7B-class gptq.int4 models on a 256-CU device
- * (kernel csrc/fused_step_ring.hip, host entry csrc/fused_step.hip; mi355_fused_step_supported tells; MI355_FUSED_IMPL=lds in
- * the environment selects the LDS-DMA implementation of the same step, csrc/fused_step.hip).  Everything the launch touches is laid out in
+ * (kernel csrc/fused_step_ring.hip, host entry csrc/fused_step.hip; mi355_fused_step_supported tells).  Everything the launch touches is laid out in
  * arenas so that a layer is addressed by a stride:
  *   w        Q4 streams (mi355_q4_repack) of layer l at w + l * layer_stride: c_attn (R = 1) at off_attn, attn.c_proj
  *            (R = 1) at off_proj, the interleaved c_fc1 / c_fc2 pair (R = 2) at off_fc, mlp.c_proj (R = 1) at off_mproj;

@@ -157,7 +157,7 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
         # unquantised models (BASELINE configs[1]) and LLM.int8 models (configs[3]): the BF16 / int8 instantiations of the
         # register-ring kernel (round 4) over BF16 / I8 streams
         wfmt, fmt, env = (W_BF16, 1, "MI355_FUSED_BF16") if kinds == {"bf16"} else (W_I8, 2, "MI355_FUSED_INT8")
-        if _env_int(env, 1) == 0 or os.environ.get("MI355_FUSED_IMPL", "") == "lds":
+        if _env_int(env, 1) == 0:
             return None
         sizes = [ops.packed_bytes(wfmt, 3 * C_, C_, 1, False), ops.packed_bytes(wfmt, C_, C_, 1, False),
                  ops.packed_bytes(wfmt, H, C_, 2, True), ops.packed_bytes(wfmt, C_, H, 1, False)]
@@ -174,7 +174,7 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
         # 128 * 2^n columns throughout, dividing n_embd and n_hidden, bf16 tables
         group_cols = first.attn.c_attn.tile_cols
         ok = (_env_int("MI355_FUSED_GROUPED", 1) != 0 and group_cols >= 128 and (group_cols & (group_cols - 1)) == 0
-              and C_ % group_cols == 0 and H % group_cols == 0 and os.environ.get("MI355_FUSED_IMPL", "") != "lds"
+              and C_ % group_cols == 0 and H % group_cols == 0
               and all(m_.tile_cols == group_cols and m_.grouped_fast() for m_ in mods))
         if not ok or any(m_.out_features % 16 for m_ in mods):
             return None  # (group_table packs whole 16-row tiles: other row counts stay on the launch-per-operator engine)
