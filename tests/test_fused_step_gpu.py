@@ -518,3 +518,25 @@ def test_int8_fused_step_matches_launch_per_operator_engine(dev, outliers):
     model.reset_cache()
     again = teacher_forced(model, outs[False].to(dev), 20, 64, dev)
     assert torch.equal(again, logits[True])
+
+
+def test_int8_fused_step_long_context_row_split(dev):
+    """LLM.int8 streams at a position past the row-split threshold of the attention (384) and past two cache blocks: fused vs launch path
+    inside the LLM.int8 band, bit-reproducible."""
+    model, _, cfg = build_int8(1, dev)
+    eng = need_fused(model)
+    T = 700
+    prompt = synth.make_prompt(T).to(dev)
+    res = {}
+    for fused in (False, True, True):
+        eng.fused_enabled = fused
+        model.reset_cache()
+        out = lit_llama_amd.generate(model, prompt, 4, top_k=1, max_seq_length=T + 8)
+        lg = eng.logits[0].clone().float().cpu()
+        eng.check_status()
+        res.setdefault(fused, []).append((out.cpu(), lg))
+    eng.fused_enabled = True
+    std = float(res[False][0][1].std())
+    assert torch.isfinite(res[True][0][1]).all()
+    assert (res[True][0][1] - res[False][0][1]).abs().max().item() <= 0.15 * std
+    assert torch.equal(res[True][0][1], res[True][1][1]) and torch.equal(res[True][0][0], res[True][1][0])
