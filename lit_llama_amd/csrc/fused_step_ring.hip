@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         if (a0 >= 6.0f) om |= 1u << (2 * e); else amax = fmaxf(amax, a0);
                         if (a1 >= 6.0f) om |= 2u << (2 * e); else amax = fmaxf(amax, a1);
                     }
-                    if (xedge) *(u32x4*)(xs + (size_t)u0 * 256 + (size_t)o * 16) = v;
+                    if (xedge && om != 0u) *(u32x4*)(xs + (size_t)u0 * 256 + (size_t)o * 16) = v;  // (only the outlier side product reads xh back)
                     q8v[it] = v;
                     q8o[it] = om;
                     if (om != 0u) {  // rare: a handful of columns per vector (four octets share a word of the bit set)

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Build lit_llama_amd/_variants/libmi355llama_<tag>.so with extra defines for one source of csrc/ (A / B of tuning knobs on
 # one box: MI355_LLAMA_LIB=<path> selects the library).
-#   bash scripts/build_variant.sh w8 [-s fused_step_ring.hip] -DMI355_FUSED_SPLIT_POS=256 ...     (default source: fused_step.hip)
+#   bash scripts/build_variant.sh w8 [-s fused_step_ring.hip] -DMI355_FUSED_SPLIT_POS=256 ...     (default source: fused_step_ring.hip)
 set -e
 cd "$(dirname "$0")/.."
 tag=$1; shift
-src=fused_step.hip
+src=fused_step_ring.hip
 if [ "$1" = "-s" ]; then src=$2; shift 2; fi
 mkdir -p lit_llama_amd/_variants /tmp/variants
 obj=/tmp/variants/${src%.hip}_$tag.o
