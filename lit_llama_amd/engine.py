@@ -455,6 +455,13 @@ class DecodeEngine:
                           RuntimeWarning, stacklevel=2)
         if code != 0:
             self._fused_ws[:4].zero_()
+            if 0x700 <= code < 0x800:
+                # LLM.int8 streams: a gathered vector had more outlier columns (|x| >= 6) than the persistent step's list holds
+                # (1024) — the launch-per-operator step has no such limit: decode the rest of this model there
+                self.fused_enabled = False
+                raise nat.NativeError(f"fused decode step aborted (code 0x{code:x}): more than 1024 LLM.int8 outlier columns in one "
+                                      "activation vector; the step's outputs are invalid — this engine now uses the "
+                                      "launch-per-operator step (re-run the generation)")
             raise nat.NativeError(f"fused decode step aborted (code 0x{code:x}): a workgroup hand-off timed out or the "
                                   "step was entered with pos >= S; the step's outputs are invalid")
 
