@@ -66,7 +66,8 @@ constexpr unsigned kSpinLimit = 400000u;
 #define MI355_FUSED_G0_PAIRS 6
 #endif
 #ifndef MI355_FUSED_VSPLIT
-#define MI355_FUSED_VSPLIT 0  // c_attn epilogue: gatherer 1 dequantises and publishes the v rows (int4 streams; A / B knob)
+#define MI355_FUSED_VSPLIT 0  // c_attn epilogue: gatherer 1 dequantises and publishes the v rows (int4 streams; A / B knob: 926 vs 935 us per
+                              // step with 4-KiB partial tiles on one box, 928.5 vs 921.4 with whole tiles on another — off)
 #endif
 #ifndef MI355_FUSED_GPRIO
 #define MI355_FUSED_GPRIO 0
