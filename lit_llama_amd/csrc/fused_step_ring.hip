@@ -65,6 +65,9 @@ constexpr unsigned kSpinLimit = 400000u;
 #ifndef MI355_FUSED_G0_PAIRS
 #define MI355_FUSED_G0_PAIRS 6
 #endif
+#ifndef MI355_FUSED_PROXY_NOB
+#define MI355_FUSED_PROXY_NOB 0  // MEASUREMENT ONLY (wrong results): the int4 streamers read their B operands once per phase — what do the LDS reads cost?
+#endif
 #ifndef MI355_FUSED_VSPLIT
 #define MI355_FUSED_VSPLIT 0  // c_attn epilogue: gatherer 1 dequantises and publishes the v rows (int4 streams; A / B knob: 926 vs 935 us per
                               // step with 4-KiB partial tiles on one box, 928.5 vs 921.4 with whole tiles on another — off)
@@ -400,7 +403,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         const int nun__ = (PH_).u0 + (nst__ < (PH_).nu ? nst__ : 0);                                  \
                         const bool mine__ = !GRP || cc__ == (nun__ >> p.gsh) - gfirst__;                              \
                         const char* xbn__ = (mine__ ? xs + nun__ * 256 : smem + kOffZero) + g * 64;                   \
-                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const f16x8*)(xbn__ + 16 * d__); \
+                        if (!MI355_FUSED_PROXY_NOB) {                                                                 \
+                            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const f16x8*)(xbn__ + 16 * d__); \
+                        }                                                                                             \
                     }                                                                                                 \
                     if constexpr (GRP) {                                                                              \
                         /* first step of a tile: request its table entries (consumed at the tile's last step) */      \
