@@ -314,6 +314,60 @@ def big_p400_case():
                nocache=False)
 
 
+def big_none_case():
+    """BASELINE.json configs[1] at FULL depth: LLaMA-7B (32 layers) WITHOUT quantisation, seeded synthetic weights (every value a bf16
+    number, held in f32: 27 GB), prompt of 8, six greedy tokens, teacher-forced logits — the unmodified reference in f32 on the CPU.
+    Built to fit the container: the state dict is ASSIGNED to a meta-device reference model (no second copy) and the oracle reads the
+    same tensors.  `--big-none`; its bf16 calibration twin: `--big-none --bf16`."""
+    torch.set_num_threads(max(8, (torch.get_num_threads() or 8)))
+    name = "cfg1_7b_none"
+    cfg_kwargs = dict(n_layer=32, n_head=32, n_embd=4096)
+    ref_cfg = ref.LLaMAConfig(**cfg_kwargs)
+    prompt_len, new_tokens, seed = 8, 6, 0
+    sd = synth.make_state_dict(OurConfig(**cfg_kwargs), seed=seed, mode=None)
+    if "--bf16" in sys.argv:
+        # the reference's own bf16 run (`--precision bf16-true`) on the tokens of the f32 fixture: the calibration of the GPU test's bar
+        fx = np.load(OUT / f"{name}.npz")
+        sd = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+        with torch.device("meta"):
+            model = ref.LLaMA(ref_cfg)
+        model.load_state_dict(sd, assign=True)
+        model.eval()
+        toks = torch.from_numpy(fx["tokens"].astype(np.int32))
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(torch.bfloat16)
+        try:
+            logits = ref_teacher_forced(model, toks, prompt_len, int(fx["max_seq_length"]))
+        finally:
+            torch.set_default_dtype(old)
+        probes_bf = logits[:, torch.from_numpy(probe_index(ref_cfg.padded_vocab_size))].float().numpy().astype(np.float32)
+        d = np.abs(probes_bf - fx["probes"]).max(axis=1) / fx["std"]
+        np.savez_compressed(OUT / f"{name}_bf16ref.npz", probes=probes_bf, argmax=logits.float().argmax(-1).numpy().astype(np.int32),
+                            dist_std=d.astype(np.float32), max_dist_std=np.float32(d.max()), source=np.array(name))
+        print(f"{name}_bf16ref.npz: reference bf16 vs reference f32, max |dlogit| / std per step:", np.round(d, 4).tolist())
+        return
+    with torch.device("meta"):
+        model = ref.LLaMA(ref_cfg)
+    model.load_state_dict(sd, assign=True)
+    model.eval()
+    prompt = synth.make_prompt(prompt_len, vocab=ref_cfg.vocab_size)
+    toks = ref_generate.generate(model, prompt, new_tokens, top_k=1)
+    model.reset_cache()
+    S = prompt_len + new_tokens
+    logits = ref_teacher_forced(model, toks, prompt_len, S)
+    fix = dict(tokens=toks.numpy().astype(np.int32), prompt_len=np.int32(prompt_len), seed=np.int32(seed), max_seq_length=np.int32(S))
+    fix.update(summarize(logits, ref_cfg.padded_vocab_size))
+    om = oracle.Model(oracle.Config(**cfg_kwargs), sd, mode=None)
+    otoks = oracle.generate(om, prompt, new_tokens, top_k=1)
+    assert torch.equal(otoks, toks), f"{name}: oracle tokens differ from the reference"
+    om.reset_cache()
+    ologits = oracle.teacher_forced_logits(om, toks, prompt_len, S)
+    err = (ologits - logits).abs().max().item()
+    assert err <= 1e-5 * max(1.0, logits.abs().max().item()), f"{name}: oracle logits off by {err}"
+    print(f"  {name}: oracle == reference (tokens equal, max |dlogit| {err:.2e}, min margin {fix['margin'].min():.3e})")
+    np.savez_compressed(OUT / f"{name}.npz", **fix)
+
+
 def big_bf16_case(name="cfg2_7b_int4"):
     """Calibrates the engine's parity bar: the REFERENCE ITSELF in bf16 on the CPU (what `--precision bf16-true` makes
     of it: parameters, scales / zeros and activations in bf16, generate.py:123-134) on the tokens of the f32 fixture,
@@ -389,6 +443,10 @@ def main():
     if "--lazy-load" in sys.argv:
         print("generating the lazy_load fixture from", REF)
         lazy_load_case()
+        return
+    if "--big-none" in sys.argv:
+        print("generating the full-depth unquantised 7B fixture from", REF)
+        big_none_case()
         return
     if "--big-p400" in sys.argv:
         print("generating the 400-token-prompt full-depth 7B fixture from", REF)

@@ -90,3 +90,56 @@ def test_full_depth_7b_int4_against_the_reference_golden_run(dev, golden):
             print(f"{name} fused={fused}: max |dlogit| {err:.4f} = {err / std:.4f} std (reference bf16 vs f32: {ref_dist:.4f} std); "
                   f"min margin {g['margin'].min():.3f}")
     eng.fused_enabled = True
+
+
+@torch.no_grad()
+def test_full_depth_7b_unquantised_against_the_reference_golden_run(dev, golden):
+    """BASELINE.json configs[1] at FULL depth against the reference itself (round 4): LLaMA-7B without quantisation, seeded synthetic
+    weights (every value a bf16 number), prompt of 8, six greedy tokens.  tests/golden/cfg1_7b_none.npz holds what the UNMODIFIED
+    /root/reference produced in f32 on the CPU (oracle/gen_golden.py --big-none, oracle == reference with max |dlogit| ~ 0), its
+    `_bf16ref` twin the reference's own bf16 run on the same tokens.  Here the bf16 model goes through the engine: prefill on the wide path,
+    decode steps on the persistent step over BF16 streams (and on the launch-per-operator step).  Bar: within HALF the reference's own bf16
+    distance, argmax wherever the reference's margin is decisive, greedy tokens up to the first near tie."""
+    g, ref_bf16 = golden("cfg1_7b_none"), golden("cfg1_7b_none_bf16ref")
+    cfg = LLaMAConfig.from_name("7B")
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]), mode=None, dtype=torch.bfloat16)
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16):
+        model = LLaMA(cfg)
+    model.load_state_dict(sd)
+    del sd
+    model.eval()
+    eng = model.engine()
+    assert eng is not None, model._engine_failed
+    T, S = int(g["prompt_len"]), int(g["max_seq_length"])
+    toks = torch.from_numpy(g["tokens"]).to(dev)
+    std = float(g["std"].mean())
+    ref_dist = float(ref_bf16["max_dist_std"])
+    assert 0.005 < ref_dist < 0.5
+    tol = 0.5 * ref_dist * std
+    for fused in ([True, False] if eng.fused is not None else [False]):
+        eng.fused_enabled = fused
+        model.reset_cache()
+        rows = []
+        input_pos = torch.arange(0, T, device=dev)
+        pos0 = 0
+        for _ in range(toks.numel() - T):
+            x = toks.index_select(0, input_pos).view(1, -1)
+            input_pos._mi355_pos0 = pos0
+            rows.append(model(x, S, input_pos)[0, -1].float().cpu())
+            pos0 += input_pos.numel()
+            input_pos = input_pos[-1:] + 1
+        logits = torch.stack(rows)
+        eng.check_status()
+        err = np.abs(logits[:, PROBES].numpy() - g["probes"]).max()
+        assert err <= tol, f"fused={fused}: 7B bf16 logits off by {err:.4f} (std {std:.3f}, tol {tol:.4f})"
+        decisive = g["margin"] > 2 * tol
+        assert np.array_equal(logits.argmax(-1).numpy()[decisive], g["argmax"][decisive])
+        model.reset_cache()
+        out = lit_llama_amd.generate(model, toks[:T], toks.numel() - T, top_k=1).cpu()
+        first_tie = next((i for i, m_ in enumerate(g["margin"]) if m_ <= 2 * tol), len(g["margin"]))
+        n = T + first_tie
+        assert torch.equal(out[:n], torch.from_numpy(g["tokens"])[:n]), f"fused={fused}: {out.tolist()} vs {g['tokens'].tolist()}"
+        print(f"cfg1_7b_none fused={fused}: max |dlogit| {err:.4f} = {err / std:.4f} std (reference bf16 vs f32: {ref_dist:.4f} std); "
+              f"min margin {g['margin'].min():.3f}")
+    eng.fused_enabled = True
