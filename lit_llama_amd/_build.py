@@ -37,7 +37,7 @@ def _stale(target: Path, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> Path:
     hipcc = _hipcc()
     OBJ_DIR.mkdir(exist_ok=True)
-    headers = [CSRC / "common.h", CSRC / "fused_step_common.h", PKG.parent / "include" / "mi355_llama.h"]
+    headers = [CSRC / "common.h", CSRC / "fused_step_common.h", CSRC / "gemm_fuse.h", PKG.parent / "include" / "mi355_llama.h"]
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
     def compile_one(name: str):

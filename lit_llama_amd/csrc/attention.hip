@@ -14,10 +14,8 @@
 // global round trip) sits between the qkv projection and the attention output.
 #include "common.h"
 
-// flash_prefill.hip
-int mi355_flash_prefill(const void* qkv, int qkv_dtype, int64_t ld_qkv, const float* rope, int rope_gathered,
-                        const int32_t* pos, const void* kcache, const void* vcache, int T, int n_head, int S, void* y,
-                        int64_t ldy, float scale, hipStream_t s);
+// flash_prefill.hip: declared in gemm_fuse.h
+#include "gemm_fuse.h"
 
 namespace {
 
@@ -580,7 +578,7 @@ extern "C" int mi355_attention(const mi355_attn_args* a, mi355_stream_t stream) 
         a->y_dtype == MI355_BF16 && a->n_split <= 1 && a->ld_qkv % 8 == 0 && a->ldy % 4 == 0 &&
         (int64_t)p.S * 256 < 0x7fffffffLL) {
         if (int rc = mi355_flash_prefill(a->qkv, a->qkv_dtype, a->ld_qkv, a->rope, a->rope_gathered, p.pos, p.kcache, p.vcache,
-                                         a->T, a->n_head, p.S, a->y, a->ldy, p.scale, s))
+                                         a->T, a->n_head, p.S, a->y, a->ldy, p.scale, nullptr, s))
             return rc;
         if (!adapter) return 0;
         mi355_adapter_args b;

@@ -8,7 +8,11 @@
 //     -> [RMSNorm -> c_fc1/c_fc2 -> SwiGLU]  ->  [mlp.c_proj + residual]
 // and token ids / positions live in device memory (mi355_set_step writes them), so the captured graph
 // is static and nothing on the host depends on device results.
+#include <math.h>
+#include <stdlib.h>
+
 #include "common.h"
+#include "gemm_fuse.h"
 
 // implemented in int8.hip: the LLM.int8 linear driven from a mi355_weight descriptor
 int mi355_linear_int8_from_weight(const mi355_weight* w, const mi355_model* m, const void* x, int x_dtype, int M,
@@ -75,6 +79,94 @@ int run_linear_rows(const mi355_model* m, const mi355_weight& w, const void* x, 
                     const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy, hipStream_t s,
                     const float* attn_partials);
 
+// The wide-GEMM chain of one prompt pass with the staging passes and the K / V cache write folded into the producers'
+// epilogues (gemm_fuse.h).  Decided once per mi355_forward call: every layer linear on the wide path over per-row scales,
+// no launch of the chunk split over K (mi355_linear_gemm_plan), a bf16 cache at head size 128, no adapter prefix, one GPU.
+struct FuseCtx {
+    bool on;
+    bf16_t* xb;        // [T][n_embd]: the operand the last residual epilogue emitted (start of the GEMM workspace)
+    float* ssA;        // [nA][T] partial sums of squares / operand sums from the residual epilogues
+    float* sxA;
+    float* sxB;        // [nB][T] partial operand sums from the SwiGLU epilogue
+    float* sxC;        // [n_head][T] from the attention kernel
+    int nA, nB;
+    bool have_x;       // xb / ssA / sxA hold the input of the next normalised linear
+};
+
+void fill_linear_args(mi355_linear_args& a, const mi355_model* m, const mi355_weight& w, const void* x, int x_dtype, int M,
+                      int64_t ldx, const void* norm_scale, int epi, void* y, int y_dtype, int64_t ldy) {
+    memset(&a, 0, sizeof(a));
+    a.fmt = w.fmt;
+    a.R = w.R;
+    a.w = w.w;
+    a.N = w.N;
+    a.K = w.K;
+    a.x = x;
+    a.x_dtype = x_dtype;
+    a.M = M;
+    a.ldx = ldx;
+    a.norm_scale = norm_scale;
+    a.norm_dtype = m->param_dtype;
+    a.eps = m->eps;
+    a.scales = w.scales;
+    a.zeros = w.zeros;
+    a.scales2 = w.scales2;
+    a.zeros2 = w.zeros2;
+    a.sz_dtype = w.sz_dtype;
+    a.group_cols = w.group_cols;
+    a.epi = epi;
+    a.y = y;
+    a.y_dtype = y_dtype;
+    a.ldy = ldy;
+}
+
+bool wide_plain(const mi355_weight& w) {  // a linear the fused chain can run: int4 / bf16 stream, one scale per row
+    return (w.fmt == MI355_W_Q4 || w.fmt == MI355_W_BF16) && (w.group_cols == 0 || w.group_cols >= w.K) && w.N % 4 == 0 &&
+           w.K % 128 == 0;
+}
+
+FuseCtx plan_fusion(const mi355_model* m, int T) {
+    FuseCtx z;
+    memset(&z, 0, sizeof(z));
+    const char* env = getenv("MI355_GEMM_FUSE");
+    if (env != nullptr && env[0] == '0') return z;
+    if (T < 32 || m->tp_world > 1 || m->gemm_ws == nullptr || m->hs != 128 || m->cache_dtype != MI355_BF16 ||
+        (int64_t)m->S * 256 >= 0x7fffffffLL || m->n_head * m->hs != m->n_embd)
+        return z;
+    const int C = m->n_embd, H = m->n_hidden;
+    int nA = 0, nB = 0;
+    for (int l = 0; l < m->n_layer; ++l) {
+        const mi355_layer& L = m->layers[l];
+        if (L.adapter_len > 0 || !wide_plain(L.attn) || !wide_plain(L.proj) || !wide_plain(L.fc) || !wide_plain(L.mproj)) return z;
+        if (L.attn.N != 3 * C || L.attn.K != C || L.proj.N != C || L.proj.K != C || L.fc.N != H || L.fc.K != C || L.fc.R != 2 ||
+            L.mproj.N != C || L.mproj.K != H || L.kcache == nullptr || L.vcache == nullptr)
+            return z;
+    }
+    int ks[4], rb[4];
+    mi355_linear_gemm_plan(T, 3 * C, C, 1, &ks[0], &rb[0]);
+    mi355_linear_gemm_plan(T, C, C, 1, &ks[1], &rb[1]);
+    mi355_linear_gemm_plan(T, H, C, 2, &ks[2], &rb[2]);
+    mi355_linear_gemm_plan(T, C, H, 1, &ks[3], &rb[3]);
+    if (ks[0] != 1 || ks[1] != 1 || ks[2] != 1 || ks[3] != 1 || rb[1] != rb[3]) return z;
+    nA = rb[1];
+    nB = rb[2];
+    // scratch: the last 16 MiB of the workspace (the split-K budget, unused by whole-K launches)
+    const size_t need = (size_t)T * (size_t)(2 * nA + nB + m->n_head) * 4 + 64;
+    const size_t tail = (size_t)16 << 20;
+    const int kmax = H > C ? H : C;
+    if (need > tail || (size_t)m->gemm_ws_bytes < mi355_linear_gemm_workspace_bytes(T, kmax)) return z;
+    char* base = (char*)m->gemm_ws + (((size_t)m->gemm_ws_bytes - tail) & ~(size_t)15);
+    z.on = true;
+    z.xb = (bf16_t*)m->gemm_ws;
+    z.ssA = (float*)base;
+    z.sxA = z.ssA + (size_t)nA * T;
+    z.sxB = z.sxA + (size_t)nA * T;
+    z.sxC = z.sxB + (size_t)nB * T;
+    z.nA = nA;
+    z.nB = nB;
+    return z;
+}
+
 // One linear over M <= max_T rows.  The rows of one launch must fit the workgroup's LDS next to the combine
 // buffers (7B: 13 rows at K = 4096, 5 at K = 11008), so wide inputs are fed in equal sub-chunks of rows: the
 // prompt chunk size is set by the NARROW linears and only mlp.c_proj pays extra launches.
@@ -86,29 +178,7 @@ int run_linear(const mi355_model* m, const mi355_weight& w, const void* x, int x
     if ((w.fmt == MI355_W_Q4 || w.fmt == MI355_W_BF16) && M >= 32 && m->gemm_ws != nullptr &&
         attn_partials == nullptr && w.N % 4 == 0 && ldy % 4 == 0 && (w.group_cols == 0 || w.K % 128 == 0)) {
         mi355_linear_args a;
-        memset(&a, 0, sizeof(a));
-        a.fmt = w.fmt;
-        a.R = w.R;
-        a.w = w.w;
-        a.N = w.N;
-        a.K = w.K;
-        a.x = x;
-        a.x_dtype = x_dtype;
-        a.M = M;
-        a.ldx = ldx;
-        a.norm_scale = norm_scale;
-        a.norm_dtype = m->param_dtype;
-        a.eps = m->eps;
-        a.scales = w.scales;
-        a.zeros = w.zeros;
-        a.scales2 = w.scales2;
-        a.zeros2 = w.zeros2;
-        a.sz_dtype = w.sz_dtype;
-        a.group_cols = w.group_cols;
-        a.epi = epi;
-        a.y = y;
-        a.y_dtype = y_dtype;
-        a.ldy = ldy;
+        fill_linear_args(a, m, w, x, x_dtype, M, ldx, norm_scale, epi, y, y_dtype, ldy);
         return mi355_linear_gemm(&a, m->gemm_ws, (size_t)m->gemm_ws_bytes, s);
     }
     if (w.fmt == MI355_W_I8 && M >= 32 && m->gemm_ws != nullptr && attn_partials == nullptr &&
@@ -217,6 +287,9 @@ extern "C" int mi355_set_step(const mi355_model* m, const void* idx, int idx_is_
     return 0;
 }
 
+static int forward_segment_impl(const mi355_model* m, int T, int layer, int seg_begin, int seg_end, mi355_stream_t stream,
+                                FuseCtx* fz);
+
 extern "C" int mi355_forward(const mi355_model* m, int T, int logits_mode, int argmax, mi355_stream_t stream) {
     MI355_CHECK_ARG(m != nullptr && m->layers != nullptr, MI355_E_ARG, "forward: null model");
     MI355_CHECK_ARG(T >= 1 && T <= m->max_T, MI355_E_SHAPE, "forward: T=%d outside 1..%d", T, m->max_T);
@@ -237,8 +310,9 @@ extern "C" int mi355_forward(const mi355_model* m, int T, int logits_mode, int a
         if (int rc = mi355_embedding(m->tokens, 0, m->wte, m->param_dtype, m->x, MI355_F32, T, C, m->vocab, s)) return rc;
     }
 
+    FuseCtx fz = plan_fusion(m, T);
     for (int l = 0; l < m->n_layer; ++l) {
-        if (int rc = mi355_forward_segment(m, T, l, 0, 4, s)) return rc;
+        if (int rc = forward_segment_impl(m, T, l, 0, 4, s, fz.on ? &fz : nullptr)) return rc;
     }
     return mi355_forward_head(m, T, logits_mode, argmax, s);
 }
@@ -248,6 +322,83 @@ extern "C" int mi355_forward(const mi355_model* m, int T, int logits_mode, int a
 // calls mi355_residual_add); with tp_world == 1 they accumulate into the residual stream directly.
 extern "C" int mi355_forward_segment(const mi355_model* m, int T, int layer, int seg_begin, int seg_end,
                                      mi355_stream_t stream) {
+    return forward_segment_impl(m, T, layer, seg_begin, seg_end, stream, nullptr);
+}
+
+// the fused chain of a prompt pass (FuseCtx above): one segment with its producer / consumer roles
+static int fused_segment(const mi355_model* m, int T, int layer, int seg, hipStream_t s, FuseCtx* fz) {
+    const mi355_layer& L = m->layers[layer];
+    const int C = m->n_embd, H = m->n_hidden;
+    mi355_linear_args a;
+    mi355_gemm_fuse f;
+    memset(&f, 0, sizeof(f));
+    switch (seg) {
+        case 0: {
+            // RMSNorm + c_attn; the epilogue rotates k and writes the K / V cache rows, q goes to qkv; then causal attention
+            if (fz->have_x) {
+                fill_linear_args(a, m, L.attn, fz->xb, MI355_BF16, T, C, nullptr, MI355_EPI_STORE, m->qkv, MI355_F32, 3 * C);
+                f.prestaged = 1;
+                f.in_sx = fz->sxA;
+                f.in_ss = fz->ssA;
+                f.in_sx_n = f.in_ss_n = fz->nA;
+            } else {
+                fill_linear_args(a, m, L.attn, m->x, MI355_F32, T, C, L.rms1, MI355_EPI_STORE, m->qkv, MI355_F32, 3 * C);
+            }
+            f.rope = m->rope;
+            f.pos = m->pos;
+            f.kcache = (bf16_t*)L.kcache;
+            f.vcache = (bf16_t*)L.vcache;
+            f.S = m->S;
+            f.n_head = m->n_head;
+            f.hs = m->hs;
+            if (int rc = mi355_linear_gemm_fused(&a, &f, m->gemm_ws, (size_t)m->gemm_ws_bytes, s)) return rc;
+            fz->have_x = false;
+            return mi355_flash_prefill(m->qkv, MI355_F32, 3 * C, m->rope, 0, m->pos, L.kcache, L.vcache, T, m->n_head, m->S, m->att,
+                                       C, 1.0f / sqrtf((float)m->hs), fz->sxC, s);
+        }
+        case 1:  // attn.c_proj over the attention output as it is; the residual epilogue emits the operand of c_fc1 / c_fc2
+            fill_linear_args(a, m, L.proj, m->att, MI355_BF16, T, C, nullptr, MI355_EPI_ACCUM, m->x, MI355_F32, C);
+            f.prestaged = 1;
+            f.in_sx = fz->sxC;
+            f.in_sx_n = m->n_head;
+            f.out_xb = fz->xb;
+            f.out_ld = C;
+            f.next_norm = L.rms2;
+            f.next_norm_dtype = m->param_dtype;
+            f.out_ss = fz->ssA;
+            f.out_sx = fz->sxA;
+            fz->have_x = true;
+            return mi355_linear_gemm_fused(&a, &f, m->gemm_ws, (size_t)m->gemm_ws_bytes, s);
+        case 2:  // c_fc1 / c_fc2 + SwiGLU over the emitted operand; partial operand sums of the hidden vector
+            MI355_CHECK_ARG(fz->have_x, MI355_E_STATE, "forward: the fused chain lost its operand before layer %d's MLP", layer);
+            fill_linear_args(a, m, L.fc, fz->xb, MI355_BF16, T, C, nullptr, MI355_EPI_SWIGLU, m->hbuf, MI355_BF16, H);
+            f.prestaged = 1;
+            f.in_sx = fz->sxA;
+            f.in_ss = fz->ssA;
+            f.in_sx_n = f.in_ss_n = fz->nA;
+            f.out_sx = fz->sxB;
+            fz->have_x = false;
+            return mi355_linear_gemm_fused(&a, &f, m->gemm_ws, (size_t)m->gemm_ws_bytes, s);
+        default:  // mlp.c_proj; the residual epilogue emits the next layer's c_attn operand
+            fill_linear_args(a, m, L.mproj, m->hbuf, MI355_BF16, T, H, nullptr, MI355_EPI_ACCUM, m->x, MI355_F32, C);
+            f.prestaged = 1;
+            f.in_sx = fz->sxB;
+            f.in_sx_n = fz->nB;
+            if (layer + 1 < m->n_layer) {
+                f.out_xb = fz->xb;
+                f.out_ld = C;
+                f.next_norm = m->layers[layer + 1].rms1;
+                f.next_norm_dtype = m->param_dtype;
+                f.out_ss = fz->ssA;
+                f.out_sx = fz->sxA;
+                fz->have_x = true;
+            }
+            return mi355_linear_gemm_fused(&a, &f, m->gemm_ws, (size_t)m->gemm_ws_bytes, s);
+    }
+}
+
+static int forward_segment_impl(const mi355_model* m, int T, int layer, int seg_begin, int seg_end, mi355_stream_t stream,
+                                FuseCtx* fz) {
     MI355_CHECK_ARG(m != nullptr && m->layers != nullptr, MI355_E_ARG, "forward_segment: null model");
     MI355_CHECK_ARG(layer >= 0 && layer < m->n_layer, MI355_E_ARG, "forward_segment: bad layer %d", layer);
     MI355_CHECK_ARG(seg_begin >= 0 && seg_end <= 4 && seg_begin < seg_end, MI355_E_ARG, "forward_segment: bad range");
@@ -260,6 +411,10 @@ extern "C" int mi355_forward_segment(const mi355_model* m, int T, int layer, int
     // decode steps spread each head's K/V over attn_splits workgroups; the c_proj prologue combines the partials
     const bool split = T == 1 && m->attn_splits > 1 && m->attn_part != nullptr;
     for (int seg = seg_begin; seg < seg_end; ++seg) {
+        if (fz != nullptr) {
+            if (int rc = fused_segment(m, T, layer, seg, s, fz)) return rc;
+            continue;
+        }
         switch (seg) {
             case 0: {
                 if (int rc = run_linear(m, L.attn, m->x, MI355_F32, T, C, L.rms1, MI355_EPI_STORE, m->qkv, MI355_F32,

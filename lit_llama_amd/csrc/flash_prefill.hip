@@ -22,6 +22,7 @@
 //   * q is RoPE'd in registers while it is loaded (f32 qkv rows, rope row = the token's position); the new K / V rows
 //     were written to the cache by rope_kv_write_kernel before this launch.
 #include "common.h"
+#include "gemm_fuse.h"
 
 namespace {
 
@@ -50,6 +51,7 @@ struct FlashParams {
     const bf16_t* kcache;
     const bf16_t* vcache;  // [n_head, S, 128]
     bf16_t* y;           // [T, ldy]
+    float* sx_part;      // [n_head][T] sums of this head's bf16 outputs per token (partial operand sums of attn.c_proj, gemm_fuse.h) or NULL
     int64_t ld_qkv, ldy;
     int T, n_head, S, qkv_dtype, rope_gathered, q_blocks;
     float scale;
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
         __syncthreads();
     }
     float l = l_run + lane_xor32(l_run);
+    float osum = 0.f;  // this lane's 64 of the query's 128 outputs, as the bf16 values the consumer multiplies
     if (q_ok) {
         const float inv = 1.0f / l;
         bf16_t* yrow = p.y + (int64_t)q_idx * p.ldy + h * kHs;
@@ -274,11 +277,19 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
+                bf16_t ob[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(acc[dt][4 * gq + r] * inv);
                 u32x2 o;
-                o[0] = (uint32_t)f32_to_bf16(acc[dt][4 * gq] * inv) | ((uint32_t)f32_to_bf16(acc[dt][4 * gq + 1] * inv) << 16);
-                o[1] = (uint32_t)f32_to_bf16(acc[dt][4 * gq + 2] * inv) | ((uint32_t)f32_to_bf16(acc[dt][4 * gq + 3] * inv) << 16);
+                o[0] = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
+                o[1] = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
                 *(u32x2*)(yrow + dt * 32 + 8 * gq + 4 * hh) = o;
+                osum += (bf16_to_f32(ob[0]) + bf16_to_f32(ob[1])) + (bf16_to_f32(ob[2]) + bf16_to_f32(ob[3]));
             }
+    }
+    if (p.sx_part != nullptr) {  // (wave-uniform; the other half of the dimensions sits in lane ^ 32)
+        osum += lane_xor32(osum);
+        if (q_ok && hh == 0) p.sx_part[(int64_t)h * p.T + q_idx] = osum;
     }
 }
 
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
 // y[t, h * 128 + d] for T query tokens against cache rows [0, pos[t]] (K / V rows of the T tokens already written).
 int mi355_flash_prefill(const void* qkv, int qkv_dtype, int64_t ld_qkv, const float* rope, int rope_gathered,
                         const int32_t* pos, const void* kcache, const void* vcache, int T, int n_head, int S, void* y,
-                        int64_t ldy, float scale, hipStream_t s) {
+                        int64_t ldy, float scale, float* sx_part, hipStream_t s) {
     static hipError_t attr_err =
         hipFuncSetAttribute((const void*)flash_prefill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (attr_err != hipSuccess) {
@@ -301,6 +312,7 @@ int mi355_flash_prefill(const void* qkv, int qkv_dtype, int64_t ld_qkv, const fl
     p.kcache = (const bf16_t*)kcache;
     p.vcache = (const bf16_t*)vcache;
     p.y = (bf16_t*)y;
+    p.sx_part = sx_part;
     p.ld_qkv = ld_qkv;
     p.ldy = ldy;
     p.T = T;

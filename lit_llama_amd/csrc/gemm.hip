@@ -25,6 +25,7 @@
 //    per-row factor for the epilogue, and the per-row operand sum that undoes the +128 / zero-point offset:
 //        y[m, n] = scale[n] * (acc[m, n] - (128 + zero[n]) * sum_k xb[m, k]) * rinv[m]      (same arithmetic as gemv.hip).
 #include "common.h"
+#include "gemm_fuse.h"
 
 namespace {
 
@@ -32,7 +33,10 @@ constexpr int kBM = 128;     // tokens per block
 #ifndef MI355_GEMM_TPW
 #define MI355_GEMM_TPW 2
 #endif
-constexpr int kTPW = MI355_GEMM_TPW;  // 16-row tile slots per wave: one B fragment read from LDS feeds kTPW MFMAs
+constexpr int kTPW = MI355_GEMM_TPW;
+#ifndef MI355_GEMM_BF16_OCC
+#define MI355_GEMM_BF16_OCC 1
+#endif  // 16-row tile slots per wave: one B fragment read from LDS feeds kTPW MFMAs
 // Waves per workgroup: 8 (a block = 16 row tiles x 128 tokens) for prompts that fill the chip; 2 (4 row tiles) when the
 // launch would otherwise be a few dozen workgroups — a 128-token prompt of a 7B model is ONE token block, i.e. 16 workgroups
 // for attn.c_proj / mlp.c_proj (N = 4096) on 256 CUs, each streaming its 0.5-1.4 MB of weights alone: ~96 us per launch.
@@ -61,6 +65,23 @@ struct GemmParams {
     const uint32_t* gtab;
     const float* sxt;
     int n_groups, gq_shift, upg, tab_ld;
+    // producer / consumer fusion (gemm_fuse.h; FUSE kernels only).  f_in: xb is the caller's operand, 1/rms and the operand
+    // sums of the block's rows are rebuilt from the partial sums in_ss / in_sx ([partial][M])
+    int f_in, in_sx_n, in_ss_n;
+    const float* in_sx;
+    const float* in_ss;
+    float eps;
+    bf16_t* out_xb;       // ACCUM: bf16(next_norm * y_new)
+    int64_t out_ld;
+    const void* next_norm;
+    int next_norm_dtype;
+    float* out_ss;        // [n_blocks][M]
+    float* out_sx;
+    const float* rope;    // STORE of c_attn: k rotated + K / V cache rows written here
+    const int32_t* pos;
+    bf16_t* kcache;
+    bf16_t* vcache;
+    int S, C, rope_gathered;
 };
 
 constexpr size_t kSplitBudget = (size_t)32 << 20;  // bytes of split-K partials a workspace holds
@@ -214,9 +235,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
 // s past the last group = 0; X_g = the group's operand sum from stage_rows_grouped_kernel): two FMAs per output element
 // and group, no accumulator reset.  The k columns of ONE MFMA are spread over the unit (lane group g holds columns
 // 32 g + 8 d ..), so sub-unit groups take one pass per group with the other lane groups' activations zeroed, as in gemv.hip.
-template <int EPI, bool PAIR, int FMT, int kWaves, int BM, int GRP = 0>
-__global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p) {
+// FUSE: the producer / consumer fusion of gemm_fuse.h (ungrouped launches without a K split): operand sums and 1/rms from
+// partial sums instead of the staging pass; the residual epilogue emits the next linear's bf16 operand and its partial
+// sums, the SwiGLU epilogue the partial operand sums of its output, the c_attn epilogue rotates k and writes the K / V cache
+// (BF16 streams, 8 waves: four pieces per (tile, unit) in flight took the kernel to 130-136 VGPRs, i.e. ONE workgroup per CU;
+// the second launch-bound argument — waves per SIMD — holds it at 128)
+template <int EPI, bool PAIR, int FMT, int kWaves, int BM, int GRP = 0, bool FUSE = false>
+__global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 && MI355_GEMM_BF16_OCC) ? 4 : 1) void gemm_q4_kernel(const GemmParams p) {
     static_assert(GRP == 0 || FMT == MI355_W_Q4, "grouped scales are a Q4 feature");
+    static_assert(!FUSE || GRP == 0, "the fused chain runs over per-row scales");
     constexpr int kTT = BM / 16;                   // 16-token tiles per block
     constexpr int kSlots = kWaves * kTPW;          // tile slots per block
     constexpr int kThreads = 64 * kWaves;
@@ -235,6 +262,7 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
     const int L = L2 / p.ksplit, ks = L2 - L * p.ksplit;  // (ksplit = 1: ks = 0, all units)
     const int mb = L / n_blocks, nb = L - mb * n_blocks;
     const int m0 = mb * BM;
+    [[maybe_unused]] float* fr = (float*)(smem + 2 * BM * 256);  // FUSE: [BM] 1/rms, [BM] operand sums of the block's rows
     // K-slice: units [u_lo, u_hi); GRP 1 cuts at group boundaries (groups [g_lo, g_hi) of upg units each)
     const int g_lo = GRP == 1 ? slice_lo(ks, p.n_groups, p.ksplit) : 0, g_hi = GRP == 1 ? slice_lo(ks + 1, p.n_groups, p.ksplit) : 0;
     const int u_lo = GRP == 1 ? g_lo * p.upg : slice_lo(ks, p.units, p.ksplit);
@@ -297,8 +325,63 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
 #pragma unroll
     for (int t = 0; t < kTPW; ++t) wload(t, u_lo, wcur[t]);
     xload(u_lo);
+    if constexpr (FUSE) {
+        if (p.f_in) {
+            // (behind the first unit's operand requests, in front of its barrier)
+            // partial sums -> per-row factors.  Every thread takes a row and every kP-th partial, four loads in flight
+            // (a plain loop over the partials is one memory round trip per partial: 13-15 us per launch, measured), the
+            // kP shares are added in share order through LDS: a fixed order, deterministic
+            constexpr int kP = kThreads >= BM ? kThreads / BM : 1;
+            float* frp = fr + 2 * BM;  // [kP][2][BM]
+            for (int idx = threadIdx.x; idx < kP * BM; idx += kThreads) {
+                const int t = idx % BM, part = idx / BM;
+                const int64_t m = m0 + t < p.M ? m0 + t : p.M - 1;
+                float sxs = 0.f, sss = 0.f;
+                for (int j0 = part; j0 < p.in_sx_n; j0 += 4 * kP) {
+                    const int j1 = j0 + kP, j2 = j0 + 2 * kP, j3 = j0 + 3 * kP;
+                    const float v0 = p.in_sx[j0 * (int64_t)p.M + m];
+                    const float v1 = p.in_sx[(j1 < p.in_sx_n ? j1 : j0) * (int64_t)p.M + m];
+                    const float v2 = p.in_sx[(j2 < p.in_sx_n ? j2 : j0) * (int64_t)p.M + m];
+                    const float v3 = p.in_sx[(j3 < p.in_sx_n ? j3 : j0) * (int64_t)p.M + m];
+                    sxs += v0;
+                    sxs += j1 < p.in_sx_n ? v1 : 0.f;
+                    sxs += j2 < p.in_sx_n ? v2 : 0.f;
+                    sxs += j3 < p.in_sx_n ? v3 : 0.f;
+                }
+                for (int j0 = part; j0 < p.in_ss_n; j0 += 4 * kP) {
+                    const int j1 = j0 + kP, j2 = j0 + 2 * kP, j3 = j0 + 3 * kP;
+                    const float v0 = p.in_ss[j0 * (int64_t)p.M + m];
+                    const float v1 = p.in_ss[(j1 < p.in_ss_n ? j1 : j0) * (int64_t)p.M + m];
+                    const float v2 = p.in_ss[(j2 < p.in_ss_n ? j2 : j0) * (int64_t)p.M + m];
+                    const float v3 = p.in_ss[(j3 < p.in_ss_n ? j3 : j0) * (int64_t)p.M + m];
+                    sss += v0;
+                    sss += j1 < p.in_ss_n ? v1 : 0.f;
+                    sss += j2 < p.in_ss_n ? v2 : 0.f;
+                    sss += j3 < p.in_ss_n ? v3 : 0.f;
+                }
+                frp[(part * 2 + 0) * BM + t] = sss;
+                frp[(part * 2 + 1) * BM + t] = sxs;
+            }
+        }
+    }
     xstore(u_lo & 1);
     __syncthreads();
+    if constexpr (FUSE) {
+        if (p.f_in) {
+            constexpr int kP = kThreads >= BM ? kThreads / BM : 1;
+            const float* frp = fr + 2 * BM;
+            for (int t = threadIdx.x; t < BM; t += kThreads) {
+                float sss = 0.f, sxs = 0.f;
+#pragma unroll
+                for (int part = 0; part < kP; ++part) {
+                    sss += frp[(part * 2 + 0) * BM + t];
+                    sxs += frp[(part * 2 + 1) * BM + t];
+                }
+                fr[t] = p.in_ss_n > 0 ? rsqrtf(sss / (float)p.K + p.eps) : 1.0f;
+                fr[BM + t] = sxs;
+            }
+        }
+    }
 
     // next unit's operands, requested UNCONDITIONALLY (a load inside `if (more)` makes hipcc drain vmcnt at the join,
     // i.e. wait for these very loads before the first MFMA): past the last unit the offsets fall into the next row /
@@ -447,6 +530,9 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
 
     // ---- epilogue: lane (g, c) holds rows 4 g .. 4 g + 3 of its tiles for token tt * 16 + c
     float sc[kTPW][4], zp[kTPW][4];
+    [[maybe_unused]] float ns[kTPW][4];  // FUSE, residual epilogue: the next RMSNorm's scales of this lane's rows
+    const bool emit = FUSE && EPI == MI355_EPI_ACCUM && p.out_xb != nullptr;
+    const bool sums = FUSE && EPI != MI355_EPI_STORE && p.out_sx != nullptr;
 #pragma unroll
     for (int t = 0; t < kTPW; ++t)
 #pragma unroll
@@ -462,12 +548,22 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
                 sc[t][r] = ok ? ldsz(sp, n, p.sz_dtype) : 0.f;
                 zp[t][r] = ok ? 128.f + ldsz(zq, n, p.sz_dtype) : 0.f;
             }
+            if constexpr (FUSE && EPI == MI355_EPI_ACCUM) ns[t][r] = (emit && ok) ? ldsz(p.next_norm, n, p.next_norm_dtype) : 0.f;
         }
+    [[maybe_unused]] float es1[kTT], es2[kTT];  // FUSE: this lane's share of the rows' partial sums (operand values, squares)
 #pragma unroll
     for (int tt = 0; tt < kTT; ++tt) {
+        if constexpr (FUSE) es1[tt] = es2[tt] = 0.f;
         const int m = m0 + tt * 16 + c;
         if (m >= p.M) continue;
-        const float sxm = GRP ? 0.f : p.sx[(int64_t)m * p.ksplit + ks], ri = p.rinv[m];
+        float sxm, ri;
+        if (FUSE && p.f_in) {
+            ri = fr[tt * 16 + c];
+            sxm = fr[BM + tt * 16 + c];
+        } else {
+            sxm = GRP ? 0.f : p.sx[(int64_t)m * p.ksplit + ks];
+            ri = p.rinv[m];
+        }
         float v[kTPW][4];
 #pragma unroll
         for (int t = 0; t < kTPW; ++t)
@@ -495,24 +591,65 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
                 const int n = tile[t] * 16 + 4 * g;
                 if (n < p.N) {  // N % 4 == 0 (host check)
                     bf16_t* dst = (bf16_t*)p.y + (int64_t)m * p.ldy + n;
+                    bf16_t ob[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(swiglu_f32(v[t][r], v[t + 1][r]));
                     u32x2 o;
-                    o[0] = (uint32_t)f32_to_bf16(swiglu_f32(v[t][0], v[t + 1][0])) |
-                           ((uint32_t)f32_to_bf16(swiglu_f32(v[t][1], v[t + 1][1])) << 16);
-                    o[1] = (uint32_t)f32_to_bf16(swiglu_f32(v[t][2], v[t + 1][2])) |
-                           ((uint32_t)f32_to_bf16(swiglu_f32(v[t][3], v[t + 1][3])) << 16);
+                    o[0] = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
+                    o[1] = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
                     *(u32x2*)dst = o;
+                    if constexpr (FUSE) es1[tt] += (bf16_to_f32(ob[0]) + bf16_to_f32(ob[1])) + (bf16_to_f32(ob[2]) + bf16_to_f32(ob[3]));
                 }
             }
         } else {
+            [[maybe_unused]] int posm = 0;
+            if constexpr (FUSE && EPI == MI355_EPI_STORE) {
+                if (p.rope != nullptr) posm = p.pos[m];
+            }
 #pragma unroll
             for (int t = 0; t < kTPW; ++t) {
                 const int n = tile[t] * 16 + 4 * g;
                 if (n >= p.N) continue;
+                if constexpr (FUSE && EPI == MI355_EPI_STORE) {
+                    // c_attn (model.py:197-221): rows [C, 2C) are k — rotated in f32 (model.py:306-323; the lane's four rows
+                    // are two interleaved pairs) — rows [2C, 3C) are v; both go to their bf16 cache rows, q goes to y
+                    const int sec = p.rope != nullptr ? (n >= p.C) + (n >= 2 * p.C) : 0;
+                    if (sec != 0) {
+                        const int cn = n - sec * p.C, h = cn >> 7, d = cn & 127;
+                        float o0 = v[t][0], o1 = v[t][1], o2 = v[t][2], o3 = v[t][3];
+                        if (sec == 1) {
+                            const f32x4 cs = *(const f32x4*)(p.rope + (int64_t)(p.rope_gathered ? m : posm) * 128 + d);
+                            const float k0 = o0 * cs[0] - o1 * cs[1], k1 = o1 * cs[0] + o0 * cs[1];
+                            const float k2 = o2 * cs[2] - o3 * cs[3], k3 = o3 * cs[2] + o2 * cs[3];
+                            o0 = k0, o1 = k1, o2 = k2, o3 = k3;
+                        }
+                        const int slot = posm < p.S - 1 ? posm : p.S - 1;
+                        bf16_t* dst = (sec == 1 ? p.kcache : p.vcache) + ((int64_t)h * p.S + slot) * 128 + d;
+                        u32x2 pk;
+                        pk[0] = (uint32_t)f32_to_bf16(o0) | ((uint32_t)f32_to_bf16(o1) << 16);
+                        pk[1] = (uint32_t)f32_to_bf16(o2) | ((uint32_t)f32_to_bf16(o3) << 16);
+                        *(u32x2*)dst = pk;
+                        continue;
+                    }
+                }
                 if (p.y_dtype == MI355_F32) {
                     float* dst = (float*)p.y + (int64_t)m * p.ldy + n;
                     f32x4 o = {v[t][0], v[t][1], v[t][2], v[t][3]};
                     if constexpr (EPI == MI355_EPI_ACCUM) o += *(const f32x4*)dst;
                     *(f32x4*)dst = o;
+                    if constexpr (FUSE && EPI == MI355_EPI_ACCUM) {
+                        if (emit) {  // the next linear's operand: bf16(norm scale * x), as stage_rows_kernel rounds it
+                            bf16_t ob[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(o[r] * ns[t][r]);
+                            u32x2 pk;
+                            pk[0] = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
+                            pk[1] = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
+                            *(u32x2*)(p.out_xb + (int64_t)m * p.out_ld + n) = pk;
+                            es1[tt] += (bf16_to_f32(ob[0]) + bf16_to_f32(ob[1])) + (bf16_to_f32(ob[2]) + bf16_to_f32(ob[3]));
+                            es2[tt] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                        }
+                    }
                 } else {
                     bf16_t* dst = (bf16_t*)p.y + (int64_t)m * p.ldy + n;
                     float o[4] = {v[t][0], v[t][1], v[t][2], v[t][3]};
@@ -528,12 +665,46 @@ __global__ __launch_bounds__(64 * kWaves) void gemm_q4_kernel(const GemmParams p
             }
         }
     }
+    if constexpr (FUSE && EPI != MI355_EPI_STORE) {
+        // partial sums of the block's rows per token: lane groups (permlane swaps), then the waves through LDS in wave
+        // order (the activation buffers are free: every wave is past its last unit's barrier), one entry per row block
+        if (sums) {
+            float* red = (float*)smem;  // [kWaves][2][BM]
+#pragma unroll
+            for (int tt = 0; tt < kTT; ++tt) {
+                float a = es1[tt], b = es2[tt];
+                a += lane_xor16(a);
+                a += lane_xor32(a);
+                b += lane_xor16(b);
+                b += lane_xor32(b);
+                if (g == 0) {
+                    red[(wave * 2 + 0) * BM + tt * 16 + c] = a;
+                    red[(wave * 2 + 1) * BM + tt * 16 + c] = b;
+                }
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < BM; t += kThreads) {
+                const int m = m0 + t;
+                if (m < p.M) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int w = 0; w < kWaves; ++w) {
+                        a += red[(w * 2 + 0) * BM + t];
+                        b += red[(w * 2 + 1) * BM + t];
+                    }
+                    p.out_sx[(int64_t)nb * p.M + m] = a;
+                    if (p.out_ss != nullptr) p.out_ss[(int64_t)nb * p.M + m] = b;
+                }
+            }
+        }
+    }
 }
 
-template <int EPI, bool PAIR, int FMT, int kWaves, int BM, int GRP = 0>
+template <int EPI, bool PAIR, int FMT, int kWaves, int BM, int GRP = 0, bool FUSE = false>
 int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row tiles (pair tiles for the SwiGLU stream)
-    static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR, FMT, kWaves, BM, GRP>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BM * 256);
+    constexpr int kLdsW = 2 * BM * 256 + (FUSE ? 2 * BM * 4 + 4096 : 0);  // two activation buffers (+ the rows' factors and the shares they are summed from)
+    static hipError_t attr_err = hipFuncSetAttribute((const void*)gemm_q4_kernel<EPI, PAIR, FMT, kWaves, BM, GRP, FUSE>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsW);
     if (attr_err != hipSuccess) {
         mi355_set_error("hipFuncSetAttribute(gemm) failed: %s", hipGetErrorString(attr_err));
         return (int)attr_err;
@@ -544,7 +715,7 @@ int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row ti
     q.n_blocks = (p.n_tiles + per_block - 1) / per_block;
     q.total_blocks = q.n_blocks * ((p.M + BM - 1) / BM);
     q.per_xcd = (q.total_blocks * q.ksplit + 7) / 8;
-    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR, FMT, kWaves, BM, GRP>), dim3(8 * q.per_xcd), dim3(64 * kWaves), 2 * BM * 256, s, q);
+    hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR, FMT, kWaves, BM, GRP, FUSE>), dim3(8 * q.per_xcd), dim3(64 * kWaves), kLdsW, s, q);
     MI355_LAUNCH_CHECK();
     if (q.ksplit > 1) {
         const int64_t n = (int64_t)p.M * (p.N >> 2);
@@ -554,23 +725,47 @@ int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row ti
     }
     return 0;
 }
-template <int EPI, bool PAIR, int FMT>
-int launch_gemm(const GemmParams& p, hipStream_t s) {
-    // blocks of 16 row tiles x 128 tokens if that gives every CU two workgroups to overlap; the narrow outputs of a long
-    // prompt (attn.c_proj / mlp.c_proj, N = 4096: 16 row blocks, at T = 2048 one workgroup per CU, matrix pipes 37 % busy
-    // against 53 % for the c_fc1 / c_fc2 pair) take 64-token blocks instead: twice the workgroups, half the LDS each;
-    // short prompts: split-K brings the blocks, or blocks of 4 / 2 row tiles
-    const int per_block8 = PAIR ? 8 * kTPW / 2 : 8 * kTPW;
-    const int blocks8 = ((p.n_tiles + per_block8 - 1) / per_block8) * ((p.M + kBM - 1) / kBM);
-    if (p.ksplit > 1) return launch_gemm_w<EPI, PAIR, FMT, 8, kBM>(p, s);
+// The shape of an ungrouped launch: blocks of 16 row tiles x 128 tokens if that gives every CU two workgroups to overlap;
+// the narrow outputs of a long prompt (attn.c_proj / mlp.c_proj, N = 4096: 16 row blocks, at T = 2048 one workgroup per
+// CU, matrix pipes 37 % busy against 53 % for the c_fc1 / c_fc2 pair) take 64-token blocks instead: twice the
+// workgroups, half the LDS each; short prompts: split-K brings the blocks, or blocks of 4 / 2 row tiles
+struct GemmShape {
+    int waves, bm;
+};
+GemmShape gemm_shape(int n_tiles, int M, bool pair, int ksplit) {
+    const int per_block8 = pair ? 8 * kTPW / 2 : 8 * kTPW;
+    const int blocks8 = ((n_tiles + per_block8 - 1) / per_block8) * ((M + kBM - 1) / kBM);
+    if (ksplit > 1) return {8, kBM};
     if (blocks8 >= 128) {
 #ifndef MI355_GEMM_NO_BM64
-        if (blocks8 < 384 && p.M >= 256) return launch_gemm_w<EPI, PAIR, FMT, 8, 64>(p, s);
+        if (blocks8 < 384 && M >= 256) return {8, 64};
 #endif
-        return launch_gemm_w<EPI, PAIR, FMT, 8, kBM>(p, s);
+        return {8, kBM};
     }
-    if (blocks8 * 4 >= 128) return launch_gemm_w<EPI, PAIR, FMT, 2, kBM>(p, s);
-    return launch_gemm_w<EPI, PAIR, FMT, 1, kBM>(p, s);
+    if (blocks8 * 4 >= 128) return {2, kBM};
+    return {1, kBM};
+}
+// split-K of an ungrouped launch: fewer than 96 blocks (a 128-token prompt against N = 4096 is 16) cut K into up to 8
+// slices, as many as bring the launch to ~128 workgroups and fit the partial buffer
+int gemm_ksplit(int M, int N, int K, bool swiglu) {
+    const int units = (K + 127) / 128;
+    const int rows_per_block = swiglu ? 16 * 8 * kTPW / 2 : 16 * 8 * kTPW;
+    const int blocks8 = ((N + rows_per_block - 1) / rows_per_block) * ((M + kBM - 1) / kBM);
+    const size_t row_floats = (size_t)N * (swiglu ? 2 : 1);
+    int ksplit = 1;
+    while (ksplit < kMaxSplit && blocks8 * ksplit < 96 && units >= 8 * ksplit && (size_t)2 * ksplit * M * row_floats * 4 <= kSplitBudget)
+        ksplit *= 2;
+    return ksplit;
+}
+template <int EPI, bool PAIR, int FMT, bool FUSE>
+int launch_gemm(const GemmParams& p, hipStream_t s) {
+    const GemmShape sh = gemm_shape(p.n_tiles, p.M, PAIR, p.ksplit);
+    if (sh.waves == 8) {
+        if (sh.bm == 64) return launch_gemm_w<EPI, PAIR, FMT, 8, 64, 0, FUSE>(p, s);
+        return launch_gemm_w<EPI, PAIR, FMT, 8, kBM, 0, FUSE>(p, s);
+    }
+    if (sh.waves == 2) return launch_gemm_w<EPI, PAIR, FMT, 2, kBM, 0, FUSE>(p, s);
+    return launch_gemm_w<EPI, PAIR, FMT, 1, kBM, 0, FUSE>(p, s);
 }
 // grouped scales: blocks of kGrpBM tokens x 4 waves (the second accumulator set costs the registers of more tokens or
 // waves)
@@ -593,11 +788,11 @@ int launch_gemm_grouped_epi(const GemmParams& p, int epi, hipStream_t s) {
     if (epi == MI355_EPI_ACCUM) return launch_gemm_grouped<MI355_EPI_ACCUM, false, GRP>(p, s);
     return launch_gemm_grouped<MI355_EPI_STORE, false, GRP>(p, s);
 }
-template <int FMT>
+template <int FMT, bool FUSE>
 int launch_gemm_epi(const GemmParams& p, int epi, hipStream_t s) {
-    if (epi == MI355_EPI_SWIGLU) return launch_gemm<MI355_EPI_SWIGLU, true, FMT>(p, s);
-    if (epi == MI355_EPI_ACCUM) return launch_gemm<MI355_EPI_ACCUM, false, FMT>(p, s);
-    return launch_gemm<MI355_EPI_STORE, false, FMT>(p, s);
+    if (epi == MI355_EPI_SWIGLU) return launch_gemm<MI355_EPI_SWIGLU, true, FMT, FUSE>(p, s);
+    if (epi == MI355_EPI_ACCUM) return launch_gemm<MI355_EPI_ACCUM, false, FMT, FUSE>(p, s);
+    return launch_gemm<MI355_EPI_STORE, false, FMT, FUSE>(p, s);
 }
 
 }  // namespace
@@ -611,6 +806,20 @@ extern "C" size_t mi355_linear_gemm_workspace_bytes(int M, int K) {
 
 extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, size_t workspace_bytes,
                                  mi355_stream_t stream) {
+    return mi355_linear_gemm_fused(a, nullptr, workspace, workspace_bytes, stream);
+}
+
+void mi355_linear_gemm_plan(int M, int N, int K, int R, int* ksplit, int* row_blocks) {
+    const bool pair = R == 2;
+    const int ks = gemm_ksplit(M, N, K, pair);
+    const GemmShape sh = gemm_shape((N + 15) / 16, M, pair, ks);
+    const int per_block = pair ? sh.waves * kTPW / 2 : sh.waves * kTPW;
+    *ksplit = ks;
+    *row_blocks = ((N + 15) / 16 + per_block - 1) / per_block;
+}
+
+int mi355_linear_gemm_fused(const mi355_linear_args* a, const mi355_gemm_fuse* f, void* workspace, size_t workspace_bytes,
+                            mi355_stream_t stream) {
     MI355_CHECK_ARG(a != nullptr && workspace != nullptr, MI355_E_ARG, "linear_gemm: null argument");
     MI355_CHECK_ARG(a->fmt == MI355_W_Q4 || a->fmt == MI355_W_BF16, MI355_E_ARG,
                     "linear_gemm: the wide path handles the Q4 and BF16 streams (fmt %d)", a->fmt);
@@ -665,12 +874,27 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
                (size_t)2 * ksplit * a->M * row_floats * 4 <= kSplitBudget / 2)
             ksplit *= 2;
     } else {
-        const int rows_per_block = swiglu ? 16 * 8 * kTPW / 2 : 16 * 8 * kTPW;
-        const int blocks8 = ((a->N + rows_per_block - 1) / rows_per_block) * ((a->M + kBM - 1) / kBM);
-        const size_t row_floats = (size_t)a->N * (swiglu ? 2 : 1);
-        while (ksplit < kMaxSplit && blocks8 * ksplit < 96 && units >= 8 * ksplit &&
-               (size_t)2 * ksplit * a->M * row_floats * 4 <= kSplitBudget)
-            ksplit *= 2;
+        ksplit = gemm_ksplit(a->M, a->N, a->K, swiglu);
+    }
+    // producer / consumer fusion (gemm_fuse.h): whole-K launches over per-row scales only — the caller plans with
+    // mi355_linear_gemm_plan
+    const bool fused = f != nullptr;
+    const bool f_in = fused && f->prestaged;
+    if (fused) {
+        MI355_CHECK_ARG(!grouped && ksplit == 1, MI355_E_STATE, "linear_gemm: fusion over a grouped or K-split launch (M=%d N=%d K=%d)",
+                        a->M, a->N, a->K);
+        MI355_CHECK_ARG(!f_in || (a->x_dtype == MI355_BF16 && a->norm_scale == nullptr && a->K % 128 == 0 && a->ldx % 8 == 0 &&
+                                  (uintptr_t)a->x % 16 == 0 && f->in_sx != nullptr && f->in_sx_n > 0 && (f->in_ss == nullptr || f->in_ss_n > 0)),
+                        MI355_E_ARG, "linear_gemm: a pre-staged operand is bf16 [M, ldx] with K %% 128 == 0 and partial operand sums");
+        MI355_CHECK_ARG(f->out_xb == nullptr || (a->epi == MI355_EPI_ACCUM && a->y_dtype == MI355_F32 && f->next_norm && f->out_ss &&
+                                                 f->out_sx && f->out_ld % 4 == 0 && (void*)f->out_xb != a->x &&
+                                                 (f_in || (void*)f->out_xb != workspace)),
+                        MI355_E_ARG, "linear_gemm: the next operand is emitted by the f32 residual epilogue, next to its partial sums");
+        MI355_CHECK_ARG(f->out_sx == nullptr || a->epi == MI355_EPI_SWIGLU || f->out_xb != nullptr, MI355_E_ARG,
+                        "linear_gemm: partial operand sums come from the SwiGLU or the emitting residual epilogue");
+        MI355_CHECK_ARG(f->rope == nullptr || (a->epi == MI355_EPI_STORE && f->pos && f->kcache && f->vcache && f->hs == 128 && f->S > 0 &&
+                                               a->N == 3 * f->n_head * f->hs),
+                        MI355_E_ARG, "linear_gemm: the K / V cache epilogue is c_attn's (N = 3 n_head x 128, STORE)");
     }
     float* part = (float*)((char*)workspace + (size_t)a->M * kp * 2 + (size_t)a->M * 4 * (1 + kMaxSplit) + 256);
     part = (float*)(((uintptr_t)part + 15) & ~(uintptr_t)15);
@@ -696,7 +920,7 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
         p.gq_shift = gq_shift;
         p.upg = a->group_cols >= 128 ? a->group_cols / 128 : 1;
         p.tab_ld = tab_ld;
-    } else {
+    } else if (!f_in) {
         hipLaunchKernelGGL(stage_rows_kernel, dim3(a->M), dim3(256), 0, s, a->x, a->x_dtype, a->ldx, a->norm_scale, a->norm_dtype,
                            a->eps, a->K, kp, xb, (int64_t)kp, rinv, sx, ksplit);
         MI355_LAUNCH_CHECK();
@@ -707,9 +931,10 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
         MI355_CHECK_ARG(wb > 0 && wb < 0xFFFFFFF0ull, MI355_E_SHAPE, "linear_gemm: weight stream of %zu B", wb);
         p.w_bytes = (unsigned)wb;
     }
-    MI355_CHECK_ARG((size_t)a->M * kp * 2 < 0xFFFFFFF0ull, MI355_E_SHAPE, "linear_gemm: M x K too large for one launch");
-    p.xb = xb;
-    p.ldxb = kp;
+    MI355_CHECK_ARG((size_t)a->M * (f_in ? (size_t)a->ldx : (size_t)kp) * 2 < 0xFFFFFFF0ull, MI355_E_SHAPE,
+                    "linear_gemm: M x K too large for one launch");
+    p.xb = f_in ? (const bf16_t*)a->x : xb;
+    p.ldxb = f_in ? a->ldx : (int64_t)kp;
     p.rinv = rinv;
     p.sx = sx;
     p.scales = a->scales;
@@ -728,6 +953,29 @@ extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, si
     p.ksplit = ksplit;
     p.part = part;
     if (grouped) return a->group_cols >= 128 ? launch_gemm_grouped_epi<1>(p, a->epi, s) : launch_gemm_grouped_epi<2>(p, a->epi, s);
-    if (q4) return launch_gemm_epi<MI355_W_Q4>(p, a->epi, s);
-    return launch_gemm_epi<MI355_W_BF16>(p, a->epi, s);
+    if (fused) {
+        p.f_in = f_in ? 1 : 0;
+        p.in_sx = f->in_sx;
+        p.in_sx_n = f_in ? f->in_sx_n : 0;
+        p.in_ss = f->in_ss;
+        p.in_ss_n = f_in && f->in_ss != nullptr ? f->in_ss_n : 0;
+        p.eps = a->eps;
+        p.out_xb = f->out_xb;
+        p.out_ld = f->out_ld;
+        p.next_norm = f->next_norm;
+        p.next_norm_dtype = f->next_norm_dtype;
+        p.out_ss = f->out_ss;
+        p.out_sx = f->out_sx;
+        p.rope = f->rope;
+        p.pos = f->pos;
+        p.kcache = f->kcache;
+        p.vcache = f->vcache;
+        p.S = f->S;
+        p.C = f->n_head * f->hs;
+        p.rope_gathered = f->rope_gathered;
+        if (q4) return launch_gemm_epi<MI355_W_Q4, true>(p, a->epi, s);
+        return launch_gemm_epi<MI355_W_BF16, true>(p, a->epi, s);
+    }
+    if (q4) return launch_gemm_epi<MI355_W_Q4, false>(p, a->epi, s);
+    return launch_gemm_epi<MI355_W_BF16, false>(p, a->epi, s);
 }

@@ -12,9 +12,17 @@ from lit_llama_amd.utils import EmptyInitOnDevice  # noqa: E402
 
 dev = torch.device("cuda:0")
 cfg = LLaMAConfig.from_name("7B")
-with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
-    model = LLaMA(cfg)
-synth.fill_model_random_int4(model, seed=0)
+mode = sys.argv[2] if len(sys.argv) > 2 else "gptq.int4"  # "none": the bf16 model (BASELINE configs[1])
+if mode == "none":
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16):
+        model = LLaMA(cfg)
+    for prm in model.parameters():
+        prm.data.normal_(0.0, 0.02)
+else:
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
+        model = LLaMA(cfg)
+    synth.fill_model_random_int4(model, seed=0)
+model.eval()
 eng = model.engine()
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 prompt = synth.make_prompt(T).to(dev)

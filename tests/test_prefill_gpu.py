@@ -188,3 +188,49 @@ def test_llm_int8_prompt_takes_the_int8_gemm_and_matches_oracle(dev):
     e2 = (got2 - ref2).abs().max().item() / std
     assert e2 <= 0.15, f"int8 no-cache forward: {e2:.4f} std"
     print(f"llm.int8 7B-width layer, {T} tokens: engine prefill {e1:.4f} std, module path {e2:.4f} std")
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("mode", ["gptq.int4", None])
+def test_fused_prompt_chain_matches_oracle_and_the_staged_chain(dev, monkeypatch, mode):
+    """Round 5: a prompt chunk wide enough that no GEMM launch is split over K (7B width: more than 640 tokens) runs the layer
+    as a producer / consumer chain (csrc/gemm_fuse.h): no staging pass in front of a linear (the residual epilogues emit the
+    next operand and its partial sums, the SwiGLU and attention outputs are operands as they are), the c_attn epilogue rotates
+    k and writes the K / V cache rows.  Two 7B-width layers (the mlp.c_proj -> next layer's c_attn hand-over included), 700
+    prompt tokens through the engine: against the oracle (/root/reference lit_llama/model.py:76-122 with T > 1), against the
+    staged chain of rounds 2-4 (MI355_GEMM_FUSE=0) on the same weights, and one decode step on top of each cache."""
+    cfg_kw = dict(n_layer=2, n_head=32, n_embd=4096)
+    cfg = LLaMAConfig(**cfg_kw)
+    sd = synth.make_state_dict(cfg, seed=11, mode=mode, **(dict(dtype=torch.bfloat16) if mode is None else {}))
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode=mode):
+        model = LLaMA(cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    om = oracle.Model(oracle.Config(**cfg_kw), {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}, mode=mode)
+    eng = model.engine()
+    assert eng is not None and eng.max_T >= 700 and eng.gemm_ws is not None, model._engine_failed
+    T, S = 700, 712
+    prompt = synth.make_prompt(T + 1, seed=21)
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    ref = om(prompt[:T].view(1, -1), S, torch.arange(T))[0].float()
+    ref1 = om(prompt[T:T + 1].view(1, -1), S, torch.tensor([T]))[0].float()
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MI355_GEMM_FUSE", fuse)
+        model.reset_cache()
+        got = model(prompt[:T].view(1, -1).to(dev), S, _pos(T, dev))[0].float().cpu()
+        p1 = torch.tensor([T], device=dev)
+        p1._mi355_pos0 = T
+        got1 = model(prompt[T:T + 1].view(1, -1).to(dev), S, p1)[0].float().cpu()
+        eng.check_status()
+        e = check(got, ref, f"prefill, MI355_GEMM_FUSE={fuse}")
+        e1 = check(got1, ref1, f"decode step on that cache, MI355_GEMM_FUSE={fuse}")
+        out[fuse] = (got, got1, e, e1)
+    std = float(ref.std(-1).mean())
+    d = (out["1"][0] - out["0"][0]).abs().max().item() / std
+    d1 = (out["1"][1] - out["0"][1]).abs().max().item() / std
+    # the two chains round the same operands; they differ in the ORDER of the per-row sums (partial sums per block) and in
+    # where k is rotated: f32 noise in front of a bf16 rounding
+    assert d <= 0.02 and d1 <= 0.02, (d, d1)
+    print(f"{mode}: fused chain {out['1'][2]:.4f} / {out['1'][3]:.4f} std vs oracle (staged {out['0'][2]:.4f} / {out['0'][3]:.4f}); "
+          f"fused vs staged {d:.4f} / {d1:.4f} std")
