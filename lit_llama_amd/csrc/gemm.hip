@@ -34,6 +34,9 @@ constexpr int kBM = 128;     // tokens per block
 #define MI355_GEMM_TPW 2
 #endif
 constexpr int kTPW = MI355_GEMM_TPW;
+#ifndef MI355_GEMM_PIN_LOADS
+#define MI355_GEMM_PIN_LOADS 1
+#endif
 #ifndef MI355_GEMM_BF16_OCC
 #define MI355_GEMM_BF16_OCC 1
 #endif  // 16-row tile slots per wave: one B fragment read from LDS feeds kTPW MFMAs
@@ -390,6 +393,11 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
         xload(u + 1);
 #pragma unroll
         for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
+        // hipcc sinks these requests to the END of the unit, right in front of the LDS stores that wait for them (the
+        // 24 registers they land in would otherwise be live across the MFMAs): a unit pays the memory latency in front
+        // of its barrier, covered by the other waves of the SIMD.  Pinned here they fly under the unit's MFMAs — at
+        // 141-145 VGPRs for 128-token blocks (one workgroup per CU), so only the 64-token blocks (95) can take it.
+        if constexpr (MI355_GEMM_PIN_LOADS && BM <= 64 && GRP == 0) __builtin_amdgcn_sched_barrier(0);
     };
     // the 4 x kTT x kTPW MFMAs of a unit; sub >= 0 (GRP 2): only the lane groups of sub-group `sub` contribute
     // (explicitly software-pipelined B-fragment reads — 16 fragments in registers, pinned with sched_barrier —

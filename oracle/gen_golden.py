@@ -305,6 +305,15 @@ def big_long_case():
                nocache=False)
 
 
+def big_s1_case():
+    """A SECOND full-depth 7B int4 checkpoint (seed 1: other weights, scales and zero points), prompt of 24, 32 greedy tokens: the
+    token-for-token evidence of north_star on more than one checkpoint ("one fixture pair is one fixture pair").
+    `--big-s1`; bf16 calibration twin: `--big-bf16 --s1`."""
+    torch.set_num_threads(max(8, (torch.get_num_threads() or 8)))
+    model_case("cfg2_7b_int4_s1", dict(n_layer=32, n_head=32, n_embd=4096), "gptq.int4", prompt_len=24, new_tokens=32, seed=1,
+               nocache=False)
+
+
 def big_p400_case():
     """The same checkpoint with a 400-token prompt and 16 greedy tokens: decode runs at positions
     400..415, i.e. past the fused step's row-split threshold (position 384) at FULL depth — where the reference's own
@@ -448,6 +457,10 @@ def main():
         print("generating the full-depth unquantised 7B fixture from", REF)
         big_none_case()
         return
+    if "--big-s1" in sys.argv:
+        print("generating the second-checkpoint full-depth 7B fixture from", REF)
+        big_s1_case()
+        return
     if "--big-p400" in sys.argv:
         print("generating the 400-token-prompt full-depth 7B fixture from", REF)
         big_p400_case()
@@ -458,7 +471,7 @@ def main():
         return
     if "--big-bf16" in sys.argv:
         print("running the reference in bf16 on the full-depth fixture from", REF)
-        big_bf16_case("cfg2_7b_int4_p400" if "--p400" in sys.argv else
+        big_bf16_case("cfg2_7b_int4_s1" if "--s1" in sys.argv else "cfg2_7b_int4_p400" if "--p400" in sys.argv else
                       "cfg2_7b_int4_long" if "--long" in sys.argv else "cfg2_7b_int4")
         return
     if "--adapter-v2" in sys.argv:
