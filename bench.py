@@ -506,7 +506,7 @@ def main():
         # prompt prefill at the reference's evaluation length (evaluate/full.py:120-129: T = 2048): wide int4 GEMM +
         # flash attention, MFMA-bound
         prefill = None
-        if args.quantize == "gptq.int4" and cfg.block_size >= 2048:
+        if args.quantize in ("gptq.int4", "none") and cfg.block_size >= 2048:
             T2 = 2048
             long_prompt = synth.make_prompt(T2, vocab=cfg.vocab_size, seed=4321).to(dev)
             with torch.cuda.stream(eng.stream):
@@ -523,7 +523,10 @@ def main():
             prefill = {"tokens": T2, "ms": round(ms, 2), "tokens_per_s": round(T2 / ms * 1e3, 1),
                        "tflops": round(flops / ms / 1e9, 1), "peak_tflops": 2500.0, "bound": "mfma",
                        "frac": round(flops / ms / 1e9 / 2500.0, 4), "chunk": eng.max_T,
-                       "kernels": "gemm_q4_kernel (int4 stream -> bf16 MFMA 16x16x32) + flash_prefill_kernel"}
+                       "chain": "staged (MI355_GEMM_FUSE=0)" if os.environ.get("MI355_GEMM_FUSE", "1")[:1] == "0" else
+                       "fused: producers' epilogues write the next operand / the K, V cache rows (csrc/gemm_fuse.h)",
+                       "kernels": ("gemm_q4_kernel (int4 stream -> bf16 MFMA 16x16x32)" if args.quantize == "gptq.int4" else
+                                   "gemm_q4_kernel<BF16> (bf16 stream, MFMA 16x16x32)") + " + flash_prefill_kernel"}
     tp_res = None
     if not args.no_tp and args.quantize == "gptq.int4":
         # free the 7B replica first: the 65B shard of a small world is tens of GB

@@ -3,7 +3,7 @@
 // Replaces, for prompt chunks wide enough that no launch is split over K, the per-linear staging pass
 // (stage_rows_kernel: f32 row -> bf16 operand + 1/rms + operand sum, four launches per layer) and the K / V cache
 // write (rope_kv_write_kernel) of /root/reference lit_llama/model.py:185-237,251-254 as this library ran them in
-// rounds 2-4: 13 % of a 2048-token 7B prompt (profiles/r05_prefill_kernel_stats_before.csv).
+// rounds 2-4: 14 % of a 2048-token 7B prompt (profiles/r04_prefill_kernel_stats_staged_chain.csv).
 //   * a producer's epilogue writes what the next linear consumes: the residual epilogue of attn.c_proj / mlp.c_proj
 //     emits bf16(next_norm_scale * x_new) next to the f32 residual row, the SwiGLU epilogue's bf16 output and the
 //     flash-attention output ARE operands already;

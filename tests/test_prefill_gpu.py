@@ -193,12 +193,12 @@ def test_llm_int8_prompt_takes_the_int8_gemm_and_matches_oracle(dev):
 @torch.no_grad()
 @pytest.mark.parametrize("mode", ["gptq.int4", None])
 def test_fused_prompt_chain_matches_oracle_and_the_staged_chain(dev, monkeypatch, mode):
-    """Round 5: a prompt chunk wide enough that no GEMM launch is split over K (7B width: more than 640 tokens) runs the layer
+    """Round 4: a prompt chunk wide enough that no GEMM launch is split over K (7B width: more than 640 tokens) runs the layer
     as a producer / consumer chain (csrc/gemm_fuse.h): no staging pass in front of a linear (the residual epilogues emit the
     next operand and its partial sums, the SwiGLU and attention outputs are operands as they are), the c_attn epilogue rotates
     k and writes the K / V cache rows.  Two 7B-width layers (the mlp.c_proj -> next layer's c_attn hand-over included), 700
     prompt tokens through the engine: against the oracle (/root/reference lit_llama/model.py:76-122 with T > 1), against the
-    staged chain of rounds 2-4 (MI355_GEMM_FUSE=0) on the same weights, and one decode step on top of each cache."""
+    staged chain of rounds 2-3 (MI355_GEMM_FUSE=0) on the same weights, and one decode step on top of each cache."""
     cfg_kw = dict(n_layer=2, n_head=32, n_embd=4096)
     cfg = LLaMAConfig(**cfg_kw)
     sd = synth.make_state_dict(cfg, seed=11, mode=mode, **(dict(dtype=torch.bfloat16) if mode is None else {}))
