@@ -37,6 +37,9 @@ constexpr int kTPW = MI355_GEMM_TPW;
 #ifndef MI355_GEMM_PIN_LOADS
 #define MI355_GEMM_PIN_LOADS 1
 #endif
+#ifndef MI355_GEMM_PIN_W
+#define MI355_GEMM_PIN_W 0
+#endif
 #ifndef MI355_GEMM_BF16_OCC
 #define MI355_GEMM_BF16_OCC 1
 #endif  // 16-row tile slots per wave: one B fragment read from LDS feeds kTPW MFMAs
@@ -390,6 +393,17 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
     // i.e. wait for these very loads before the first MFMA): past the last unit the offsets fall into the next row /
     // tile or out of the descriptors (zeros) and the values are never used
     auto prefetch = [&](int u) {
+#if MI355_GEMM_PIN_W
+        // (A / B knob, off: 128-token blocks with only the WEIGHT requests — HBM latency — pinned at the unit's start, the
+        // activation requests, L2 hits, free to sink: 116-124 VGPRs, measured neutral — profiles/r04_prefill_fused_chain_ab.txt)
+        if constexpr (BM > 64 && GRP == 0 && FMT == MI355_W_Q4) {
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            xload(u + 1);
+            return;
+        }
+#endif
         xload(u + 1);
 #pragma unroll
         for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
