@@ -81,16 +81,20 @@ int run_linear_rows(const mi355_model* m, const mi355_weight& w, const void* x, 
 
 // The wide-GEMM chain of one prompt pass with the staging passes and the K / V cache write folded into the producers'
 // epilogues (gemm_fuse.h).  Decided once per mi355_forward call: every layer linear on the wide path over per-row scales,
-// no launch of the chunk split over K (mi355_linear_gemm_plan), a bf16 cache at head size 128, no adapter prefix, one GPU.
+// widths of whole 128-column units, a bf16 cache at head size 128, no adapter prefix, one GPU.
+struct FuseEdge {      // partial sums ("shares") a producer leaves per row, [share][T] f32
+    float* ss;         // sums of squares of the f32 residual row (residual epilogues only)
+    float* sx;         // operand sums
+    int n, ppu;        // shares, shares per 128-column unit (mi355_linear_gemm_plan of the producer's launch)
+};
 struct FuseCtx {
     bool on;
     bf16_t* xb;        // [T][n_embd]: the operand the last residual epilogue emitted (start of the GEMM workspace)
-    float* ssA;        // [nA][T] partial sums of squares / operand sums from the residual epilogues
-    float* sxA;
-    float* sxB;        // [nB][T] partial operand sums from the SwiGLU epilogue
-    float* sxC;        // [n_head][T] from the attention kernel
-    int nA, nB;
-    bool have_x;       // xb / ssA / sxA hold the input of the next normalised linear
+    FuseEdge proj;     // attn.c_proj -> c_fc1 / c_fc2
+    FuseEdge mproj;    // mlp.c_proj -> the next layer's c_attn
+    FuseEdge fc;       // SwiGLU output -> mlp.c_proj
+    FuseEdge att;      // attention output -> attn.c_proj (one share per head)
+    bool have_x;       // xb and the mproj edge hold the input of the next c_attn
 };
 
 void fill_linear_args(mi355_linear_args& a, const mi355_model* m, const mi355_weight& w, const void* x, int x_dtype, int M,
@@ -134,7 +138,6 @@ FuseCtx plan_fusion(const mi355_model* m, int T) {
         (int64_t)m->S * 256 >= 0x7fffffffLL || m->n_head * m->hs != m->n_embd)
         return z;
     const int C = m->n_embd, H = m->n_hidden;
-    int nA = 0, nB = 0;
     for (int l = 0; l < m->n_layer; ++l) {
         const mi355_layer& L = m->layers[l];
         if (L.adapter_len > 0 || !wide_plain(L.attn) || !wide_plain(L.proj) || !wide_plain(L.fc) || !wide_plain(L.mproj)) return z;
@@ -142,28 +145,35 @@ FuseCtx plan_fusion(const mi355_model* m, int T) {
             L.mproj.N != C || L.mproj.K != H || L.kcache == nullptr || L.vcache == nullptr)
             return z;
     }
-    int ks[4], rb[4];
-    mi355_linear_gemm_plan(T, 3 * C, C, 1, &ks[0], &rb[0]);
-    mi355_linear_gemm_plan(T, C, C, 1, &ks[1], &rb[1]);
-    mi355_linear_gemm_plan(T, H, C, 2, &ks[2], &rb[2]);
-    mi355_linear_gemm_plan(T, C, H, 1, &ks[3], &rb[3]);
-    if (ks[0] != 1 || ks[1] != 1 || ks[2] != 1 || ks[3] != 1 || rb[1] != rb[3]) return z;
-    nA = rb[1];
-    nB = rb[2];
-    // scratch: the last 16 MiB of the workspace (the split-K budget, unused by whole-K launches)
-    const size_t need = (size_t)T * (size_t)(2 * nA + nB + m->n_head) * 4 + 64;
-    const size_t tail = (size_t)16 << 20;
+    if (C % 128 != 0 || H % 128 != 0) return z;
+    int ks, n, ppu;
+    const size_t Ts = (size_t)T;
+    // scratch: the tail of the workspace (mi355_linear_gemm_workspace_bytes reserves it behind the split-K partials)
     const int kmax = H > C ? H : C;
-    if (need > tail || (size_t)m->gemm_ws_bytes < mi355_linear_gemm_workspace_bytes(T, kmax)) return z;
-    char* base = (char*)m->gemm_ws + (((size_t)m->gemm_ws_bytes - tail) & ~(size_t)15);
+    const size_t tail = mi355_linear_gemm_fuse_scratch_bytes();
+    if ((size_t)m->gemm_ws_bytes < mi355_linear_gemm_workspace_bytes(T, kmax)) return z;
+    float* cur = (float*)((char*)m->gemm_ws + (((size_t)m->gemm_ws_bytes - tail) & ~(size_t)15));
+    float* const end = (float*)((char*)m->gemm_ws + (size_t)m->gemm_ws_bytes);
+    auto edge = [&](FuseEdge& e, int N, int K, int R, bool with_ss) {
+        mi355_linear_gemm_plan(T, N, K, R, &ks, &n, &ppu);
+        e.n = n;
+        e.ppu = ppu;
+        e.sx = cur;
+        cur += (size_t)n * Ts;
+        e.ss = with_ss ? cur : nullptr;
+        if (with_ss) cur += (size_t)n * Ts;
+    };
+    edge(z.proj, C, C, 1, true);
+    edge(z.mproj, C, H, 1, true);
+    edge(z.fc, H, C, 2, false);
+    z.att.n = m->n_head;
+    z.att.ppu = 1;
+    z.att.sx = cur;
+    z.att.ss = nullptr;
+    cur += (size_t)m->n_head * Ts;
+    if (cur > end) return z;
     z.on = true;
     z.xb = (bf16_t*)m->gemm_ws;
-    z.ssA = (float*)base;
-    z.sxA = z.ssA + (size_t)nA * T;
-    z.sxB = z.sxA + (size_t)nA * T;
-    z.sxC = z.sxB + (size_t)nB * T;
-    z.nA = nA;
-    z.nB = nB;
     return z;
 }
 
@@ -338,9 +348,10 @@ static int fused_segment(const mi355_model* m, int T, int layer, int seg, hipStr
             if (fz->have_x) {
                 fill_linear_args(a, m, L.attn, fz->xb, MI355_BF16, T, C, nullptr, MI355_EPI_STORE, m->qkv, MI355_F32, 3 * C);
                 f.prestaged = 1;
-                f.in_sx = fz->sxA;
-                f.in_ss = fz->ssA;
-                f.in_sx_n = f.in_ss_n = fz->nA;
+                f.in_sx = fz->mproj.sx;
+                f.in_ss = fz->mproj.ss;
+                f.in_sx_n = f.in_ss_n = fz->mproj.n;
+                f.in_ppu = fz->mproj.ppu;
             } else {
                 fill_linear_args(a, m, L.attn, m->x, MI355_F32, T, C, L.rms1, MI355_EPI_STORE, m->qkv, MI355_F32, 3 * C);
             }
@@ -354,43 +365,46 @@ static int fused_segment(const mi355_model* m, int T, int layer, int seg, hipStr
             if (int rc = mi355_linear_gemm_fused(&a, &f, m->gemm_ws, (size_t)m->gemm_ws_bytes, s)) return rc;
             fz->have_x = false;
             return mi355_flash_prefill(m->qkv, MI355_F32, 3 * C, m->rope, 0, m->pos, L.kcache, L.vcache, T, m->n_head, m->S, m->att,
-                                       C, 1.0f / sqrtf((float)m->hs), fz->sxC, s);
+                                       C, 1.0f / sqrtf((float)m->hs), fz->att.sx, s);
         }
         case 1:  // attn.c_proj over the attention output as it is; the residual epilogue emits the operand of c_fc1 / c_fc2
             fill_linear_args(a, m, L.proj, m->att, MI355_BF16, T, C, nullptr, MI355_EPI_ACCUM, m->x, MI355_F32, C);
             f.prestaged = 1;
-            f.in_sx = fz->sxC;
-            f.in_sx_n = m->n_head;
+            f.in_sx = fz->att.sx;
+            f.in_sx_n = fz->att.n;
+            f.in_ppu = fz->att.ppu;
             f.out_xb = fz->xb;
             f.out_ld = C;
             f.next_norm = L.rms2;
             f.next_norm_dtype = m->param_dtype;
-            f.out_ss = fz->ssA;
-            f.out_sx = fz->sxA;
+            f.out_ss = fz->proj.ss;
+            f.out_sx = fz->proj.sx;
             fz->have_x = true;
             return mi355_linear_gemm_fused(&a, &f, m->gemm_ws, (size_t)m->gemm_ws_bytes, s);
         case 2:  // c_fc1 / c_fc2 + SwiGLU over the emitted operand; partial operand sums of the hidden vector
             MI355_CHECK_ARG(fz->have_x, MI355_E_STATE, "forward: the fused chain lost its operand before layer %d's MLP", layer);
             fill_linear_args(a, m, L.fc, fz->xb, MI355_BF16, T, C, nullptr, MI355_EPI_SWIGLU, m->hbuf, MI355_BF16, H);
             f.prestaged = 1;
-            f.in_sx = fz->sxA;
-            f.in_ss = fz->ssA;
-            f.in_sx_n = f.in_ss_n = fz->nA;
-            f.out_sx = fz->sxB;
+            f.in_sx = fz->proj.sx;
+            f.in_ss = fz->proj.ss;
+            f.in_sx_n = f.in_ss_n = fz->proj.n;
+            f.in_ppu = fz->proj.ppu;
+            f.out_sx = fz->fc.sx;
             fz->have_x = false;
             return mi355_linear_gemm_fused(&a, &f, m->gemm_ws, (size_t)m->gemm_ws_bytes, s);
         default:  // mlp.c_proj; the residual epilogue emits the next layer's c_attn operand
             fill_linear_args(a, m, L.mproj, m->hbuf, MI355_BF16, T, H, nullptr, MI355_EPI_ACCUM, m->x, MI355_F32, C);
             f.prestaged = 1;
-            f.in_sx = fz->sxB;
-            f.in_sx_n = fz->nB;
+            f.in_sx = fz->fc.sx;
+            f.in_sx_n = fz->fc.n;
+            f.in_ppu = fz->fc.ppu;
             if (layer + 1 < m->n_layer) {
                 f.out_xb = fz->xb;
                 f.out_ld = C;
                 f.next_norm = m->layers[layer + 1].rms1;
                 f.next_norm_dtype = m->param_dtype;
-                f.out_ss = fz->ssA;
-                f.out_sx = fz->sxA;
+                f.out_ss = fz->mproj.ss;
+                f.out_sx = fz->mproj.sx;
                 fz->have_x = true;
             }
             return mi355_linear_gemm_fused(&a, &f, m->gemm_ws, (size_t)m->gemm_ws_bytes, s);

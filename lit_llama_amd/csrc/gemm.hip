@@ -73,7 +73,7 @@ struct GemmParams {
     int n_groups, gq_shift, upg, tab_ld;
     // producer / consumer fusion (gemm_fuse.h; FUSE kernels only).  f_in: xb is the caller's operand, 1/rms and the operand
     // sums of the block's rows are rebuilt from the partial sums in_ss / in_sx ([partial][M])
-    int f_in, in_sx_n, in_ss_n;
+    int f_in, in_sx_n, in_ss_n, in_ppu;  // in_ppu: partial operand sums per 128-column unit (a K-slice sums its own units' shares)
     const float* in_sx;
     const float* in_ss;
     float eps;
@@ -92,6 +92,7 @@ struct GemmParams {
 
 constexpr size_t kSplitBudget = (size_t)32 << 20;  // bytes of split-K partials a workspace holds
 constexpr int kMaxSplit = 8;
+constexpr size_t kFuseScratch = (size_t)8 << 20;  // partial sums of the fused prompt chain: <= 2048 tokens x ~500 shares x 4 B
 // first unit of K-slice s of `ksplit` (slice s = units [lo(s), lo(s + 1)))
 __host__ __device__ __forceinline__ int slice_lo(int s, int units, int ksplit) { return (int)((int64_t)s * units / ksplit); }
 
@@ -231,6 +232,82 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
     }
 }
 
+// The split-K reduction of a launch of the fused chain (gemm_fuse.h): sums the K-slices in slice order as splitk_reduce_kernel
+// does, and is the producer epilogue the whole-K kernel has — the residual rows also leave as the next linear's bf16 operand
+// with their partial sums, the SwiGLU output with its partial operand sums, c_attn's k rotated and K / V written to the cache.
+// One half wave (32 lanes x 4 columns) per (row, 128-column unit): a unit is what a consumer's K-slices are cut at.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_fused_reduce_kernel(const GemmParams p) {
+    const int units_n = p.N >> 7;  // N % 128 == 0 (host check)
+    const int64_t groups = (int64_t)p.M * units_n;
+    const int l32 = threadIdx.x & 31;
+    for (int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5; grp < groups; grp += (int64_t)gridDim.x * 8) {
+        const int m = (int)(grp / units_n), un = (int)(grp - (int64_t)m * units_n);
+        const int n = un * 128 + l32 * 4;
+        if constexpr (EPI == MI355_EPI_SWIGLU) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            for (int sl = 0; sl < p.ksplit; ++sl) {
+                const float* row = p.part + ((int64_t)sl * p.M + m) * (2 * (int64_t)p.N);
+                a += *(const f32x4*)(row + n);
+                b += *(const f32x4*)(row + p.N + n);
+            }
+            bf16_t ob[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(swiglu_f32(a[r], b[r]));
+            u32x2 pk;
+            pk[0] = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
+            pk[1] = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
+            *(u32x2*)((bf16_t*)p.y + (int64_t)m * p.ldy + n) = pk;
+            if (p.out_sx != nullptr) {
+                const float s1 = group_sum((bf16_to_f32(ob[0]) + bf16_to_f32(ob[1])) + (bf16_to_f32(ob[2]) + bf16_to_f32(ob[3])), 32);
+                if (l32 == 0) p.out_sx[(int64_t)un * p.M + m] = s1;
+            }
+        } else {
+            float* dst = (float*)p.y + (int64_t)m * p.ldy + n;  // (f32 outputs only: host check)
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == MI355_EPI_ACCUM) o = *(const f32x4*)dst;
+            for (int sl = 0; sl < p.ksplit; ++sl) o += *(const f32x4*)(p.part + ((int64_t)sl * p.M + m) * p.N + n);
+            if constexpr (EPI == MI355_EPI_STORE) {
+                const int sec = p.rope != nullptr ? (n >= p.C) + (n >= 2 * p.C) : 0;
+                if (sec != 0) {  // as the whole-K epilogue: k rotated in f32, K / V rows to the bf16 cache
+                    const int cn = n - sec * p.C, h = cn >> 7, d = cn & 127;
+                    const int posm = p.pos[m];
+                    if (sec == 1) {
+                        const f32x4 cs = *(const f32x4*)(p.rope + (int64_t)(p.rope_gathered ? m : posm) * 128 + d);
+                        const float k0 = o[0] * cs[0] - o[1] * cs[1], k1 = o[1] * cs[0] + o[0] * cs[1];
+                        const float k2 = o[2] * cs[2] - o[3] * cs[3], k3 = o[3] * cs[2] + o[2] * cs[3];
+                        o = f32x4{k0, k1, k2, k3};
+                    }
+                    const int slot = posm < p.S - 1 ? posm : p.S - 1;
+                    u32x2 pk;
+                    pk[0] = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                    pk[1] = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    *(u32x2*)((sec == 1 ? p.kcache : p.vcache) + ((int64_t)h * p.S + slot) * 128 + d) = pk;
+                    continue;
+                }
+            }
+            *(f32x4*)dst = o;
+            if constexpr (EPI == MI355_EPI_ACCUM) {
+                if (p.out_xb != nullptr) {
+                    bf16_t ob[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(o[r] * ldsz(p.next_norm, n + r, p.next_norm_dtype));
+                    u32x2 pk;
+                    pk[0] = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
+                    pk[1] = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
+                    *(u32x2*)(p.out_xb + (int64_t)m * p.out_ld + n) = pk;
+                    const float s1 = group_sum((bf16_to_f32(ob[0]) + bf16_to_f32(ob[1])) + (bf16_to_f32(ob[2]) + bf16_to_f32(ob[3])), 32);
+                    const float s2 = group_sum((o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]), 32);
+                    if (l32 == 0) {
+                        p.out_sx[(int64_t)un * p.M + m] = s1;
+                        p.out_ss[(int64_t)un * p.M + m] = s2;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // FMT = MI355_W_Q4: int4 stream, one 1-KiB piece per (tile, unit), converted below; MI355_W_BF16: unquantised weights
 // (BASELINE configs[1]), four 1-KiB pieces per (tile, unit) whose piece d IS the A fragment of k-quarter d — same k
 // order as the int4 conversion produces, no conversion, scale 1 / zero-point 0 in the epilogue
@@ -343,16 +420,19 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
                 const int t = idx % BM, part = idx / BM;
                 const int64_t m = m0 + t < p.M ? m0 + t : p.M - 1;
                 float sxs = 0.f, sss = 0.f;
-                for (int j0 = part; j0 < p.in_sx_n; j0 += 4 * kP) {
+                // (a K-slice of a split launch takes the shares of its own units: the operand sum of ITS columns)
+                const int jlo = p.ksplit > 1 ? slice_lo(ks, p.units, p.ksplit) * p.in_ppu : 0;
+                const int jhi = p.ksplit > 1 ? slice_lo(ks + 1, p.units, p.ksplit) * p.in_ppu : p.in_sx_n;
+                for (int j0 = jlo + part; j0 < jhi; j0 += 4 * kP) {
                     const int j1 = j0 + kP, j2 = j0 + 2 * kP, j3 = j0 + 3 * kP;
                     const float v0 = p.in_sx[j0 * (int64_t)p.M + m];
-                    const float v1 = p.in_sx[(j1 < p.in_sx_n ? j1 : j0) * (int64_t)p.M + m];
-                    const float v2 = p.in_sx[(j2 < p.in_sx_n ? j2 : j0) * (int64_t)p.M + m];
-                    const float v3 = p.in_sx[(j3 < p.in_sx_n ? j3 : j0) * (int64_t)p.M + m];
+                    const float v1 = p.in_sx[(j1 < jhi ? j1 : j0) * (int64_t)p.M + m];
+                    const float v2 = p.in_sx[(j2 < jhi ? j2 : j0) * (int64_t)p.M + m];
+                    const float v3 = p.in_sx[(j3 < jhi ? j3 : j0) * (int64_t)p.M + m];
                     sxs += v0;
-                    sxs += j1 < p.in_sx_n ? v1 : 0.f;
-                    sxs += j2 < p.in_sx_n ? v2 : 0.f;
-                    sxs += j3 < p.in_sx_n ? v3 : 0.f;
+                    sxs += j1 < jhi ? v1 : 0.f;
+                    sxs += j2 < jhi ? v2 : 0.f;
+                    sxs += j3 < jhi ? v3 : 0.f;
                 }
                 for (int j0 = part; j0 < p.in_ss_n; j0 += 4 * kP) {
                     const int j1 = j0 + kP, j2 = j0 + 2 * kP, j3 = j0 + 3 * kP;
@@ -691,6 +771,9 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
         // partial sums of the block's rows per token: lane groups (permlane swaps), then the waves through LDS in wave
         // order (the activation buffers are free: every wave is past its last unit's barrier), one entry per row block
         if (sums) {
+            // (a block of 256 rows — 8 waves, no pair — writes one share per 128 rows: the granularity a K-split consumer's
+            // slices are cut at; smaller blocks are shares of their own)
+            constexpr int kHalves = (!PAIR && kWaves == 8) ? 2 : 1;
             float* red = (float*)smem;  // [kWaves][2][BM]
 #pragma unroll
             for (int tt = 0; tt < kTT; ++tt) {
@@ -705,17 +788,19 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
                 }
             }
             __syncthreads();
-            for (int t = threadIdx.x; t < BM; t += kThreads) {
+            for (int idx = threadIdx.x; idx < kHalves * BM; idx += kThreads) {
+                const int t = idx % BM, half = idx / BM;
                 const int m = m0 + t;
-                if (m < p.M) {
+                const int share = nb * kHalves + half;
+                if (m < p.M && share * (kHalves == 2 ? 128 : (PAIR ? kSlots / 2 : kSlots) * 16) < p.N) {
                     float a = 0.f, b = 0.f;
 #pragma unroll
-                    for (int w = 0; w < kWaves; ++w) {
-                        a += red[(w * 2 + 0) * BM + t];
-                        b += red[(w * 2 + 1) * BM + t];
+                    for (int w = 0; w < kWaves / kHalves; ++w) {
+                        a += red[((half * (kWaves / kHalves) + w) * 2 + 0) * BM + t];
+                        b += red[((half * (kWaves / kHalves) + w) * 2 + 1) * BM + t];
                     }
-                    p.out_sx[(int64_t)nb * p.M + m] = a;
-                    if (p.out_ss != nullptr) p.out_ss[(int64_t)nb * p.M + m] = b;
+                    p.out_sx[(int64_t)share * p.M + m] = a;
+                    if (p.out_ss != nullptr) p.out_ss[(int64_t)share * p.M + m] = b;
                 }
             }
         }
@@ -737,8 +822,24 @@ int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row ti
     q.n_blocks = (p.n_tiles + per_block - 1) / per_block;
     q.total_blocks = q.n_blocks * ((p.M + BM - 1) / BM);
     q.per_xcd = (q.total_blocks * q.ksplit + 7) / 8;
+    if constexpr (FUSE) {
+        if (q.ksplit > 1) {  // the producer roles move to the reduction of the K-slices
+            q.out_xb = nullptr;
+            q.out_ss = q.out_sx = nullptr;
+            q.rope = nullptr;
+        }
+    }
     hipLaunchKernelGGL((gemm_q4_kernel<EPI, PAIR, FMT, kWaves, BM, GRP, FUSE>), dim3(8 * q.per_xcd), dim3(64 * kWaves), kLdsW, s, q);
     MI355_LAUNCH_CHECK();
+    if constexpr (FUSE) {
+        if (q.ksplit > 1) {
+            const int64_t groups = (int64_t)p.M * (p.N >> 7);
+            const int grid = (int)((groups + 7) / 8 < 4096 ? (groups + 7) / 8 : 4096);
+            hipLaunchKernelGGL(splitk_fused_reduce_kernel<EPI>, dim3(grid), dim3(256), 0, s, p);
+            MI355_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (q.ksplit > 1) {
         const int64_t n = (int64_t)p.M * (p.N >> 2);
         const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
@@ -823,21 +924,28 @@ extern "C" size_t mi355_linear_gemm_workspace_bytes(int M, int K) {
     if (M <= 0 || K <= 0) return 0;
     const size_t kp = ((size_t)K + 127) / 128 * 128;
     // staged operands, 1/rms, per-slice operand sums, split-K partials (used when a launch would be a few dozen blocks)
-    return (size_t)M * kp * 2 + (size_t)M * 4 * (1 + kMaxSplit) + 256 + kSplitBudget;
+    // ... and, at the very end, the partial sums of the fused prompt chain (gemm_fuse.h)
+    return (size_t)M * kp * 2 + (size_t)M * 4 * (1 + kMaxSplit) + 256 + kSplitBudget + kFuseScratch;
 }
+
+size_t mi355_linear_gemm_fuse_scratch_bytes() { return kFuseScratch; }
 
 extern "C" int mi355_linear_gemm(const mi355_linear_args* a, void* workspace, size_t workspace_bytes,
                                  mi355_stream_t stream) {
     return mi355_linear_gemm_fused(a, nullptr, workspace, workspace_bytes, stream);
 }
 
-void mi355_linear_gemm_plan(int M, int N, int K, int R, int* ksplit, int* row_blocks) {
+void mi355_linear_gemm_plan(int M, int N, int K, int R, int* ksplit, int* shares, int* shares_per_unit) {
     const bool pair = R == 2;
     const int ks = gemm_ksplit(M, N, K, pair);
     const GemmShape sh = gemm_shape((N + 15) / 16, M, pair, ks);
-    const int per_block = pair ? sh.waves * kTPW / 2 : sh.waves * kTPW;
+    // rows (hidden rows of a pair stream) behind one share of a producer's partial sums: a 128-column unit when the K-slices'
+    // reduction writes them or a block holds 256 rows, else the block's rows
+    int rows = (pair ? sh.waves * kTPW / 2 : sh.waves * kTPW) * 16;
+    if (ks > 1 || rows > 128) rows = 128;
     *ksplit = ks;
-    *row_blocks = ((N + 15) / 16 + per_block - 1) / per_block;
+    *shares = (N + rows - 1) / rows;
+    *shares_per_unit = 128 / rows;
 }
 
 int mi355_linear_gemm_fused(const mi355_linear_args* a, const mi355_gemm_fuse* f, void* workspace, size_t workspace_bytes,
@@ -903,8 +1011,13 @@ int mi355_linear_gemm_fused(const mi355_linear_args* a, const mi355_gemm_fuse* f
     const bool fused = f != nullptr;
     const bool f_in = fused && f->prestaged;
     if (fused) {
-        MI355_CHECK_ARG(!grouped && ksplit == 1, MI355_E_STATE, "linear_gemm: fusion over a grouped or K-split launch (M=%d N=%d K=%d)",
-                        a->M, a->N, a->K);
+        MI355_CHECK_ARG(!grouped, MI355_E_STATE, "linear_gemm: fusion over a grouped launch (M=%d N=%d K=%d)", a->M, a->N, a->K);
+        const bool produces = f->out_xb != nullptr || f->out_sx != nullptr || f->rope != nullptr;
+        MI355_CHECK_ARG(!produces || a->N % 128 == 0, MI355_E_SHAPE, "linear_gemm: a producer of the fused chain has N %% 128 == 0 (N=%d)", a->N);
+        MI355_CHECK_ARG(ksplit == 1 || !produces || a->epi == MI355_EPI_SWIGLU || a->y_dtype == MI355_F32, MI355_E_DTYPE,
+                        "linear_gemm: the fused reduction of a K-split launch writes f32 rows (or the SwiGLU pair's bf16)");
+        MI355_CHECK_ARG(!f_in || ksplit == 1 || (f->in_ppu >= 1 && f->in_sx_n == units * f->in_ppu), MI355_E_ARG,
+                        "linear_gemm: a K-split consumer needs %d x in_ppu partial operand sums (got %d, in_ppu %d)", units, f->in_sx_n, f->in_ppu);
         MI355_CHECK_ARG(!f_in || (a->x_dtype == MI355_BF16 && a->norm_scale == nullptr && a->K % 128 == 0 && a->ldx % 8 == 0 &&
                                   (uintptr_t)a->x % 16 == 0 && f->in_sx != nullptr && f->in_sx_n > 0 && (f->in_ss == nullptr || f->in_ss_n > 0)),
                         MI355_E_ARG, "linear_gemm: a pre-staged operand is bf16 [M, ldx] with K %% 128 == 0 and partial operand sums");
@@ -979,6 +1092,7 @@ int mi355_linear_gemm_fused(const mi355_linear_args* a, const mi355_gemm_fuse* f
         p.f_in = f_in ? 1 : 0;
         p.in_sx = f->in_sx;
         p.in_sx_n = f_in ? f->in_sx_n : 0;
+        p.in_ppu = f_in ? f->in_ppu : 0;
         p.in_ss = f->in_ss;
         p.in_ss_n = f_in && f->in_ss != nullptr ? f->in_ss_n : 0;
         p.eps = a->eps;

@@ -1,6 +1,6 @@
 // Internal (NOT part of the C ABI): producer / consumer fusion of the wide-GEMM chain of a prompt pass.
 //
-// Replaces, for prompt chunks wide enough that no launch is split over K, the per-linear staging pass
+// Replaces the per-linear staging pass
 // (stage_rows_kernel: f32 row -> bf16 operand + 1/rms + operand sum, four launches per layer) and the K / V cache
 // write (rope_kv_write_kernel) of /root/reference lit_llama/model.py:185-237,251-254 as this library ran them in
 // rounds 2-4: 14 % of a 2048-token 7B prompt (profiles/r04_prefill_kernel_stats_staged_chain.csv).
@@ -17,8 +17,9 @@
 struct mi355_gemm_fuse {
     // ---- consumer side: a->x is the bf16 operand itself ([M, ldx], K % 128 == 0), no staging pass
     int prestaged;
-    const float* in_sx;   // [in_sx_n][M] partial operand sums
+    const float* in_sx;   // [in_sx_n][M] partial operand sums ("shares"), in column order
     int in_sx_n;
+    int in_ppu;           // shares per 128-column unit (a K-split consumer's slice adds the shares of its own units)
     const float* in_ss;   // [in_ss_n][M] partial sums of squares of the f32 row behind the operand, or NULL (1/rms = 1)
     int in_ss_n;
     // ---- producer side, MI355_EPI_ACCUM with f32 y: also emit the next linear's operand
@@ -26,9 +27,9 @@ struct mi355_gemm_fuse {
     int64_t out_ld;
     const void* next_norm;
     int next_norm_dtype;
-    float* out_ss;        // [blocks][M] sums of y_new^2 over the block's rows (with out_xb)
+    float* out_ss;        // [shares][M] sums of y_new^2 over a share's rows (with out_xb)
     // ACCUM: sums of the out_xb values; MI355_EPI_SWIGLU: sums of the bf16 outputs; NULL: none
-    float* out_sx;        // [blocks][M]
+    float* out_sx;        // [shares][M]     (shares: mi355_linear_gemm_plan)
     // ---- producer side, MI355_EPI_STORE of c_attn: rows [C, 2C) are rotated and written to kcache, [2C, 3C) to vcache
     const float* rope;    // [block_size, hs / 2, 2], or NULL: plain store
     const int32_t* pos;   // [M]
@@ -37,8 +38,12 @@ struct mi355_gemm_fuse {
     int S, n_head, hs, rope_gathered;
 };
 
-// how a launch of the wide GEMM is cut: K-slices (1 = none) and partial sums a producer writes per row (row blocks)
-void mi355_linear_gemm_plan(int M, int N, int K, int R, int* ksplit, int* row_blocks);
+// how a launch of the wide GEMM is cut: K-slices (1 = none), the partial sums ("shares") a producer writes per row and how
+// many of them make a 128-column unit.  A launch split over K produces through the reduction of its slices
+// (splitk_fused_reduce_kernel), one share per unit.
+void mi355_linear_gemm_plan(int M, int N, int K, int R, int* ksplit, int* shares, int* shares_per_unit);
+// bytes mi355_linear_gemm_workspace_bytes reserves at the END of a workspace for the chain's partial sums
+size_t mi355_linear_gemm_fuse_scratch_bytes();
 // as mi355_linear_gemm, with the fusion described by `f` (NULL: none)
 int mi355_linear_gemm_fused(const mi355_linear_args* a, const mi355_gemm_fuse* f, void* workspace, size_t workspace_bytes,
                             mi355_stream_t stream);

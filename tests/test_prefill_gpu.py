@@ -191,14 +191,18 @@ def test_llm_int8_prompt_takes_the_int8_gemm_and_matches_oracle(dev):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("T", [700, 300, 100])
 @pytest.mark.parametrize("mode", ["gptq.int4", None])
-def test_fused_prompt_chain_matches_oracle_and_the_staged_chain(dev, monkeypatch, mode):
+def test_fused_prompt_chain_matches_oracle_and_the_staged_chain(dev, monkeypatch, mode, T):
     """Round 4: a prompt chunk wide enough that no GEMM launch is split over K (7B width: more than 640 tokens) runs the layer
     as a producer / consumer chain (csrc/gemm_fuse.h): no staging pass in front of a linear (the residual epilogues emit the
     next operand and its partial sums, the SwiGLU and attention outputs are operands as they are), the c_attn epilogue rotates
     k and writes the K / V cache rows.  Two 7B-width layers (the mlp.c_proj -> next layer's c_attn hand-over included), 700
     prompt tokens through the engine: against the oracle (/root/reference lit_llama/model.py:76-122 with T > 1), against the
-    staged chain of rounds 2-3 (MI355_GEMM_FUSE=0) on the same weights, and one decode step on top of each cache."""
+    staged chain of rounds 2-3 (MI355_GEMM_FUSE=0) on the same weights, and one decode step on top of each cache.
+    T = 700: no launch is split over K, the GEMM epilogues are the producers; T = 100: every launch is split and the reduction of
+    the K-slices (splitk_fused_reduce_kernel) produces, the consumers' slices add the shares of their own units; T = 300: mixed
+    (c_attn and the pair whole, the N = 4096 linears split)."""
     cfg_kw = dict(n_layer=2, n_head=32, n_embd=4096)
     cfg = LLaMAConfig(**cfg_kw)
     sd = synth.make_state_dict(cfg, seed=11, mode=mode, **(dict(dtype=torch.bfloat16) if mode is None else {}))
@@ -209,7 +213,7 @@ def test_fused_prompt_chain_matches_oracle_and_the_staged_chain(dev, monkeypatch
     om = oracle.Model(oracle.Config(**cfg_kw), {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}, mode=mode)
     eng = model.engine()
     assert eng is not None and eng.max_T >= 700 and eng.gemm_ws is not None, model._engine_failed
-    T, S = 700, 712
+    S = T + 12
     prompt = synth.make_prompt(T + 1, seed=21)
     torch.set_num_threads(max(torch.get_num_threads(), 16))
     ref = om(prompt[:T].view(1, -1), S, torch.arange(T))[0].float()
@@ -232,5 +236,5 @@ def test_fused_prompt_chain_matches_oracle_and_the_staged_chain(dev, monkeypatch
     # the two chains round the same operands; they differ in the ORDER of the per-row sums (partial sums per block) and in
     # where k is rotated: f32 noise in front of a bf16 rounding
     assert d <= 0.02 and d1 <= 0.02, (d, d1)
-    print(f"{mode}: fused chain {out['1'][2]:.4f} / {out['1'][3]:.4f} std vs oracle (staged {out['0'][2]:.4f} / {out['0'][3]:.4f}); "
+    print(f"{mode} T={T}: fused chain {out['1'][2]:.4f} / {out['1'][3]:.4f} std vs oracle (staged {out['0'][2]:.4f} / {out['0'][3]:.4f}); "
           f"fused vs staged {d:.4f} / {d1:.4f} std")
