@@ -24,6 +24,8 @@
 //  * operands are staged once per linear by stage_rows_kernel: bf16(norm_scale * x) with RMSNorm's 1/rms kept as a
 //    per-row factor for the epilogue, and the per-row operand sum that undoes the +128 / zero-point offset:
 //        y[m, n] = scale[n] * (acc[m, n] - (128 + zero[n]) * sum_k xb[m, k]) * rinv[m]      (same arithmetic as gemv.hip).
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_fuse.h"
 
@@ -848,30 +850,46 @@ int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row ti
     }
     return 0;
 }
-// The shape of an ungrouped launch: blocks of 16 row tiles x 128 tokens if that gives every CU two workgroups to overlap;
-// the narrow outputs of a long prompt (attn.c_proj / mlp.c_proj, N = 4096: 16 row blocks, at T = 2048 one workgroup per
-// CU, matrix pipes 37 % busy against 53 % for the c_fc1 / c_fc2 pair) take 64-token blocks instead: twice the
-// workgroups, half the LDS each; short prompts: split-K brings the blocks, or blocks of 4 / 2 row tiles
+// The shape of an ungrouped launch: blocks of 16 row tiles x 128 tokens when that fills the chip (256 CUs x 2 workgroups);
+// anything smaller — the N = 4096 outputs of a long prompt (16 row blocks: at T = 2048 one workgroup per CU, matrix pipes
+// 37 % busy against 53 % for the c_fc1 / c_fc2 pair), and every launch of a short prompt, K-split or not — takes 64-token
+// blocks: twice the workgroups, half the LDS each.  Sweep over (waves, tokens per block, K-slices) at 128 / 256 / 512 tokens
+// (scripts/sweep_gemm_shapes.sh, profiles/r04_gemm_shape_sweep.txt): 64-token blocks win every linear (one layer's linears
+// 216 -> 183 / 269 -> 226 / 361 -> 320 us), the 2-wave blocks of round 3 never do; those stay for launches too small to split.
 struct GemmShape {
     int waves, bm;
 };
+// tuning override for sweeps (scripts/sweep_gemm_shapes.sh): MI355_GEMM_FORCE="waves:bm:ksplit", 0 = the rule's choice
+struct GemmForce {
+    int waves, bm, ksplit;
+};
+GemmForce gemm_force() {
+    GemmForce f = {0, 0, 0};
+    if (const char* e = getenv("MI355_GEMM_FORCE")) sscanf(e, "%d:%d:%d", &f.waves, &f.bm, &f.ksplit);
+    return f;
+}
 GemmShape gemm_shape(int n_tiles, int M, bool pair, int ksplit) {
+    const GemmForce fo = gemm_force();
+    if ((fo.waves == 8 && (fo.bm == 64 || fo.bm == kBM)) || ((fo.waves == 2 || fo.waves == 1) && (fo.bm == 0 || fo.bm == kBM)))
+        return {fo.waves, fo.bm ? fo.bm : kBM};
     const int per_block8 = pair ? 8 * kTPW / 2 : 8 * kTPW;
     const int blocks8 = ((n_tiles + per_block8 - 1) / per_block8) * ((M + kBM - 1) / kBM);
-    if (ksplit > 1) return {8, kBM};
-    if (blocks8 >= 128) {
-#ifndef MI355_GEMM_NO_BM64
-        if (blocks8 < 384 && M >= 256) return {8, 64};
-#endif
-        return {8, kBM};
+    if (ksplit == 1 && blocks8 < 96) {  // (K < 1024: nothing to split)
+        if (blocks8 * 4 >= 128) return {2, kBM};
+        return {1, kBM};
     }
-    if (blocks8 * 4 >= 128) return {2, kBM};
-    return {1, kBM};
+#ifndef MI355_GEMM_NO_BM64
+    if (blocks8 * ksplit < 384) return {8, 64};
+#endif
+    return {8, kBM};
 }
 // split-K of an ungrouped launch: fewer than 96 blocks (a 128-token prompt against N = 4096 is 16) cut K into up to 8
 // slices, as many as bring the launch to ~128 workgroups and fit the partial buffer
 int gemm_ksplit(int M, int N, int K, bool swiglu) {
     const int units = (K + 127) / 128;
+    if (const int fk = gemm_force().ksplit) {
+        if (fk >= 1 && fk <= kMaxSplit && units >= fk && (size_t)2 * fk * M * (size_t)N * (swiglu ? 2 : 1) * 4 <= kSplitBudget) return fk;
+    }
     const int rows_per_block = swiglu ? 16 * 8 * kTPW / 2 : 16 * 8 * kTPW;
     const int blocks8 = ((N + rows_per_block - 1) / rows_per_block) * ((M + kBM - 1) / kBM);
     const size_t row_floats = (size_t)N * (swiglu ? 2 : 1);
