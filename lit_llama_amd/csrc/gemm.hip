@@ -39,6 +39,9 @@ constexpr int kTPW = MI355_GEMM_TPW;
 #ifndef MI355_GEMM_PIN_LOADS
 #define MI355_GEMM_PIN_LOADS 1
 #endif
+#ifndef MI355_GEMM_AND_OR
+#define MI355_GEMM_AND_OR 1
+#endif
 #ifndef MI355_GEMM_PIN_W
 #define MI355_GEMM_PIN_W 0
 #endif
@@ -498,6 +501,11 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
     // the 4 x kTT x kTPW MFMAs of a unit; sub >= 0 (GRP 2): only the lane groups of sub-group `sub` contribute
     // (explicitly software-pipelined B-fragment reads — 16 fragments in registers, pinned with sched_barrier —
     // measured SLOWER, 600-670 vs 760-800 TFLOP/s: with 4 waves per SIMD the hardware hides the LDS latency itself)
+#if MI355_GEMM_AND_OR
+    uint32_t cmask = 0x000F000Fu, cmagic = 0x43004300u;
+    asm volatile("" : "+s"(cmask));
+    asm volatile("" : "+v"(cmagic));
+#endif
     auto mfmas = [&](int buf, int sub, int sub_shift) {
         const char* xs = smem + buf * (BM * 256);
         const bool mine = GRP != 2 || (g >> sub_shift) == sub;
@@ -512,10 +520,20 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
                 } else {
                     const uint32_t v = wcur[t][0][d];
                     u32x4 f;
+#if MI355_GEMM_AND_OR
+                    // (mask and exponent pattern as OPAQUE register values: hipcc then selects one v_and_or_b32 per field
+                    // — from literals it emits v_and + v_or, 11 instead of 7 VALU per dword — and pads the VALU -> MFMA
+                    // hazard itself, which an inline-asm v_and_or_b32 does not get: csrc/fused_step_ring.hip nib2f16)
+                    f[0] = (v & cmask) | cmagic;
+                    f[1] = ((v >> 4) & cmask) | cmagic;
+                    f[2] = ((v >> 8) & cmask) | cmagic;
+                    f[3] = ((v >> 12) & cmask) | cmagic;
+#else
                     f[0] = (v & 0x000F000Fu) | 0x43004300u;
                     f[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
                     f[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
                     f[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+#endif
                     a[t] = __builtin_bit_cast(bf16x8, f);
                 }
             }

@@ -27,6 +27,11 @@
 
 #include "common.h"
 
+#ifndef MI355_GEMV_AND_OR
+#define MI355_GEMV_AND_OR 1
+#endif
+
+
 namespace {
 
 constexpr int kUnitK = 128;        // input columns per stream unit
@@ -429,6 +434,14 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P, GRP>)) void gemv_kernel(const 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = blockDim.x >> 6;
+    // int4 -> bf16: nibble mask and exponent pattern as OPAQUE register values — hipcc then selects ONE v_and_or_b32 per
+    // field (7 VALU per 8 weights; from literals it emits v_and + v_or: 11) and pads the VALU -> MFMA hazard itself, which an
+    // inline-asm v_and_or_b32 does not get (csrc/fused_step_ring.hip nib2f16, NOTES.md)
+    [[maybe_unused]] uint32_t cmask = 0x000F000Fu, cmagic = 0x43004300u;
+#if MI355_GEMV_AND_OR
+    asm volatile("" : "+s"(cmask));
+    asm volatile("" : "+v"(cmagic));
+#endif
     char* xs = part + 2 * W * RS * 1024;
     // GRP: [2][R * 16 rows][n_groups] dwords (scale bf16 | zero bf16 << 16) behind the activation rows
     uint32_t* szl = (uint32_t*)(xs + (((size_t)M * p.xs_stride + 15) & ~(size_t)15));
@@ -635,10 +648,10 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P, GRP>)) void gemv_kernel(const 
                     for (int d = 0; d < 4; ++d) {
                         const uint32_t v = q[d];
                         u32x4 a;
-                        a[0] = (v & 0x000F000Fu) | 0x43004300u;
-                        a[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
-                        a[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
-                        a[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+                        a[0] = (v & cmask) | cmagic;
+                        a[1] = ((v >> 4) & cmask) | cmagic;
+                        a[2] = ((v >> 8) & cmask) | cmagic;
+                        a[3] = ((v >> 12) & cmask) | cmagic;
                         acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), bc[d], acc[r], 0, 0, 0);
                     }
                 }
@@ -667,10 +680,10 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P, GRP>)) void gemv_kernel(const 
                     for (int r = 0; r < R; ++r) {
                         const uint32_t v = ring[j][r][d];
                         u32x4 a;
-                        a[0] = (v & 0x000F000Fu) | 0x43004300u;
-                        a[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
-                        a[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
-                        a[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+                        a[0] = (v & cmask) | cmagic;
+                        a[1] = ((v >> 4) & cmask) | cmagic;
+                        a[2] = ((v >> 8) & cmask) | cmagic;
+                        a[3] = ((v >> 12) & cmask) | cmagic;
                         acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), bm, acc[r], 0, 0, 0);
                     }
                 }
@@ -710,10 +723,10 @@ __global__ __launch_bounds__((kMaxThreads<FMT, P, GRP>)) void gemv_kernel(const 
                 for (int d = 0; d < 4; ++d) {
                     const uint32_t v = q[d];
                     u32x4 a;
-                    a[0] = (v & 0x000F000Fu) | 0x43004300u;
-                    a[1] = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
-                    a[2] = ((v >> 8) & 0x000F000Fu) | 0x43004300u;
-                    a[3] = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+                    a[0] = (v & cmask) | cmagic;
+                    a[1] = ((v >> 4) & cmask) | cmagic;
+                    a[2] = ((v >> 8) & cmask) | cmagic;
+                    a[3] = ((v >> 12) & cmask) | cmagic;
                     acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), b[d], acc[r], 0, 0, 0);
                 }
             } else {
