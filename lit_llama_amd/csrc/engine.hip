@@ -132,9 +132,10 @@ bool wide_plain(const mi355_weight& w) {  // a linear the fused chain can run: i
 FuseCtx plan_fusion(const mi355_model* m, int T) {
     FuseCtx z;
     memset(&z, 0, sizeof(z));
+    if (T < 32) return z;  // (decode steps and short chunks: the streaming kernels, nothing to plan)
     const char* env = getenv("MI355_GEMM_FUSE");
     if (env != nullptr && env[0] == '0') return z;
-    if (T < 32 || m->tp_world > 1 || m->gemm_ws == nullptr || m->hs != 128 || m->cache_dtype != MI355_BF16 ||
+    if (m->tp_world > 1 || m->gemm_ws == nullptr || m->hs != 128 || m->cache_dtype != MI355_BF16 ||
         (int64_t)m->S * 256 >= 0x7fffffffLL || m->n_head * m->hs != m->n_embd)
         return z;
     const int C = m->n_embd, H = m->n_hidden;
