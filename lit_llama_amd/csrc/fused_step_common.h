@@ -43,7 +43,7 @@ struct FusedParams {
     u64 gt_layer_stride;
     unsigned gt_layer_bytes, gt_head_bytes;
     int grouped, gsh, ngc, ngh;
-    int fmt;                 // 0: int4 streams, 1: BF16 streams (register-ring kernel only)
+    int fmt;                 // 0: int4 streams, 1: BF16 streams, 2: LLM.int8 streams, 3: int4 streams through fp8-limb operands
 };
 
 

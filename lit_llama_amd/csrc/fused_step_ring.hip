@@ -106,16 +106,56 @@ constexpr int kOffXq = kOffOpart + 512;
 constexpr int kMaxOut = 1024;
 constexpr int kOffObits = kOffXq + 96 * 128;      // u32 [96 * 4]: outlier columns as a bit set (atomic OR by whichever lane stages the column)
 constexpr int kOffOlist = kOffObits + 96 * 16;    // u16 [kMaxOut]: the same columns in ascending order (gatherer 0, behind B1b)
+// fp8-limb operands (FMT 3, round 4): the activation vector as THREE byte planes in MFMA-B order (limb 0 / 1 / 2 of every value; load I
+// of the granule sweep owns dword I of each plane), <= 95 units of 128 bytes.  The planes start 64 B (16 banks) apart modulo 256 so that
+// the lanes of MFMA columns 0 / 1 / 2 of one lane group read different banks: planes 0 and 1 share the 16-bit vector's room, plane 2
+// takes the int8 path's.
+constexpr int kF8Units = 95;
+constexpr int kF8P0 = kOffXs, kF8P1 = kOffXs + kF8Units * 128 + 192, kF8P2 = kOffXq + 128;
+static_assert(kF8P1 + kF8Units * 128 <= kOffPart && (kF8P1 - kF8P0) % 256 == 64 && (kF8P2 - kF8P0) % 256 == 128, "fp8 limb planes");
+// power-of-two pre-scales of the three kinds of edge (published value = x * 2^-E; the consumer's block scale undoes it): an E4M3 limb
+// holds |v| <= 448 and is exact to 12 bits from 2^-6 up
+#ifndef MI355_F8_EX
+#define MI355_F8_EX 0  // x edges: norm_scale * x / ~rms
+#endif
+#ifndef MI355_F8_EA
+#define MI355_F8_EA 2  // attention output
+#endif
+#ifndef MI355_F8_EH
+#define MI355_F8_EH 4  // SwiGLU output
+#endif
 [[maybe_unused]] constexpr int kMaxS = 32768;     // cache rows (the attention keeps no per-row state in LDS)
 #ifndef MI355_FUSED_LDS_PAD
 #define MI355_FUSED_LDS_PAD 0  // (A / B knob: bytes of LDS requested on top of the map)
 #endif
 constexpr int kLdsBytes = kOffOlist + kMaxOut * 2 + MI355_FUSED_LDS_PAD;
-static_assert(kLdsBytes <= 160 * 1024 && kPartBytes >= kSW * 128 * 4, "LDS map");
+static_assert(kLdsBytes <= 160 * 1024 && kPartBytes >= kSW * 128 * 4 && kF8P2 + kF8Units * 128 <= kLdsBytes - MI355_FUSED_LDS_PAD, "LDS map");
 
 // ------------------------------------------------------------------------------------------------ granules
 __device__ __forceinline__ void gr_store(u64* p, unsigned tag, unsigned val) {
     __hip_atomic_store(p, ((u64)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // one 8-B sc1 store
+}
+// fp8-limb operands (FMT 3): a granule is {tag: 16 bits, payload: 48 bits} = limb 0 / 1 / 2 of TWO values, low to high:
+// l0a l0b l1a l1b | l2a l2b tag16 — still one 8-B sc1 store
+__device__ __forceinline__ void gr_store16(u64* p, unsigned tag, unsigned lo32, unsigned hi16) {
+    __hip_atomic_store(p, ((u64)(((tag & 0xFFFFu) << 16) | hi16) << 32) | lo32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// x -> three OCP E4M3 limbs, x ~ l0 + l1 / 16 + l2 / 256 (residual splitting: every difference below is exact in f32, the conversions
+// round to nearest even; past +-448 v_cvt_pk_fp8_f32 returns NaN, hence the clamps).  12 significant bits for 2^-6 <= |x| <= 448, an
+// absolute error of ~2^-19 below (scripts/micro/mx_fp8.hip checks the instruction semantics and prints the error per binade).
+__device__ __forceinline__ void f8_limbs(float a, float b, unsigned& lo32, unsigned& hi16) {
+    const int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.f, 448.f), __builtin_amdgcn_fmed3f(b, -448.f, 448.f), 0, false);
+    const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false);
+    float ra = a - f0[0], rb = b - f0[1];
+    const int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(ra * 16.f, -448.f, 448.f),
+                                                   __builtin_amdgcn_fmed3f(rb * 16.f, -448.f, 448.f), 0, false);
+    const auto f1 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false);
+    ra -= f1[0] * 0.0625f;
+    rb -= f1[1] * 0.0625f;
+    const int w2 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(ra * 256.f, -448.f, 448.f),
+                                                   __builtin_amdgcn_fmed3f(rb * 256.f, -448.f, 448.f), 0, false);
+    lo32 = ((unsigned)w0 & 0xFFFFu) | ((unsigned)w1 << 16);
+    hi16 = (unsigned)w2 & 0xFFFFu;
 }
 __device__ __forceinline__ bool aborted(const FusedParams& p) {
     return __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
@@ -139,7 +179,8 @@ __device__ __forceinline__ void sweep_issue(__amdgpu_buffer_rsrc_t rs, unsigned 
     }
 }
 // `preissued`: the caller has requested v already (sweep_issue) — several chunks of one edge in flight at once
-template <int NL>
+// T16: granules with 16-bit tags in the top half of their second dword (fp8-limb operands, gr_store16); `epoch` is then 16 bits wide
+template <int NL, bool T16 = false>
 __device__ __forceinline__ bool sweep(const FusedParams& p, __amdgpu_buffer_rsrc_t rs, unsigned base, int first, int end,
                                       unsigned epoch, u32x4 (&v)[NL], unsigned code, int lane, unsigned* iters = nullptr,
                                       bool preissued = false) {
@@ -154,7 +195,8 @@ __device__ __forceinline__ bool sweep(const FusedParams& p, __amdgpu_buffer_rsrc
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             const int i = first + k * 64 + lane;
-            ok &= i >= end || (v[k][1] == epoch && v[k][3] == epoch);
+            if constexpr (T16) ok &= i >= end || ((v[k][1] >> 16) == epoch && (v[k][3] >> 16) == epoch);
+            else ok &= i >= end || (v[k][1] == epoch && v[k][3] == epoch);
         }
         if (__all(ok)) return true;
         if (spins > kSpinLimit || aborted(p)) {
@@ -209,6 +251,7 @@ __device__ __forceinline__ unsigned piece_off(const PhaseW& ph, int gstep, int r
 // VALU -> MFMA hazard, which an inline-asm v_and_or_b32 does not get: that variant produced NaNs).
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 __device__ __forceinline__ uint32_t nib2f16(uint32_t x, uint32_t mask_s, uint32_t magic_v) { return (x & mask_s) | magic_v; }
 __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rs_null, bool ok,
                                            unsigned lane_off, unsigned soff) {
@@ -241,10 +284,28 @@ __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_b
 // steps per unit; the streamer waves quantise the gathered vector themselves — f16 cast, outlier columns |x| >= 6, absmax of the rest,
 // rint(x 127 / absmax), the arithmetic of csrc/int8.hip (bitsandbytes' MatMul8bitLt as oracle/oracle.py restates it: PARITY
 // UNPINNED) — and the gatherers' epilogue dequantises and adds the f16 outlier side product.
+// 3 = FMT 0's int4 streams through fp8 operands (round 4, EXPERIMENTAL: mi355_fused_step_args.weight_fmt = 3; built on the CPU
+// container after the round's GPU budget, see DESIGN.md section 7 and scripts/micro/mx_fp8.hip for what IS measured).  A compute
+// phase of FMT 0 is bound by MFMA issue: four 16x16x32 f16 MFMAs (35.5 ns per SIMD) + 20 conversion instructions per 1-KiB piece.
+// Here a piece is ONE v_mfma_scale_f32_16x16x128_f8f6f4 (15.2 ns) + 12 instructions:
+//  * weights: a byte holding an int4 level q IS the OCP E4M3 code of q * 2^-9 (codes 0..7 are the subnormals, 8..15 the first
+//    binade), so `v & 0x0F0F0F0F` and `(v >> 4) & 0x0F0F0F0F` of a piece's four dwords are the A operand (lane (g, row): k = 32 g +
+//    8 d + (0 4 1 5 | 2 6 3 7), tests/layouts.py) and the A block scale 2^9 makes the pipe multiply by q itself — no +1024 offset, no
+//    factor 16 on odd pairs;
+//  * activations: every PUBLISHER splits its values into three E4M3 limbs (x ~ l0 + l1 / 16 + l2 / 256, f8_limbs) — 16 values per
+//    workgroup and edge, nothing on the consumers' chain (round 4's integer path quantised on the consumer side and lost 4.4 % there);
+//    a granule carries the limbs of the values at k offsets (j, j + 4) of an octet under a 16-bit tag, so that a 16-B sweep load is
+//    one dword of each limb plane in exactly the byte order of the A operand: the gatherers stage with three ds_write_b32 per load
+//    and take no operand sums; the limbs ride in MFMA token columns 0 / 1 / 2 (copies at M = 1) under the per-lane B block scales
+//    2^(E - 0 / 4 / 8), E = the edge's pre-scale; a tile end adds the three columns up (two DPP adds per register);
+//  * the zero-point term needs S = sum_k x~_k of exactly the operands multiplied: during a phase's first tile every step issues one
+//    more MFMA with an all-ones A operand; the wave leaves its S in misc[32 + wave].
+// Numerics (measured by the microbenchmark): the pipe sums the 128 products of an instruction to ~2^-11..2^-13 of the largest one —
+// the size of the fp16 operand rounding this replaces.
 template <bool GRP, int FMT>
 __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedParams p) {
-    static_assert(!(GRP && FMT != 0), "grouped scales exist for int4 only");
-    constexpr int kSub = FMT == 1 ? 4 : FMT == 2 ? 2 : 1;  // ring steps per 128-column unit
+    static_assert(!(GRP && FMT != 0), "grouped scales exist for the fp16-operand int4 kernel only");
+    constexpr int kSub = FMT == 1 ? 4 : FMT == 2 ? 2 : 1;  // ring steps per 128-column unit (FMT 3 reads FMT 0's streams)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -291,6 +352,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         asm volatile("" : "+s"(nmask16));
         u32x4 ring[kRing];
         int buf = 0;
+        // FMT 3: nibble mask, this lane's limb plane (+ its lane group's 32 bytes of a unit) and block-scale step, the all-ones operand
+        [[maybe_unused]] uint32_t nib8 = 0x0F0F0F0Fu;
+        if constexpr (FMT == 3) asm volatile("" : "+s"(nib8));  // (opaque: hipcc then keeps the mask in an SGPR operand)
+        [[maybe_unused]] const int f8_col = lane & 15;
+        [[maybe_unused]] const unsigned f8_plane = (f8_col == 0 ? (unsigned)kF8P0 : f8_col == 1 ? (unsigned)kF8P1 : (unsigned)kF8P2) + (unsigned)g * 32u;
+        [[maybe_unused]] const int f8_dsb = f8_col == 0 ? 0 : f8_col == 1 ? 4 : 8;
 
         PhaseW ph_attn, ph_proj, ph_fc, ph_mp, ph_head;
         ph_attn = {p.off_attn, head * 8 + hj, kC / 16, 1, kUnitsC, wave * 4, 4};
@@ -655,11 +722,92 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         }                                                                                                             \
         __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
     } while (0)
+        // ---- one phase over the int4 stream with fp8 operands (FMT 3): FS_RUN's ring discipline (turns, refills, barriers; whole tiles
+        // per ring turn), ONE scaled MFMA per piece.  E8_: pre-scale exponent of the phase's input edge.
+#define FS_RUN_F(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, E8_)                                      \
+    do {                                                                                                             \
+        constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
+        const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
+        f32x4 acc__[R__][2];                                                                                          \
+        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+        f32x4 accs__ = f32x4{0.f, 0.f, 0.f, 0.f}; /* all-ones rows: the operand sums of this wave's units, per limb column */ \
+        i32x8 ones__;                                                                                                 \
+        _Pragma("unroll") for (int e__ = 0; e__ < 8; ++e__) ones__[e__] = 0x38383838; /* E4M3 1.0 */                  \
+        const int sb__ = 127 + (E8_) - f8_dsb; /* E8M0 block scale of this lane's 32 operand bytes */                 \
+        __syncthreads(); /* B1: the limb planes are staged */                                                        \
+        FS_SSTAMP(STAMP_);                                                                                            \
+        const char* xl__ = smem + f8_plane;                                                                           \
+        i32x8 bn__ = *(const i32x8*)(xl__ + (PH_).u0 * 128); /* B operands are read one step ahead */                 \
+        for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
+            _Pragma("unroll") for (int t__ = 0; t__ < (TURNS_); ++t__) {                                              \
+                _Pragma("unroll") for (int s__ = 0; s__ < STEPS__; ++s__) {                                           \
+                    const int gstep__ = (body__ * (TURNS_) + t__) * STEPS__ + s__;                                    \
+                    const int ti__ = gstep__ / SPT__, st__ = gstep__ - ti__ * SPT__;                                  \
+                    const i32x8 b__ = bn__;                                                                           \
+                    {                                                                                                 \
+                        const int nst__ = (st__ + 1 == SPT__) ? 0 : st__ + 1;                                         \
+                        const int nun__ = (PH_).u0 + (nst__ < (PH_).nu ? nst__ : 0);                                  \
+                        bn__ = *(const i32x8*)(xl__ + nun__ * 128);                                                   \
+                    }                                                                                                 \
+                    /* idle steps (padding of the ring turn) carry no data: skip their MFMAs (wave-uniform) */        \
+                    if (st__ < (PH_).nu && ((QKV_) || ti__ < (PH_).ntiles)) {                                         \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
+                            const u32x4 v__ = ring[s__ * R__ + r__];                                                  \
+                            i32x8 a__;                                                                                \
+                            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                     \
+                                a__[2 * d__] = (int)(v__[d__] & nib8);                                                \
+                                a__[2 * d__ + 1] = (int)((v__[d__] >> 4) & nib8);                                     \
+                            }                                                                                         \
+                            acc__[r__][s__ & 1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                   \
+                                a__, b__, acc__[r__][s__ & 1], 0, 0, 0, 136, 0, sb__);                                \
+                        }                                                                                             \
+                        if (ti__ == 0)                                                                                \
+                            accs__ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones__, b__, accs__, 0, 0, 0, 127, 0, sb__); \
+                    }                                                                                                 \
+                    _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                           \
+                        const int nstep__ = gstep__ + STEPS__;                                                        \
+                        bool ok__;                                                                                    \
+                        const unsigned so__ = piece_off<SPT__, PAIR_, QKV_, kSub>(PH_, nstep__, r__, ok__);           \
+                        ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
+                    }                                                                                                 \
+                    if ((t__ * STEPS__ + s__ + 1) % SPT__ == 0) {                                                     \
+                        if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
+                        if (ti__ == 0) {                                                                              \
+                            /* S of this wave's units: limb columns 0 + 1 + 2 of any row (quad broadcasts of lanes 1 / 2) */ \
+                            float ssum__ = accs__[0];                                                                 \
+                            ssum__ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, accs__[0]), 0x55, 0xF, 0xF, false)) + \
+                                      __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, accs__[0]), 0xAA, 0xF, 0xF, false)); \
+                            if (lane_off == 0u) misc[32 + wave] = ssum__;                                             \
+                        }                                                                                             \
+                        f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
+                        const bool col0__ = MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u;                       \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
+                            f32x4 t4__ = acc__[r__][0] + acc__[r__][1];                                               \
+                            _Pragma("unroll") for (int e__ = 0; e__ < 4; ++e__) {                                     \
+                                const float c0__ = t4__[e__];                                                         \
+                                t4__[e__] = c0__ +                                                                    \
+                                    (__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c0__), 0x55, 0xF, 0xF, false)) + \
+                                     __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c0__), 0xAA, 0xF, 0xF, false))); \
+                            }                                                                                         \
+                            if (col0__) pp__[r__ * (kPartTile / 16)] = t4__;                                          \
+                            acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                                \
+                        }                                                                                             \
+                        __syncthreads(); /* Bt */                                                                     \
+                        buf ^= 1;                                                                                     \
+                    }                                                                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                                \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+        __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
+    } while (0)
         // a phase: (int4 SPT / TURNS, wide-format SPT / TURNS) — steps per tile and ring turns differ with the piece width
-#define FS_PHASE(RS_, R_, SPT_, TURNS_, SPTW_, TURNSW_, PAIR_, QKV_, PH_, NBODIES_, STAMP_, RST_, XEDGE_)             \
+#define FS_PHASE(RS_, R_, SPT_, TURNS_, SPTW_, TURNSW_, PAIR_, QKV_, PH_, NBODIES_, STAMP_, RST_, XEDGE_, E8_)        \
     do {                                                                                                             \
         if constexpr (FMT == 0) {                                                                                    \
             FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_);                                  \
+        } else if constexpr (FMT == 3) {                                                                             \
+            FS_RUN_F(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, E8_);                                 \
         } else if constexpr (FMT == 1) {                                                                             \
             FS_RUN_W(RS_, R_, SPTW_, PAIR_, QKV_, TURNSW_, PH_, NBODIES_, STAMP_);                                    \
         } else {                                                                                                     \
@@ -668,7 +816,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
     } while (0)
 #define FS_PBURST(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_)                                                             \
     do {                                                                                                             \
-        if constexpr (FMT == 0) {                                                                                    \
+        if constexpr (FMT == 0 || FMT == 3) {                                                                                  \
             FS_BURST(RS_, R_, SPT_, PAIR_, QKV_, PH_);                                                                \
         } else {                                                                                                     \
             FS_BURST(RS_, R_, SPTW_, PAIR_, QKV_, PH_);                                                               \
@@ -686,7 +834,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             dbg_on = p.dbg != nullptr && l == p.dbg_layer;
             asm volatile("" : "+v"(lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
             // ---------------- c_attn (q, k, v tiles of this workgroup's 16 dimensions of its head)
-            FS_PHASE(rs_l, 3, 4, 1, 4 * kSub, kSub, false, true, ph_attn, 1, 20, rs_t, true);
+            FS_PHASE(rs_l, 3, 4, 1, 4 * kSub, kSub, false, true, ph_attn, 1, 20, rs_t, true, MI355_F8_EX);
             // ---------------- attention: scores over the whole context, then this workgroup's 16 output dims
             {
                 const bf16_t* kc = kv_l + (size_t)head * p.S * kHs;
@@ -908,11 +1056,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }
             // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows)
             FS_PBURST(rs_l, 1, 12, 4 * kSub, false, false, ph_proj);
-            FS_PHASE(rs_l, 1, 12, 1, 4 * kSub, (4 * kSub + 11) / 12, false, false, ph_proj, 1, 26, rs_t, false);
+            FS_PHASE(rs_l, 1, 12, 1, 4 * kSub, (4 * kSub + 11) / 12, false, false, ph_proj, 1, 26, rs_t, false, MI355_F8_EA);
             FS_PBURST(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
-            FS_PHASE(rs_l, 2, 4, 2, 4 * kSub, 2 * kSub, true, false, ph_fc, 1, 28, rs_t, true);
+            FS_PHASE(rs_l, 2, 4, 2, 4 * kSub, 2 * kSub, true, false, ph_fc, 1, 28, rs_t, true, MI355_F8_EX);
             FS_PBURST(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
-            FS_PHASE(rs_l, 1, 12, 1, 12 * kSub, kSub, false, false, ph_mp, 1, 30, rs_t, false);
+            FS_PHASE(rs_l, 1, 12, 1, 12 * kSub, kSub, false, false, ph_mp, 1, 30, rs_t, false, MI355_F8_EH);
             // next layer (or the head)
             kv_l += (size_t)2 * kHeads * p.S * kHs;
             if (l + 1 < p.n_layer) {
@@ -927,10 +1075,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }
         }
         dbg_on = false;
-        FS_PHASE(rs_h, 1, 4, 1, 4 * kSub, 1, false, false, ph_head, p.head_turns, 32, rs_th, true);
+        FS_PHASE(rs_h, 1, 4, 1, 4 * kSub, 1, false, false, ph_head, p.head_turns, 32, rs_th, true, MI355_F8_EX);
         if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
 #undef FS_PBURST
 #undef FS_PHASE
+#undef FS_RUN_F
 #undef FS_RUN_8
 #undef FS_RUN_W
 #undef FS_RUN
@@ -974,7 +1123,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             return float2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
         };
         auto ldsz = [&](const bf16_t* q) {  // per-row scale / zero pair (GRP: the streamers hold the group tables; BF16: none)
-            if constexpr (GRP || FMT != 0) return float2{0.f, 0.f};
+            if constexpr (GRP || FMT == 1 || FMT == 2) return float2{0.f, 0.f};
             return ldpair(q);
         };
         auto bfpair = [&](float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); };
@@ -1000,6 +1149,29 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             if constexpr (FMT == 2) return hpair(bf16_to_f32(f32_to_bf16(a)), bf16_to_f32(f32_to_bf16(b)));
             return hpair(a, b);
         };
+        // FMT 3 (fp8-limb operands): this lane's granule.  The lane holds rows (2 pg, 2 pg + 1) of a 16-row tile; a granule carries the
+        // values at offsets (j, j + 4) of an octet of rows, so the lanes of pairs pg and pg ^ 2 (lane ^ 16) exchange one value: the lower
+        // one (rows j, j + 1 with j = 0 or 2) publishes (j, j + 4), the upper one (rows j + 4, j + 5) publishes (j + 1, j + 5).  Granule
+        // index inside the tile's 8: 4 (octet) + j.  `e8`: the edge's pre-scale exponent.  Every lane of the wave must call it.
+        [[maybe_unused]] auto f8_slot = [&]() { return 4 * (pg >> 2) + 2 * (pg & 1) + ((pg >> 1) & 1); };
+        [[maybe_unused]] auto f8_publish = [&](u64* tile_dst, unsigned ep, float a, float b, int e8, bool store) {
+            const float pre = __uint_as_float((unsigned)(127 - e8) << 23);
+            a *= pre;
+            b *= pre;
+            const bool up = (pg & 2) != 0;
+            const float got = lane_xor16(up ? a : b);
+            const float va = up ? got : a, vb = up ? b : got;
+            if (store && fmaxf(fabsf(va), fabsf(vb)) > 448.f) atomicAdd(p.state + 2, 1u);  // clipped: counted like the fp16 clips
+            unsigned lo32, hi16;
+            f8_limbs(va, vb, lo32, hi16);
+            if (store) gr_store16(tile_dst + f8_slot(), ep, lo32, hi16);
+        };
+        // FMT 3: stage one 16-B sweep load (two granules) = dword `i` of each limb plane
+        [[maybe_unused]] auto f8_stage = [&](const u32x4& v, int i) {
+            *(unsigned*)(smem + kF8P0 + (size_t)i * 4) = __builtin_amdgcn_perm(v[2], v[0], 0x05040100u);  // l0: low halves of dwords 0 / 2
+            *(unsigned*)(smem + kF8P1 + (size_t)i * 4) = __builtin_amdgcn_perm(v[2], v[0], 0x07060302u);  // l1: high halves of dwords 0 / 2
+            *(unsigned*)(smem + kF8P2 + (size_t)i * 4) = __builtin_amdgcn_perm(v[3], v[1], 0x05040100u);  // l2: low halves of dwords 1 / 3
+        };
         // sums of the staged operands, even pairs in .x and odd pairs in .y (one v_dot2_f32_f16 per dword).  They undo
         // the +1024 / zero-point offsets of the int4 operands:
         //   y = scale (acc - 1024 (S_even + S_odd) - zero (S_even + 16 S_odd));
@@ -1007,7 +1179,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         // MFMAs in every streamer wave.
         const f16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
         auto pair_sums = [&](float2& sx, unsigned even, unsigned odd) {
-            if constexpr (FMT != 0) return;  // (no operand offsets to undo)
+            if constexpr (FMT != 0) return;  // (no operand offsets to undo; FMT 3: the streamers take the sums)
             sx.x = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, even), ones2, sx.x, false);
             sx.y = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, odd), ones2, sx.y, false);
         };
@@ -1023,6 +1195,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }
         };
         auto get_sums = [&]() {
+            if constexpr (FMT == 3) {
+                // the streamer waves' operand sums (all-ones MFMAs of the phase's first tile: valid behind its Bt); the A block scale
+                // made the products q x~ themselves, so there is no offset term: y = scale (acc - zero S)
+                const f32x4 sa = *(const f32x4*)(misc + 32), sb = *(const f32x4*)(misc + 36);
+                return float2{0.f, ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sb[0] + sb[1]) + (sb[2] + sb[3]))};
+            }
             const float se = misc[4] + misc[5], so = misc[6] + misc[7];
             return float2{1024.f * (se + so), se + 16.f * so};
         };
@@ -1043,7 +1221,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             const unsigned ep = ebase + edge;
             u64* dst = p.gx + (size_t)xpar * 2304;
             x_scale = __uint_as_float((__float_as_uint(rinv_seen) + 0x00400000u) & 0x7F800000u);
-            if (w8 == 0) gr_store(dst + bid * 8 + pg, ep, hpair(x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y));
+            if constexpr (FMT == 3) {
+                f8_publish(dst + bid * 8, ep, x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y, MI355_F8_EX, w8 == 0);
+            } else {
+                if (w8 == 0) gr_store(dst + bid * 8 + pg, ep, hpair(x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y));
+            }
             float ss = xv.x * xv.x + xv.y * xv.y;  // the same in the 8 lanes of a pair: sum over the 8 pairs
             ss = MI355_DPP_ADD(ss, 0x140);
             ss += lane_xor16(ss);
@@ -1089,7 +1271,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gx, off, 0, 16));
                     }
 #pragma unroll
-                    for (int k = 0; k < kG0 + 2; ++k) ok &= v[k][1] == ep && v[k][3] == ep;
+                    for (int k = 0; k < kG0 + 2; ++k) {
+                        if (FMT == 3 && k < kG0) ok &= (v[k][1] >> 16) == (ep & 0xFFFFu) && (v[k][3] >> 16) == (ep & 0xFFFFu);
+                        else ok &= v[k][1] == ep && v[k][3] == ep;
+                    }
                     if (__all(ok)) break;
                     if (spins > kSpinLimit || aborted(p)) {
                         if (lane == 0) raise_abort(p, 0x100u + edge);
@@ -1100,8 +1285,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 float2 sx = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < kG0; ++k) {
-                    *(u64*)(xs + (size_t)(k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
-                    pair_sums(sx, v[k][0], v[k][2]);
+                    if constexpr (FMT == 3) {
+                        f8_stage(v[k], k * 64 + lane_v);
+                    } else {
+                        *(u64*)(xs + (size_t)(k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                        pair_sums(sx, v[k][0], v[k][2]);
+                    }
                 }
                 float ss = ((__uint_as_float(v[kG0][0]) + __uint_as_float(v[kG0][2])) + __uint_as_float(v[kG0 + 1][0])) +
                            __uint_as_float(v[kG0 + 1][2]);
@@ -1117,12 +1306,16 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             } else {
                 if constexpr (FMT == 2) zero_obits();
                 u32x4 v[16 - kG0];
-                sweep<16 - kG0>(p, rs_gx, base, kG0 * 64, 1024, ep, v, 0x200u + edge, lane_v);
+                sweep<16 - kG0, FMT == 3>(p, rs_gx, base, kG0 * 64, 1024, FMT == 3 ? (ep & 0xFFFFu) : ep, v, 0x200u + edge, lane_v);
                 float2 sx = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 16 - kG0; ++k) {
-                    *(u64*)(xs + (size_t)(kG0 * 64 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
-                    pair_sums(sx, v[k][0], v[k][2]);
+                    if constexpr (FMT == 3) {
+                        f8_stage(v[k], kG0 * 64 + k * 64 + lane_v);
+                    } else {
+                        *(u64*)(xs + (size_t)(kG0 * 64 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                        pair_sums(sx, v[k][0], v[k][2]);
+                    }
                 }
                 put_sums(sx);
             }
@@ -1130,7 +1323,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             ++edge;
         };
         auto deq = [&](float2 t, float2 sc_, float2 z_, float2 sx) {
-            if constexpr (GRP || FMT != 0) return t;  // the streamers applied the group scales / unquantised weights
+            if constexpr (GRP || FMT == 1 || FMT == 2) return t;  // the streamers applied the group scales / unquantised weights
             return float2{sc_.x * (t.x - sx.x - z_.x * sx.y), sc_.y * (t.y - sx.x - z_.y * sx.y)};
         };
 
@@ -1359,8 +1552,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     o.y = group_sum(o.y * wsc, 8);
                     const float inv = 1.0f / group_sum(misc[24 + w8] * wsc, 8);
                     // attention output elements head * 128 + hj * 16 + 2 pg, + 1 -> one pair granule
-                    if (w8 == 0)
-                        gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair_b(o.x * inv, o.y * inv));
+                    if constexpr (FMT == 3) {
+                        f8_publish(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8, ebase + edge, o.x * inv, o.y * inv, MI355_F8_EA, w8 == 0);
+                    } else {
+                        if (w8 == 0)
+                            gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair_b(o.x * inv, o.y * inv));
+                    }
                 }
                 if (split) {
                     // row-split attention: this workgroup's partial over ITS rows (all 128 dimensions) goes to the head
@@ -1415,8 +1612,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         const float ox = group_sum(__uint_as_float(v1[0]) * wsc, 8);
                         const float oy = group_sum(__uint_as_float(v1[2]) * wsc, 8);
                         const float inv = 1.0f / group_sum(lj * wsc, 8);
-                        if (w8 == 0)
-                            gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair_b(ox * inv, oy * inv));
+                        if constexpr (FMT == 3) {
+                            f8_publish(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8, ebase + edge, ox * inv, oy * inv, MI355_F8_EA, w8 == 0);
+                        } else {
+                            if (w8 == 0)
+                                gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair_b(ox * inv, oy * inv));
+                        }
                     }
                     ppar ^= 1;
                 }
@@ -1440,13 +1641,18 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if (gw == 1) zero_obits();
                 }
                 u32x4 v[8];
-                sweep<8>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, ep, v, 0x400u + edge, lane_v, &n_sweeps);
+                sweep<8, FMT == 3>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, FMT == 3 ? (ep & 0xFFFFu) : ep, v,
+                                   0x400u + edge, lane_v, &n_sweeps);
                 FS_GCOUNT(42);
                 float2 sxp = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
-                    pair_sums(sxp, v[k][0], v[k][2]);
+                    if constexpr (FMT == 3) {
+                        f8_stage(v[k], gw * 512 + k * 64 + lane_v);
+                    } else {
+                        *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                        pair_sums(sxp, v[k][0], v[k][2]);
+                    }
                 }
                 put_sums(sxp);
                 apar ^= 1;
@@ -1509,10 +1715,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 u64* dst = p.gh + (size_t)hpar * (p.H / 2);
                 rinv_seen = misc[0];
                 const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;
-                const float2 sx = get_sums();
+                float2 sx = {0.f, 0.f};
+                if constexpr (FMT != 3) sx = get_sums();
 #pragma unroll
                 for (int t = 0; t < kMaxFcTiles; ++t) {
                     __syncthreads();  // Bt
+                    if constexpr (FMT == 3) {
+                        if (t == 0) sx = get_sums();  // (the streamers' operand sums exist behind the first tile end)
+                    }
                     if (gw == 0 && t < n_fc) {
                         float2 a, b;
                         if constexpr (FMT == 2) {
@@ -1523,9 +1733,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                             a = deq(tile_pair(0), fs1[t], fz1[t], sx);
                             b = deq(tile_pair(1), fs2[t], fz2[t], sx);
                         }
-                        if (w8 == 0)
-                            gr_store(dst + (bid + t * kG) * 8 + pg, ep,
-                                     hpair_b(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv)));
+                        if constexpr (FMT == 3) {
+                            f8_publish(dst + (bid + t * kG) * 8, ep, swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv),
+                                       MI355_F8_EH, w8 == 0);
+                        } else {
+                            if (w8 == 0)
+                                gr_store(dst + (bid + t * kG) * 8 + pg, ep,
+                                         hpair_b(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv)));
+                        }
                     }
                     buf ^= 1;
                 }
@@ -1549,6 +1764,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if constexpr (FMT == 2) {
                     if (gw == 1) zero_obits();
                 }
+                [[maybe_unused]] const unsigned eph = FMT == 3 ? (ep & 0xFFFFu) : ep;
                 const int n_loads = p.H / 4, half_l = (n_loads + 1) / 2;
                 const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
                 float2 sxp = {0.f, 0.f};
@@ -1567,8 +1783,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         for (int k = 0; k < 8; ++k) {
                             const int i = c0 + k * 64 + lh;
                             if (i < end) {
-                                *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
-                                pair_sums(sxp, v[k][0], v[k][2]);
+                                if constexpr (FMT == 3) {
+                                    f8_stage(v[k], i);
+                                } else {
+                                    *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                                    pair_sums(sxp, v[k][0], v[k][2]);
+                                }
                             }
                         }
                     };
@@ -1576,12 +1796,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     sweep_issue<8>(rs_gh, hbase, first, end, va, lh);
                     sweep_issue<8>(rs_gh, hbase, c1, end, vb, lh);
                     sweep_issue<8>(rs_gh, hbase, c2, end, vc, lh);
-                    sweep<8>(p, rs_gh, hbase, first, end, ep, va, 0x500u + edge, lh, &n_sweeps, true);
+                    sweep<8, FMT == 3>(p, rs_gh, hbase, first, end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
                     FS_GCOUNT(44);
                     stage8(va, first);
-                    sweep<8>(p, rs_gh, hbase, c1, end, ep, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep<8, FMT == 3>(p, rs_gh, hbase, c1, end, eph, vb, 0x500u + edge, lh, nullptr, true);
                     stage8(vb, c1);
-                    sweep<8>(p, rs_gh, hbase, c2, end, ep, vc, 0x500u + edge, lh, nullptr, true);
+                    sweep<8, FMT == 3>(p, rs_gh, hbase, c2, end, eph, vc, 0x500u + edge, lh, nullptr, true);
                     stage8(vc, c2);
                 }
 #else
@@ -1592,8 +1812,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         for (int k = 0; k < 8; ++k) {
                             const int i = c0 + k * 64 + lh;
                             if (i < end) {
-                                *(u64*)(xs + (size_t)i * 8) = ((u64)va[k][2] << 32) | va[k][0];
-                                pair_sums(sxp, va[k][0], va[k][2]);
+                                if constexpr (FMT == 3) {
+                                    f8_stage(va[k], i);
+                                } else {
+                                    *(u64*)(xs + (size_t)i * 8) = ((u64)va[k][2] << 32) | va[k][0];
+                                    pair_sums(sxp, va[k][0], va[k][2]);
+                                }
                             }
                         }
                     };
@@ -1602,24 +1826,28 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         for (int k = 0; k < 4; ++k) {
                             const int i = c0 + k * 64 + lh;
                             if (i < end) {
-                                *(u64*)(xs + (size_t)i * 8) = ((u64)vb[k][2] << 32) | vb[k][0];
-                                pair_sums(sxp, vb[k][0], vb[k][2]);
+                                if constexpr (FMT == 3) {
+                                    f8_stage(vb[k], i);
+                                } else {
+                                    *(u64*)(xs + (size_t)i * 8) = ((u64)vb[k][2] << 32) | vb[k][0];
+                                    pair_sums(sxp, vb[k][0], vb[k][2]);
+                                }
                             }
                         }
                     };
                     const int c1 = first + 512, c2 = first + 768, c3 = first + 1280;
                     sweep_issue<8>(rs_gh, hbase, first, end, va, lh);
                     sweep_issue<4>(rs_gh, hbase, c1, end, vb, lh);
-                    sweep<8>(p, rs_gh, hbase, first, end, ep, va, 0x500u + edge, lh, &n_sweeps, true);
+                    sweep<8, FMT == 3>(p, rs_gh, hbase, first, end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
                     FS_GCOUNT(44);
                     stage_a(first);
                     sweep_issue<8>(rs_gh, hbase, c2, end, va, lh);
-                    sweep<4>(p, rs_gh, hbase, c1, end, ep, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep<4, FMT == 3>(p, rs_gh, hbase, c1, end, eph, vb, 0x500u + edge, lh, nullptr, true);
                     stage_b(c1);
                     sweep_issue<4>(rs_gh, hbase, c3, end, vb, lh);
-                    sweep<8>(p, rs_gh, hbase, c2, end, ep, va, 0x500u + edge, lh, nullptr, true);
+                    sweep<8, FMT == 3>(p, rs_gh, hbase, c2, end, eph, va, 0x500u + edge, lh, nullptr, true);
                     stage_a(c2);
-                    sweep<4>(p, rs_gh, hbase, c3, end, ep, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep<4, FMT == 3>(p, rs_gh, hbase, c3, end, eph, vb, 0x500u + edge, lh, nullptr, true);
                     stage_b(c3);
                 }
 #endif
@@ -1675,7 +1903,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             post_b1();
             rinv_seen = misc[0];
             const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;
-            const float2 sx = get_sums();
+            float2 sx = {0.f, 0.f};
+            if constexpr (FMT != 3) sx = get_sums();
             float best = -INFINITY;
             int bi = 0x7fffffff;
             const int tiles_pad = p.head_turns * 12 / (4 * kSub);  // tile ends the streamers pass (4 kSub ring steps per tile and wave)
@@ -1683,6 +1912,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 float2 scn = {0.f, 0.f}, zn = {0.f, 0.f};
                 if (gw == 0) head_sz(t + 1, scn, zn);
                 __syncthreads();  // Bt
+                if constexpr (FMT == 3) {
+                    if (t == 0) sx = get_sums();
+                }
                 if (gw == 0 && t < n_head_t) {
                     const int n = (bid + t * kG) * 16 + 2 * pg;
                     float2 y;
@@ -1777,17 +2009,19 @@ int fused_step_ring_occupancy_ok() {
     static int ok = -1;
     static std::once_flag once;
     std::call_once(once, [] {
-        const void* fn[4] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
-                             (const void*)fused_step_ring_kernel<false, 1>, (const void*)fused_step_ring_kernel<false, 2>};
+        const void* fn[5] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
+                             (const void*)fused_step_ring_kernel<false, 1>, (const void*)fused_step_ring_kernel<false, 2>,
+                             (const void*)fused_step_ring_kernel<false, 3>};
         ok = 0;
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 5; ++i) {
             int per_cu = 0;
             (void)hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn[i], kThreads, kLdsBytes) == hipSuccess && per_cu >= 1)
                 ok |= 1 << i;
         }
     });
-    return ok;  // bit 0: the per-row int4 kernel fits one workgroup per CU, bit 1: the grouped-scale kernel, bit 2: BF16, bit 3: LLM.int8
+    return ok;  // bit 0: the per-row int4 kernel fits one workgroup per CU, bit 1: the grouped-scale kernel, bit 2: BF16, bit 3: LLM.int8,
+                // bit 4: int4 streams through fp8 operands
 }
 
 // launched by mi355_fused_step (fused_step.hip)
@@ -1795,9 +2029,10 @@ int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t 
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        const void* fn[4] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
-                             (const void*)fused_step_ring_kernel<false, 1>, (const void*)fused_step_ring_kernel<false, 2>};
-        for (int i = 0; i < 4 && attr_err == hipSuccess; ++i)
+        const void* fn[5] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
+                             (const void*)fused_step_ring_kernel<false, 1>, (const void*)fused_step_ring_kernel<false, 2>,
+                             (const void*)fused_step_ring_kernel<false, 3>};
+        for (int i = 0; i < 5 && attr_err == hipSuccess; ++i)
             attr_err = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     });
     MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "fused_step: hipFuncSetAttribute failed: %s",
@@ -1810,7 +2045,9 @@ int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t 
             hipLaunchKernelGGL((K_), dim3(kG), dim3(kThreads), kLdsBytes, stream, p);                                  \
         }                                                                                                             \
     } while (0)
-    if (p.fmt == 2) {
+    if (p.fmt == 3) {
+        FS_LAUNCH((fused_step_ring_kernel<false, 3>));
+    } else if (p.fmt == 2) {
         FS_LAUNCH((fused_step_ring_kernel<false, 2>));
     } else if (p.fmt == 1) {
         FS_LAUNCH((fused_step_ring_kernel<false, 1>));

@@ -419,6 +419,11 @@ class DecodeEngine:
         a.w_head = head.desc.w
         a.sz, a.sz_head, a.norms = ptr(sz), ptr(sz_head), ptr(norms)
         a.weight_fmt = fmt
+        if fmt == 0 and not gc and H // 128 <= 95 and _env_int("MI355_FUSED_F8", 0) != 0:
+            # EXPERIMENTAL (round 4, built after the round's GPU budget — see DESIGN.md section 7): the same int4 streams through fp8
+            # operands, one scaled K = 128 MFMA per 1-KiB piece instead of four f16 ones; the publishers split the activations into E4M3
+            # limbs.  tests/test_zz_fused_f8_gpu.py and scripts/ab_fused.py --f8 toggle `fused.weight_fmt` on a live engine.
+            a.weight_fmt = 3
         if gc:
             a.group_cols, a.gt, a.gt_head, a.gt_layer_stride = gc, ptr(gt), ptr(gt_head), gt.shape[1] * 4
         a.wte, a.rope = self.m.wte, self.m.rope
