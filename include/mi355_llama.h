@@ -533,10 +533,10 @@ typedef struct mi355_fused_step_args {
      * Linear8bitLt model (lit_llama/quantization.py:38-77, BASELINE configs[3], threshold 6.0) — `sz` then holds per layer (stride
      * 5 C + 2 H floats) the f32 row scales SCB of c_attn[3C] attn.c_proj[C] c_fc1[H] c_fc2[H] mlp.c_proj[C], `sz_head` lm_head's [V];
      * at most 1024 outlier columns per gathered vector (more raise the abort word: such a step belongs on mi355_forward).
-     * 3 (round 4, EXPERIMENTAL — selected by nothing unless MI355_FUSED_F8=1): the streams, scales and zeros of 0, computed through
-     * fp8 operands: one v_mfma_scale_f32_16x16x128_f8f6f4 per 1-KiB piece (an int4 level in a byte is the E4M3 code of q * 2^-9), the
-     * hand-offs carry three E4M3 limbs per activation under 16-bit tags; per-row scales only, n_hidden <= 12160.  A workspace that
-     * has carried hand-offs of another weight_fmt must be zeroed (all but its first 256 bytes) before the first step.
+     * 3 (round 4; what lit_llama_amd's engine selects for per-row int4 models unless MI355_FUSED_F8=0): the streams, scales and zeros
+     * of 0, computed through fp8 operands: one v_mfma_scale_f32_16x16x128_f8f6f4 per 1-KiB piece (an int4 level in a byte is the E4M3
+     * code of q * 2^-9), the hand-offs carry three E4M3 limbs per activation under 16-bit tags; per-row scales only, n_hidden <= 12160.
+     * A workspace that has carried hand-offs of another weight_fmt must be zeroed (all but its first 256 bytes) before the first step.
      * Register-ring implementation only. */
     int32_t weight_fmt;
     const void* gt;

@@ -284,8 +284,9 @@ __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_b
 // steps per unit; the streamer waves quantise the gathered vector themselves — f16 cast, outlier columns |x| >= 6, absmax of the rest,
 // rint(x 127 / absmax), the arithmetic of csrc/int8.hip (bitsandbytes' MatMul8bitLt as oracle/oracle.py restates it: PARITY
 // UNPINNED) — and the gatherers' epilogue dequantises and adds the f16 outlier side product.
-// 3 = FMT 0's int4 streams through fp8 operands (round 4, EXPERIMENTAL: mi355_fused_step_args.weight_fmt = 3; built on the CPU
-// container after the round's GPU budget, see DESIGN.md section 7 and scripts/micro/mx_fp8.hip for what IS measured).  A compute
+// 3 = FMT 0's int4 streams through fp8 operands (round 4: mi355_fused_step_args.weight_fmt = 3, the engine's choice for per-row int4
+// models; primitives measured by scripts/micro/mx_fp8.hip, the step by scripts/ab_fused.py --f8: profiles/r04_f8_operands_ab.txt,
+// 920.6 -> 899.0 us per step on one box, parity = FMT 0's).  A compute
 // phase of FMT 0 is bound by MFMA issue: four 16x16x32 f16 MFMAs (35.5 ns per SIMD) + 20 conversion instructions per 1-KiB piece.
 // Here a piece is ONE v_mfma_scale_f32_16x16x128_f8f6f4 (15.2 ns) + 12 instructions:
 //  * weights: a byte holding an int4 level q IS the OCP E4M3 code of q * 2^-9 (codes 0..7 are the subnormals, 8..15 the first

@@ -419,10 +419,11 @@ class DecodeEngine:
         a.w_head = head.desc.w
         a.sz, a.sz_head, a.norms = ptr(sz), ptr(sz_head), ptr(norms)
         a.weight_fmt = fmt
-        if fmt == 0 and not gc and H // 128 <= 95 and _env_int("MI355_FUSED_F8", 0) != 0:
-            # EXPERIMENTAL (round 4, built after the round's GPU budget — see DESIGN.md section 7): the same int4 streams through fp8
-            # operands, one scaled K = 128 MFMA per 1-KiB piece instead of four f16 ones; the publishers split the activations into E4M3
-            # limbs.  tests/test_zz_fused_f8_gpu.py and scripts/ab_fused.py --f8 toggle `fused.weight_fmt` on a live engine.
+        if fmt == 0 and not gc and H // 128 <= 95 and _env_int("MI355_FUSED_F8", 1) != 0:
+            # round 4: the same int4 streams through fp8 operands — one scaled K = 128 MFMA per 1-KiB piece instead of four f16 ones, the
+            # publishers split the activations into three E4M3 limbs (csrc/fused_step_ring.hip FMT 3; DESIGN.md section 5: +2.4..2.8 % on
+            # the headline, the same distance from the reference's run as the fp16 operands).  MI355_FUSED_F8=0 keeps weight_fmt 0;
+            # tests/test_zz_fused_f8_gpu.py and scripts/ab_fused.py --f8 toggle `fused.weight_fmt` on a live engine.
             a.weight_fmt = 3
         if gc:
             a.group_cols, a.gt, a.gt_head, a.gt_layer_stride = gc, ptr(gt), ptr(gt_head), gt.shape[1] * 4
@@ -449,13 +450,14 @@ class DecodeEngine:
         words = self._fused_ws[:12].view(torch.int32).tolist()  # [0] abort code, [1] step counter, [2] clipped fp16 granules
         code, clipped = words[0], words[2]
         if clipped:
-            # the attention-output / SwiGLU edges travel as fp16 and saturate at +-65504 (csrc/fused_step.hip hpair): the
-            # steps since the last check computed with clipped activations, i.e. NOT what the reference computes
+            # the attention-output / SwiGLU edges travel as fp16 and saturate at +-65504 (csrc/fused_step_ring.hip hpair; as fp8 limbs,
+            # weight_fmt 3: at +-448 x 2^2 / 2^4, x edges at +-448 after their 1/rms scale): the steps since the last check computed
+            # with clipped activations, i.e. NOT what the reference computes
             self._fused_ws[8:12].zero_()
             self.fused_clipped += clipped
             import warnings
 
-            warnings.warn(f"fused decode step: {clipped} activation pairs exceeded the fp16 range and were clipped since the "
+            warnings.warn(f"fused decode step: {clipped} activation pairs exceeded the range of the step's hand-off format and were clipped since the "
                           "last check; set MI355_FUSED=0 to decode such a checkpoint on the launch-per-operator path",
                           RuntimeWarning, stacklevel=2)
         if code != 0:

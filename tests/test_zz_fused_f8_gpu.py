@@ -1,11 +1,11 @@
-"""EXPERIMENTAL operand path of the persistent int4 decode step: mi355_fused_step_args.weight_fmt = 3 (csrc/fused_step_ring.hip
-`fused_step_ring_kernel<false, 3>`): the int4 streams of weight_fmt 0 through fp8 operands — one v_mfma_scale_f32_16x16x128_f8f6f4 per
-1-KiB piece, activations published as three E4M3 limbs under 16-bit tags.
-
-The kernel was written on the CPU-only build container after round 4's GPU budget was spent; what IS measured on the GPU are its
-primitives (scripts/micro/mx_fp8.hip: int4 bytes as E4M3 subnormals, per-lane block scales, the limb split, 15.2 against 35.5 ns of
-matrix pipe per piece).  Until these tests have passed on an MI355X they are opt-in — MI355_TEST_F8=1 — so that an unvalidated
-kernel cannot take the GPU suite down; the file sorts last for the same reason.  Nothing selects weight_fmt 3 unless MI355_FUSED_F8=1.
+"""The fp8-operand path of the persistent int4 decode step: mi355_fused_step_args.weight_fmt = 3 (csrc/fused_step_ring.hip
+`fused_step_ring_kernel<false, 3>`, what the engine selects for per-row int4 models since round 4): the int4 streams of weight_fmt 0
+through fp8 operands — one v_mfma_scale_f32_16x16x128_f8f6f4 per 1-KiB piece, activations published as three E4M3 limbs under 16-bit
+tags.  Every other GPU test of an int4 model runs the default path, i.e. this one; here BOTH operand paths run on one engine
+(`fused.weight_fmt` toggled, hand-off workspace zeroed in between) against the launch-per-operator step and the oracle.
+Primitives: scripts/micro/mx_fp8.hip (int4 bytes as E4M3 subnormals, per-lane block scales, the limb split, 15.2 against 35.5 ns of
+matrix pipe per piece); first GPU run of this file and of the full-depth golden test under the path: profiles/r04_f8_operands_tests.txt.
+MI355_TEST_F8=0 skips the file.
 
 Reference path: /root/reference generate.py:63-91 -> lit_llama/model.py:76-122 for one token at a time (as tests/test_fused_step_gpu.py).
 Bars = those of the fp16-operand step: within 0.03 logit-std of the launch-per-operator step on the same weights, greedy tokens equal
@@ -23,8 +23,7 @@ from lit_llama_amd.utils import EmptyInitOnDevice
 from oracle import oracle
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("MI355_TEST_F8", "0") != "1",
-                                 reason="weight_fmt 3 is unvalidated on hardware: opt in with MI355_TEST_F8=1")]
+              pytest.mark.skipif(os.environ.get("MI355_TEST_F8", "1") == "0", reason="MI355_TEST_F8=0")]
 
 W7B = dict(n_head=32, n_embd=4096)
 
