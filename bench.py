@@ -482,7 +482,9 @@ def main():
             try:  # (the committed PMC pass is of the headline configuration)
                 traffic = json.loads(pmc.read_text()).get(key)
                 traffic_source = ("profiles/pmc_traffic.json: committed rocprofv3 --pmc FETCH_SIZE pass over this command "
-                                  "(x2 gfx950 wide-read correction); static, not measured in this run") if traffic else None
+                                  "(x2 gfx950 wide-read correction); static, not measured in this run"
+                                  + ("; taken on the fp16-operand kernel (weight_fmt 0) — the fp8-operand kernel reads the same streams, "
+                                     "tables, cache rows and granule counts" if f8_operands else "")) if traffic else None
             except Exception:
                 traffic = None
         # tokens/s of generate() including the prompt (generate.py:146-153 prints this figure)
