@@ -311,3 +311,55 @@ def test_import_paths_of_the_reference_resolve():
     w = torch.zeros((8, 32), dtype=torch.uint8)
     with pytest.raises(nat.NativeError):  # no CPU fallback: the product path needs the GPU
         qlinear_4bit_weight(x, w, torch.ones((8, 1), dtype=torch.bfloat16), torch.zeros((8, 1), dtype=torch.bfloat16))
+
+
+def test_fp8_operand_hand_off_format_statement():
+    """The numpy statement (tests/layouts.py) of what csrc/fused_step_ring.hip FMT 3 puts on the wire and in LDS: an int4 level in a byte is
+    the E4M3 code of q * 2^-9; three E4M3 limbs hold 12 significant bits from 2^-6 to 448 (the per-binade errors the GPU microbenchmark
+    printed, profiles/r04_mx_fp8_microbench.txt); and a staged limb plane lists a unit's k in exactly the order in which the nibble masks
+    leave the weights of a Q4 stream dword, so that A and B operand bytes of the scaled MFMA meet on the same k."""
+    import layouts
+
+    # (1) int4 levels are E4M3 codes
+    q = np.arange(16, dtype=np.uint8)
+    assert np.array_equal(layouts.e4m3_decode(q) * 512.0, q.astype(np.float64))
+    # (2) encode / decode round trip on every finite code, ties to even, clamp
+    codes = np.array([c for c in range(256) if (c & 0x7F) != 0x7F], dtype=np.uint8)
+    assert np.array_equal(layouts.e4m3_encode(layouts.e4m3_decode(codes)) & 0x7F, codes & 0x7F)
+    assert layouts.e4m3_decode(layouts.e4m3_encode(np.array([17.0, 19.0, 2.0 ** -10, 1.5 * 2.0 ** -9, 1.0e6, -1.0e6]))).tolist() == \
+        [16.0, 20.0, 0.0, 2.0 ** -8, 448.0, -448.0]
+    # (3) precision of the limb split per binade (12-bit inputs, as the microbenchmark's)
+    rng = np.random.default_rng(0)
+    for e in range(-14, 9):
+        x = (1.0 + rng.integers(0, 4096, size=512) / 4096.0) * 2.0 ** e * rng.choice([-1.0, 1.0], size=512)
+        limbs = layouts.f8_limbs(x)
+        rec = layouts.e4m3_decode(limbs[0]) + layouts.e4m3_decode(limbs[1]) / 16.0 + layouts.e4m3_decode(limbs[2]) / 256.0
+        rel = np.abs(rec - x).max() / 2.0 ** e
+        if -5 <= e <= 7:
+            assert rel == 0.0, (e, rel)          # 12-bit values are exact
+        elif e == -6:
+            assert rel <= 2.0 ** -12 + 1e-12, (e, rel)
+        elif e < -6:
+            assert np.abs(rec - x).max() <= 2.0 ** -18, (e, rel)  # absolute floor: half a subnormal step of the last limb
+        else:
+            assert (np.abs(rec - x) / np.abs(x)).max() <= 0.07, e  # past +-448 the limbs saturate at 477.75 (the step counts such granules)
+    # (4) plane byte order == the A operand's nibble order
+    K = 256
+    x = rng.standard_normal(K)
+    gran, planes = layouts.f8_planes(x, tag=0x1234)
+    assert gran.shape == (K // 2,) and np.all((gran >> np.uint64(48)) == np.uint64(0x1234))
+    limbs = layouts.f8_limbs(x)
+    order = [0, 4, 1, 5, 2, 6, 3, 7]
+    for c in range(3):
+        assert np.array_equal(planes[c].reshape(-1, 8), limbs[c].reshape(-1, 8)[:, order])
+    # the Q4 stream's nibbles under the two masks, for one lane's dword: bytes of `v & 0x0F0F0F0F` then of `(v >> 4) & 0x0F0F0F0F`
+    lv = rng.integers(0, 16, size=(16, 128)).astype(np.uint8)
+    stream = layouts.q4_levels_to_stream(lv, None, 1).view(np.uint32).reshape(1, 1, 1, 64, 4)
+    for lane in (0, 17, 63):
+        g, row = lane >> 4, lane & 15
+        for d in range(4):
+            v = int(stream[0, 0, 0, lane, d])
+            a_bytes = list(np.frombuffer(np.uint32(v & 0x0F0F0F0F).tobytes(), dtype=np.uint8)) + \
+                list(np.frombuffer(np.uint32((v >> 4) & 0x0F0F0F0F).tobytes(), dtype=np.uint8))
+            ks = [32 * g + 8 * d + j for j in order]
+            assert a_bytes == [int(lv[row, k]) for k in ks]
