@@ -41,14 +41,6 @@ def test_full_depth_7b_int4_against_the_reference_golden_run(dev, golden):
     _int4_checkpoint_against_its_fixtures(dev, golden, (("cfg2_7b_int4", 0.03), ("cfg2_7b_int4_long", None), ("cfg2_7b_int4_p400", None)))
 
 
-@torch.no_grad()
-def test_full_depth_7b_int4_second_checkpoint_against_the_reference_golden_run(dev, golden):
-    """Another 7B int4 checkpoint (seed 1: other weights, scales, zero points), prompt of 24, 32 greedy tokens from the UNMODIFIED
-    reference on the CPU (oracle/gen_golden.py --big-s1; bf16 calibration twin --big-bf16 --s1): north_star's "token-for-token" on
-    more than one checkpoint.  Same bars as above."""
-    _int4_checkpoint_against_its_fixtures(dev, golden, (("cfg2_7b_int4_s1", None),))
-
-
 def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures):
     g0 = golden(fixtures[0][0])
     cfg = LLaMAConfig.from_name("7B")
