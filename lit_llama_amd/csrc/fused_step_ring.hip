@@ -136,7 +136,12 @@ __device__ __forceinline__ void gr_store(u64* p, unsigned tag, unsigned val) {
     __hip_atomic_store(p, ((u64)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // one 8-B sc1 store
 }
 // fp8-limb operands (FMT 3): a granule is {tag: 16 bits, payload: 48 bits} = limb 0 / 1 / 2 of TWO values, low to high:
-// l0a l0b l1a l1b | l2a l2b tag16 — still one 8-B sc1 store
+// l0a l0b l1a l1b | l2a l2b tag16 — still one 8-B sc1 store.  Why 16 bits of (step * 1024 + 1 + edge) are enough: a consumer can only
+// mistake a STALE granule for the one it waits for, and what a slot holds is at most one step old (every slot of gx / ga / gh is
+// rewritten in every step), i.e. its tag differs from the awaited one by less than 2 * 1024 and not by 0; tags repeat after 64 steps;
+// the low 10 bits (1 + edge, < 1024 by the host's n_layer check) are never 0, so a zeroed workspace matches nothing.  What the width does
+// NOT survive is a workspace that carried 32-bit-tagged granules a moment ago (their upper tag half is small): zero it when the
+// weight_fmt of a live workspace changes (include/mi355_llama.h).
 __device__ __forceinline__ void gr_store16(u64* p, unsigned tag, unsigned lo32, unsigned hi16) {
     __hip_atomic_store(p, ((u64)(((tag & 0xFFFFu) << 16) | hi16) << 32) | lo32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -363,3 +363,37 @@ def test_fp8_operand_hand_off_format_statement():
                 list(np.frombuffer(np.uint32((v >> 4) & 0x0F0F0F0F).tobytes(), dtype=np.uint8))
             ks = [32 * g + 8 * d + j for j in order]
             assert a_bytes == [int(lv[row, k]) for k in ks]
+
+
+def test_fp8_operand_linear_arithmetic_statement():
+    """One int4 linear the way the fp8-operand step computes it (csrc/fused_step_ring.hip FMT 3), stated in numpy: A = the level bytes read as
+    E4M3 times the block scale 2^9, B = the three limb planes under 2^(E - 0 / 4 / 8), y = scale (sum_c D[:, c] - zero S) with S from an
+    all-ones row — against the exact (q - zero) scale x, and next to the fp16-operand statement (activations rounded to fp16).  The limb
+    path may not be worse than the fp16 path by more than a quarter (exact products here; the matrix pipe's own 2^-11..2^-13 is measured
+    by scripts/micro/mx_fp8.hip)."""
+    import layouts
+
+    rng = np.random.default_rng(3)
+    for K, E in ((4096, 0), (11008, 4)):
+        N = 32
+        q = rng.integers(0, 16, size=(N, K)).astype(np.float64)
+        zero = rng.integers(5, 11, size=(N, 1)).astype(np.float64)
+        scale = (0.03 * (1.0 + 0.1 * rng.random((N, 1))))
+        x = rng.standard_normal(K) * (4.0 if E else 1.0)
+        x[rng.integers(0, K, size=4)] *= 30.0  # a few outlier channels
+        exact = scale[:, 0] * ((q - zero) @ x)
+        # fp8-operand statement
+        a_op = layouts.e4m3_decode(q.astype(np.uint8)) * 2.0 ** 9                     # = q
+        limbs = layouts.f8_limbs(x * 2.0 ** -E)                                        # what the publisher stores
+        b_op = np.stack([layouts.e4m3_decode(limbs[c]) * 2.0 ** (E - 4 * c) for c in range(3)], axis=1)  # [K, 3 columns]
+        d = a_op @ b_op
+        s_ones = np.ones(K) @ b_op
+        y8 = scale[:, 0] * (d.sum(1) - zero[:, 0] * s_ones.sum())
+        # fp16-operand statement (weight_fmt 0): activations as fp16
+        x16 = x.astype(np.float16).astype(np.float64)
+        y16 = scale[:, 0] * ((q - zero) @ x16)
+        ref = np.abs(exact).mean()
+        e8, e16 = np.abs(y8 - exact).max() / ref, np.abs(y16 - exact).max() / ref
+        assert np.array_equal(a_op, q)
+        assert e8 <= 1.25 * e16 + 1e-6, (K, e8, e16)
+        assert e8 < 2e-3
