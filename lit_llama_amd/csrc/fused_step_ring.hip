@@ -124,6 +124,9 @@ static_assert(kF8P1 + kF8Units * 128 <= kOffPart && (kF8P1 - kF8P0) % 256 == 64 
 #ifndef MI355_F8_EH
 #define MI355_F8_EH 4  // SwiGLU output
 #endif
+#ifndef MI355_F8_XSCALE0
+#define MI355_F8_XSCALE0 0  // scale of a step's FIRST x edge from the token's embedding row (see the gatherers' entry)
+#endif
 [[maybe_unused]] constexpr int kMaxS = 32768;     // cache rows (the attention keeps no per-row state in LDS)
 #ifndef MI355_FUSED_LDS_PAD
 #define MI355_FUSED_LDS_PAD 0  // (A / B knob: bytes of LDS requested on top of the map)
@@ -1435,6 +1438,16 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         const bf16_t* sz_l = p.sz;
         bf16_t* kv_l = p.kv;
         const float2 cs = *(const float2*)(p.rope + ((size_t)pos * (kHs / 2) + hj * 8 + pg) * 2);
+#if MI355_F8_XSCALE0
+        if constexpr (FMT == 3) {
+            // (knob, default off — written after round 4's GPU budget, to be measured in round 5)  The first edge of a step is published
+            // before any 1/rms is known, i.e. with scale 1: the embedding row times rms_1's scale.  An E4M3 limb triple is exact to 12
+            // bits only from 2^-6 up, and a trained checkpoint's embeddings are ~2^-6..2^-12.  1/rms of the row's first 64 values — the
+            // same number in every workgroup — stands in for the edge's 1/rms (publish_x rounds it to a power of two).
+            const float e0 = bf16_to_f32(p.wte[(size_t)token * kC + lane]);
+            rinv_seen = rsqrtf(group_sum(e0 * e0, 64) * (1.0f / 64.0f) + 1.0e-30f);
+        }
+#endif
         if (gw == 0) publish_x(xres, ldpair(norms_l + r0));
         for (int l = 0; l < p.n_layer; ++l) {
             dbg_on = p.dbg != nullptr && l == p.dbg_layer;
