@@ -103,9 +103,20 @@ class ColBlockQuantizedLinear(torch.nn.Module):
 
     # ---- format utilities (checkpoint tooling: tensor reshuffling on whatever device the buffers live on; NOT compute entry
     # points — `forward` and every kernel-backed op refuse CPU tensors, DESIGN.md section 1) ---------------------------------
+    def _per_column(self, table: torch.Tensor) -> torch.Tensor:
+        """[N, groups] scales / zeros -> what multiplies column k: [N, groups, 1] against the [N, groups, tile_cols] view of the
+        weight when the groups tile K exactly, else [N, K] with group j covering columns j * tile_cols .. (j + 1) * tile_cols - 1
+        and a SHORTER last group (the reference allocates ceil(in / tile_cols) groups and slices, lit_llama/quantization.py:360-369,
+        :381-384, :404-410: GPTQ groupsize 512 against K = 11008 is such a shape; advisor r4)."""
+        if self.in_features % self.tile_cols == 0:
+            return table.unsqueeze(-1)
+        return table.repeat_interleave(self.tile_cols, dim=1)[:, : self.in_features]
+
     def _grouped(self, t: torch.Tensor) -> torch.Tensor:
-        """[N, K] -> a [N, groups, tile_cols] view (one scale / zero per row and group)."""
-        return t.view(t.shape[0], self.scales.size(1), -1)
+        """[N, K] -> the view `_per_column` broadcasts against: [N, groups, tile_cols], or [N, K] itself for a ragged last group."""
+        if self.in_features % self.tile_cols == 0:
+            return t.view(t.shape[0], self.scales.size(1), -1)
+        return t
 
     def pack_weight(self, weight):
         """Quantise `weight` with the current scales / zeros and pack it: levels = clamp(w / scale + zero) with the reference's
@@ -115,7 +126,7 @@ class ColBlockQuantizedLinear(torch.nn.Module):
         dev = self.quant_weight.device
         w = weight.to(device=dev, copy=True).contiguous()
         g = self._grouped(w)
-        g.div_(self.scales.unsqueeze(-1)).add_(self.zeros.unsqueeze(-1))
+        g.div_(self._per_column(self.scales)).add_(self._per_column(self.zeros))
         levels = w.clamp_(min=0, max=2**self.bits - 1).to(dtype=torch.uint8)
         epb = self.entries_per_byte
         shifts = torch.arange(epb, device=dev, dtype=torch.int32) * self.bits
@@ -133,7 +144,7 @@ class ColBlockQuantizedLinear(torch.nn.Module):
         shifts = torch.arange(epb, dtype=torch.int32) * self.bits
         levels = (self.quant_weight.to(torch.int32).unsqueeze(-1) >> shifts) & ((1 << self.bits) - 1)
         weight = levels.reshape(self.out_features, self.in_features).to(dtype)
-        self._grouped(weight).sub_(self.zeros.unsqueeze(-1)).mul_(self.scales.unsqueeze(-1))
+        self._grouped(weight).sub_(self._per_column(self.zeros)).mul_(self._per_column(self.scales))
         return weight
 
     # ---- hot path -----------------------------------------------------------------------------------
@@ -211,10 +222,10 @@ class Linear8bitLt(torch.nn.Linear):
         # (lit_llama/quantization.py:52-67; the reference looks the key up by its `weight` suffix, here it is
         # addressed by the module prefix so the order of the checkpoint's keys does not matter).
         weight_key = prefix + "weight"
-        if weight_key not in state_dict:
-            return
-        weight = state_dict.pop(weight_key)
-        self._quantize_weight(weight)
+        if weight_key in state_dict:
+            self._quantize_weight(state_dict.pop(weight_key))
+        # else: an adapter-only checkpoint loaded with strict=False behind the pretrained one (generate/adapter_v2.py:94-101): the
+        # int8 weight stays, the keys below still have to land (advisor r4: they used to be skipped with the weight)
         # the module's other parameters — the bias, and the adapter_scale / adapter_bias pair LLaMA-Adapter v2 attaches to every
         # nn.Linear, this class included (generate/adapter_v2.py with --quantize llm.int8) — go through nn.Module's loader, as the
         # reference's `if local_state_dict: super()._load_from_state_dict(...)` does (round 4: only the bias used to be loaded)

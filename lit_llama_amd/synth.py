@@ -12,6 +12,13 @@ load into `lit_llama.LLaMA` (the reference, in tests) and `lit_llama_amd.LLaMA` 
   llm.int8    : fp weights with a few input channels of the embedding / norm scales boosted so activations cross
                 the |x| >= 6 outlier threshold
 
+`stats="llama"` (round 5) bends the same random draws towards what a TRAINED LLaMA checkpoint looks like to a kernel that
+stages activations in a narrow format (the persistent step's fp8-limb hand-offs): embeddings of std 0.02, RMSNorm scales from
+~0.05 (first block) to ~0.5 (last block) with a log-normal spread per channel, a few hidden units of block 1 whose
+c_fc1 / c_fc2 rows coincide and are scaled so that their SwiGLU output reaches 10^3..10^4 on the tokens that excite them, and an
+mlp.c_proj that routes those units into three fixed residual channels only ("massive activations": hundreds of times the
+rms of the stream, carried to the last block).  See `llama_stats_plan`.
+
 `device="cuda"` generates directly in HBM with the torch CUDA generator (bench); the CPU generator (tests) is
 what the golden fixtures were produced from.
 """
@@ -65,6 +72,24 @@ def _randn(shape, gen, device, std=1.0):
     return torch.randn(shape, generator=gen, device=device, dtype=torch.float32) * std
 
 
+def llama_stats_plan(cfg: LLaMAConfig) -> dict:
+    """Where `stats="llama"` puts its structure: the block, the hidden units with coinciding c_fc1 / c_fc2 rows (SwiGLU output
+    a * silu(a) ~ a^2 for a > 0), the residual channels they feed, and the sizes involved.  Kept in one place so that the tests can
+    look at the very rows / channels the generator touched."""
+    C, H = cfg.n_embd, cfg.n_hidden
+    return dict(
+        layer=min(1, cfg.n_layer - 1),
+        hidden_units=[H * k // 11008 for k in (7003, 4242, 9000, 1234)],
+        channels=[C * k // 4096 for k in (1415, 2533, 3431)],
+        sigma_a=64.0,        # nominal std of the pre-activation a = b of a massive hidden unit over tokens (measured on the
+                             # quantised 7B-width rows: ~47, i.e. a^2 passes 7168 — the fp8 hand-off's SwiGLU limit — in ~3.5 % of
+                             # the (token, unit) pairs and reaches ~10^4)
+        w_massive=0.004,     # mlp.c_proj weight from a massive hidden unit into a massive channel
+        row_shrink=0.25,     # the other entries of those mlp.c_proj rows (keeps w_massive several int4 steps wide)
+        emb_std=0.02, norm_lo=0.05, norm_hi=0.5, norm_spread=0.3,
+    )
+
+
 def make_state_dict(
     cfg: LLaMAConfig,
     *,
@@ -75,12 +100,14 @@ def make_state_dict(
     outlier_channels: int = 0,
     bf16_exact: bool = True,
     group_cols: int = 0,
+    stats: str = "unit",
 ) -> Dict[str, torch.Tensor]:
     """Synthetic checkpoint.  mode None / "llm.int8": float weights in `dtype`; "gptq.int4": packed buffers with
     scales / zeros in `dtype` (one pair per row, or per row and group of `group_cols` input columns: the
     ColBlockQuantizedLinear layout with tile_cols = group_cols, lit_llama/quantization.py:350-374).  With `bf16_exact` every float value is rounded to bf16 once at generation time
     (and stored in `dtype`), so a bf16 GPU model and the f32 CPU oracle hold identical parameters."""
-    assert mode in (None, "gptq.int4", "llm.int8")
+    assert mode in (None, "gptq.int4", "llm.int8") and stats in ("unit", "llama")
+    plan = llama_stats_plan(cfg) if stats == "llama" else None
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     C = cfg.n_embd
@@ -91,6 +118,14 @@ def make_state_dict(
     for i in range(cfg.n_layer):
         norms[f"transformer.h.{i}.rms_1.scale"] = ln()
         norms[f"transformer.h.{i}.rms_2.scale"] = ln()
+    if plan is not None:
+        # (the same draws, re-read: d = (scale - 1) / 0.1 is the N(0, 1) sample behind a norm scale)
+        wte = wte * plan["emb_std"]
+        for i in range(cfg.n_layer):
+            base = plan["norm_lo"] * (plan["norm_hi"] / plan["norm_lo"]) ** (i / max(cfg.n_layer - 1, 1))
+            for j in (1, 2):
+                k = f"transformer.h.{i}.rms_{j}.scale"
+                norms[k] = base * torch.exp(plan["norm_spread"] * (norms[k] - 1.0) / 0.1)
     if outlier_channels:
         # fixed channels x20: after RMSNorm these exceed the LLM.int8 threshold of 6
         ch = torch.arange(outlier_channels, device=device) * (C // max(outlier_channels, 1)) + 3
@@ -100,8 +135,23 @@ def make_state_dict(
     sd["transformer.wte.weight"] = rnd(wte).to(dtype)
     for k, v in norms.items():
         sd[k] = rnd(v).to(dtype)
+    fc1_rows = None
     for prefix, N, K in linear_shapes(cfg):
         w = _randn((N, K), gen, device, std=K**-0.5)
+        if plan is not None and prefix.startswith(f"transformer.h.{plan['layer']}.mlp."):
+            hu = torch.tensor(plan["hidden_units"], device=device)
+            if prefix.endswith("c_fc1"):
+                # a = row . (g x / rms) has std ~ sqrt(mean g^2) for a N(0, 1/K) row: the gain brings it to sigma_a
+                g2 = norms[f"transformer.h.{plan['layer']}.rms_2.scale"]
+                w[hu] *= plan["sigma_a"] / float(g2.square().mean().sqrt())
+                fc1_rows = w[hu].clone()
+            elif prefix.endswith("c_fc2"):
+                w[hu] = fc1_rows  # b = a: silu(a) * b = a^2 sigmoid(a)
+            else:  # mlp.c_proj: the massive units feed the massive channels and nothing else
+                ch = torch.tensor(plan["channels"], device=device)
+                w[:, hu] = 0.0
+                w[ch] *= plan["row_shrink"]
+                w[ch[:, None], hu[None, :]] = plan["w_massive"]
         if mode == "gptq.int4" and 0 < group_cols < K:
             ng = -(-K // group_cols)
             q = torch.empty((N, K), dtype=torch.uint8, device=device)

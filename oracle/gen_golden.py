@@ -62,11 +62,11 @@ def summarize(logits: torch.Tensor, vocab: int):
     )
 
 
-def model_case(name, cfg_kwargs, mode, prompt_len, new_tokens, max_seq_length=None, seed=0, nocache=True):
+def model_case(name, cfg_kwargs, mode, prompt_len, new_tokens, max_seq_length=None, seed=0, nocache=True, stats="unit"):
     torch.manual_seed(1234)
     ref_cfg = ref.LLaMAConfig(**cfg_kwargs)
     our_cfg = OurConfig(**cfg_kwargs)
-    sd = synth.make_state_dict(our_cfg, seed=seed, mode=mode)
+    sd = synth.make_state_dict(our_cfg, seed=seed, mode=mode, stats=stats)
     with ref_quantization(mode):
         model = ref.LLaMA(ref_cfg)
     model.load_state_dict(sd)
@@ -78,6 +78,8 @@ def model_case(name, cfg_kwargs, mode, prompt_len, new_tokens, max_seq_length=No
     rolled = prompt_len + new_tokens > S
     fix = dict(tokens=toks.numpy().astype(np.int32), prompt_len=np.int32(prompt_len), seed=np.int32(seed),
                max_seq_length=np.int32(S))
+    if stats != "unit":
+        fix["stats"] = np.array(stats)
     if not rolled:
         logits = ref_teacher_forced(model, toks, prompt_len, S)
         fix.update(summarize(logits, ref_cfg.padded_vocab_size))
@@ -314,6 +316,16 @@ def big_s1_case():
                nocache=False)
 
 
+def big_real_case():
+    """A full-depth 7B int4 checkpoint with the statistics of a TRAINED LLaMA as a narrow hand-off format sees them (VERDICT r4 item 1:
+    `synth.make_state_dict(stats="llama")` — embeddings of std 0.02, norm scales 0.05 .. 0.5, massive-activation channels hundreds of
+    times the rms of the residual stream, SwiGLU outputs up to ~10^4), prompt of 24, 24 greedy tokens from the UNMODIFIED reference on
+    the CPU.  `--big-real`; bf16 calibration twin: `--big-bf16 --real`."""
+    torch.set_num_threads(max(8, (torch.get_num_threads() or 8)))
+    model_case("cfg2_7b_int4_real", dict(n_layer=32, n_head=32, n_embd=4096), "gptq.int4", prompt_len=24, new_tokens=24, seed=2,
+               nocache=False, stats="llama")
+
+
 def big_p400_case():
     """The same checkpoint with a 400-token prompt and 16 greedy tokens: decode runs at positions
     400..415, i.e. past the fused step's row-split threshold (position 384) at FULL depth — where the reference's own
@@ -387,7 +399,8 @@ def big_bf16_case(name="cfg2_7b_int4"):
     fx = np.load(OUT / f"{name}.npz")
     cfg_kwargs = dict(n_layer=32, n_head=32, n_embd=4096)
     ref_cfg = ref.LLaMAConfig(**cfg_kwargs)
-    sd = synth.make_state_dict(OurConfig(**cfg_kwargs), seed=int(fx["seed"]), mode="gptq.int4")
+    sd = synth.make_state_dict(OurConfig(**cfg_kwargs), seed=int(fx["seed"]), mode="gptq.int4",
+                               stats=str(fx["stats"]) if "stats" in fx.files else "unit")
     with ref_quantization("gptq.int4"):
         model = ref.LLaMA(ref_cfg)
     model.load_state_dict(sd)
@@ -457,6 +470,10 @@ def main():
         print("generating the full-depth unquantised 7B fixture from", REF)
         big_none_case()
         return
+    if "--big-real" in sys.argv:
+        print("generating the LLaMA-statistics full-depth 7B fixture from", REF)
+        big_real_case()
+        return
     if "--big-s1" in sys.argv:
         print("generating the second-checkpoint full-depth 7B fixture from", REF)
         big_s1_case()
@@ -471,7 +488,7 @@ def main():
         return
     if "--big-bf16" in sys.argv:
         print("running the reference in bf16 on the full-depth fixture from", REF)
-        big_bf16_case("cfg2_7b_int4_s1" if "--s1" in sys.argv else "cfg2_7b_int4_p400" if "--p400" in sys.argv else
+        big_bf16_case("cfg2_7b_int4_real" if "--real" in sys.argv else "cfg2_7b_int4_s1" if "--s1" in sys.argv else "cfg2_7b_int4_p400" if "--p400" in sys.argv else
                       "cfg2_7b_int4_long" if "--long" in sys.argv else "cfg2_7b_int4")
         return
     if "--adapter-v2" in sys.argv:

@@ -76,6 +76,54 @@ def test_pack_and_get_weight_against_reference_golden(golden):
         assert torch.equal(mod.get_weight(), _t(g[f"{tag}_wdq"]))
 
 
+def test_pack_and_get_weight_with_a_partial_last_group():
+    """in_features % tile_cols != 0 (GPTQ groupsize 512 against K = 11008): the reference allocates ceil(K / tile_cols) groups and
+    slices `j * tile_cols:(j + 1) * tile_cols` (lit_llama/quantization.py:360-369, :381-384, :404-410) — spelled here as that loop.
+    Advisor r4: the vectorised pack / unpack used to split K into EQUAL groups and round-tripped self-consistently."""
+    gen = torch.Generator().manual_seed(3)
+    for N, K, bits, tc in ((6, 12, 4, 8), (16, 88, 4, 32), (8, 40, 8, 16)):
+        mod = ColBlockQuantizedLinear(K, N, False, bits=bits, tile_cols=tc)
+        G = -(-K // tc)
+        assert mod.scales.shape == (N, G) and K % tc != 0
+        w = torch.randn((N, K), generator=gen)
+        scales = 0.05 + 0.2 * torch.rand((N, G), generator=gen)
+        zeros = torch.randint(0, 2**bits, (N, G), generator=gen).float()
+        mod.scales.copy_(scales)
+        mod.zeros.copy_(zeros)
+        mod.pack_weight(w)
+        # the reference's arithmetic, slice by slice
+        lv = w.clone()
+        for j in range(G):
+            lv[:, j * tc:(j + 1) * tc] /= scales[:, j:j + 1]
+            lv[:, j * tc:(j + 1) * tc] += zeros[:, j:j + 1]
+        lv = lv.clamp_(min=0, max=2**bits - 1).to(torch.uint8)
+        epb = 8 // bits
+        packed = torch.zeros((N, K // epb), dtype=torch.uint8)
+        for nr in range(epb):
+            packed |= lv[:, nr::epb] << (nr * bits)
+        assert torch.equal(mod.quant_weight, packed), (N, K, tc)
+        wd = lv.float()
+        for j in range(G):
+            wd[:, j * tc:(j + 1) * tc] -= zeros[:, j:j + 1]
+            wd[:, j * tc:(j + 1) * tc] *= scales[:, j:j + 1]
+        assert torch.equal(mod.get_weight(), wd), (N, K, tc)
+
+
+def test_linear8bit_two_phase_load_keeps_adapter_keys():
+    """generate/adapter_v2.py:94-101 with --quantize llm.int8: the pretrained checkpoint, then an adapter-only checkpoint with
+    strict=False.  The second load has no `weight` key: adapter_scale / adapter_bias must still land (advisor r4)."""
+    lin = Linear8bitLt(32, 8, bias=False)
+    lin.adapter_scale = torch.nn.Parameter(torch.ones(8))
+    lin.adapter_bias = torch.nn.Parameter(torch.zeros(8))
+    w = torch.randn(8, 32)
+    lin.load_state_dict({"weight": w}, strict=False)
+    pending = lin._pending_fp
+    res = lin.load_state_dict({"adapter_scale": torch.full((8,), 0.5), "adapter_bias": torch.full((8,), 0.25)}, strict=False)
+    assert not res.unexpected_keys
+    assert torch.equal(lin.adapter_scale.detach(), torch.full((8,), 0.5)) and torch.equal(lin.adapter_bias.detach(), torch.full((8,), 0.25))
+    assert lin._pending_fp is pending  # the (deferred) weight of the first load is untouched
+
+
 def test_reference_state_dict_loads_and_round_trips():
     cfg = LLaMAConfig(**CFG1)
     sd = synth.make_state_dict(cfg, seed=0, mode="gptq.int4")
