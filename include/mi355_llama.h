@@ -489,7 +489,10 @@ int mi355_graph_destroy(mi355_graph* g);
  *            library: word 0 = abort code (0 = fine; a non-zero value after the launch means a hand-off timed
  *            out and the outputs are garbage), word 1 = step counter, word 2 = fp16 activation pairs that had to be
  *            clipped at +-65504 on the attention-output / SwiGLU edges since the caller last zeroed the word (non-zero:
- *            the steps computed with saturated activations, not what lit_llama/model.py computes)
+ *            the steps computed with saturated activations, not what lit_llama/model.py computes; weight_fmt 3: pairs past the
+ *            E4M3 limbs' range, +-448 x the edge's pre-scale), word 3 = 0x7FFFFFFF - the LOWEST pos[0] of a step that clipped (or
+ *            overflowed the LLM.int8 outlier list, abort code 0x7xx) since the caller last zeroed it (0: none): everything
+ *            generated from that position on has to be recomputed in a wider hand-off format (weight_fmt 3 -> 0) or by mi355_forward
  *   mode     0: logits only; 1: + greedy arg-max into next_token[0] / out_tokens[pos + 1]; 3: + chaining
  *            (tokens[0] = arg-max, pos[0] += 1), so a captured launch replays the loop of generate.py:63-91
  *   logits   f32 [vocab]

@@ -247,10 +247,16 @@ def lib() -> C.CDLL:
     return _lib
 
 
+E_ARG, E_SHAPE, E_DTYPE, E_STATE = -1, -2, -3, -4  # include/mi355_llama.h MI355_E_*
+
+
+def last_error() -> str:
+    return lib().mi355_last_error().decode(errors="replace")
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
-        msg = lib().mi355_last_error().decode(errors="replace")
-        raise NativeError(f"{what or 'libmi355llama'} failed (rc={rc}): {msg}")
+        raise NativeError(f"{what or 'libmi355llama'} failed (rc={rc}): {last_error()}")
 
 
 def require_gpu(t: torch.Tensor, what: str) -> None:

@@ -133,6 +133,8 @@ FuseCtx plan_fusion(const mi355_model* m, int T) {
     FuseCtx z;
     memset(&z, 0, sizeof(z));
     if (T < 32) return z;  // (decode steps and short chunks: the streaming kernels, nothing to plan)
+    // (read once per mi355_forward call, here, and nowhere on the launch path: the plan this returns is what every launch of the
+    // call follows; tests/test_prefill_gpu.py toggles the variable between two calls of one process)
     const char* env = getenv("MI355_GEMM_FUSE");
     if (env != nullptr && env[0] == '0') return z;
     if (m->tp_world > 1 || m->gemm_ws == nullptr || m->hs != 128 || m->cache_dtype != MI355_BF16 ||

@@ -1143,11 +1143,17 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         // power of two that brings its rms near 1 (publish_x).
         // Every clip is COUNTED in state[2] (mi355_fused_step_status / DecodeEngine.check_status report it): the step's
         // outputs then differ from the unclipped arithmetic of the reference.
+        // state[2] counts the clips, state[3] keeps 0x7FFFFFFF - (the LOWEST position whose step clipped) since the host last zeroed the
+        // words: the host re-runs the generation from that position in a wider hand-off format (DecodeEngine.recover, round 5)
+        auto note_clip = [&]() {
+            atomicAdd(p.state + 2, 1u);
+            atomicMax(p.state + 3, 0x7FFFFFFFu - (unsigned)pos);
+        };
         auto hpair = [&](float a, float b) {
             if constexpr (FMT == 1) return bfpair(a, b);  // BF16 streams: the operands of the launch-per-operator path, no range to guard
             const float k = (FMT == 0 && (pg & 1)) ? 0.0625f : 1.0f;
             const float ak = a * k, bk = b * k;
-            if (fmaxf(fabsf(ak), fabsf(bk)) > 65504.f) atomicAdd(p.state + 2, 1u);
+            if (fmaxf(fabsf(ak), fabsf(bk)) > 65504.f) note_clip();
             const f16x2 h = {(_Float16)__builtin_amdgcn_fmed3f(ak, -65504.f, 65504.f),
                              (_Float16)__builtin_amdgcn_fmed3f(bk, -65504.f, 65504.f)};
             return __builtin_bit_cast(unsigned, h);
@@ -1170,7 +1176,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             const bool up = (pg & 2) != 0;
             const float got = lane_xor16(up ? a : b);
             const float va = up ? got : a, vb = up ? b : got;
-            if (store && fmaxf(fabsf(va), fabsf(vb)) > 448.f) atomicAdd(p.state + 2, 1u);  // clipped: counted like the fp16 clips
+            if (store && fmaxf(fabsf(va), fabsf(vb)) > 448.f) note_clip();  // clipped: counted like the fp16 clips
             unsigned lo32, hi16;
             f8_limbs(va, vb, lo32, hi16);
             if (store) gr_store16(tile_dst + f8_slot(), ep, lo32, hi16);
@@ -1369,7 +1375,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         }
                     }
                     if (oc > kMaxOut) {  // (a vector with more than 1024 columns past the threshold: not what LLM.int8 is for)
-                        if (lane == 0) raise_abort(p, 0x700u + edge);
+                        if (lane == 0) {
+                            atomicMax(p.state + 3, 0x7FFFFFFFu - (unsigned)pos);  // (the position the host resumes from on mi355_forward)
+                            raise_abort(p, 0x700u + edge);
+                        }
                         oc = kMaxOut;
                     }
                     n_out8 = oc;

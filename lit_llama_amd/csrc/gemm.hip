@@ -882,8 +882,14 @@ struct GemmForce {
     int waves, bm, ksplit;
 };
 GemmForce gemm_force() {
-    GemmForce f = {0, 0, 0};
-    if (const char* e = getenv("MI355_GEMM_FORCE")) sscanf(e, "%d:%d:%d", &f.waves, &f.bm, &f.ksplit);
+    // parsed ONCE per process (advisor r4: a getenv + sscanf per launch sat on the production path, and a change of the variable
+    // between mi355_linear_gemm_plan and the launch would have desynchronised the share layout of the fused chain; the sweep starts
+    // one process per setting)
+    static const GemmForce f = [] {
+        GemmForce g = {0, 0, 0};
+        if (const char* e = getenv("MI355_GEMM_FORCE")) sscanf(e, "%d:%d:%d", &g.waves, &g.bm, &g.ksplit);
+        return g;
+    }();
     return f;
 }
 GemmShape gemm_shape(int n_tiles, int M, bool pair, int ksplit) {

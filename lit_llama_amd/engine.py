@@ -433,44 +433,77 @@ class DecodeEngine:
         a.n_layer, a.n_head, a.n_embd, a.hs = cfg.n_layer, self.local_heads, C_, C_ // cfg.n_head
         a.n_hidden, a.vocab, a.eps = H, V, self.m.eps
         self.fused = a
+        self._fused_top_fmt = int(a.weight_fmt)
         self._fused_keep = [sz, sz_head, norms, ws, gt, gt_head]
         self._fused_ws = ws
         self._fused_warm = False
-        self.fused_clipped = 0  # fp16 granules clipped by the persistent step so far (check_status)
+        self.fused_clipped = 0  # activation pairs clipped by the persistent step so far (check_status)
+        self.fused_demotions: List[tuple] = []  # (why, to what, first bad position) every time the hand-off format proved too narrow
 
     def fused_ready(self) -> bool:
         return (self.fused is not None and self.fused_enabled and self.fused.kv is not None and self.fused.S == self.S
                 and self.S > 0)
 
-    def check_status(self) -> None:
-        """Raise if a hand-off of the fused step timed out (abort word of the workspace); one device->host read, so
-        call it where the host synchronises anyway (end of generate, after a timed loop, in tests)."""
+    def _demote_fused(self, why: str, bad: Optional[int] = None) -> str:
+        """The persistent step met a checkpoint (or prompt) its hand-off format is too narrow for — E4M3 limbs clip at +-448 x the
+        edge's pre-scale, fp16 at +-65504, the LLM.int8 outlier list holds 1024 columns.  Move this engine ONE rung down the ladder
+        fp8-limb operands (weight_fmt 3) -> fp16 operands (weight_fmt 0) -> launch-per-operator step (f32 residual, bf16 staging, no
+        list limit), for good: a checkpoint that clipped once will clip again, and every clip costs a replay."""
+        if self.fused.weight_fmt == 3 and self.fused_enabled:
+            self.fused.weight_fmt = 0
+            self._fused_ws[256:].zero_()  # the granules carried 16-bit tags: include/mi355_llama.h, weight_fmt
+            to = "fp16 operands (weight_fmt 0)"
+        else:
+            self.fused_enabled = False
+            to = "the launch-per-operator step"
+        self.fused_demotions.append((why, to, bad))
+        return to
+
+    def reset_fused_format(self) -> None:
+        """Tests / measurements: back to the top rung of the ladder (what `_build_fused` chose), with a clean hand-off workspace."""
         if self.fused is None:
             return
-        words = self._fused_ws[:12].view(torch.int32).tolist()  # [0] abort code, [1] step counter, [2] clipped fp16 granules
-        code, clipped = words[0], words[2]
-        if clipped:
-            # the attention-output / SwiGLU edges travel as fp16 and saturate at +-65504 (csrc/fused_step_ring.hip hpair; as fp8 limbs,
-            # weight_fmt 3: at +-448 x 2^2 / 2^4, x edges at +-448 after their 1/rms scale): the steps since the last check computed
-            # with clipped activations, i.e. NOT what the reference computes
-            self._fused_ws[8:12].zero_()
+        top = self._fused_top_fmt
+        if int(self.fused.weight_fmt) != top:
+            self.fused.weight_fmt = top
+            self._fused_ws[256:].zero_()
+        self.fused_enabled = True
+
+    def check_status(self) -> Optional[int]:
+        """One device->host read of the persistent step's status words — call it where the host synchronises anyway (end of
+        generate, after a timed loop, in tests).
+
+        * a hand-off timed out / the step was entered with pos >= S (abort word): raises, the outputs are garbage;
+        * activations exceeded the range of the step's hand-off format, or an LLM.int8 vector had more than 1024 outlier columns,
+          since the last call: the steps from the returned position on did NOT compute what the reference computes.  The engine
+          has then already demoted itself (`_demote_fused`) and warned; the caller re-runs the generation from that position
+          (`generate()` and `forward()` do) — a caller that drives `run_step` itself and ignores the return value keeps tokens
+          that are wrong from there on, which is what the RuntimeWarning says;
+        * otherwise returns None."""
+        if self.fused is None:
+            return None
+        words = self._fused_ws[:16].view(torch.int32).tolist()  # abort code, step counter, clipped pairs, 0x7FFFFFFF - first bad position
+        code, clipped, first = words[0], words[2], words[3]
+        overflow8 = 0x700 <= code < 0x800
+        if clipped or overflow8:
+            self._fused_ws[:16].view(torch.int32)[[0, 2, 3]] = 0
             self.fused_clipped += clipped
+            bad = 0x7FFFFFFF - first if first else 0
+            was = self.fused.weight_fmt
+            why = (f"{clipped} activation pairs past the range of the hand-off format (weight_fmt {was})" if clipped else
+                   f"more than 1024 LLM.int8 outlier columns in one activation vector (abort code 0x{code:x})")
+            to = self._demote_fused(why, bad)
             import warnings
 
-            warnings.warn(f"fused decode step: {clipped} activation pairs exceeded the range of the step's hand-off format and were clipped since the "
-                          "last check; set MI355_FUSED=0 to decode such a checkpoint on the launch-per-operator path",
+            warnings.warn(f"fused decode step: {why} — clipped / invalid from position {bad} on; this engine now decodes through {to} "
+                          "and the tokens from that position on must be recomputed (generate() and LLaMA.forward do so themselves)",
                           RuntimeWarning, stacklevel=2)
+            return bad
         if code != 0:
             self._fused_ws[:4].zero_()
-            if 0x700 <= code < 0x800:
-                # LLM.int8 streams: a gathered vector had more outlier columns (|x| >= 6) than the persistent step's list holds
-                # (1024) — the launch-per-operator step has no such limit: decode the rest of this model there
-                self.fused_enabled = False
-                raise nat.NativeError(f"fused decode step aborted (code 0x{code:x}): more than 1024 LLM.int8 outlier columns in one "
-                                      "activation vector; the step's outputs are invalid — this engine now uses the "
-                                      "launch-per-operator step (re-run the generation)")
             raise nat.NativeError(f"fused decode step aborted (code 0x{code:x}): a workgroup hand-off timed out or the "
                                   "step was entered with pos >= S; the step's outputs are invalid")
+        return None
 
     # ---- bookkeeping ---------------------------------------------------------------------------------
     def weight_stream_bytes(self) -> int:
@@ -561,11 +594,17 @@ class DecodeEngine:
         logits only, True/1 greedy argmax, 3 chained greedy step (needs `embed_step()` before the first one)."""
         s = self.stream.cuda_stream
         argmax = int(argmax)
-        if allow_fused and self.fused_ready():
+        while allow_fused and self.fused_ready():
             # one persistent launch per token; launches are asynchronous, so the host runs ahead without a graph
             self.fused.mode = argmax
-            check(lib().mi355_fused_step(C.byref(self.fused), s), "mi355_fused_step")
-            return
+            rc = lib().mi355_fused_step(C.byref(self.fused), s)
+            if rc == 0:
+                return
+            if rc != nat.E_STATE:
+                check(rc, "mi355_fused_step")
+            # refused BEFORE anything was launched (the device does not admit a workgroup of this instantiation per CU — advisor r4:
+            # the fp8-operand kernel used to fail every step here instead of falling back): next rung, same step
+            self._demote_fused(f"mi355_fused_step refused weight_fmt {self.fused.weight_fmt}: {nat.last_error()}")
         if self.use_graph:
             try:
                 if argmax not in self._graphs:
@@ -634,13 +673,15 @@ class DecodeEngine:
                         ops.kv_roll(k, v)
                 self.set_step(idx.reshape(-1), 1, pos0)
                 self.run_step(False, allow_fused=not roll)  # logits land in row 0
+                # raw `model(idx, S, input_pos)` callers (the reference's generate loop) never see the status words of the
+                # persistent step otherwise: a timed-out hand-off would hand them garbage logits, silently and for good (the
+                # word is sticky) -> raise; a step whose activations left the range of its hand-off format -> the engine has
+                # moved to a wider one, compute THIS step again.  One 16-byte read; this path synchronises per token anyway.
+                while self.fused is not None and self.check_status() is not None:
+                    self.set_step(idx.reshape(-1), 1, pos0)
+                    self.run_step(False, allow_fused=not roll)
                 logits = self.logits[:1].clone()
             else:
                 logits = self.prefill(idx, pos0, all_logits=True)
         cur.wait_stream(self.stream)
-        if T == 1 and self.fused is not None:
-            # raw `model(idx, S, input_pos)` callers (the reference's generate loop) never see the abort word of the
-            # persistent step otherwise: a timed-out hand-off would hand them garbage logits, silently and for good
-            # (the word is sticky).  One 4-byte read; this path synchronises with the host per token anyway.
-            self.check_status()
         return logits.view(1, T, -1)

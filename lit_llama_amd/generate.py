@@ -73,6 +73,14 @@ def generate(
     return idx
 
 
+def _replay_from(eng, bad: int):
+    """The persistent step's activations left the range of its hand-off format at position `bad` (DecodeEngine.check_status: the
+    engine has moved to a wider format / the launch-per-operator step by now).  out_tokens[: bad + 1] and the cache rows below
+    `bad` come from unclipped steps: make out_tokens[bad] at position `bad` the step to run next.  The caller recomputes from there."""
+    eng.set_step(eng.out_tokens[bad:bad + 1], 1, bad)
+    eng.embed_step()
+
+
 def _generate_sampled(model, eng, idx, max_new_tokens, max_seq_length, temperature, top_k, eos_id):
     """generate.py:63-91 with sampling, entirely on the device: per token one decode step (logits) + one `mi355_sample`
     launch (temperature, exact top-k threshold, softmax, inverse-CDF draw from a uniform of THIS call's torch generator
@@ -95,16 +103,23 @@ def _generate_sampled(model, eng, idx, max_new_tokens, max_seq_length, temperatu
         kw = dict(out_tokens=eng.out_tokens, tokens=eng.tokens, advance=True)
         ops.sample(row, temperature, top_k, uniforms, eng.pos, eng.next_token, **kw)
         done = 1
-        while done < max_new_tokens:
-            eng.run_step(0)
-            ops.sample(row, temperature, top_k, uniforms, eng.pos, eng.next_token, **kw)
-            done += 1
-            if eos_id is not None and (done % 16 == 0 or done == max_new_tokens):
-                toks = eng.out_tokens[T:T + done].tolist()
-                if eos_id in toks:
-                    break
+        stop = False
+        while True:
+            while done < max_new_tokens and not stop:
+                eng.run_step(0)
+                ops.sample(row, temperature, top_k, uniforms, eng.pos, eng.next_token, **kw)
+                done += 1
+                if eos_id is not None and (done % 16 == 0 or done == max_new_tokens):
+                    toks = eng.out_tokens[T:T + done].tolist()
+                    stop = eos_id in toks
+            bad = eng.check_status()
+            if bad is None:
+                break
+            # a step left the range of the persistent step's hand-off format: the draws are per position, so the replay through the
+            # wider format continues the very same sample path
+            _replay_from(eng, bad)
+            done, stop = bad + 1 - T, False  # (0 when the clipped step was the prompt's last token, run as a T = 1 chunk)
         out = eng.out_tokens[:T + done].to(dtype).clone()
-        eng.check_status()
     cur.wait_stream(eng.stream)
     if eos_id is not None:
         gen = out[T:].tolist()
@@ -130,17 +145,24 @@ def _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id):
             # From here every step's last node writes the next token / position / embedding itself.
             eng.set_step(None, 1, T, from_next=True)
             eng.embed_step()
-        while done < max_new_tokens:
-            eng.run_step(3)
-            done += 1
-            if eos_id is not None and (done % 16 == 0 or done == max_new_tokens):
-                # bounded-lag EOS check: the reference tests every token (generate.py:88-89) and pays a
-                # device->host sync for it; here the sync is amortised and the tail is cut off afterwards
-                toks = eng.out_tokens[T:T + done].tolist()
-                if eos_id in toks:
-                    break
+        stop = False
+        while True:
+            while done < max_new_tokens and not stop:
+                eng.run_step(3)
+                done += 1
+                if eos_id is not None and (done % 16 == 0 or done == max_new_tokens):
+                    # bounded-lag EOS check: the reference tests every token (generate.py:88-89) and pays a
+                    # device->host sync for it; here the sync is amortised and the tail is cut off afterwards
+                    toks = eng.out_tokens[T:T + done].tolist()
+                    stop = eos_id in toks
+            # one read after the loop: a hand-off of the fused step timed out -> raise, never garbage; activations past the range of
+            # its hand-off format at some position -> the engine has moved to a wider format, recompute from that position
+            bad = eng.check_status()
+            if bad is None:
+                break
+            _replay_from(eng, bad)
+            done, stop = bad + 1 - T, False  # out_tokens[T .. bad] stand; the step at `bad` produces out_tokens[bad + 1]
         out = eng.out_tokens[:T + done].to(dtype).clone()
-        eng.check_status()  # one read after the loop: a hand-off of the fused step timed out -> raise, never garbage
     cur.wait_stream(eng.stream)
     if eos_id is not None:
         gen = out[T:].tolist()

@@ -326,6 +326,51 @@ def big_real_case():
                nocache=False, stats="llama")
 
 
+def big_real_aux():
+    """Adds `oracle_swiglu_absmax` [positions] to cfg2_7b_int4_real.npz: the largest |silu(c_fc1 x) * c_fc2 x| of the block that holds
+    the massive hidden units (synth.llama_stats_plan), per position of the fixture's token sequence, from the ORACLE's activations
+    (oracle == reference on this fixture, checked when it was written; the first blocks only — seconds).  The GPU test uses it to
+    say which decode steps must leave the range of the persistent step's fp8 hand-off (+-7168 on this edge)."""
+    import torch.nn.functional as F
+
+    name = "cfg2_7b_int4_real"
+    with np.load(OUT / f"{name}.npz") as z:
+        fx = {k: z[k] for k in z.files}
+    cfg_kwargs = dict(n_layer=32, n_head=32, n_embd=4096)
+    our = OurConfig(**cfg_kwargs)
+    plan = synth.llama_stats_plan(our)
+    L = plan["layer"] + 1
+    small = OurConfig(n_layer=L, n_head=32, n_embd=4096)
+    sd_full_seed = int(fx["seed"])
+    # the first L blocks of the fixture's checkpoint: the generator draws lm_head, then the blocks in order, so a model of L layers
+    # built from the same seed shares embedding, norms of those blocks and their linears with the 32-layer one ONLY if the norm draws
+    # agree — they do not (all norm scales are drawn before the linears), so build the full state dict and keep what is needed
+    sd = synth.make_state_dict(our, seed=sd_full_seed, mode="gptq.int4", stats=str(fx["stats"]))
+    keep = {k: v for k, v in sd.items() if not k.startswith("transformer.h.") or int(k.split(".")[2]) < L}
+    del sd
+    om = oracle.Model(oracle.Config(n_layer=L, n_head=32, n_embd=4096), keep, mode="gptq.int4")
+    toks = torch.from_numpy(fx["tokens"].astype(np.int64)).view(1, -1)
+    T = toks.shape[1]
+    rope = oracle.build_rope_cache(2048, 128)[:T]
+    mask = torch.tril(torch.ones(T, T, dtype=torch.bool))[None, None]
+    with torch.no_grad():
+        x = F.embedding(toks, keep["transformer.wte.weight"].float())
+        for i in range(L):
+            pre = f"transformer.h.{i}."
+            h, _ = om.attention(i, oracle.rmsnorm(x, keep[pre + "rms_1.scale"].float()), rope, mask, 2048, None, None)
+            x = x + h
+            xn = oracle.rmsnorm(x, keep[pre + "rms_2.scale"].float())
+            hh = F.silu(oracle.linear(keep, pre + "mlp.c_fc1", xn, "gptq.int4")) * oracle.linear(keep, pre + "mlp.c_fc2", xn, "gptq.int4")
+            if i == plan["layer"]:
+                amax = hh[0].abs().amax(-1)
+            x = x + oracle.linear(keep, pre + "mlp.c_proj", hh, "gptq.int4")
+    fx["oracle_swiglu_absmax"] = amax.numpy().astype(np.float32)
+    np.savez_compressed(OUT / f"{name}.npz", **fx)
+    Tp = int(fx["prompt_len"])
+    print("oracle_swiglu_absmax (decode positions):", np.round(fx["oracle_swiglu_absmax"][Tp:], 0).tolist())
+    print("positions past 7168:", [int(p) for p in np.nonzero(fx["oracle_swiglu_absmax"] > 7168)[0]])
+
+
 def big_p400_case():
     """The same checkpoint with a 400-token prompt and 16 greedy tokens: decode runs at positions
     400..415, i.e. past the fused step's row-split threshold (position 384) at FULL depth — where the reference's own
@@ -469,6 +514,9 @@ def main():
     if "--big-none" in sys.argv:
         print("generating the full-depth unquantised 7B fixture from", REF)
         big_none_case()
+        return
+    if "--big-real-aux" in sys.argv:
+        big_real_aux()
         return
     if "--big-real" in sys.argv:
         print("generating the LLaMA-statistics full-depth 7B fixture from", REF)

@@ -42,3 +42,22 @@ def golden():
 @pytest.fixture(scope="session")
 def dev():
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def record():
+    """Append one JSON line of measured parity numbers to gpurun_out/parity_numbers.jsonl (merged back from the GPU box; the round's
+    copy is committed under profiles/): `pytest -q` prints nothing of a passing test, and a bar only says "below"."""
+    import json
+
+    out = ROOT / "gpurun_out"
+
+    def rec(test: str, **kv):
+        try:
+            out.mkdir(exist_ok=True)
+            with open(out / "parity_numbers.jsonl", "a") as f:
+                f.write(json.dumps({"test": test, **kv}) + "\n")
+        except OSError:
+            pass
+
+    return rec

@@ -36,16 +36,43 @@ pytestmark = pytest.mark.gpu
 PROBES = (np.arange(64) * (32000 // 64) + 7) % 32000
 
 
+# absolute regression bars in logit-std on top of the calibrated one (half the reference's own bf16 distance is
+# 0.157 std on the 400-token fixture against a measured 0.025 — a 6x regression would have passed).  Measured in round 4: 0.016 / 0.017 /
+# 0.025 / (s1: first GPU run in the driver's suite, no number recorded); the launch-per-operator path 0.024 / 0.024 / 0.025.
+ABS_BAR = {"cfg2_7b_int4": 0.03, "cfg2_7b_int4_long": 0.04, "cfg2_7b_int4_p400": 0.04, "cfg2_7b_int4_s1": 0.04, "cfg2_7b_int4_real": 0.04}
+
+
 @torch.no_grad()
-def test_full_depth_7b_int4_against_the_reference_golden_run(dev, golden):
-    _int4_checkpoint_against_its_fixtures(dev, golden, (("cfg2_7b_int4", 0.03), ("cfg2_7b_int4_long", None), ("cfg2_7b_int4_p400", None)))
+def test_full_depth_7b_int4_against_the_reference_golden_run(dev, golden, record):
+    _int4_checkpoint_against_its_fixtures(dev, golden, ("cfg2_7b_int4", "cfg2_7b_int4_long", "cfg2_7b_int4_p400"), record)
 
 
-def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures):
-    g0 = golden(fixtures[0][0])
+def _teacher_forced(model, eng, toks, T, S, dev, on_step=None):
+    model.reset_cache()
+    rows = []
+    input_pos = torch.arange(0, T, device=dev)
+    pos0 = 0
+    for i in range(toks.numel() - T):
+        x = toks.index_select(0, input_pos).view(1, -1)
+        input_pos._mi355_pos0 = pos0
+        rows.append(model(x, S, input_pos)[0, -1].float().cpu())
+        if on_step is not None:
+            on_step(i, pos0 + input_pos.numel() - 1)
+        pos0 += input_pos.numel()
+        input_pos = input_pos[-1:] + 1
+    return torch.stack(rows)
+
+
+def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures, record=None):
+    """Every fixture of ONE seeded checkpoint through the three rungs of the engine's ladder: the persistent step with fp8-limb
+    operands (weight_fmt 3, the default), with fp16 operands (weight_fmt 0) and the launch-per-operator step."""
+    import warnings
+
+    g0 = golden(fixtures[0])
+    stats = str(g0["stats"]) if "stats" in g0 else "unit"
     cfg = LLaMAConfig.from_name("7B")
     torch.set_num_threads(max(torch.get_num_threads(), 16))
-    sd = synth.make_state_dict(cfg, seed=int(g0["seed"]), mode="gptq.int4")
+    sd = synth.make_state_dict(cfg, seed=int(g0["seed"]), mode="gptq.int4", stats=stats)
     with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
         model = LLaMA(cfg)
     model.load_state_dict(sd)
@@ -53,7 +80,11 @@ def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures):
     model.eval()
     eng = model.engine()
     assert eng is not None, model._engine_failed
-    for name, regression_bar in fixtures:
+    rungs = [("launch", None)]
+    if eng.fused is not None:
+        top = eng._fused_top_fmt
+        rungs = [(f"fused/fmt{top}", top)] + ([("fused/fmt0", 0)] if top != 0 else []) + rungs
+    for name in fixtures:
         g, ref_bf16 = golden(name), golden(name + "_bf16ref")
         assert int(g["seed"]) == int(g0["seed"])
         T, S = int(g["prompt_len"]), int(g["max_seq_length"])
@@ -61,39 +92,75 @@ def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures):
         std = float(g["std"].mean())
         ref_dist = float(ref_bf16["max_dist_std"])  # the reference's own bf16 run vs its f32 run, in logit std
         assert 0.02 < ref_dist < 0.5
-        tol = 0.5 * ref_dist * std
-        if regression_bar is not None:
-            tol = min(tol, regression_bar * std)
-        for fused in ([True, False] if eng.fused is not None else [False]):
-            eng.fused_enabled = fused
-            # teacher-forced on the reference's tokens
-            model.reset_cache()
-            rows = []
-            input_pos = torch.arange(0, T, device=dev)
-            pos0 = 0
-            for _ in range(toks.numel() - T):
-                x = toks.index_select(0, input_pos).view(1, -1)
-                input_pos._mi355_pos0 = pos0
-                rows.append(model(x, S, input_pos)[0, -1].float().cpu())
-                pos0 += input_pos.numel()
-                input_pos = input_pos[-1:] + 1
-            logits = torch.stack(rows)
-            eng.check_status()
-            assert getattr(eng, "fused_clipped", 0) == 0
-            err = np.abs(logits[:, PROBES].numpy() - g["probes"]).max()
-            assert err <= tol, f"{name} fused={fused}: 7B logits off by {err:.4f} (std {std:.3f}, tol {tol:.4f})"
+        tol = min(0.5 * ref_dist, ABS_BAR[name]) * std
+        def set_rung(fmt):
+            eng.reset_fused_format()
+            if fmt is None:
+                eng.fused_enabled = False
+            elif int(eng.fused.weight_fmt) != fmt:
+                eng.fused.weight_fmt = fmt
+                eng._fused_ws[256:].zero_()  # (the tag width of the granules changes with the format)
+
+        for label, fmt in rungs:
+            set_rung(fmt)
+            # teacher-forced on the reference's tokens.  A step whose activations leave the range of the hand-off format is
+            # recomputed one rung down by LLaMA.forward (engine.check_status); on the unit-statistics fixtures that must not happen,
+            # on the LLaMA-statistics one (test_zz_golden_7b_real_gpu.py) the engine is put back on the rung under test after
+            # every such step, so that every OTHER step is still measured there
+            demoted, seen = [], [len(eng.fused_demotions)]
+
+            def on_step(i, pos, fmt=fmt, demoted=demoted, seen=seen):
+                if len(eng.fused_demotions) > seen[0]:
+                    demoted.append((i, pos, eng.fused_demotions[-1][1]))
+                    set_rung(fmt)
+                seen[0] = len(eng.fused_demotions)
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                logits = _teacher_forced(model, eng, toks, T, S, dev, on_step)
+            assert eng.check_status() is None
+            if stats == "unit":
+                assert eng.fused_clipped == 0 and not demoted, (label, demoted)
+            per_step = np.abs(logits[:, PROBES].numpy() - g["probes"]).max(axis=1) / std
+            err = float(per_step.max()) * std
+            if record is not None:
+                record("full_depth_7b_int4", fixture=name, path=label, max_dist_std=round(err / std, 5),
+                       per_step_dist_std=[round(float(v), 5) for v in per_step], ref_bf16_dist_std=round(ref_dist, 5),
+                       bar_std=round(tol / std, 5), recomputed_steps=[[i, p, to] for i, p, to in demoted],
+                       clipped_pairs=int(eng.fused_clipped))
+            assert err <= tol, f"{name} {label}: 7B logits off by {err:.4f} = {err / std:.4f} std (tol {tol / std:.4f} std)"
             assert np.abs(logits.std(-1).numpy() - g["std"]).max() <= 0.02 * std
             decisive = g["margin"] > 2 * tol
             assert np.array_equal(logits.argmax(-1).numpy()[decisive], g["argmax"][decisive])
-            # free running (generate.py:63-91): equal up to the first near tie
+            if "oracle_swiglu_absmax" in g and fmt == 3:
+                # the steps that HAD to be recomputed are the ones whose SwiGLU output (position of the step's token) passes the fp8
+                # hand-off's +-7168 — known from the oracle's activations (2 % guard band around the limit)
+                a = g["oracle_swiglu_absmax"]
+                must = {i for i in range(1, logits.shape[0]) if a[T + i - 1] > 7168 * 1.02}
+                may = {i for i in range(1, logits.shape[0]) if a[T + i - 1] > 7168 * 0.98}
+                got_steps = {i for i, _, _ in demoted}
+                assert must <= got_steps <= may, (sorted(must), sorted(got_steps), sorted(may))
+                assert all(to.startswith("fp16") for _, _, to in demoted), demoted
+                assert len(must) >= 1, "the LLaMA-statistics fixture no longer exercises the fp8 hand-off's range limit"
+            # free running (generate.py:63-91) on the product's own ladder (sticky demotion, replay from the clipped position):
+            # equal up to the first near tie
+            eng.fused_demotions.clear()
+            eng.fused_clipped = 0
             model.reset_cache()
-            out = lit_llama_amd.generate(model, toks[:T], toks.numel() - T, top_k=1).cpu()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                out = lit_llama_amd.generate(model, toks[:T], toks.numel() - T, top_k=1).cpu()
+            assert eng.check_status() is None
             first_tie = next((i for i, m_ in enumerate(g["margin"]) if m_ <= 2 * tol), len(g["margin"]))
             n = T + first_tie
-            assert torch.equal(out[:n], torch.from_numpy(g["tokens"])[:n]), f"{name} fused={fused}: {out.tolist()} vs {g['tokens'].tolist()}"
-            print(f"{name} fused={fused}: max |dlogit| {err:.4f} = {err / std:.4f} std (reference bf16 vs f32: {ref_dist:.4f} std); "
-                  f"min margin {g['margin'].min():.3f}")
-    eng.fused_enabled = True
+            assert torch.equal(out[:n], torch.from_numpy(g["tokens"])[:n]), f"{name} {label}: {out.tolist()} vs {g['tokens'].tolist()}"
+            if stats == "unit":
+                assert not eng.fused_demotions
+            print(f"{name} {label}: max |dlogit| {err:.4f} = {err / std:.4f} std (reference bf16 vs f32: {ref_dist:.4f} std); "
+                  f"min margin {g['margin'].min():.3f}; recomputed steps {demoted}; generate() demotions {eng.fused_demotions}")
+            eng.fused_demotions.clear()
+            eng.fused_clipped = 0
+    eng.reset_fused_format()
 
 
 @torch.no_grad()
@@ -134,7 +201,7 @@ def test_full_depth_7b_unquantised_against_the_reference_golden_run(dev, golden)
             pos0 += input_pos.numel()
             input_pos = input_pos[-1:] + 1
         logits = torch.stack(rows)
-        eng.check_status()
+        assert eng.check_status() is None
         err = np.abs(logits[:, PROBES].numpy() - g["probes"]).max()
         assert err <= tol, f"fused={fused}: 7B bf16 logits off by {err:.4f} (std {std:.3f}, tol {tol:.4f})"
         decisive = g["margin"] > 2 * tol

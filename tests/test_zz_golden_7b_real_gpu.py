@@ -1,0 +1,26 @@
+"""A full-depth LLaMA-7B gptq.int4 checkpoint with the statistics of a TRAINED model against the reference itself (round 5; VERDICT r4
+item 1): `synth.make_state_dict(stats="llama")` — embeddings of std 0.02 (every value of a step's first hand-off sits below the 2^-6 from
+which E4M3 limbs are exact to 12 bits), RMSNorm scales 0.05 .. 0.5, three residual channels hundreds of times the rms of the stream
+from block 1 on, SwiGLU outputs of ~10^3 .. 10^4 in that block — i.e. past the +-7168 the fp8-limb hand-off of the persistent step
+holds on some decode steps.  tests/golden/cfg2_7b_int4_real.npz holds what the UNMODIFIED /root/reference produced on the CPU (prompt of
+24, 24 greedy tokens, teacher-forced logits; `oracle/gen_golden.py --big-real`, oracle == reference with max |dlogit| = 0), `_bf16ref`
+the reference's own bf16 run on the same tokens, `oracle_swiglu_absmax` the largest |SwiGLU output| of block 1 per position (oracle
+activations, `--big-real-aux`).
+
+Through all three rungs of the engine's ladder (persistent step with fp8-limb operands = the default, with fp16 operands, launch-per-
+operator step), same bars as the other full-depth fixtures (half the reference's own bf16 distance, at most 0.04 logit-std): the steps
+whose SwiGLU output passes the limit are exactly the ones the engine recomputes with fp16 operands, no clipped step's logits or
+tokens reach the caller, and generate() — sticky demotion, replay from the clipped position — follows the reference's tokens.
+The file sorts last: rebuilding a 3.6 GB checkpoint from its seed takes host minutes.
+"""
+import pytest
+import torch
+
+from test_golden_7b_gpu import _int4_checkpoint_against_its_fixtures
+
+pytestmark = pytest.mark.gpu
+
+
+@torch.no_grad()
+def test_full_depth_7b_int4_llama_statistics_against_the_reference_golden_run(dev, golden, record):
+    _int4_checkpoint_against_its_fixtures(dev, golden, ("cfg2_7b_int4_real",), record)

@@ -17,5 +17,5 @@ pytestmark = pytest.mark.gpu
 
 
 @torch.no_grad()
-def test_full_depth_7b_int4_second_checkpoint_against_the_reference_golden_run(dev, golden):
-    _int4_checkpoint_against_its_fixtures(dev, golden, (("cfg2_7b_int4_s1", None),))
+def test_full_depth_7b_int4_second_checkpoint_against_the_reference_golden_run(dev, golden, record):
+    _int4_checkpoint_against_its_fixtures(dev, golden, ("cfg2_7b_int4_s1",), record)
