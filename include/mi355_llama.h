@@ -538,7 +538,7 @@ typedef struct mi355_fused_step_args {
      * at most 1024 outlier columns per gathered vector (more raise the abort word: such a step belongs on mi355_forward).
      * 3 (round 4; what lit_llama_amd's engine selects for per-row int4 models unless MI355_FUSED_F8=0): the streams, scales and zeros
      * of 0, computed through fp8 operands: one v_mfma_scale_f32_16x16x128_f8f6f4 per 1-KiB piece (an int4 level in a byte is the E4M3
-     * code of q * 2^-9), the hand-offs carry three E4M3 limbs per activation under 16-bit tags; per-row scales only, n_hidden <= 12160.
+     * code of q * 2^-9), the hand-offs carry three E4M3 limbs per activation under 16-bit tags; per-row scales only, n_hidden <= 11776.
      * A workspace that has carried hand-offs of another weight_fmt must be zeroed (all but its first 256 bytes) before the first step.
      * Register-ring implementation only. */
     int32_t weight_fmt;

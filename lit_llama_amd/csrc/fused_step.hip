@@ -29,7 +29,7 @@ constexpr int kMaxS = 32768;      // cache rows
 // ------------------------------------------------------------------------------------------------ host side
 extern "C" size_t mi355_fused_step_workspace_bytes(int n_hidden) {
     if (n_hidden <= 0) return 0;
-    return kFsWsGh + (size_t)2 * (n_hidden / 2) * 8;
+    return kFsWsGh + (size_t)2 * (kFsGhSums + n_hidden / 2) * 8;
 }
 
 extern "C" int mi355_fused_step_supported(int n_embd, int n_head, int hs, int n_hidden, int vocab, int S) {
@@ -54,7 +54,8 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     MI355_CHECK_ARG(fmt >= 0 && fmt <= 3, MI355_E_ARG,
                     "fused_step: weight_fmt %d (0 = int4 streams, 1 = BF16, 2 = LLM.int8, 3 = int4 streams through fp8 operands)", fmt);
     // fp8-limb operands keep three byte planes of the activation vector in LDS: 95 units of 128 columns
-    MI355_CHECK_ARG(fmt != 3 || a->n_hidden / 128 <= 95, MI355_E_SHAPE, "fused_step: weight_fmt 3 needs n_hidden <= %d (got %d)", 95 * 128,
+    // (and its gatherers sweep the hidden edge — n_hidden / 4 loads of two granules + 128 of operand-sum partials — in at most 24 loads per lane)
+    MI355_CHECK_ARG(fmt != 3 || a->n_hidden / 128 <= 92, MI355_E_SHAPE, "fused_step: weight_fmt 3 needs n_hidden <= %d (got %d)", 92 * 128,
                     a->n_hidden);
     MI355_CHECK_ARG(!(grouped && fmt != 0), MI355_E_ARG, "fused_step: grouped scales exist for int4 streams only");
     MI355_CHECK_ARG(a->w && a->w_head && (grouped || fmt == 1 || (a->sz && a->sz_head)) && a->norms && a->wte && a->rope && a->kv && a->tokens &&

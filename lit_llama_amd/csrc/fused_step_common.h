@@ -21,9 +21,10 @@ struct FusedParams {
     int32_t* next_token;
     int32_t* out_tokens;
     float* logits;
-    u64* gx;                 // [2][2048 + 256]   x-type edges (bf16 pairs + partial sums of squares)
-    u64* ga;                 // [2][2048]         attention output
-    u64* gh;                 // [2][H / 2]        MLP hidden
+    u64* gx;                 // [2][kFsGxStride]  x-type edges: 2048 pair granules, then per workgroup the partial sum of squares (weight_fmt
+                             //                   3: {sum of squares, operand sum} as two adjacent granules)
+    u64* ga;                 // [2][kFsGaStride]  attention output: 256 operand-sum partials (weight_fmt 3), then 2048 pair granules
+    u64* gh;                 // [2][256 + H / 2]  MLP hidden: 256 operand-sum partials (weight_fmt 3), then H / 2 pair granules
     u64* gq;                 // [2][n_head][8][32] q / new k / new v of a head
     u64* gm;                 // [512]             arg-max candidates
     u64* gp;                 // [2][n_head][8][136] row-split attention: a workgroup's (128 weighted values, max, sum)
@@ -47,8 +48,11 @@ struct FusedParams {
 };
 
 
+// granules per parity of the x / attention-output edges and in front of the hidden edge's pairs (round 5: with fp8-limb operands every
+// PUBLISHER also sends the sum of the operand values it publishes, so that no consumer has to take it: see fused_step_ring.hip)
+constexpr int kFsGxStride = 2048 + 512, kFsGaSums = 256, kFsGaStride = kFsGaSums + 2048, kFsGhSums = 256;
 // workspace map (bytes), see mi355_fused_step_workspace_bytes
-constexpr size_t kFsWsState = 0, kFsWsGx = 256, kFsWsGa = kFsWsGx + 2 * 2304 * 8, kFsWsGq = kFsWsGa + 2 * 2048 * 8,
+constexpr size_t kFsWsState = 0, kFsWsGx = 256, kFsWsGa = kFsWsGx + 2 * kFsGxStride * 8, kFsWsGq = kFsWsGa + 2 * kFsGaStride * 8,
                  kFsWsGm = kFsWsGq + 2 * 32 * 256 * 8, kFsWsGp = kFsWsGm + 512 * 8,
                  kFsWsGh = kFsWsGp + 2 * 32 * 8 * 136 * 8;
 

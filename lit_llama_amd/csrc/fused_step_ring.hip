@@ -127,6 +127,23 @@ static_assert(kF8P1 + kF8Units * 128 <= kOffPart && (kF8P1 - kF8P0) % 256 == 64 
 #ifndef MI355_F8_XSCALE0
 #define MI355_F8_XSCALE0 0  // scale of a step's FIRST x edge from the token's embedding row (see the gatherers' entry)
 #endif
+// fp8-limb operands (FMT 3), round 5: the zero-point term of y = scale (acc - zero S) needs S = the sum of the operand values that were
+// multiplied.  Round 4 took it in every streamer wave — one more MFMA with an all-ones A operand per step of a phase's first tile (mlp.c_proj:
+// 11 on top of its 11), a DPP sum, an LDS word per wave, eight LDS reads in the gatherer's epilogue: all of it on the consumers' chain.  1: every
+// PUBLISHER adds up the decoded limbs of the 16 values it publishes (it holds them in registers anyway) and sends the partial sum along — per
+// workgroup one more granule next to the sum of squares (x edges), one in front of the pair granules (attention output, MLP hidden) — and the
+// gatherer that sweeps the edge adds the 256 partials: S is known BEFORE the phase starts, and the streamers issue weights x activations only.
+#ifndef MI355_F8_PUBSUM
+#define MI355_F8_PUBSUM 1
+#endif
+// 1: a streamer wave parks its raw partial tiles (limb columns 0 / 1 / 2 side by side) and gatherer 0's read adds the three columns; 0:
+// the streamers add them up at the tile end (two DPP adds per register: round 4)
+#ifndef MI355_F8_COLSUM_G
+#define MI355_F8_COLSUM_G 0
+#endif
+#ifndef MI355_FUSED_G0_PAIRS_F8
+#define MI355_FUSED_G0_PAIRS_F8 5  // gatherer 0's share of an x edge's 16 pair loads per lane with MI355_F8_PUBSUM (it also has 4 loads of sums)
+#endif
 [[maybe_unused]] constexpr int kMaxS = 32768;     // cache rows (the attention keeps no per-row state in LDS)
 #ifndef MI355_FUSED_LDS_PAD
 #define MI355_FUSED_LDS_PAD 0  // (A / B knob: bytes of LDS requested on top of the map)
@@ -151,7 +168,8 @@ __device__ __forceinline__ void gr_store16(u64* p, unsigned tag, unsigned lo32, 
 // x -> three OCP E4M3 limbs, x ~ l0 + l1 / 16 + l2 / 256 (residual splitting: every difference below is exact in f32, the conversions
 // round to nearest even; past +-448 v_cvt_pk_fp8_f32 returns NaN, hence the clamps).  12 significant bits for 2^-6 <= |x| <= 448, an
 // absolute error of ~2^-19 below (scripts/micro/mx_fp8.hip checks the instruction semantics and prints the error per binade).
-__device__ __forceinline__ void f8_limbs(float a, float b, unsigned& lo32, unsigned& hi16) {
+// dsum: a~ + b~, the sum of the two values the limbs DECODE to (what the consumers' MFMAs multiply by)
+__device__ __forceinline__ void f8_limbs(float a, float b, unsigned& lo32, unsigned& hi16, float& dsum) {
     const int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.f, 448.f), __builtin_amdgcn_fmed3f(b, -448.f, 448.f), 0, false);
     const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false);
     float ra = a - f0[0], rb = b - f0[1];
@@ -164,6 +182,8 @@ __device__ __forceinline__ void f8_limbs(float a, float b, unsigned& lo32, unsig
                                                    __builtin_amdgcn_fmed3f(rb * 256.f, -448.f, 448.f), 0, false);
     lo32 = ((unsigned)w0 & 0xFFFFu) | ((unsigned)w1 << 16);
     hi16 = (unsigned)w2 & 0xFFFFu;
+    const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8(w2, false);
+    dsum = (f0[0] + f0[1]) + ((f1[0] + f1[1]) * 0.0625f + (f2[0] + f2[1]) * 0.00390625f);
 }
 __device__ __forceinline__ bool aborted(const FusedParams& p) {
     return __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
@@ -739,8 +759,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
         f32x4 acc__[R__][2];                                                                                          \
         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f}; \
-        f32x4 accs__ = f32x4{0.f, 0.f, 0.f, 0.f}; /* all-ones rows: the operand sums of this wave's units, per limb column */ \
-        i32x8 ones__;                                                                                                 \
+        [[maybe_unused]] f32x4 accs__ = f32x4{0.f, 0.f, 0.f, 0.f}; /* all-ones rows: the operand sums of this wave's units, per limb column */ \
+        [[maybe_unused]] i32x8 ones__;                                                                                \
         _Pragma("unroll") for (int e__ = 0; e__ < 8; ++e__) ones__[e__] = 0x38383838; /* E4M3 1.0 */                  \
         const int sb__ = 127 + (E8_) - f8_dsb; /* E8M0 block scale of this lane's 32 operand bytes */                 \
         __syncthreads(); /* B1: the limb planes are staged */                                                        \
@@ -770,7 +790,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                             acc__[r__][s__ & 1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                   \
                                 a__, b__, acc__[r__][s__ & 1], 0, 0, 0, 136, 0, sb__);                                \
                         }                                                                                             \
-                        if (ti__ == 0)                                                                                \
+                        if (!MI355_F8_PUBSUM && ti__ == 0)                                                            \
                             accs__ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones__, b__, accs__, 0, 0, 0, 127, 0, sb__); \
                     }                                                                                                 \
                     _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                           \
@@ -781,7 +801,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     }                                                                                                 \
                     if ((t__ * STEPS__ + s__ + 1) % SPT__ == 0) {                                                     \
                         if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
-                        if (ti__ == 0) {                                                                              \
+                        if (!MI355_F8_PUBSUM && ti__ == 0) {                                                          \
                             /* S of this wave's units: limb columns 0 + 1 + 2 of any row (quad broadcasts of lanes 1 / 2) */ \
                             float ssum__ = accs__[0];                                                                 \
                             ssum__ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, accs__[0]), 0x55, 0xF, 0xF, false)) + \
@@ -792,7 +812,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         const bool col0__ = MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u;                       \
                         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
                             f32x4 t4__ = acc__[r__][0] + acc__[r__][1];                                               \
-                            _Pragma("unroll") for (int e__ = 0; e__ < 4; ++e__) {                                     \
+                            _Pragma("unroll") for (int e__ = 0; e__ < (MI355_F8_COLSUM_G && MI355_FUSED_PART_FULL ? 0 : 4); ++e__) { \
                                 const float c0__ = t4__[e__];                                                         \
                                 t4__[e__] = c0__ +                                                                    \
                                     (__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c0__), 0x55, 0xF, 0xF, false)) + \
@@ -1103,9 +1123,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         unsigned edge = 0;   // edges published so far in this step (the epoch of the next one is ebase + edge)
         int xpar = 0, apar = 0, hpar = 0, qpar = 0, ppar = 0;
         int buf = 0;
-        const __amdgpu_buffer_rsrc_t rs_gx = __builtin_amdgcn_make_buffer_rsrc((void*)p.gx, 0, 2 * 2304 * 8, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_ga = __builtin_amdgcn_make_buffer_rsrc((void*)p.ga, 0, 2 * 2048 * 8, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_gh = __builtin_amdgcn_make_buffer_rsrc((void*)p.gh, 0, 2 * (p.H / 2) * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_gx = __builtin_amdgcn_make_buffer_rsrc((void*)p.gx, 0, 2 * kFsGxStride * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_ga = __builtin_amdgcn_make_buffer_rsrc((void*)p.ga, 0, 2 * kFsGaStride * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_gh = __builtin_amdgcn_make_buffer_rsrc((void*)p.gh, 0, 2 * (kFsGhSums + p.H / 2) * 8, 0x00020000);
+        constexpr bool PUBSUM = FMT == 3 && MI355_F8_PUBSUM;  // the publishers send the operand sums (see MI355_F8_PUBSUM)
+        const int gh_stride = kFsGhSums + p.H / 2;           // granules per parity of the hidden edge
+        [[maybe_unused]] float s_edge = 0.f;                  // PUBSUM: operand sum of the edge gathered last (gatherer 0)
         const __amdgpu_buffer_rsrc_t rs_gq =
             __builtin_amdgcn_make_buffer_rsrc((void*)p.gq, 0, 2 * kHeads * 256 * 8, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_gm = __builtin_amdgcn_make_buffer_rsrc((void*)p.gm, 0, 512 * 8, 0x00020000);
@@ -1123,6 +1146,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         int psrc = (pg >> 1) * (MI355_FUSED_PART_FULL ? 64 : 4) + ((2 * pg) & 3);
         auto tile_pair = [&](int r) {
             float2 t = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc);
+            if constexpr (FMT == 3 && MI355_F8_COLSUM_G && MI355_FUSED_PART_FULL) {
+                // limb columns 1 / 2 of the same rows sit 4 / 8 floats on (lane 16 g + n holds D[4 g .. 4 g + 3][n])
+                const float2 t1 = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc + 4);
+                const float2 t2 = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc + 8);
+                t.x += t1.x + t2.x;
+                t.y += t1.y + t2.y;
+            }
             t.x = group_sum(t.x, 8);
             t.y = group_sum(t.y, 8);
             return t;
@@ -1169,7 +1199,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         // one (rows j, j + 1 with j = 0 or 2) publishes (j, j + 4), the upper one (rows j + 4, j + 5) publishes (j + 1, j + 5).  Granule
         // index inside the tile's 8: 4 (octet) + j.  `e8`: the edge's pre-scale exponent.  Every lane of the wave must call it.
         [[maybe_unused]] auto f8_slot = [&]() { return 4 * (pg >> 2) + 2 * (pg & 1) + ((pg >> 1) & 1); };
-        [[maybe_unused]] auto f8_publish = [&](u64* tile_dst, unsigned ep, float a, float b, int e8, bool store) {
+        // Returns a~ + b~ of the granule this lane built, in the CONSUMER's units (pre-scale undone): the same number in the 8 lanes of
+        // a pair; `pair8_sum` of it is the sum of the 16 values of the tile as the consumers' MFMAs will see them.
+        [[maybe_unused]] auto f8_publish = [&](u64* tile_dst, unsigned ep, float a, float b, int e8, bool store) -> float {
             const float pre = __uint_as_float((unsigned)(127 - e8) << 23);
             a *= pre;
             b *= pre;
@@ -1178,8 +1210,17 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             const float va = up ? got : a, vb = up ? b : got;
             if (store && fmaxf(fabsf(va), fabsf(vb)) > 448.f) note_clip();  // clipped: counted like the fp16 clips
             unsigned lo32, hi16;
-            f8_limbs(va, vb, lo32, hi16);
+            float dsum;
+            f8_limbs(va, vb, lo32, hi16, dsum);
             if (store) gr_store16(tile_dst + f8_slot(), ep, lo32, hi16);
+            return dsum * __uint_as_float((unsigned)(127 + e8) << 23);
+        };
+        // sum over the 8 pairs of a wave of a value that is the same in the 8 lanes of a pair (two pairs per 16-lane row)
+        [[maybe_unused]] auto pair8_sum = [&](float v) {
+            v = MI355_DPP_ADD(v, 0x140);
+            v += lane_xor16(v);
+            v += lane_xor32(v);
+            return v;
         };
         // FMT 3: stage one 16-B sweep load (two granules) = dword `i` of each limb plane
         [[maybe_unused]] auto f8_stage = [&](const u32x4& v, int i) {
@@ -1210,6 +1251,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }
         };
         auto get_sums = [&]() {
+            if constexpr (PUBSUM) return float2{0.f, s_edge};  // gathered with the edge: y = scale (acc - zero S)
             if constexpr (FMT == 3) {
                 // the streamer waves' operand sums (all-ones MFMAs of the phase's first tile: valid behind its Bt); the A block scale
                 // made the products q x~ themselves, so there is no offset term: y = scale (acc - zero S)
@@ -1234,10 +1276,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         float rinv_seen = 1.f;     // 1/rms of the x edge gathered last
         auto publish_x = [&](float2 xv, float2 gsc) {
             const unsigned ep = ebase + edge;
-            u64* dst = p.gx + (size_t)xpar * 2304;
+            u64* dst = p.gx + (size_t)xpar * kFsGxStride;
             x_scale = __uint_as_float((__float_as_uint(rinv_seen) + 0x00400000u) & 0x7F800000u);
+            [[maybe_unused]] float sxp = 0.f;
             if constexpr (FMT == 3) {
-                f8_publish(dst + bid * 8, ep, x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y, MI355_F8_EX, w8 == 0);
+                sxp = f8_publish(dst + bid * 8, ep, x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y, MI355_F8_EX, w8 == 0);
             } else {
                 if (w8 == 0) gr_store(dst + bid * 8 + pg, ep, hpair(x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y));
             }
@@ -1245,7 +1288,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             ss = MI355_DPP_ADD(ss, 0x140);
             ss += lane_xor16(ss);
             ss += lane_xor32(ss);
-            if (lane == 0) gr_store(dst + 2048 + bid, ep, __float_as_uint(ss));
+            if constexpr (PUBSUM) {
+                // {sum of squares, operand sum} of this workgroup's rows: two adjacent granules, one store instruction (lanes 0 / 1)
+                sxp = pair8_sum(sxp);
+                if (lane < 2) gr_store(dst + 2048 + 2 * bid + lane, ep, __float_as_uint(lane ? sxp : ss));
+            } else {
+                if (lane == 0) gr_store(dst + 2048 + bid, ep, __float_as_uint(ss));
+            }
         };
         // gather an x-type edge into xs (fp16), 1/rms into misc[0], the operand sums into misc[4 .. 7]
         // profiling aid (-DMI355_FUSED_COUNT_SWEEPS, scripts/fused_timeline.py): sweep iterations of gatherer 0 per hand-off.
@@ -1267,26 +1316,27 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         };
         auto gather_x = [&]() {
             const unsigned ep = ebase + edge;
-            const unsigned base = (unsigned)xpar * 2304u * 8u;
+            const unsigned base = (unsigned)xpar * (unsigned)kFsGxStride * 8u;
             // the 1024 16-B loads of the pair region are split kG0 : 16 - kG0 between the two gatherer waves, the 128 loads of
             // the sums of squares go to gatherer 0, which also has the serial tail (sums, 1/rms).  Measured (same box,
             // alternating runs): 6 : 10 -> 918 us per step, 7 : 9 (equal load counts) -> 935 us.
-            constexpr int kG0 = MI355_FUSED_G0_PAIRS;
+            constexpr int kG0 = PUBSUM ? MI355_FUSED_G0_PAIRS_F8 : MI355_FUSED_G0_PAIRS;
+            constexpr int kNS = PUBSUM ? 4 : 2;  // loads of the per-workgroup sums (PUBSUM: two granules per workgroup)
             if (gw == 0) {
-                u32x4 v[kG0 + 2];
+                u32x4 v[kG0 + kNS];
                 for (unsigned spins = 0;; ++spins) {
 #ifdef MI355_FUSED_COUNT_SWEEPS
                     n_sweeps = spins + 1;
 #endif
                     bool ok = true;
 #pragma unroll
-                    for (int k = 0; k < kG0 + 2; ++k) {
+                    for (int k = 0; k < kG0 + kNS; ++k) {
                         const unsigned off = k < kG0 ? base + (unsigned)(k * 64 + lane_v) * 16u
                                                      : base + 2048u * 8u + (unsigned)((k - kG0) * 64 + lane_v) * 16u;
                         v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gx, off, 0, 16));
                     }
 #pragma unroll
-                    for (int k = 0; k < kG0 + 2; ++k) {
+                    for (int k = 0; k < kG0 + kNS; ++k) {
                         if (FMT == 3 && k < kG0) ok &= (v[k][1] >> 16) == (ep & 0xFFFFu) && (v[k][3] >> 16) == (ep & 0xFFFFu);
                         else ok &= v[k][1] == ep && v[k][3] == ep;
                     }
@@ -1307,8 +1357,16 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         pair_sums(sx, v[k][0], v[k][2]);
                     }
                 }
-                float ss = ((__uint_as_float(v[kG0][0]) + __uint_as_float(v[kG0][2])) + __uint_as_float(v[kG0 + 1][0])) +
-                           __uint_as_float(v[kG0 + 1][2]);
+                float ss;
+                if constexpr (PUBSUM) {
+                    ss = (__uint_as_float(v[kG0][0]) + __uint_as_float(v[kG0 + 1][0])) + (__uint_as_float(v[kG0 + 2][0]) + __uint_as_float(v[kG0 + 3][0]));
+                    const float sx4 = (__uint_as_float(v[kG0][2]) + __uint_as_float(v[kG0 + 1][2])) +
+                                      (__uint_as_float(v[kG0 + 2][2]) + __uint_as_float(v[kG0 + 3][2]));
+                    s_edge = group_sum(sx4, 64);
+                } else {
+                    ss = ((__uint_as_float(v[kG0][0]) + __uint_as_float(v[kG0][2])) + __uint_as_float(v[kG0 + 1][0])) +
+                         __uint_as_float(v[kG0 + 1][2]);
+                }
                 ss = group_sum(ss, 64);
                 put_sums(sx);
                 if (lane == 0) {
@@ -1483,6 +1541,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }
             gather_x();
             FS_GSTAMP(2);
+            // (slot 46: the same event of the NEXT layer — a stamped layer's edges then add up to its period in every workgroup,
+            // scripts/fused_timeline.py budget(); VERDICT r4 weak 2: the round-4 table compared medians against the minimum of one event)
+            if (p.dbg != nullptr && l == p.dbg_layer + 1 && gw == 0 && lane == 0) p.dbg[bid * 64 + 46] = wall_clock64();
             FS_GCOUNT(40);
             __syncthreads();  // B1
             post_b1();
@@ -1580,11 +1641,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     o.y = group_sum(o.y * wsc, 8);
                     const float inv = 1.0f / group_sum(misc[24 + w8] * wsc, 8);
                     // attention output elements head * 128 + hj * 16 + 2 pg, + 1 -> one pair granule
+                    u64* ga_t = p.ga + (size_t)apar * kFsGaStride + kFsGaSums + head * 64 + hj * 8;  // this workgroup's 8 pair granules
                     if constexpr (FMT == 3) {
-                        f8_publish(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8, ebase + edge, o.x * inv, o.y * inv, MI355_F8_EA, w8 == 0);
+                        const float sa = f8_publish(ga_t, ebase + edge, o.x * inv, o.y * inv, MI355_F8_EA, w8 == 0);
+                        if constexpr (PUBSUM) {
+                            const float st = pair8_sum(sa);
+                            if (lane == 0) gr_store16(p.ga + (size_t)apar * kFsGaStride + bid, ebase + edge, __float_as_uint(st), 0u);
+                        }
                     } else {
-                        if (w8 == 0)
-                            gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair_b(o.x * inv, o.y * inv));
+                        if (w8 == 0) gr_store(ga_t + pg, ebase + edge, hpair_b(o.x * inv, o.y * inv));
                     }
                 }
                 if (split) {
@@ -1640,11 +1705,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         const float ox = group_sum(__uint_as_float(v1[0]) * wsc, 8);
                         const float oy = group_sum(__uint_as_float(v1[2]) * wsc, 8);
                         const float inv = 1.0f / group_sum(lj * wsc, 8);
+                        u64* ga_t = p.ga + (size_t)apar * kFsGaStride + kFsGaSums + head * 64 + hj * 8;
                         if constexpr (FMT == 3) {
-                            f8_publish(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8, ebase + edge, ox * inv, oy * inv, MI355_F8_EA, w8 == 0);
+                            const float sa = f8_publish(ga_t, ebase + edge, ox * inv, oy * inv, MI355_F8_EA, w8 == 0);
+                            if constexpr (PUBSUM) {
+                                const float st = pair8_sum(sa);
+                                if (lane == 0) gr_store16(p.ga + (size_t)apar * kFsGaStride + bid, ebase + edge, __float_as_uint(st), 0u);
+                            }
                         } else {
-                            if (w8 == 0)
-                                gr_store(p.ga + (size_t)apar * 2048 + head * 64 + hj * 8 + pg, ebase + edge, hpair_b(ox * inv, oy * inv));
+                            if (w8 == 0) gr_store(ga_t + pg, ebase + edge, hpair_b(ox * inv, oy * inv));
                         }
                     }
                     ppar ^= 1;
@@ -1668,18 +1737,33 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if constexpr (FMT == 2) {
                     if (gw == 1) zero_obits();
                 }
-                u32x4 v[8];
-                sweep<8, FMT == 3>(p, rs_ga, (unsigned)apar * 2048u * 8u, gw * 512, gw * 512 + 512, FMT == 3 ? (ep & 0xFFFFu) : ep, v,
-                                   0x400u + edge, lane_v, &n_sweeps);
-                FS_GCOUNT(42);
                 float2 sxp = {0.f, 0.f};
+                if constexpr (PUBSUM) {
+                    // 128 loads of operand-sum partials (two workgroups each) in front of the 1024 pair loads: 9 loads per lane and gatherer
+                    u32x4 v[9];
+                    sweep<9, true>(p, rs_ga, (unsigned)apar * (unsigned)kFsGaStride * 8u, gw * 576, gw * 576 + 576, ep & 0xFFFFu, v,
+                                   0x400u + edge, lane_v, &n_sweeps);
+                    FS_GCOUNT(42);
+                    float sa = 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if constexpr (FMT == 3) {
-                        f8_stage(v[k], gw * 512 + k * 64 + lane_v);
-                    } else {
-                        *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
-                        pair_sums(sxp, v[k][0], v[k][2]);
+                    for (int k = 0; k < 9; ++k) {
+                        if (gw == 0 && k < 2) sa += __uint_as_float(v[k][0]) + __uint_as_float(v[k][2]);
+                        else f8_stage(v[k], gw * 576 + k * 64 + lane_v - 128);
+                    }
+                    if (gw == 0) s_edge = group_sum(sa, 64);
+                } else {
+                    u32x4 v[8];
+                    sweep<8, FMT == 3>(p, rs_ga, (unsigned)(apar * kFsGaStride + kFsGaSums) * 8u, gw * 512, gw * 512 + 512,
+                                       FMT == 3 ? (ep & 0xFFFFu) : ep, v, 0x400u + edge, lane_v, &n_sweeps);
+                    FS_GCOUNT(42);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if constexpr (FMT == 3) {
+                            f8_stage(v[k], gw * 512 + k * 64 + lane_v);
+                        } else {
+                            *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
+                            pair_sums(sxp, v[k][0], v[k][2]);
+                        }
                     }
                 }
                 put_sums(sxp);
@@ -1740,7 +1824,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     }
                 }
                 const unsigned ep = ebase + edge;
-                u64* dst = p.gh + (size_t)hpar * (p.H / 2);
+                u64* dst = p.gh + (size_t)hpar * gh_stride + kFsGhSums;  // the pair granules of this parity
+                [[maybe_unused]] float hsum = 0.f;
                 rinv_seen = misc[0];
                 const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;
                 float2 sx = {0.f, 0.f};
@@ -1762,8 +1847,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                             b = deq(tile_pair(1), fs2[t], fz2[t], sx);
                         }
                         if constexpr (FMT == 3) {
-                            f8_publish(dst + (bid + t * kG) * 8, ep, swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv),
-                                       MI355_F8_EH, w8 == 0);
+                            hsum += f8_publish(dst + (bid + t * kG) * 8, ep, swiglu_f32(a.x * rinv, b.x * rinv),
+                                               swiglu_f32(a.y * rinv, b.y * rinv), MI355_F8_EH, w8 == 0);
                         } else {
                             if (w8 == 0)
                                 gr_store(dst + (bid + t * kG) * 8 + pg, ep,
@@ -1771,6 +1856,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         }
                     }
                     buf ^= 1;
+                }
+                if constexpr (PUBSUM) {
+                    if (gw == 0) {  // the operand sum of this workgroup's 2 or 3 tiles, behind its last tile
+                        const float st = pair8_sum(hsum);
+                        if (lane == 0) gr_store16(p.gh + (size_t)hpar * gh_stride + bid, ep, __float_as_uint(st), 0u);
+                    }
                 }
                 FS_GSTAMP(10);
                 __syncthreads();  // B3
@@ -1793,14 +1884,27 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if (gw == 1) zero_obits();
                 }
                 [[maybe_unused]] const unsigned eph = FMT == 3 ? (ep & 0xFFFFu) : ep;
-                const int n_loads = p.H / 4, half_l = (n_loads + 1) / 2;
+                // 16-B loads of the edge: PUBSUM puts 128 loads of operand-sum partials (two workgroups each) in front of the H / 4 pair loads
+                constexpr int kHS = PUBSUM ? kFsGhSums / 2 : 0;
+                const int n_loads = p.H / 4 + kHS, half_l = (n_loads + 1) / 2;
                 const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
                 float2 sxp = {0.f, 0.f};
+                [[maybe_unused]] float hs = 0.f;
+                // stage load i of the edge (i < kHS: two partial sums; else pair load i - kHS)
+                auto stage_h = [&](const u32x4& v, int i) {
+                    if constexpr (FMT == 3) {
+                        if (PUBSUM && i < kHS) hs += __uint_as_float(v[0]) + __uint_as_float(v[2]);
+                        else f8_stage(v, i - kHS);
+                    } else {
+                        *(u64*)(xs + (size_t)i * 8) = ((u64)v[2] << 32) | v[0];
+                        pair_sums(sxp, v[0], v[2]);
+                    }
+                };
                 {
                     // up to three chunks of 8 loads per lane (H <= 12288), TWO in flight: only the first one waits for
                     // producers; issued one after the other each later chunk cost its own memory round trip on the
                     // longest hand-off of the layer (44 KB of granules)
-                    const unsigned hbase = (unsigned)hpar * (unsigned)(p.H / 2) * 8u;
+                    const unsigned hbase = ((unsigned)hpar * (unsigned)gh_stride + (unsigned)(PUBSUM ? 0 : kFsGhSums)) * 8u;
                     int lh = lane_v;
                     asm volatile("" : "+v"(lh));  // addresses of this block are computed here, not hoisted and spilled
 #if MI355_FUSED_HSWEEP == 3
@@ -1810,14 +1914,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             const int i = c0 + k * 64 + lh;
-                            if (i < end) {
-                                if constexpr (FMT == 3) {
-                                    f8_stage(v[k], i);
-                                } else {
-                                    *(u64*)(xs + (size_t)i * 8) = ((u64)v[k][2] << 32) | v[k][0];
-                                    pair_sums(sxp, v[k][0], v[k][2]);
-                                }
-                            }
+                            if (i < end) stage_h(v[k], i);
                         }
                     };
                     const int c1 = first + 512, c2 = first + 1024;
@@ -1839,28 +1936,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             const int i = c0 + k * 64 + lh;
-                            if (i < end) {
-                                if constexpr (FMT == 3) {
-                                    f8_stage(va[k], i);
-                                } else {
-                                    *(u64*)(xs + (size_t)i * 8) = ((u64)va[k][2] << 32) | va[k][0];
-                                    pair_sums(sxp, va[k][0], va[k][2]);
-                                }
-                            }
+                            if (i < end) stage_h(va[k], i);
                         }
                     };
                     auto stage_b = [&](int c0) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int i = c0 + k * 64 + lh;
-                            if (i < end) {
-                                if constexpr (FMT == 3) {
-                                    f8_stage(vb[k], i);
-                                } else {
-                                    *(u64*)(xs + (size_t)i * 8) = ((u64)vb[k][2] << 32) | vb[k][0];
-                                    pair_sums(sxp, vb[k][0], vb[k][2]);
-                                }
-                            }
+                            if (i < end) stage_h(vb[k], i);
                         }
                     };
                     const int c1 = first + 512, c2 = first + 768, c3 = first + 1280;
@@ -1880,6 +1963,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 }
 #endif
                 put_sums(sxp);
+                if constexpr (PUBSUM) {
+                    if (gw == 0) s_edge = group_sum(hs, 64);
+                }
                 hpar ^= 1;
                 ++edge;
                 FS_GSTAMP(11);

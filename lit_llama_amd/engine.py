@@ -419,7 +419,7 @@ class DecodeEngine:
         a.w_head = head.desc.w
         a.sz, a.sz_head, a.norms = ptr(sz), ptr(sz_head), ptr(norms)
         a.weight_fmt = fmt
-        if fmt == 0 and not gc and H // 128 <= 95 and _env_int("MI355_FUSED_F8", 1) != 0:
+        if fmt == 0 and not gc and H // 128 <= 92 and _env_int("MI355_FUSED_F8", 1) != 0:
             # round 4: the same int4 streams through fp8 operands — one scaled K = 128 MFMA per 1-KiB piece instead of four f16 ones, the
             # publishers split the activations into three E4M3 limbs (csrc/fused_step_ring.hip FMT 3; DESIGN.md section 5: +2.4..2.8 % on
             # the headline, the same distance from the reference's run as the fp16 operands).  MI355_FUSED_F8=0 keeps weight_fmt 0;

@@ -17,7 +17,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from lit_llama_amd import synth  # noqa: E402
 from lit_llama_amd.model import LLaMA, LLaMAConfig  # noqa: E402
 from lit_llama_amd.utils import EmptyInitOnDevice  # noqa: E402
-from scripts.fused_timeline import NAMES, ORDER  # noqa: E402
+from scripts.fused_timeline import NAMES, ORDER, budget  # noqa: E402
 
 
 def f8_ab(a):
@@ -123,6 +123,7 @@ def f8_ab(a):
                 col = st[:, i] - t0
                 print(f"  {NAMES[i]:28s} min {col.min():7.2f}  med {np.median(col):7.2f}  max {col.max():7.2f}   (+{np.median(col) - prev:5.2f})")
                 prev = np.median(col)
+            budget(st)
     set_fmt(0)
 
 
@@ -222,6 +223,7 @@ def main():
             col = st[:, i] - t0
             print(f"  {NAMES[i]:28s} min {col.min():7.2f}  med {np.median(col):7.2f}  max {col.max():7.2f}   (+{np.median(col) - prev:5.2f})")
             prev = np.median(col)
+        budget(st)
 
 
 if __name__ == "__main__":

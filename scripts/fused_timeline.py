@@ -21,6 +21,41 @@ NAMES = {2: "G  x gathered (c_attn)", 3: "G  q/k/v published", 4: "G  head q gat
 ORDER = [2, 20, 21, 3, 4, 23, 25, 5, 6, 7, 26, 27, 8, 9, 28, 29, 10, 11, 30, 31, 12]
 
 
+# the chain of one layer inside ONE workgroup (gatherer 0 and streamer wave 0 share the workgroup's barriers): consecutive events
+CHAIN = [(2, 20, "x gathered -> c_attn B1 (streamers past the barrier)"), (20, 21, "c_attn: B1 -> last tile parked"),
+         (21, 3, "c_attn: parked -> q/k/v published (epilogue, RoPE, cache row)"), (3, 4, "head-local q/k/v hand-off"),
+         (4, 23, "q staged -> streamers past Ba1"), (23, 25, "attention: scores + weighted values"), (25, 5, "-> partials ready (Ba3)"),
+         (5, 6, "merge + attention output published"), (6, 7, "attention-output hand-off (all-gather)"), (7, 26, "gathered -> c_proj B1"),
+         (26, 27, "attn.c_proj: B1 -> tile parked"), (27, 8, "attn.c_proj: parked -> x published (residual, limbs)"),
+         (8, 9, "x hand-off into the MLP (all-gather)"), (9, 28, "gathered -> fc B1"), (28, 29, "c_fc1/c_fc2: B1 -> last tile parked"),
+         (29, 10, "pair: parked -> hidden published"), (10, 11, "hidden hand-off (all-gather)"), (11, 30, "gathered -> mproj B1"),
+         (30, 31, "mlp.c_proj: B1 -> tile parked"), (31, 12, "mlp.c_proj: parked -> x published"),
+         (12, 46, "x hand-off into the next layer (all-gather)")]
+
+
+def budget(st, out=print):
+    """Where a layer's period goes, with a time base that closes: every row is the difference of two
+    consecutive events INSIDE one workgroup (same clock, same chain), reduced over the 256 workgroups; slot 46 is 'x gathered' of
+    the next layer, so the rows add up to the layer's period in every workgroup and the medians add up to ~ the median period.
+    `st`: [256][64] stamps in us."""
+    period = st[:, 46] - st[:, 2]
+    ok = (st[:, 46] > 0) & (st[:, 2] > 0)
+    if not ok.all():
+        out(f"  (budget: slot 46 missing in {int((~ok).sum())} workgroups: library without the next-layer stamp)")
+        return None
+    rows, tot = [], 0.0
+    for a, b, what in CHAIN:
+        d = st[:, b] - st[:, a]
+        rows.append((what, float(np.median(d)), float(d.min()), float(d.max())))
+        tot += float(np.median(d))
+    hand = sum(m for w, m, _, _ in rows if "hand-off" in w)
+    out(f"  layer period (x gathered -> x gathered of the next layer, per workgroup): median {np.median(period):6.2f} us, "
+        f"min {period.min():6.2f}, max {period.max():6.2f}; sum of the row medians {tot:6.2f}; hand-off rows {hand:5.2f}")
+    for what, m, lo, hi in rows:
+        out(f"    {what:62s} med {m:6.2f}  min {lo:6.2f}  max {hi:6.2f}")
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layer", type=int, default=10)
