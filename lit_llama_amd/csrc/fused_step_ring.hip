@@ -34,6 +34,7 @@
 #include <math.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include <hip/hip_ext.h>
 
@@ -71,6 +72,10 @@ constexpr unsigned kSpinLimit = 400000u;
 #ifndef MI355_FUSED_VSPLIT
 #define MI355_FUSED_VSPLIT 0  // c_attn epilogue: gatherer 1 dequantises and publishes the v rows (int4 streams; A / B knob: 926 vs 935 us per
                               // step with 4-KiB partial tiles on one box, 928.5 vs 921.4 with whole tiles on another — off)
+#endif
+#ifndef MI355_FUSED_EARLY_BURST
+#define MI355_FUSED_EARLY_BURST 1  // (same box, two rounds, profiles/r05_early_burst_ab.txt: bf16 454.8 -> 459.5 tok/s, llm.int8 719.7 -> 727.4)
+                                   // BF16 / LLM.int8 streams: request a phase's first ring turn in front of the previous phase's publish barrier
 #endif
 #ifndef MI355_FUSED_GPRIO
 #define MI355_FUSED_GPRIO 0
@@ -133,16 +138,29 @@ static_assert(kF8P1 + kF8Units * 128 <= kOffPart && (kF8P1 - kF8P0) % 256 == 64 
 // PUBLISHER adds up the decoded limbs of the 16 values it publishes (it holds them in registers anyway) and sends the partial sum along — per
 // workgroup one more granule next to the sum of squares (x edges), one in front of the pair granules (attention output, MLP hidden) — and the
 // gatherer that sweeps the edge adds the 256 partials: S is known BEFORE the phase starts, and the streamers issue weights x activations only.
+// MEASURED (profiles/r05_ab1..3_*.txt, three boxes): the phases do get shorter (mlp.c_proj B1 -> parked 1.04 -> 0.80 us, its epilogue 0.76 -> 0.64,
+// c_attn's 1.80 -> 1.56, attn.c_proj's 0.84 -> 0.72: ~0.8 us per layer) and the STEP does not: 897 vs 898 us on one box, 911 vs 898 on another —
+// a workgroup that finishes a phase earlier sends its first sweep earlier, misses the slowest publishers and pays a whole memory round trip
+// for the retry (the row "x hand-off into the next layer": 3.7 -> 4.6 us).  Default off; the code stays as the measured alternative.
 #ifndef MI355_F8_PUBSUM
-#define MI355_F8_PUBSUM 1
+#define MI355_F8_PUBSUM 0
 #endif
 // 1: a streamer wave parks its raw partial tiles (limb columns 0 / 1 / 2 side by side) and gatherer 0's read adds the three columns; 0:
 // the streamers add them up at the tile end (two DPP adds per register: round 4)
 #ifndef MI355_F8_COLSUM_G
-#define MI355_F8_COLSUM_G 0
+#define MI355_F8_COLSUM_G 1  // (same box, two rounds, profiles/r05_ab2_*.txt: 896.7 / 897.9 us per step against 906.8 / 904.8 with 0)
+#endif
+// fp8-limb operands: how the two gatherer waves sweep the hidden edge.  1 (round 5): what is published LATE — the third pair tiles of the
+// 176 workgroups that have one (pair loads from 2048 on) and the operand-sum partials, which follow a workgroup's last tile — is split
+// between the two gatherers and requested as each one's LAST chunk, behind its share of the early loads: when the slowest publisher's
+// granules land, ONE retry of one chunk is all that is left.  0: round 4's contiguous halves (gatherer 1 held every late load in three
+// of its four chunks; the chunk that was requested last only went out after an earlier one had seen the late data: one more memory round
+// trip behind the slowest publisher)
+#ifndef MI355_F8_HLATE
+#define MI355_F8_HLATE 1
 #endif
 #ifndef MI355_FUSED_G0_PAIRS_F8
-#define MI355_FUSED_G0_PAIRS_F8 5  // gatherer 0's share of an x edge's 16 pair loads per lane with MI355_F8_PUBSUM (it also has 4 loads of sums)
+#define MI355_FUSED_G0_PAIRS_F8 6  // gatherer 0's share of an x edge's 16 pair loads per lane with MI355_F8_PUBSUM
 #endif
 [[maybe_unused]] constexpr int kMaxS = 32768;     // cache rows (the attention keeps no per-row state in LDS)
 #ifndef MI355_FUSED_LDS_PAD
@@ -578,7 +596,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 }                                                                                                     \
             }                                                                                                         \
         }                                                                                                             \
-        __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
     } while (0)
 
         // ---- one phase over a BF16 stream: FS_RUN's ring discipline (turns, refills, barriers), ONE MFMA per piece against 16 B of
@@ -630,7 +647,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 }                                                                                                     \
             }                                                                                                         \
         }                                                                                                             \
-        __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
     } while (0)
         // ---- LLM.int8 streams: the streamer waves quantise the gathered vector, each its own units (lane <-> octet of 8 columns).
         // Pass 1: xh = f16 of the staged value (x edges: times 1/rms over x_scale, misc[1] — the launch path's `sc * (x * rinv)`
@@ -749,7 +765,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 }                                                                                                     \
             }                                                                                                         \
         }                                                                                                             \
-        __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
     } while (0)
         // ---- one phase over the int4 stream with fp8 operands (FMT 3): FS_RUN's ring discipline (turns, refills, barriers; whole tiles
         // per ring turn), ONE scaled MFMA per piece.  E8_: pre-scale exponent of the phase's input edge.
@@ -800,7 +815,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
                     }                                                                                                 \
                     if ((t__ * STEPS__ + s__ + 1) % SPT__ == 0) {                                                     \
-                        if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
+                        if (gstep__ + 1 == total__) {                                                                 \
+                            FS_SSTAMP((STAMP_) + 1);                                                                  \
+                            /* slots 48 + phase: when the LAST streamer wave reaches its last tile end (wave skew) */  \
+                            if (dbg_on && lane_off == 0u)                                                             \
+                                atomicMax((unsigned long long*)&p.dbg[bid * 64 + 48 + ((STAMP_) - 20) / 2], (unsigned long long)wall_clock64()); \
+                        }                                                                                             \
                         if (!MI355_F8_PUBSUM && ti__ == 0) {                                                          \
                             /* S of this wave's units: limb columns 0 + 1 + 2 of any row (quad broadcasts of lanes 1 / 2) */ \
                             float ssum__ = accs__[0];                                                                 \
@@ -828,7 +848,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 }                                                                                                     \
             }                                                                                                         \
         }                                                                                                             \
-        __syncthreads(); /* B3: the gatherers have issued the publish stores */                                       \
     } while (0)
         // a phase: (int4 SPT / TURNS, wide-format SPT / TURNS) — steps per tile and ring turns differ with the piece width
 #define FS_PHASE(RS_, R_, SPT_, TURNS_, SPTW_, TURNSW_, PAIR_, QKV_, PH_, NBODIES_, STAMP_, RST_, XEDGE_, E8_)        \
@@ -852,6 +871,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         }                                                                                                            \
     } while (0)
 
+        // B3 of a phase: the gatherers have issued its publish stores.  The next phase's first ring turn is requested BEHIND it (int4
+        // streams: a refill queued in front of the publish in the CU's in-order memory pipeline delays every consumer of the edge) or, for
+        // the wide formats whose chain is shorter than their stream (BF16, LLM.int8; MI355_FUSED_EARLY_BURST), in FRONT of it: their
+        // phases stream two to sixteen ring turns in-phase, and the gap between a phase's last tile and the next request is HBM idle time
+#define FS_B3() __syncthreads()
+        constexpr bool kEarly = (FMT == 1 || FMT == 2) && MI355_FUSED_EARLY_BURST;
         FS_PBURST(rs_l, 3, 4, 4 * kSub, false, true, ph_attn);
         const bf16_t* kv_l = (const bf16_t*)p.kv;
         bool dbg_on = false;
@@ -864,6 +889,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             asm volatile("" : "+v"(lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
             // ---------------- c_attn (q, k, v tiles of this workgroup's 16 dimensions of its head)
             FS_PHASE(rs_l, 3, 4, 1, 4 * kSub, kSub, false, true, ph_attn, 1, 20, rs_t, true, MI355_F8_EX);
+            FS_B3();
             // ---------------- attention: scores over the whole context, then this workgroup's 16 output dims
             {
                 const bf16_t* kc = kv_l + (size_t)head * p.S * kHs;
@@ -1086,10 +1112,23 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows)
             FS_PBURST(rs_l, 1, 12, 4 * kSub, false, false, ph_proj);
             FS_PHASE(rs_l, 1, 12, 1, 4 * kSub, (4 * kSub + 11) / 12, false, false, ph_proj, 1, 26, rs_t, false, MI355_F8_EA);
-            FS_PBURST(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
+            if constexpr (kEarly) {
+                FS_PBURST(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
+                FS_B3();
+            } else {
+                FS_B3();
+                FS_PBURST(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
+            }
             FS_PHASE(rs_l, 2, 4, 2, 4 * kSub, 2 * kSub, true, false, ph_fc, 1, 28, rs_t, true, MI355_F8_EX);
-            FS_PBURST(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
+            if constexpr (kEarly) {
+                FS_PBURST(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
+                FS_B3();
+            } else {
+                FS_B3();
+                FS_PBURST(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
+            }
             FS_PHASE(rs_l, 1, 12, 1, 12 * kSub, kSub, false, false, ph_mp, 1, 30, rs_t, false, MI355_F8_EH);
+            if constexpr (!kEarly) FS_B3();
             // next layer (or the head)
             kv_l += (size_t)2 * kHeads * p.S * kHs;
             if (l + 1 < p.n_layer) {
@@ -1102,10 +1141,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             } else {
                 FS_PBURST(rs_h, 1, 4, 4 * kSub, false, false, ph_head);
             }
+            if constexpr (kEarly) FS_B3();
         }
         dbg_on = false;
         FS_PHASE(rs_h, 1, 4, 1, 4 * kSub, 1, false, false, ph_head, p.head_turns, 32, rs_th, true, MI355_F8_EX);
+        FS_B3();
         if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
+#undef FS_B3
 #undef FS_PBURST
 #undef FS_PHASE
 #undef FS_RUN_F
@@ -1289,9 +1331,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             ss += lane_xor16(ss);
             ss += lane_xor32(ss);
             if constexpr (PUBSUM) {
-                // {sum of squares, operand sum} of this workgroup's rows: two adjacent granules, one store instruction (lanes 0 / 1)
+                // {sum of squares, operand sum} of this workgroup's rows in ONE granule under a 16-bit tag — no more sweep loads than the
+                // sum of squares alone took (a first version with two granules per workgroup: 4 instead of 2 loads per lane for gatherer
+                // 0, and the x hand-offs paid for it): 24 bits each, rounded — ss >= 0 keeps exponent + 16 mantissa bits, the operand sum
+                // sign + exponent + 15 (2^-16 relative on partials that are added up 256 at a time: far below the limbs' own 2^-12)
                 sxp = pair8_sum(sxp);
-                if (lane < 2) gr_store(dst + 2048 + 2 * bid + lane, ep, __float_as_uint(lane ? sxp : ss));
+                const unsigned sb = ((__float_as_uint(ss) + 0x40u) >> 7) & 0xFFFFFFu, xb = (__float_as_uint(sxp) + 0x80u) >> 8;
+                if (lane == 0) gr_store16(dst + 2048 + bid, ep, sb | (xb << 24), (xb >> 8) & 0xFFFFu);
             } else {
                 if (lane == 0) gr_store(dst + 2048 + bid, ep, __float_as_uint(ss));
             }
@@ -1321,7 +1367,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             // the sums of squares go to gatherer 0, which also has the serial tail (sums, 1/rms).  Measured (same box,
             // alternating runs): 6 : 10 -> 918 us per step, 7 : 9 (equal load counts) -> 935 us.
             constexpr int kG0 = PUBSUM ? MI355_FUSED_G0_PAIRS_F8 : MI355_FUSED_G0_PAIRS;
-            constexpr int kNS = PUBSUM ? 4 : 2;  // loads of the per-workgroup sums (PUBSUM: two granules per workgroup)
+            constexpr int kNS = 2;  // loads of the per-workgroup sums (two workgroups each)
             if (gw == 0) {
                 u32x4 v[kG0 + kNS];
                 for (unsigned spins = 0;; ++spins) {
@@ -1337,7 +1383,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     }
 #pragma unroll
                     for (int k = 0; k < kG0 + kNS; ++k) {
-                        if (FMT == 3 && k < kG0) ok &= (v[k][1] >> 16) == (ep & 0xFFFFu) && (v[k][3] >> 16) == (ep & 0xFFFFu);
+                        if (FMT == 3 && (k < kG0 || PUBSUM)) ok &= (v[k][1] >> 16) == (ep & 0xFFFFu) && (v[k][3] >> 16) == (ep & 0xFFFFu);
                         else ok &= v[k][1] == ep && v[k][3] == ep;
                     }
                     if (__all(ok)) break;
@@ -1359,9 +1405,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 }
                 float ss;
                 if constexpr (PUBSUM) {
-                    ss = (__uint_as_float(v[kG0][0]) + __uint_as_float(v[kG0 + 1][0])) + (__uint_as_float(v[kG0 + 2][0]) + __uint_as_float(v[kG0 + 3][0]));
-                    const float sx4 = (__uint_as_float(v[kG0][2]) + __uint_as_float(v[kG0 + 1][2])) +
-                                      (__uint_as_float(v[kG0 + 2][2]) + __uint_as_float(v[kG0 + 3][2]));
+                    auto ss24 = [](unsigned d0) { return __uint_as_float((d0 & 0xFFFFFFu) << 7); };
+                    auto sx24 = [](unsigned d0, unsigned d1) { return __uint_as_float(((d0 >> 24) | ((d1 & 0xFFFFu) << 8)) << 8); };
+                    ss = (ss24(v[kG0][0]) + ss24(v[kG0][2])) + (ss24(v[kG0 + 1][0]) + ss24(v[kG0 + 1][2]));
+                    const float sx4 = (sx24(v[kG0][0], v[kG0][1]) + sx24(v[kG0][2], v[kG0][3])) +
+                                      (sx24(v[kG0 + 1][0], v[kG0 + 1][1]) + sx24(v[kG0 + 1][2], v[kG0 + 1][3]));
                     s_edge = group_sum(sx4, 64);
                 } else {
                     ss = ((__uint_as_float(v[kG0][0]) + __uint_as_float(v[kG0][2])) + __uint_as_float(v[kG0 + 1][0])) +
@@ -1565,6 +1613,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if (w8 == 3) gr_store(dst + 24 + pg, ebase + edge, vp);
                 if (w8 == 5) ((unsigned*)vrow)[pg] = vp;
             }
+#ifdef MI355_FUSED_FINE_STAMPS
+#define FS_FSTAMP(i) FS_GSTAMP(i)  /* diagnostic build: where the c_attn epilogue's time goes (slots 56..59) */
+#else
+#define FS_FSTAMP(i) do { } while (0)
+#endif
+            FS_FSTAMP(56);
             if (gw == 0) {
                 rinv_seen = misc[0];
                 const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;  // (int8 streams: 1/rms is inside the quantised operand)
@@ -1577,6 +1631,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     y[r].x *= rinv;
                     y[r].y *= rinv;
                 }
+                FS_FSTAMP(57);
                 // RoPE (model.py:306-323) of the q / k pair, publish to the head group, write the cache row
                 const unsigned ep = ebase + edge;
                 u64* dst = p.gq + ((size_t)qpar * kHeads + head) * 256 + hj * 32;
@@ -1584,6 +1639,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 bf16_t* vrow = krow + (size_t)kHeads * p.S * kHs;
                 const float qa = y[0].x * cs.x - y[0].y * cs.y, qb = y[0].y * cs.x + y[0].x * cs.y;
                 const unsigned kp = bfpair(y[1].x * cs.x - y[1].y * cs.y, y[1].y * cs.x + y[1].x * cs.y);
+                FS_FSTAMP(58);
                 if (w8 == 0) gr_store(dst + 2 * pg, ep, __float_as_uint(qa));
                 if (w8 == 1) gr_store(dst + 2 * pg + 1, ep, __float_as_uint(qb));
                 if (w8 == 2) gr_store(dst + 16 + pg, ep, kp);
@@ -1824,7 +1880,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     }
                 }
                 const unsigned ep = ebase + edge;
-                u64* dst = p.gh + (size_t)hpar * gh_stride + kFsGhSums;  // the pair granules of this parity
+                u64* dst = p.gh + (size_t)hpar * gh_stride;  // the pair granules of this parity (the operand-sum partials sit behind them)
                 [[maybe_unused]] float hsum = 0.f;
                 rinv_seen = misc[0];
                 const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;
@@ -1860,7 +1916,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if constexpr (PUBSUM) {
                     if (gw == 0) {  // the operand sum of this workgroup's 2 or 3 tiles, behind its last tile
                         const float st = pair8_sum(hsum);
-                        if (lane == 0) gr_store16(p.gh + (size_t)hpar * gh_stride + bid, ep, __float_as_uint(st), 0u);
+                        if (lane == 0) gr_store16(p.gh + (size_t)hpar * gh_stride + p.H / 2 + bid, ep, __float_as_uint(st), 0u);
                     }
                 }
                 FS_GSTAMP(10);
@@ -1884,17 +1940,21 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if (gw == 1) zero_obits();
                 }
                 [[maybe_unused]] const unsigned eph = FMT == 3 ? (ep & 0xFFFFu) : ep;
-                // 16-B loads of the edge: PUBSUM puts 128 loads of operand-sum partials (two workgroups each) in front of the H / 4 pair loads
+                // 16-B loads of the edge: the H / 4 pair loads, then (PUBSUM) 128 loads of operand-sum partials (two workgroups each).  BEHIND
+                // the pairs, i.e. in gatherer 1's last chunk: a partial is published behind its workgroup's LAST tile, and a first version
+                // that swept them in gatherer 0's first chunk kept that chunk spinning until the slowest workgroup was done — and only
+                // then requested the later chunks: the hidden hand-off 4.96 -> 5.9-6.5 us (profiles/r05_ab1_*.txt)
                 constexpr int kHS = PUBSUM ? kFsGhSums / 2 : 0;
-                const int n_loads = p.H / 4 + kHS, half_l = (n_loads + 1) / 2;
+                const int n_pairs = p.H / 4;
+                const int n_loads = n_pairs + kHS, half_l = (n_loads + 1) / 2;
                 const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
                 float2 sxp = {0.f, 0.f};
                 [[maybe_unused]] float hs = 0.f;
-                // stage load i of the edge (i < kHS: two partial sums; else pair load i - kHS)
+                // stage load i of the edge (i >= n_pairs: two partial sums)
                 auto stage_h = [&](const u32x4& v, int i) {
                     if constexpr (FMT == 3) {
-                        if (PUBSUM && i < kHS) hs += __uint_as_float(v[0]) + __uint_as_float(v[2]);
-                        else f8_stage(v, i - kHS);
+                        if (PUBSUM && i >= n_pairs) hs += __uint_as_float(v[0]) + __uint_as_float(v[2]);
+                        else f8_stage(v, i);
                     } else {
                         *(u64*)(xs + (size_t)i * 8) = ((u64)v[2] << 32) | v[0];
                         pair_sums(sxp, v[0], v[2]);
@@ -1904,9 +1964,42 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     // up to three chunks of 8 loads per lane (H <= 12288), TWO in flight: only the first one waits for
                     // producers; issued one after the other each later chunk cost its own memory round trip on the
                     // longest hand-off of the layer (44 KB of granules)
-                    const unsigned hbase = ((unsigned)hpar * (unsigned)gh_stride + (unsigned)(PUBSUM ? 0 : kFsGhSums)) * 8u;
+                    const unsigned hbase = (unsigned)hpar * (unsigned)gh_stride * 8u;
                     int lh = lane_v;
                     asm volatile("" : "+v"(lh));  // addresses of this block are computed here, not hoisted and spilled
+                if constexpr (FMT == 3 && MI355_F8_HLATE) {
+                    // per gatherer: its half of the early loads (first and second tiles of every workgroup: pair loads below 2048) in
+                    // chunks of 8 / 4 / 4 per lane, its half of the late loads (third tiles from load 2048 on, then the operand-sum
+                    // partials: contiguous) as ONE chunk of <= 8, requested as soon as the first early chunk has landed (see
+                    // MI355_F8_HLATE); buffers as in round 4 (8 + 4 loads per lane)
+                    const int n_early = n_pairs < 2048 ? n_pairs : 2048, he = (n_early + 1) / 2;
+                    const int hl = (n_loads - n_early + 1) / 2;  // <= 512: host check (n_hidden <= 11776)
+                    const int e0 = gw * he, e_end = gw == 0 ? he : n_early;
+                    const int l0 = n_early + gw * hl, l_end = gw == 0 ? n_early + hl : n_loads;
+                    auto stage_c = [&](const auto& v, auto n_c, int c0, int lim) {
+#pragma unroll
+                        for (int k = 0; k < decltype(n_c)::value; ++k) {
+                            const int i = c0 + k * 64 + lh;
+                            if (i < lim) stage_h(v[k], i);
+                        }
+                    };
+                    constexpr std::integral_constant<int, 8> n8{};
+                    constexpr std::integral_constant<int, 4> n4{};
+                    u32x4 va[8], vb[4];
+                    sweep_issue<8>(rs_gh, hbase, e0, e_end, va, lh);
+                    sweep_issue<4>(rs_gh, hbase, e0 + 512, e_end, vb, lh);
+                    sweep<8, true>(p, rs_gh, hbase, e0, e_end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
+                    FS_GCOUNT(44);
+                    stage_c(va, n8, e0, e_end);
+                    sweep_issue<8>(rs_gh, hbase, l0, l_end, va, lh);  // (waits below, behind the early chunks)
+                    sweep<4, true>(p, rs_gh, hbase, e0 + 512, e_end, eph, vb, 0x500u + edge, lh, nullptr, true);
+                    stage_c(vb, n4, e0 + 512, e_end);
+                    sweep_issue<4>(rs_gh, hbase, e0 + 768, e_end, vb, lh);
+                    sweep<4, true>(p, rs_gh, hbase, e0 + 768, e_end, eph, vb, 0x500u + edge, lh, nullptr, true);
+                    stage_c(vb, n4, e0 + 768, e_end);
+                    sweep<8, true>(p, rs_gh, hbase, l0, l_end, eph, va, 0x500u + edge, lh, nullptr, true);
+                    stage_c(va, n8, l0, l_end);
+                } else {
 #if MI355_FUSED_HSWEEP == 3
                     // all three chunks of 8 loads per lane (24 >= 12288 / 4 / 2 / 64) in flight at once
                     u32x4 va[8], vb[8], vc[8];
@@ -1962,9 +2055,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     stage_b(c3);
                 }
 #endif
+                }
                 put_sums(sxp);
                 if constexpr (PUBSUM) {
-                    if (gw == 0) s_edge = group_sum(hs, 64);
+                    hs = group_sum(hs, 64);  // (each gatherer has summed the partials among ITS loads)
+                    if (gw == 1) {  // -> gatherer 0's epilogue, through LDS (two workgroup barriers in between)
+                        if (lane == 0) misc[33] = hs;
+                    } else {
+                        s_edge = hs;
+                    }
                 }
                 hpar ^= 1;
                 ++edge;
@@ -1977,6 +2076,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 __syncthreads();  // Bt
                 if (gw == 0) {
                     float2 d;
+                    if constexpr (PUBSUM) s_edge += misc[33];
                     if constexpr (FMT == 2) d = tile_deq8(0, s1, wl8 + p.off_mproj, p.units_h, 1, 0, r0, pb0[0], pb1[0]);
                     else d = deq(tile_pair(0), s1, z1, get_sums());
                     xres.x += d.x;

@@ -73,6 +73,12 @@ def generate(
     return idx
 
 
+# The persistent step records a hand-off that left the range of its format; the host learns of it at its next status read.  The loops
+# below read every CHECK_EVERY tokens (one 16-byte device->host read: ~20 us against ~58 ms of decoding) and at their end, so a clip
+# costs at most that many recomputed steps — not the rest of a long generation.
+CHECK_EVERY = 64
+
+
 def _replay_from(eng, bad: int):
     """The persistent step's activations left the range of its hand-off format at position `bad` (DecodeEngine.check_status: the
     engine has moved to a wider format / the launch-per-operator step by now).  out_tokens[: bad + 1] and the cache rows below
@@ -105,6 +111,7 @@ def _generate_sampled(model, eng, idx, max_new_tokens, max_seq_length, temperatu
         done = 1
         stop = False
         while True:
+            bad = None
             while done < max_new_tokens and not stop:
                 eng.run_step(0)
                 ops.sample(row, temperature, top_k, uniforms, eng.pos, eng.next_token, **kw)
@@ -112,7 +119,12 @@ def _generate_sampled(model, eng, idx, max_new_tokens, max_seq_length, temperatu
                 if eos_id is not None and (done % 16 == 0 or done == max_new_tokens):
                     toks = eng.out_tokens[T:T + done].tolist()
                     stop = eos_id in toks
-            bad = eng.check_status()
+                if done % CHECK_EVERY == 0 and eng.fused_ready():
+                    bad = eng.check_status()
+                    if bad is not None:
+                        break
+            if bad is None:
+                bad = eng.check_status()
             if bad is None:
                 break
             # a step left the range of the persistent step's hand-off format: the draws are per position, so the replay through the
@@ -147,6 +159,7 @@ def _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id):
             eng.embed_step()
         stop = False
         while True:
+            bad = None
             while done < max_new_tokens and not stop:
                 eng.run_step(3)
                 done += 1
@@ -155,9 +168,14 @@ def _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id):
                     # device->host sync for it; here the sync is amortised and the tail is cut off afterwards
                     toks = eng.out_tokens[T:T + done].tolist()
                     stop = eos_id in toks
-            # one read after the loop: a hand-off of the fused step timed out -> raise, never garbage; activations past the range of
-            # its hand-off format at some position -> the engine has moved to a wider format, recompute from that position
-            bad = eng.check_status()
+                if done % CHECK_EVERY == 0 and eng.fused_ready():
+                    bad = eng.check_status()
+                    if bad is not None:
+                        break
+            # a read after the loop as well: a hand-off of the fused step timed out -> raise, never garbage; activations past the range
+            # of its hand-off format at some position -> the engine has moved to a wider format, recompute from that position
+            if bad is None:
+                bad = eng.check_status()
             if bad is None:
                 break
             _replay_from(eng, bad)

@@ -48,6 +48,17 @@ def budget(st, out=print):
         d = st[:, b] - st[:, a]
         rows.append((what, float(np.median(d)), float(d.min()), float(d.max())))
         tot += float(np.median(d))
+    # wave skew (fp8-operand kernel): slots 48 / 51 / 52 / 53 = when the LAST streamer wave reached the phase's last tile end
+    for slot, first, pub, nm in ((48, 21, 3, "c_attn"), (51, 27, 8, "attn.c_proj"), (52, 29, 10, "c_fc1/c_fc2"), (53, 31, 12, "mlp.c_proj")):
+        if (st[:, slot] > 0).all():
+            d1, d2 = st[:, slot] - st[:, first], st[:, pub] - st[:, slot]
+            rows.append((f"  [{nm}: wave 0 parked -> LAST wave parked]", float(np.median(d1)), float(d1.min()), float(d1.max())))
+            rows.append((f"  [{nm}: last wave parked -> published]", float(np.median(d2)), float(d2.min()), float(d2.max())))
+    if (st[:, 56] > 0).all():  # -DMI355_FUSED_FINE_STAMPS: inside the c_attn epilogue of gatherer 0
+        for a, b, nm in ((48, 56, "last wave parked -> gatherer 0 past Bt"), (56, 57, "partial tiles read, summed, dequantised"),
+                         (57, 58, "RoPE + bf16 pairs"), (58, 3, "six masked stores (+ the stamps themselves)")):
+            d = st[:, b] - st[:, a]
+            rows.append((f"  [c_attn epilogue: {nm}]", float(np.median(d)), float(d.min()), float(d.max())))
     hand = sum(m for w, m, _, _ in rows if "hand-off" in w)
     out(f"  layer period (x gathered -> x gathered of the next layer, per workgroup): median {np.median(period):6.2f} us, "
         f"min {period.min():6.2f}, max {period.max():6.2f}; sum of the row medians {tot:6.2f}; hand-off rows {hand:5.2f}")
