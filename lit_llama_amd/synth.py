@@ -81,12 +81,17 @@ def llama_stats_plan(cfg: LLaMAConfig) -> dict:
         layer=min(1, cfg.n_layer - 1),
         hidden_units=[H * k // 11008 for k in (7003, 4242, 9000, 1234)],
         channels=[C * k // 4096 for k in (1415, 2533, 3431)],
-        sigma_a=64.0,        # nominal std of the pre-activation a = b of a massive hidden unit over tokens (measured on the
-                             # quantised 7B-width rows: ~47, i.e. a^2 passes 7168 — the fp8 hand-off's SwiGLU limit — in ~3.5 % of
-                             # the (token, unit) pairs and reaches ~10^4)
+        sigma_a=104.0,       # nominal std of the pre-activation a = b of a massive hidden unit (as measured on the quantised 7B-width rows,
+                             # over units AND tokens: ~76; most of it is BETWEEN units — the attention output of block 0 is close to a
+                             # running mean, so a unit's a moves by only +-30 % from token to token): the strongest unit's a^2 is
+                             # 3000 .. 11000 over the tokens, i.e. on either side of the +-7168 the fp8 hand-off's SwiGLU edge holds
         w_massive=0.004,     # mlp.c_proj weight from a massive hidden unit into a massive channel
         row_shrink=0.25,     # the other entries of those mlp.c_proj rows (keeps w_massive several int4 steps wide)
         emb_std=0.02, norm_lo=0.05, norm_hi=0.5, norm_spread=0.3,
+        # trained checkpoints carry SMALL norm weights on their massive channels (the channels act as a constant the blocks read at a
+        # chosen gain): without this the three channels dominate every normalised vector behind block 1 — the first version of the
+        # fixture generated one token 23 times over
+        norm_damp=0.03, ln_f_damp=0.01,
     )
 
 
@@ -126,6 +131,9 @@ def make_state_dict(
             for j in (1, 2):
                 k = f"transformer.h.{i}.rms_{j}.scale"
                 norms[k] = base * torch.exp(plan["norm_spread"] * (norms[k] - 1.0) / 0.1)
+                if (i, j) > (plan["layer"], 2):  # every norm that reads the stream behind the block that creates the channels
+                    norms[k][plan["channels"]] *= plan["norm_damp"]
+        norms["transformer.ln_f.scale"][plan["channels"]] *= plan["ln_f_damp"]
     if outlier_channels:
         # fixed channels x20: after RMSNorm these exceed the LLM.int8 threshold of 6
         ch = torch.arange(outlier_channels, device=device) * (C // max(outlier_channels, 1)) + 3

@@ -140,7 +140,8 @@ def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures, record=None):
                 may = {i for i in range(1, logits.shape[0]) if a[T + i - 1] > 7168 * 0.98}
                 got_steps = {i for i, _, _ in demoted}
                 assert must <= got_steps <= may, (sorted(must), sorted(got_steps), sorted(may))
-                assert all(to.startswith("fp16") for _, _, to in demoted), demoted
+                # (one rung down is enough unless a value also passes fp16's +-65504 — 3.3 sigma of the generator's units)
+                assert all(to.startswith("fp16") or a[p] > 60000 for _, p, to in demoted), demoted
                 assert len(must) >= 1, "the LLaMA-statistics fixture no longer exercises the fp8 hand-off's range limit"
             # free running (generate.py:63-91) on the product's own ladder (sticky demotion, replay from the clipped position):
             # equal up to the first near tie
