@@ -321,12 +321,12 @@ def tp_leg(args, dev, rank, world, dist):
         with torch.cuda.stream(eng.stream):
             comm.step_begin(eng.stream)
             for _ in range(16):
-                comm.reduce_add(shard, 1)
+                comm.reduce_add(shard, 1, force=True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             comm.step_begin(eng.stream)
             e0.record(eng.stream)
             for _ in range(2 * cfg.n_layer):
-                comm.reduce_add(shard, 1)
+                comm.reduce_add(shard, 1, force=True)  # (at world 1 the decode step itself issues none: tp.NativeComm.reduce_add)
             e1.record(eng.stream)
         e1.synchronize()
         comm.check_status()
@@ -345,7 +345,8 @@ def tp_leg(args, dev, rank, world, dist):
         "weight_bytes_per_gpu_per_token": int(per_gpu),
         "frac_of_int4_weight_roofline_per_gpu": round(per_gpu / per_token / HBM_PEAK, 4),
         "allreduce_us": None if ar_us is None else round(ar_us, 2),
-        "collective_us_per_token": None if ar_us is None else round(ar_us * 2 * cfg.n_layer, 1),
+        "collective_us_per_token": None if ar_us is None else (0.0 if world == 1 else round(ar_us * 2 * cfg.n_layer, 1)),
+        "collective_launches_per_token": 0 if (world == 1 and args.tp_comm == "native") else 2 * cfg.n_layer + 1,
         "note": "TP > 1 has not been run on hardware by the builder (1-GPU boxes only): the curve is whatever the driver's "
                 "multi-GPU run prints here",
     }

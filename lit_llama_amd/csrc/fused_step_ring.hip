@@ -1165,17 +1165,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         unsigned edge = 0;   // edges published so far in this step (the epoch of the next one is ebase + edge)
         int xpar = 0, apar = 0, hpar = 0, qpar = 0, ppar = 0;
         int buf = 0;
-        const __amdgpu_buffer_rsrc_t rs_gx = __builtin_amdgcn_make_buffer_rsrc((void*)p.gx, 0, 2 * kFsGxStride * 8, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_ga = __builtin_amdgcn_make_buffer_rsrc((void*)p.ga, 0, 2 * kFsGaStride * 8, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_gh = __builtin_amdgcn_make_buffer_rsrc((void*)p.gh, 0, 2 * (kFsGhSums + p.H / 2) * 8, 0x00020000);
+        // ONE descriptor over the hand-off area of the workspace (gx .. gh are consecutive in it: fused_step_common.h kFsWs*; round 5: six
+        // descriptors were 24 live SGPRs of the gatherers' 102) and compile-time byte offsets of the buffers inside it
+        const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)p.gx, 0, (int)(kFsWsGh - kFsWsGx) + 2 * (kFsGhSums + p.H / 2) * 8, 0x00020000);
+        constexpr unsigned kOGa = (unsigned)(kFsWsGa - kFsWsGx), kOGq = (unsigned)(kFsWsGq - kFsWsGx), kOGm = (unsigned)(kFsWsGm - kFsWsGx),
+                           kOGp = (unsigned)(kFsWsGp - kFsWsGx), kOGh = (unsigned)(kFsWsGh - kFsWsGx);
         constexpr bool PUBSUM = FMT == 3 && MI355_F8_PUBSUM;  // the publishers send the operand sums (see MI355_F8_PUBSUM)
         const int gh_stride = kFsGhSums + p.H / 2;           // granules per parity of the hidden edge
         [[maybe_unused]] float s_edge = 0.f;                  // PUBSUM: operand sum of the edge gathered last (gatherer 0)
-        const __amdgpu_buffer_rsrc_t rs_gq =
-            __builtin_amdgcn_make_buffer_rsrc((void*)p.gq, 0, 2 * kHeads * 256 * 8, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_gm = __builtin_amdgcn_make_buffer_rsrc((void*)p.gm, 0, 512 * 8, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_gp =
-            __builtin_amdgcn_make_buffer_rsrc((void*)p.gp, 0, 2 * kHeads * kGs * kPartStride * 8, 0x00020000);
 
         // ---- epilogue mapping of gatherer 0: lane = (pair pg = lane >> 3, streamer wave w8 = lane & 7).  A lane reads
         // rows 2 pg, 2 pg + 1 of ONE wave's partial tile (8 B), the 8 lanes of a pair are summed with DPP (fixed
@@ -1379,7 +1377,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     for (int k = 0; k < kG0 + kNS; ++k) {
                         const unsigned off = k < kG0 ? base + (unsigned)(k * 64 + lane_v) * 16u
                                                      : base + 2048u * 8u + (unsigned)((k - kG0) * 64 + lane_v) * 16u;
-                        v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gx, off, 0, 16));
+                        v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, off, 0, 16));
                     }
 #pragma unroll
                     for (int k = 0; k < kG0 + kNS; ++k) {
@@ -1427,7 +1425,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             } else {
                 if constexpr (FMT == 2) zero_obits();
                 u32x4 v[16 - kG0];
-                sweep<16 - kG0, FMT == 3>(p, rs_gx, base, kG0 * 64, 1024, FMT == 3 ? (ep & 0xFFFFu) : ep, v, 0x200u + edge, lane_v);
+                sweep<16 - kG0, FMT == 3>(p, rs_ws, base, kG0 * 64, 1024, FMT == 3 ? (ep & 0xFFFFu) : ep, v, 0x200u + edge, lane_v);
                 float2 sx = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 16 - kG0; ++k) {
@@ -1658,7 +1656,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 const unsigned ep = ebase + edge;
                 if (gw == 0) {
                     u32x4 v[2];
-                    sweep<2>(p, rs_gq, (unsigned)((qpar * kHeads + head) * 256) * 8u, 0, 128, ep, v, 0x300u + edge, lane_v, &n_sweeps);
+                    sweep<2>(p, rs_ws, kOGq + (unsigned)((qpar * kHeads + head) * 256) * 8u, 0, 128, ep, v, 0x300u + edge, lane_v, &n_sweeps);
                     FS_GCOUNT(41);
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
@@ -1738,13 +1736,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     ++edge;
                     if (gw == 0) {
                         // lane = (pair pg of this workgroup's 16 output dimensions, partial w8 of the head group)
-                        const unsigned hbase = (unsigned)(((ppar * kHeads + head) * kGs) * kPartStride) * 8u;
+                        const unsigned hbase = kOGp + (unsigned)(((ppar * kHeads + head) * kGs) * kPartStride) * 8u;
                         const unsigned off1 = hbase + (unsigned)(w8 * kPartStride + hj * 16 + 2 * pg) * 8u;
                         const unsigned off2 = hbase + (unsigned)(w8 * kPartStride + 128) * 8u;
                         u32x4 v1, v2;
                         for (unsigned spins = 0;; ++spins) {
-                            v1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gp, off1, 0, 16));
-                            v2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gp, off2, 0, 16));
+                            v1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, off1, 0, 16));
+                            v2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, off2, 0, 16));
                             const bool ok = v1[1] == ep1 && v1[3] == ep1 && v2[1] == ep1 && v2[3] == ep1;
                             if (__all(ok)) break;
                             if (spins > kSpinLimit || aborted(p)) {
@@ -1797,7 +1795,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if constexpr (PUBSUM) {
                     // 128 loads of operand-sum partials (two workgroups each) in front of the 1024 pair loads: 9 loads per lane and gatherer
                     u32x4 v[9];
-                    sweep<9, true>(p, rs_ga, (unsigned)apar * (unsigned)kFsGaStride * 8u, gw * 576, gw * 576 + 576, ep & 0xFFFFu, v,
+                    sweep<9, true>(p, rs_ws, kOGa + (unsigned)apar * (unsigned)kFsGaStride * 8u, gw * 576, gw * 576 + 576, ep & 0xFFFFu, v,
                                    0x400u + edge, lane_v, &n_sweeps);
                     FS_GCOUNT(42);
                     float sa = 0.f;
@@ -1809,7 +1807,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if (gw == 0) s_edge = group_sum(sa, 64);
                 } else {
                     u32x4 v[8];
-                    sweep<8, FMT == 3>(p, rs_ga, (unsigned)(apar * kFsGaStride + kFsGaSums) * 8u, gw * 512, gw * 512 + 512,
+                    sweep<8, FMT == 3>(p, rs_ws, kOGa + (unsigned)(apar * kFsGaStride + kFsGaSums) * 8u, gw * 512, gw * 512 + 512,
                                        FMT == 3 ? (ep & 0xFFFFu) : ep, v, 0x400u + edge, lane_v, &n_sweeps);
                     FS_GCOUNT(42);
 #pragma unroll
@@ -1964,7 +1962,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     // up to three chunks of 8 loads per lane (H <= 12288), TWO in flight: only the first one waits for
                     // producers; issued one after the other each later chunk cost its own memory round trip on the
                     // longest hand-off of the layer (44 KB of granules)
-                    const unsigned hbase = (unsigned)hpar * (unsigned)gh_stride * 8u;
+                    const unsigned hbase = kOGh + (unsigned)hpar * (unsigned)gh_stride * 8u;
                     int lh = lane_v;
                     asm volatile("" : "+v"(lh));  // addresses of this block are computed here, not hoisted and spilled
                 if constexpr (FMT == 3 && MI355_F8_HLATE) {
@@ -1986,18 +1984,18 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     constexpr std::integral_constant<int, 8> n8{};
                     constexpr std::integral_constant<int, 4> n4{};
                     u32x4 va[8], vb[4];
-                    sweep_issue<8>(rs_gh, hbase, e0, e_end, va, lh);
-                    sweep_issue<4>(rs_gh, hbase, e0 + 512, e_end, vb, lh);
-                    sweep<8, true>(p, rs_gh, hbase, e0, e_end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
+                    sweep_issue<8>(rs_ws, hbase, e0, e_end, va, lh);
+                    sweep_issue<4>(rs_ws, hbase, e0 + 512, e_end, vb, lh);
+                    sweep<8, true>(p, rs_ws, hbase, e0, e_end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
                     FS_GCOUNT(44);
                     stage_c(va, n8, e0, e_end);
-                    sweep_issue<8>(rs_gh, hbase, l0, l_end, va, lh);  // (waits below, behind the early chunks)
-                    sweep<4, true>(p, rs_gh, hbase, e0 + 512, e_end, eph, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep_issue<8>(rs_ws, hbase, l0, l_end, va, lh);  // (waits below, behind the early chunks)
+                    sweep<4, true>(p, rs_ws, hbase, e0 + 512, e_end, eph, vb, 0x500u + edge, lh, nullptr, true);
                     stage_c(vb, n4, e0 + 512, e_end);
-                    sweep_issue<4>(rs_gh, hbase, e0 + 768, e_end, vb, lh);
-                    sweep<4, true>(p, rs_gh, hbase, e0 + 768, e_end, eph, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep_issue<4>(rs_ws, hbase, e0 + 768, e_end, vb, lh);
+                    sweep<4, true>(p, rs_ws, hbase, e0 + 768, e_end, eph, vb, 0x500u + edge, lh, nullptr, true);
                     stage_c(vb, n4, e0 + 768, e_end);
-                    sweep<8, true>(p, rs_gh, hbase, l0, l_end, eph, va, 0x500u + edge, lh, nullptr, true);
+                    sweep<8, true>(p, rs_ws, hbase, l0, l_end, eph, va, 0x500u + edge, lh, nullptr, true);
                     stage_c(va, n8, l0, l_end);
                 } else {
 #if MI355_FUSED_HSWEEP == 3
@@ -2011,15 +2009,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         }
                     };
                     const int c1 = first + 512, c2 = first + 1024;
-                    sweep_issue<8>(rs_gh, hbase, first, end, va, lh);
-                    sweep_issue<8>(rs_gh, hbase, c1, end, vb, lh);
-                    sweep_issue<8>(rs_gh, hbase, c2, end, vc, lh);
-                    sweep<8, FMT == 3>(p, rs_gh, hbase, first, end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
+                    sweep_issue<8>(rs_ws, hbase, first, end, va, lh);
+                    sweep_issue<8>(rs_ws, hbase, c1, end, vb, lh);
+                    sweep_issue<8>(rs_ws, hbase, c2, end, vc, lh);
+                    sweep<8, FMT == 3>(p, rs_ws, hbase, first, end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
                     FS_GCOUNT(44);
                     stage8(va, first);
-                    sweep<8, FMT == 3>(p, rs_gh, hbase, c1, end, eph, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep<8, FMT == 3>(p, rs_ws, hbase, c1, end, eph, vb, 0x500u + edge, lh, nullptr, true);
                     stage8(vb, c1);
-                    sweep<8, FMT == 3>(p, rs_gh, hbase, c2, end, eph, vc, 0x500u + edge, lh, nullptr, true);
+                    sweep<8, FMT == 3>(p, rs_ws, hbase, c2, end, eph, vc, 0x500u + edge, lh, nullptr, true);
                     stage8(vc, c2);
                 }
 #else
@@ -2040,18 +2038,18 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         }
                     };
                     const int c1 = first + 512, c2 = first + 768, c3 = first + 1280;
-                    sweep_issue<8>(rs_gh, hbase, first, end, va, lh);
-                    sweep_issue<4>(rs_gh, hbase, c1, end, vb, lh);
-                    sweep<8, FMT == 3>(p, rs_gh, hbase, first, end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
+                    sweep_issue<8>(rs_ws, hbase, first, end, va, lh);
+                    sweep_issue<4>(rs_ws, hbase, c1, end, vb, lh);
+                    sweep<8, FMT == 3>(p, rs_ws, hbase, first, end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
                     FS_GCOUNT(44);
                     stage_a(first);
-                    sweep_issue<8>(rs_gh, hbase, c2, end, va, lh);
-                    sweep<4, FMT == 3>(p, rs_gh, hbase, c1, end, eph, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep_issue<8>(rs_ws, hbase, c2, end, va, lh);
+                    sweep<4, FMT == 3>(p, rs_ws, hbase, c1, end, eph, vb, 0x500u + edge, lh, nullptr, true);
                     stage_b(c1);
-                    sweep_issue<4>(rs_gh, hbase, c3, end, vb, lh);
-                    sweep<8, FMT == 3>(p, rs_gh, hbase, c2, end, eph, va, 0x500u + edge, lh, nullptr, true);
+                    sweep_issue<4>(rs_ws, hbase, c3, end, vb, lh);
+                    sweep<8, FMT == 3>(p, rs_ws, hbase, c2, end, eph, va, 0x500u + edge, lh, nullptr, true);
                     stage_a(c2);
-                    sweep<4, FMT == 3>(p, rs_gh, hbase, c3, end, eph, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep<4, FMT == 3>(p, rs_ws, hbase, c3, end, eph, vb, 0x500u + edge, lh, nullptr, true);
                     stage_b(c3);
                 }
 #endif
@@ -2172,7 +2170,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     }
                     if (bid == 0) {
                         u32x4 v[4];
-                        const bool ok = sweep<4>(p, rs_gm, 0u, 0, 256, ep, v, 0x600u + edge, lane_v);
+                        const bool ok = sweep<4>(p, rs_ws, kOGm, 0, 256, ep, v, 0x600u + edge, lane_v);
                         float bv = -INFINITY;
                         int bx = 0x7fffffff;
 #pragma unroll

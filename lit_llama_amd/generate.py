@@ -74,9 +74,9 @@ def generate(
 
 
 # The persistent step records a hand-off that left the range of its format; the host learns of it at its next status read.  The loops
-# below read every CHECK_EVERY tokens (one 16-byte device->host read: ~20 us against ~58 ms of decoding) and at their end, so a clip
+# below read every CHECK_EVERY tokens (one 16-byte device->host read: ~30 us against ~14 ms of decoding) and at their end, so a clip
 # costs at most that many recomputed steps — not the rest of a long generation.
-CHECK_EVERY = 64
+CHECK_EVERY = 16
 
 
 def _replay_from(eng, bad: int):

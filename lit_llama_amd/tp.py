@@ -193,10 +193,16 @@ class NativeComm:
         check(lib().mi355_tp_step_begin(C.byref(self.c), stream.cuda_stream), "mi355_tp_step_begin")
         self._call = 0
 
-    def reduce_add(self, shard, T: int) -> None:
-        """x[:T] += sum over ranks of partial[:T]  (all-reduce + residual add of model.py:166-167 in one launch)."""
+    def reduce_add(self, shard, T: int, force: bool = False) -> None:
+        """x[:T] += sum over ranks of partial[:T]  (all-reduce + residual add of model.py:166-167 in one launch).
+        World 1: nothing to exchange — the engine's row-parallel segments accumulate into the residual stream themselves when
+        tp_world == 1 (csrc/engine.hip run_segment), `partial` stays zero, and the 2 x n_layer launches per token would add that
+        zero (round 5: 160 launches = 1.4 of 7.8 ms per 65B token on one GPU); `force` issues them anyway (bench.py times the
+        collective alone with it)."""
         from ._native import check, lib
 
+        if self.world == 1 and not force:
+            return
         eng = shard.eng
         n = T * eng.cfg.n_embd
         if n > self.c.slot_floats:  # prompt chunks: row by row (decode, the case that matters, is one row)
