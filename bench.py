@@ -532,6 +532,7 @@ def main():
         lit_llama_amd.generate(model, prompt, gen_new, temperature=0.8, top_k=200, max_seq_length=T + gen_new)
         torch.cuda.synchronize(dev)
         t_samp = time.perf_counter() - t_s0
+        demotions = [f"{why} -> {to} (from position {bad})" for why, to, bad in getattr(eng, "fused_demotions", [])]
         # prompt prefill at the reference's evaluation length (evaluate/full.py:120-129: T = 2048): wide int4 GEMM +
         # flash attention, MFMA-bound
         prefill = None
@@ -680,6 +681,9 @@ def main():
         "prefill": prefill,
         "generate": {"tokens_per_s_incl_prompt": round(gen_new / t_gen, 1), "sampled_tokens_per_s_incl_prompt": round(gen_new / t_samp, 1),
                      "prompt_len": T, "new_tokens": gen_new,
+                     # (the random bench model leaves the fp8 hand-off's range on some SAMPLED tokens: the engine then moves to fp16 operands
+                     # and generate() recomputes from the clipped position — the sampled figure includes that replay when it happened)
+                     "hand_off_demotions": demotions,
                      "what": "lit_llama_amd.generate(top_k=1) wall time incl. prefill, as generate.py:146-153 reports"},
     }
     if tp_res is not None:
