@@ -70,12 +70,16 @@ constexpr unsigned kSpinLimit = 400000u;
 #define MI355_FUSED_PROXY_NOB 0  // MEASUREMENT ONLY (wrong results): the int4 streamers read their B operands once per phase — what do the LDS reads cost?
 #endif
 #ifndef MI355_FUSED_VSPLIT
-#define MI355_FUSED_VSPLIT 0  // c_attn epilogue: gatherer 1 dequantises and publishes the v rows (int4 streams; A / B knob: 926 vs 935 us per
-                              // step with 4-KiB partial tiles on one box, 928.5 vs 921.4 with whole tiles on another — off)
+#define MI355_FUSED_VSPLIT 1  // c_attn epilogue: gatherer 1 dequantises and publishes the v rows (int4 streams).  Round 4, fp16 operands: 926 vs
+                              // 935 us per step on one box, 928.5 vs 921.4 on another (off).  Round 5, fp8 operands (the epilogue is a larger
+                              // share of a shorter phase): 900.9 / 899.0 against 904.7 / 908.3, two rounds on one box (profiles/r05_ab5_*.txt): on
 #endif
 #ifndef MI355_FUSED_EARLY_BURST
 #define MI355_FUSED_EARLY_BURST 1  // (same box, two rounds, profiles/r05_early_burst_ab.txt: bf16 454.8 -> 459.5 tok/s, llm.int8 719.7 -> 727.4)
                                    // BF16 / LLM.int8 streams: request a phase's first ring turn in front of the previous phase's publish barrier
+#endif
+#ifndef MI355_FUSED_POW2RCP
+#define MI355_FUSED_POW2RCP 1  // x_scale is a power of two: 1 / x_scale = the float with the mirrored exponent (exact; saves an IEEE division per epilogue)
 #endif
 #ifndef MI355_FUSED_GPRIO
 #define MI355_FUSED_GPRIO 0
@@ -1572,7 +1576,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             // ================= c_attn
             const int nq = (head * 8 + hj) * 16 + 2 * pg;  // q rows of this lane's pair; k at + C, v at + 2 C
             float2 sc[3], zr[3];
-            constexpr bool VSPLIT = MI355_FUSED_VSPLIT && FMT == 0;
+            constexpr bool VSPLIT = MI355_FUSED_VSPLIT && (FMT == 0 || FMT == 3);
             if (gw == 0 || VSPLIT) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
@@ -1619,7 +1623,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             FS_FSTAMP(56);
             if (gw == 0) {
                 rinv_seen = misc[0];
-                const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;  // (int8 streams: 1/rms is inside the quantised operand)
+                const float rinv = FMT == 2 ? 1.f : MI355_FUSED_POW2RCP ? rinv_seen * __uint_as_float(0x7F000000u - __float_as_uint(x_scale)) : rinv_seen / x_scale;  // (int8 streams: 1/rms is inside the quantised operand)
                 const float2 sx = get_sums();
                 float2 y[3];
 #pragma unroll
@@ -1881,7 +1885,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 u64* dst = p.gh + (size_t)hpar * gh_stride;  // the pair granules of this parity (the operand-sum partials sit behind them)
                 [[maybe_unused]] float hsum = 0.f;
                 rinv_seen = misc[0];
-                const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;
+                const float rinv = FMT == 2 ? 1.f : MI355_FUSED_POW2RCP ? rinv_seen * __uint_as_float(0x7F000000u - __float_as_uint(x_scale)) : rinv_seen / x_scale;
                 float2 sx = {0.f, 0.f};
                 if constexpr (FMT != 3) sx = get_sums();
 #pragma unroll
@@ -2114,7 +2118,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             __syncthreads();  // B1
             post_b1();
             rinv_seen = misc[0];
-            const float rinv = FMT == 2 ? 1.f : rinv_seen / x_scale;
+            const float rinv = FMT == 2 ? 1.f : MI355_FUSED_POW2RCP ? rinv_seen * __uint_as_float(0x7F000000u - __float_as_uint(x_scale)) : rinv_seen / x_scale;
             float2 sx = {0.f, 0.f};
             if constexpr (FMT != 3) sx = get_sums();
             float best = -INFINITY;
