@@ -70,9 +70,11 @@ constexpr unsigned kSpinLimit = 400000u;
 #define MI355_FUSED_PROXY_NOB 0  // MEASUREMENT ONLY (wrong results): the int4 streamers read their B operands once per phase — what do the LDS reads cost?
 #endif
 #ifndef MI355_FUSED_VSPLIT
-#define MI355_FUSED_VSPLIT 1  // c_attn epilogue: gatherer 1 dequantises and publishes the v rows (int4 streams).  Round 4, fp16 operands: 926 vs
-                              // 935 us per step on one box, 928.5 vs 921.4 on another (off).  Round 5, fp8 operands (the epilogue is a larger
-                              // share of a shorter phase): 900.9 / 899.0 against 904.7 / 908.3, two rounds on one box (profiles/r05_ab5_*.txt): on
+#define MI355_FUSED_VSPLIT 2  // c_attn epilogue (int4 streams): 1 = gatherer 1 dequantises and publishes the v rows, 2 = the k rows (RoPE) as well —
+                              // gatherer 0 keeps q.  Round 4, fp16 operands, 1: 926 vs 935 us per step on one box, 928.5 vs 921.4 on another (off).
+                              // Round 5, fp8 operands (the epilogue is a larger share of a shorter phase), profiles/r05_ab5_*.txt: 1 against 0:
+                              // 900.9 / 899.0 vs 904.7 / 908.3 and 902.7 / 897.0 / 896.3 vs 906.4 / 904.8 / 906.8; 2 against 1: 902.5 / 904.1 /
+                              // 904.2 vs 904.3 / 909.2 / 910.2 (alternating rounds on one box each)
 #endif
 #ifndef MI355_FUSED_EARLY_BURST
 #define MI355_FUSED_EARLY_BURST 1  // (same box, two rounds, profiles/r05_early_burst_ab.txt: bf16 454.8 -> 459.5 tok/s, llm.int8 719.7 -> 727.4)
@@ -1614,6 +1616,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 bf16_t* vrow = kv_l + ((size_t)head * p.S + pos) * kHs + hj * 16 + (size_t)kHeads * p.S * kHs;
                 if (w8 == 3) gr_store(dst + 24 + pg, ebase + edge, vp);
                 if (w8 == 5) ((unsigned*)vrow)[pg] = vp;
+                if constexpr (MI355_FUSED_VSPLIT == 2) {  // ... and the k rows (RoPE, model.py:306-323): gatherer 0 keeps q only
+                    const float2 yk = deq(tile_pair(1), sc[1], zr[1], sx);
+                    const float kx = yk.x * rinv1, ky = yk.y * rinv1;
+                    const unsigned kp = bfpair(kx * cs.x - ky * cs.y, ky * cs.x + kx * cs.y);
+                    if (w8 == 2) gr_store(dst + 16 + pg, ebase + edge, kp);
+                    if (w8 == 4) ((unsigned*)(vrow - (size_t)kHeads * p.S * kHs))[pg] = kp;
+                }
             }
 #ifdef MI355_FUSED_FINE_STAMPS
 #define FS_FSTAMP(i) FS_GSTAMP(i)  /* diagnostic build: where the c_attn epilogue's time goes (slots 56..59) */
@@ -1627,7 +1636,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 const float2 sx = get_sums();
                 float2 y[3];
 #pragma unroll
-                for (int r = 0; r < (VSPLIT ? 2 : 3); ++r) {
+                for (int r = 0; r < (VSPLIT ? (MI355_FUSED_VSPLIT == 2 ? 1 : 2) : 3); ++r) {
                     if constexpr (FMT == 2) y[r] = tile_deq8(r, sc[r], wl8 + p.off_attn, kUnitsC, 1, 0, nq + r * kC, pb0[r], pb1[r]);
                     else y[r] = deq(tile_pair(r), sc[r], zr[r], sx);
                     y[r].x *= rinv;
@@ -1640,12 +1649,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 bf16_t* krow = kv_l + ((size_t)head * p.S + pos) * kHs + hj * 16;
                 bf16_t* vrow = krow + (size_t)kHeads * p.S * kHs;
                 const float qa = y[0].x * cs.x - y[0].y * cs.y, qb = y[0].y * cs.x + y[0].x * cs.y;
-                const unsigned kp = bfpair(y[1].x * cs.x - y[1].y * cs.y, y[1].y * cs.x + y[1].x * cs.y);
                 FS_FSTAMP(58);
                 if (w8 == 0) gr_store(dst + 2 * pg, ep, __float_as_uint(qa));
                 if (w8 == 1) gr_store(dst + 2 * pg + 1, ep, __float_as_uint(qb));
-                if (w8 == 2) gr_store(dst + 16 + pg, ep, kp);
-                if (w8 == 4) ((unsigned*)krow)[pg] = kp;
+                if constexpr (!(VSPLIT && MI355_FUSED_VSPLIT == 2)) {
+                    const unsigned kp = bfpair(y[1].x * cs.x - y[1].y * cs.y, y[1].y * cs.x + y[1].x * cs.y);
+                    if (w8 == 2) gr_store(dst + 16 + pg, ep, kp);
+                    if (w8 == 4) ((unsigned*)krow)[pg] = kp;
+                }
                 if constexpr (!VSPLIT) {
                     const unsigned vp = bfpair(y[2].x, y[2].y);
                     if (w8 == 3) gr_store(dst + 24 + pg, ep, vp);
