@@ -297,7 +297,7 @@ __device__ __forceinline__ unsigned piece_off(const PhaseW& ph, int gstep, int r
 // and the same two masks on x >> 8 give nibbles 2 / 6 and 16 x nibbles 3 / 7: one shift + four v_and_or_b32 (the bf16
 // form, 7-bit mantissa, needed a shift per nibble position: 7 ops).  The factor 16 is undone on the activation side:
 // the producers publish every ODD pair of the activation vector divided by 16 (exact in fp16), and the epilogue
-// subtracts 1024 (S_even + S_odd) + zero (S_even + 16 S_odd) with the two sums taken while the vector is staged.
+// subtracts (zero - 8) (S_even + 16 S_odd) with the two sums taken while the vector is staged (the operands are centred: nib_center).
 // With literal constants hipcc emits v_and + v_or (a gfx9 VOP3 cannot carry two literals); with the masks in SGPRs and
 // the exponent pattern in a VGPR whose values the compiler cannot see, it selects v_and_or_b32 itself (and pads the
 // VALU -> MFMA hazard, which an inline-asm v_and_or_b32 does not get: that variant produced NaNs).
@@ -305,6 +305,15 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 __device__ __forceinline__ uint32_t nib2f16(uint32_t x, uint32_t mask_s, uint32_t magic_v) { return (x & mask_s) | magic_v; }
+// ... and ONE v_pk_add_f16 per dword takes the exponent pattern's offset out again together with the centre of the int4 range:
+// (1024 + q) - 1032 = q - 8 and (1024 + 16 q) - 1152 = 16 (q - 8), both exact.  Round 5: with the offsets left in (rounds 2-4) the epilogue's
+// y = scale (acc - 1024 S - zero S') is a cancellation whose error grows with the LARGEST activation — acc carries 1024 x_max in f32 —
+// and a checkpoint with LLaMA's massive activations (SwiGLU outputs of 10^4 next to a median of 10^-3: tests/golden/cfg2_7b_int4_real)
+// lost the whole output of its mlp.c_proj to it (scripts/sim_operand_arith.py: 0.06 logit-std at full depth against 0.004 for exact
+// zero points; measured on the GPU 0.108).  What is left is y = scale (acc - (zero - 8) S') with |zero - 8| of a few units.
+__device__ __forceinline__ uint32_t nib_center(uint32_t pair, f16x2 c) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, pair) - c);
+}
 __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rs_null, bool ok,
                                            unsigned lane_off, unsigned soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rs : rs_null, lane_off, ok ? soff : 0u, 2));
@@ -403,6 +412,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         asm volatile("" : "+v"(magic));  // opaque register values (see nib2f16)
         asm volatile("" : "+s"(nmask));
         asm volatile("" : "+s"(nmask16));
+        [[maybe_unused]] const f16x2 zc1 = {(_Float16)1032.0f, (_Float16)1032.0f}, zc16 = {(_Float16)1152.0f, (_Float16)1152.0f};
         u32x4 ring[kRing];
         int buf = 0;
         // FMT 3: nibble mask, this lane's limb plane (+ its lane group's 32 bytes of a unit) and block-scale step, the all-ones operand
@@ -549,10 +559,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                                 const uint32_t v__ = ring[s__ * R__ + r__][d__];                                      \
                                 const uint32_t v8__ = v__ >> 8;                                                       \
                                 u32x4 a__;                                                                            \
-                                a__[0] = nib2f16(v__, nmask, magic);                                                  \
-                                a__[1] = nib2f16(v__, nmask16, magic);                                                \
-                                a__[2] = nib2f16(v8__, nmask, magic);                                                 \
-                                a__[3] = nib2f16(v8__, nmask16, magic);                                               \
+                                a__[0] = nib_center(nib2f16(v__, nmask, magic), zc1);                                 \
+                                a__[1] = nib_center(nib2f16(v__, nmask16, magic), zc16);                              \
+                                a__[2] = nib_center(nib2f16(v8__, nmask, magic), zc1);                                \
+                                a__[3] = nib_center(nib2f16(v8__, nmask16, magic), zc16);                             \
                                 acc__[r__][d__ & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                         \
                                     __builtin_bit_cast(f16x8, a__), b__[d__], acc__[r__][d__ & 1], 0, 0, 0);          \
                             }                                                                                         \
@@ -572,17 +582,17 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
                         const bool col0__ = MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u;                       \
                         if constexpr (GRP) {                                                                          \
-                            /* column c holds group gfirst + c: y = s (acc - 1024 (Se + So) - z (Se + 16 So)) with    */ \
+                            /* column c holds group gfirst + c: y = s (acc - (z - 8) (Se + 16 So)) with                */ \
                             /* the group's operand sums (units of the group), then the 16 columns are added up        */ \
                             const float se__ = gse__, so__ = gso__; /* (0 in the columns past the wave's groups) */   \
-                            const float ga__ = 1024.f * (se__ + so__), gb__ = se__ + 16.f * so__;                     \
+                            const float gb__ = se__ + 16.f * so__; /* (operands are q - 8: see nib_center) */         \
                             _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                   \
                                 const f32x4 a4__ = acc__[r__][0] + acc__[r__][1];                                     \
                                 f32x4 y4__;                                                                           \
                                 _Pragma("unroll") for (int e__ = 0; e__ < 4; ++e__) {                                 \
                                     const uint32_t w__ = tab__[r__][e__];                                             \
                                     const float sc__ = __uint_as_float(w__ << 16), zp__ = __uint_as_float(w__ & 0xffff0000u); \
-                                    y4__[e__] = group_sum(sc__ * (a4__[e__] - ga__ - zp__ * gb__), 16);               \
+                                    y4__[e__] = group_sum(sc__ * (a4__[e__] - (zp__ - 8.f) * gb__), 16);              \
                                 }                                                                                     \
                                 if (col0__) pp__[r__ * (kPartTile / 16)] = y4__;                                                     \
                                 acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                            \
@@ -1275,8 +1285,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             *(unsigned*)(smem + kF8P2 + (size_t)i * 4) = __builtin_amdgcn_perm(v[3], v[1], 0x05040100u);  // l2: low halves of dwords 1 / 3
         };
         // sums of the staged operands, even pairs in .x and odd pairs in .y (one v_dot2_f32_f16 per dword).  They undo
-        // the +1024 / zero-point offsets of the int4 operands:
-        //   y = scale (acc - 1024 (S_even + S_odd) - zero (S_even + 16 S_odd));
+        // what is left of the zero point behind the centred int4 operands (q - 8, nib_center):
+        //   y = scale (acc - (zero - 8) (S_even + 16 S_odd));
         // every workgroup needs the same sums, so they are taken while the vector is staged instead of by all-ones
         // MFMAs in every streamer wave.
         const f16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
@@ -1304,8 +1314,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 const f32x4 sa = *(const f32x4*)(misc + 32), sb = *(const f32x4*)(misc + 36);
                 return float2{0.f, ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sb[0] + sb[1]) + (sb[2] + sb[3]))};
             }
+            // (FMT 0: the streamers' operands are q - 8, so the term left is (zero - 8) S: `deq`)
             const float se = misc[4] + misc[5], so = misc[6] + misc[7];
-            return float2{1024.f * (se + so), se + 16.f * so};
+            return float2{0.f, se + 16.f * so};
         };
         bool dbg_on = false;
 #define FS_GSTAMP(i)                                                                              \
@@ -1449,7 +1460,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         };
         auto deq = [&](float2 t, float2 sc_, float2 z_, float2 sx) {
             if constexpr (GRP || FMT == 1 || FMT == 2) return t;  // the streamers applied the group scales / unquantised weights
-            return float2{sc_.x * (t.x - sx.x - z_.x * sx.y), sc_.y * (t.y - sx.x - z_.y * sx.y)};
+            constexpr float zc = FMT == 0 ? 8.f : 0.f;  // the centre the fp16 operands already carry (nib_center)
+            return float2{sc_.x * (t.x - sx.x - (z_.x - zc) * sx.y), sc_.y * (t.y - sx.x - (z_.y - zc) * sx.y)};
         };
 
         // ---- LLM.int8 streams (FMT 2): what the gatherers add to the protocol.  After B1 the streamers quantise (FS_RUN_8): one more

@@ -39,7 +39,15 @@ PROBES = (np.arange(64) * (32000 // 64) + 7) % 32000
 # absolute regression bars in logit-std on top of the calibrated one (half the reference's own bf16 distance is
 # 0.157 std on the 400-token fixture against a measured 0.025 — a 6x regression would have passed).  Measured in round 4: 0.016 / 0.017 /
 # 0.025 / (s1: first GPU run in the driver's suite, no number recorded); the launch-per-operator path 0.024 / 0.024 / 0.025.
-ABS_BAR = {"cfg2_7b_int4": 0.03, "cfg2_7b_int4_long": 0.04, "cfg2_7b_int4_p400": 0.04, "cfg2_7b_int4_s1": 0.04, "cfg2_7b_int4_real": 0.04}
+ABS_BAR = {"cfg2_7b_int4": 0.03, "cfg2_7b_int4_long": 0.04, "cfg2_7b_int4_p400": 0.04, "cfg2_7b_int4_s1": 0.04, "cfg2_7b_int4_real": 0.07}
+# The LLaMA-statistics fixture (round 5) is judged against the reference's own bf16 run AS IT IS (0.0703 std), not against half of it:
+# with massive activations next to a median of 10^-3, the 8 significant bits of a bf16 operand cost 0.04-0.054 std at full depth even
+# when everything else is exact (scripts/sim_operand_arith.py, `bf16:exact`: the oracle with the inputs of its linears rounded to
+# bf16; `f16:exact` 0.004) — that IS the reference's GPU arithmetic (bf16 operands, quantization.py:187-333), and the prompt pass and
+# the launch-per-operator step stage their operands in bf16 like it.  On top of the absolute bar the fused rungs may not be worse than
+# the launch-per-operator rung by more than 0.015 std (they were, by 0.058, while their fp16 operands still carried a +1024 offset).
+REL_BAR = {"cfg2_7b_int4_real": 1.0}
+FUSED_OVER_LAUNCH = 0.015
 
 
 @torch.no_grad()
@@ -80,6 +88,7 @@ def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures, record=None):
     model.eval()
     eng = model.engine()
     assert eng is not None, model._engine_failed
+    failures = []
     rungs = [("launch", None)]
     if eng.fused is not None:
         top = eng._fused_top_fmt
@@ -92,7 +101,8 @@ def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures, record=None):
         std = float(g["std"].mean())
         ref_dist = float(ref_bf16["max_dist_std"])  # the reference's own bf16 run vs its f32 run, in logit std
         assert 0.02 < ref_dist < 0.5
-        tol = min(0.5 * ref_dist, ABS_BAR[name]) * std
+        tol = min(REL_BAR.get(name, 0.5) * ref_dist, ABS_BAR[name]) * std
+        measured = {}
         def set_rung(fmt):
             eng.reset_fused_format()
             if fmt is None:
@@ -128,7 +138,10 @@ def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures, record=None):
                        per_step_dist_std=[round(float(v), 5) for v in per_step], ref_bf16_dist_std=round(ref_dist, 5),
                        bar_std=round(tol / std, 5), recomputed_steps=[[i, p, to] for i, p, to in demoted],
                        clipped_pairs=int(eng.fused_clipped))
-            assert err <= tol, f"{name} {label}: 7B logits off by {err:.4f} = {err / std:.4f} std (tol {tol / std:.4f} std)"
+            measured[label] = err / std
+            if err > tol:  # (collected: every rung's numbers are recorded before the test fails)
+                failures.append(f"{name} {label}: 7B logits off by {err:.4f} = {err / std:.4f} std (tol {tol / std:.4f} std)")
+                continue
             assert np.abs(logits.std(-1).numpy() - g["std"]).max() <= 0.02 * std
             decisive = g["margin"] > 2 * tol
             assert np.array_equal(logits.argmax(-1).numpy()[decisive], g["argmax"][decisive])
@@ -161,7 +174,11 @@ def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures, record=None):
                   f"min margin {g['margin'].min():.3f}; recomputed steps {demoted}; generate() demotions {eng.fused_demotions}")
             eng.fused_demotions.clear()
             eng.fused_clipped = 0
+        for label, v in measured.items():
+            if label != "launch" and v > measured["launch"] + FUSED_OVER_LAUNCH:
+                failures.append(f"{name} {label}: {v:.4f} std, the launch-per-operator rung {measured['launch']:.4f}")
     eng.reset_fused_format()
+    assert not failures, failures
 
 
 @torch.no_grad()

