@@ -445,3 +445,50 @@ def test_fp8_operand_linear_arithmetic_statement():
         assert np.array_equal(a_op, q)
         assert e8 <= 1.25 * e16 + 1e-6, (K, e8, e16)
         assert e8 < 2e-3
+
+
+def test_fp16_centred_operand_statement_and_massive_activations():
+    """The fp16-operand rung of the persistent step (csrc/fused_step_ring.hip FMT 0, `nib2f16` + `nib_center`) stated in numpy, bit for bit:
+    (w & 0x000F000F) | 0x64006400 is the fp16 pair (1024 + q_a, 1024 + q_b), (w & 0x00F000F0) | 0x64006400 the pair (1024 + 16 q, ...); one packed
+    fp16 subtraction of 1032 / 1152 leaves q - 8 and 16 (q - 8) EXACTLY.  And why round 5 added that subtraction: with an activation vector that
+    holds a massive value (a SwiGLU output of 10^4 next to a median of 10^-3, tests/golden/cfg2_7b_int4_real) the offset form
+    y = s (sum (1024 + q) x - (1024 + z) sum x), accumulated in f32 per 32-column MFMA, loses an int4 linear's whole output to the cancellation;
+    the centred form y = s (sum (q - 8) x - (z - 8) sum x) keeps it to the operand rounding."""
+    rng = np.random.default_rng(5)
+    # (1) bit patterns: every pair of nibbles of a dword
+    w = rng.integers(0, 2 ** 32, size=4096, dtype=np.uint64).astype(np.uint32)
+    for shift in (0, 8):
+        v = w >> np.uint32(shift)
+        lo = ((v & np.uint32(0x000F000F)) | np.uint32(0x64006400)).view(np.float16).reshape(-1, 2).astype(np.float64)
+        hi = ((v & np.uint32(0x00F000F0)) | np.uint32(0x64006400)).view(np.float16).reshape(-1, 2).astype(np.float64)
+        q_lo = np.stack([(v >> np.uint32(0)) & 15, (v >> np.uint32(16)) & 15], axis=1).astype(np.float64)
+        q_hi = np.stack([(v >> np.uint32(4)) & 15, (v >> np.uint32(20)) & 15], axis=1).astype(np.float64)
+        assert np.array_equal(lo, 1024.0 + q_lo) and np.array_equal(hi, 1024.0 + 16.0 * q_hi)
+        c_lo = (lo.astype(np.float16) - np.float16(1032.0)).astype(np.float64)   # v_pk_add_f16: one fp16 rounding, none needed
+        c_hi = (hi.astype(np.float16) - np.float16(1152.0)).astype(np.float64)
+        assert np.array_equal(c_lo, q_lo - 8.0) and np.array_equal(c_hi, 16.0 * (q_hi - 8.0))
+    # (2) one linear with a massive activation, f32 accumulation per 32 columns (one MFMA), both forms
+    N, K = 64, 11008
+    q = rng.integers(0, 16, size=(N, K)).astype(np.float64)
+    z = rng.integers(6, 10, size=N).astype(np.float64)
+    s = 0.0046 * (1.0 + 0.1 * rng.random(N))
+    x = rng.standard_normal(K) * 1.0e-3
+    massive = int(rng.integers(0, K))
+    x[massive] = 2.0e4
+    q[:, massive] = z  # the massive hidden unit feeds three channels of the model only: the true weight of every other row is 0
+    x16 = x.astype(np.float16).astype(np.float64)
+    exact = s * ((q - z[:, None]) @ x16)
+
+    def mfma_sum(a):  # [N, K] operands against x16: f32 accumulator, one rounding per 32 columns
+        acc = np.zeros(N, dtype=np.float32)
+        for k0 in range(0, K, 32):
+            acc = (acc.astype(np.float64) + a[:, k0:k0 + 32] @ x16[k0:k0 + 32]).astype(np.float32)
+        return acc.astype(np.float64)
+
+    S = float(np.float32(x16.sum()))
+    y_off = s * (mfma_sum(1024.0 + q) - (1024.0 + z) * S)
+    y_cen = s * (mfma_sum(q - 8.0) - (z - 8.0) * S)
+    signal = np.sqrt(np.mean(exact ** 2))
+    err_off, err_cen = np.sqrt(np.mean((y_off - exact) ** 2)), np.sqrt(np.mean((y_cen - exact) ** 2))
+    assert err_off > 0.5 * signal, (err_off, signal)     # the offset form: error of the order of the output itself
+    assert err_cen < 0.02 * signal, (err_cen, signal)    # the centred form: two orders of magnitude below it
