@@ -309,7 +309,7 @@ __device__ __forceinline__ uint32_t nib2f16(uint32_t x, uint32_t mask_s, uint32_
 // (1024 + q) - 1032 = q - 8 and (1024 + 16 q) - 1152 = 16 (q - 8), both exact.  Round 5: with the offsets left in (rounds 2-4) the epilogue's
 // y = scale (acc - 1024 S - zero S') is a cancellation whose error grows with the LARGEST activation — acc carries 1024 x_max in f32 —
 // and a checkpoint with LLaMA's massive activations (SwiGLU outputs of 10^4 next to a median of 10^-3: tests/golden/cfg2_7b_int4_real)
-// lost the whole output of its mlp.c_proj to it (scripts/sim_operand_arith.py: 0.06 logit-std at full depth against 0.004 for exact
+// lost the whole output of its mlp.c_proj to it (oracle/sim_operand_arith.py: 0.06 logit-std at full depth against 0.004 for exact
 // zero points; measured on the GPU 0.108).  What is left is y = scale (acc - (zero - 8) S') with |zero - 8| of a few units.
 __device__ __forceinline__ uint32_t nib_center(uint32_t pair, f16x2 c) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, pair) - c);

@@ -220,10 +220,23 @@ def make_prompt(length: int, vocab: int = 32000, seed: int = 1234, device: str =
     return ids.to(torch.int32).to(device)
 
 
-def fill_model_random_int4(model, seed: int = 0) -> None:
+def fill_model_random_int4(model, seed: int = 0, zero: float = 7.5, gain: float = 1.0) -> None:
     """Bench-only shortcut for multi-GB models: fill every ColBlockQuantizedLinear of a GPU model in place with
-    uniformly random levels, scales (max - min) / 15 of a N(0, 1/K) row (~ 7.2 / sqrt(K) / 15) and zero 8, and
-    the embedding / norm scales as in make_state_dict — without materialising fp32 weights first."""
+    uniformly random levels, the zero point `zero` and scales ~ gain x 0.217 / sqrt(K) (uniform levels have a std of 4.61, so a
+    row's weights have std ~ gain / sqrt(K)), and the embedding / norm scales as in make_state_dict — without materialising fp32
+    weights first.
+
+    Defaults (round 5): zero-MEAN weights of unit gain, i.e. the statistics of make_state_dict's N(0, 1 / K) rows.  Rounds 1-4 used
+    `zero=8.0, gain=2.2` (scale = 7.2 / 15 / sqrt(K), the step of a 16-level grid over a Gaussian row, under UNIFORM levels):
+    * zero 8 puts -0.5 scale on every weight, a common-mode gain of -0.5 scale K ~ -15 on every linear: the 7B model's residual stream
+      is one constant vector that grows by ~6000 per block (mean -1.9 x 10^5 behind block 31, oracle on the CPU), its logits are a
+      common-mode term — every path agrees to 0.007 std on them whatever it does to the rest — and the x edge behind block 1 sits at
+      ~700 x the previous edge's rms, on either side of the +-448 of an fp8-limb hand-off depending on the token: the bench's own SAMPLED
+      generation clipped and was replayed one rung down (403 instead of ~1000 tok/s) while its greedy run happened not to;
+    * zero 7.5 with gain 2.2 is a CHAOTIC random network: 2 blocks sit 0.06 std from the oracle, 32 blocks 0.3-1.1 std from each other
+      on every pair of paths (tests/diag_bench_model_parity.py, profiles/r05_bench_model_zero_point.txt).
+    Timing does not see the values (same box, alternating: 900.7 / 899.2 us per step with zero 8, 907.8 / 901.3 with 7.5).
+    tests/test_fused_step_gpu.py keeps `zero=8.0, gain=2.2` as the stress case it always was."""
     from .quantization import ColBlockQuantizedLinear
 
     dev = model.transformer.wte.weight.device
@@ -237,14 +250,14 @@ def fill_model_random_int4(model, seed: int = 0) -> None:
                 raw = torch.randint(0, 256, (Kb, N), generator=gen, device=dev, dtype=torch.uint8)
                 mod.quant_weight.copy_(raw.t())
                 K = mod.in_features
-                s = (7.2 / 15.0) * K**-0.5 * (1.0 + 0.1 * torch.rand((N, 1), generator=gen, device=dev))
+                s = (7.2 / 15.0) * (gain / 2.2) * K**-0.5 * (1.0 + 0.1 * torch.rand((N, 1), generator=gen, device=dev))
                 mod.scales.copy_(s.to(mod.scales.dtype))
-                mod.zeros.fill_(8.0)
+                mod.zeros.fill_(zero)
             elif name.endswith(("rms_1", "rms_2", "ln_f")):
                 mod.scale.copy_((1.0 + 0.1 * _randn(tuple(mod.scale.shape), gen, dev)).to(mod.scale.dtype))
 
 
-def fill_tp_shard_random_int4(model, seed: int, rank: int) -> None:
+def fill_tp_shard_random_int4(model, seed: int, rank: int, zero: float = 7.5, gain: float = 1.0) -> None:
     """Bench-only: rank-local shard of a synthetic int4 model (tp.build_local_model) filled in place.  Replicated
     tensors (embedding, norm scales, scale / zero of the row-parallel linears) come from a generator seeded the same
     on every rank; sharded tensors from `seed + 1 + rank`."""
@@ -268,6 +281,6 @@ def fill_tp_shard_random_int4(model, seed: int, rank: int) -> None:
                 row_parallel = name.endswith("c_proj")  # attn.c_proj / mlp.c_proj: per-row scale / zero replicated
                 K_full = mod.in_features * (getattr(model.config, "tp_world", 1) if row_parallel else 1)
                 g = shared if row_parallel else local
-                sc = (7.2 / 15.0) * K_full**-0.5 * (1.0 + 0.1 * torch.rand((N, 1), generator=g, device=dev))
+                sc = (7.2 / 15.0) * (gain / 2.2) * K_full**-0.5 * (1.0 + 0.1 * torch.rand((N, 1), generator=g, device=dev))
                 mod.scales.copy_(sc.to(mod.scales.dtype))
-                mod.zeros.fill_(8.0)
+                mod.zeros.fill_(zero)  # (zero-mean weights: see fill_model_random_int4)

@@ -8,7 +8,7 @@ pass (teacher forced); the distance to the fixture's reference logits is printed
 (max |dlogit| over the probe columns / mean logit std).  Nothing here touches the product; it exists so that an arithmetic can be
 priced before a kernel is rewritten for it (NOTES round 5, item 68).
 
-    python scripts/sim_operand_arith.py cfg2_7b_int4_real  bf16:128 bf16:16 bf16:exact f16:1024 f16:exact
+    python oracle/sim_operand_arith.py cfg2_7b_int4_real  bf16:128 bf16:16 bf16:exact f16:1024 f16:exact
 """
 import sys
 import time

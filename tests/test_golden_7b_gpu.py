@@ -42,7 +42,7 @@ PROBES = (np.arange(64) * (32000 // 64) + 7) % 32000
 ABS_BAR = {"cfg2_7b_int4": 0.03, "cfg2_7b_int4_long": 0.04, "cfg2_7b_int4_p400": 0.04, "cfg2_7b_int4_s1": 0.04, "cfg2_7b_int4_real": 0.07}
 # The LLaMA-statistics fixture (round 5) is judged against the reference's own bf16 run AS IT IS (0.0703 std), not against half of it:
 # with massive activations next to a median of 10^-3, the 8 significant bits of a bf16 operand cost 0.04-0.054 std at full depth even
-# when everything else is exact (scripts/sim_operand_arith.py, `bf16:exact`: the oracle with the inputs of its linears rounded to
+# when everything else is exact (oracle/sim_operand_arith.py, `bf16:exact`: the oracle with the inputs of its linears rounded to
 # bf16; `f16:exact` 0.004) — that IS the reference's GPU arithmetic (bf16 operands, quantization.py:187-333), and the prompt pass and
 # the launch-per-operator step stage their operands in bf16 like it.  On top of the absolute bar the fused rungs may not be worse than
 # the launch-per-operator rung by more than 0.015 std (they were, by 0.058, while their fp16 operands still carried a +1024 offset).

