@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--model", default="7B")
-    ap.add_argument("--quantize", default="gptq.int4", choices=["gptq.int4", "llm.int8", "none"])
+    ap.add_argument("--quantize", default="gptq.int4", choices=["gptq.int4", "llm.int8", "none", "gptq.int8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tp-timeout", type=float, default=180.0, help="seconds after which a hanging TP leg is abandoned")
     ap.add_argument("--no-graph", action="store_true")
@@ -76,8 +76,10 @@ def bytes_per_token(cfg, mode: str):
     C_, H, V, L = cfg.n_embd, cfg.n_hidden, cfg.padded_vocab_size, cfg.n_layer
     params = L * (3 * C_ * C_ + C_ * C_ + 3 * C_ * H) + V * C_
     rows = L * (3 * C_ + C_ + 2 * H + C_) + V
-    wbytes = {"gptq.int4": params // 2, "llm.int8": params, "none": params * 2}[mode]
-    side = {"gptq.int4": rows * 4, "llm.int8": rows * 4, "none": 0}[mode]
+    # (gptq.int8: the reference dequantises an 8-bit ColBlock matrix into a bf16 one on every forward call, quantization.py:413-423;
+    # the engine builds it once and streams it — 2 bytes per weight is what a decode step reads)
+    wbytes = {"gptq.int4": params // 2, "llm.int8": params, "none": params * 2, "gptq.int8": params * 2}[mode]
+    side = {"gptq.int4": rows * 4, "llm.int8": rows * 4, "none": 0, "gptq.int8": 0}[mode]
     other = (2 * L + 1) * C_ * 2 + C_ * 2
     return dict(weights=wbytes, total=wbytes + side + other, kv_per_pos=2 * L * C_ * 2)
 
@@ -115,7 +117,7 @@ def build_model(args, dev):
                     w = blk.attn.adapter_wte.weight
                     w.copy_(torch.randn(w.shape, generator=gen_a, device=dev).to(w.dtype))
                     blk.attn.gating_factor.fill_(0.5)
-    if mode == "gptq.int4":
+    if mode in ("gptq.int4", "gptq.int8"):
         synth.fill_model_random_int4(model, seed=0)
     else:
         gen = torch.Generator(device=dev).manual_seed(0)
@@ -483,8 +485,8 @@ def main():
         mean_pos = T + W + K / 2
         # ---- dominant kernel roofline (c_fc1/c_fc2 + SwiGLU)
         C_, H = cfg.n_embd, cfg.n_hidden
-        wb = {"gptq.int4": C_ * H, "llm.int8": 2 * C_ * H, "none": 4 * C_ * H}[args.quantize]
-        side = {"gptq.int4": 2 * 2 * H * 2, "llm.int8": 2 * H * 4, "none": 0}[args.quantize]
+        wb = {"gptq.int4": C_ * H, "llm.int8": 2 * C_ * H, "none": 4 * C_ * H, "gptq.int8": 4 * C_ * H}[args.quantize]
+        side = {"gptq.int4": 2 * 2 * H * 2, "llm.int8": 2 * H * 4, "none": 0, "gptq.int8": 0}[args.quantize]
         algo = wb + side + C_ * 4 + C_ * 2 + H * 2
         traffic, traffic_source = None, None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
@@ -536,7 +538,7 @@ def main():
         # prompt prefill at the reference's evaluation length (evaluate/full.py:120-129: T = 2048): wide int4 GEMM +
         # flash attention, MFMA-bound
         prefill = None
-        if args.quantize in ("gptq.int4", "none") and cfg.block_size >= 2048:
+        if args.quantize in ("gptq.int4", "none", "gptq.int8") and cfg.block_size >= 2048:
             T2 = 2048
             long_prompt = synth.make_prompt(T2, vocab=cfg.vocab_size, seed=4321).to(dev)
             with torch.cuda.stream(eng.stream):
@@ -614,8 +616,8 @@ def main():
         return
     variant = args.adapter or args.group_cols > 0
     default_cfg = args.model == "7B" and args.quantize == "gptq.int4" and not variant
-    cfg_idx = {"none": 1, "gptq.int4": 2, "llm.int8": 3}[args.quantize] if args.model == "7B" and not variant else None
-    wname = {"gptq.int4": "int4", "llm.int8": "int8", "none": "bf16"}[args.quantize]
+    cfg_idx = {"none": 1, "gptq.int4": 2, "llm.int8": 3}.get(args.quantize) if args.model == "7B" and not variant else None
+    wname = {"gptq.int4": "int4", "llm.int8": "int8", "none": "bf16", "gptq.int8": "bf16"}[args.quantize]  # (gptq.int8 streams bf16 matrices: engine._dense_weight)
     out = {
         "metric": METRIC if default_cfg else f"decode tokens/sec/GPU LLaMA-{args.model}{' + LLaMA-Adapter' if args.adapter else ''} "
                                              f"{args.quantize}{' groupsize %d' % args.group_cols if args.group_cols else ''} bs=1; % HBM roofline",
@@ -659,7 +661,7 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": "fused_step_ring_kernel (the whole decode step, one launch per token)" if fused else
-                      {"gptq.int4": "gemv_kernel<Q4,R=2,SwiGLU>", "none": "gemv_kernel<BF16,R=2,SwiGLU>",
+                      {"gptq.int4": "gemv_kernel<Q4,R=2,SwiGLU>", "none": "gemv_kernel<BF16,R=2,SwiGLU>", "gptq.int8": "gemv_kernel<BF16,R=2,SwiGLU>",
                        "llm.int8": "int8_gemv_kernel<R=2>"}[args.quantize] + " (c_fc1/c_fc2 pair)",
             "achieved": round(algo / avg_s / 1e9, 1),
             "peak": HBM_PEAK / 1e9,

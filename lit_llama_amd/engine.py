@@ -49,7 +49,11 @@ def _kind(mod: nn.Module) -> str:
     if getattr(mod, "adapter_scale", None) is not None:
         raise EngineUnavailable("LLaMA-Adapter v2 scale / bias on a linear: such models run op by op")
     if isinstance(mod, ColBlockQuantizedLinear):
-        return "q4"
+        # 8-bit ColBlock (`--quantize gptq.int8`): the reference dequantises the whole matrix into the INPUT's dtype on every forward
+        # call and runs a dense linear on it (lit_llama/quantization.py:376-423: get_weight(dtype=inp.dtype), F.linear).  Here that
+        # bf16 matrix is built ONCE, at engine build, and streamed like any unquantised bf16 linear (`_dense_weight`): the same weight
+        # values bit for bit (q - zero exact in bf16, one rounding of the product with the scale), 2 bytes per weight resident in HBM.
+        return "q4" if mod.bits == 4 else "bf16"
     if isinstance(mod, Linear8bitLt):
         return "i8"
     if type(mod) is nn.Linear or getattr(mod, "_mi355_plain_weight", False):
@@ -57,6 +61,15 @@ def _kind(mod: nn.Module) -> str:
     if hasattr(mod, "lora_A"):
         raise EngineUnavailable("LoRA update not merged into the weight yet: call model.eval()")
     raise EngineUnavailable(f"unsupported linear type {type(mod).__name__}")
+
+
+def _dense_weight(mod: nn.Module) -> torch.Tensor:
+    """The [N, K] matrix of a linear the engine streams as BF16: the parameter itself, or an 8-bit ColBlock's dequantised weight."""
+    from .quantization import ColBlockQuantizedLinear
+
+    if isinstance(mod, ColBlockQuantizedLinear):
+        return mod.get_weight(torch.bfloat16)
+    return mod.weight.detach()
 
 
 def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: Optional[dict] = None,
@@ -118,10 +131,12 @@ def pack_linear(mod: nn.Module, R: int, pair: Optional[nn.Module] = None, tune: 
     else:
         if mod.bias is not None:
             raise EngineUnavailable("bias on a hot-path linear")
-        if mod.weight.dtype != torch.bfloat16:
-            raise EngineUnavailable(f"dense weights are {mod.weight.dtype}; the MFMA path needs bf16")
-        N, K = mod.weight.shape
-        stream = ops.repack_bf16(mod.weight.detach(), pair.weight.detach() if pair is not None else None, d.R, out=out)
+        w0 = _dense_weight(mod)
+        if w0.dtype != torch.bfloat16:
+            raise EngineUnavailable(f"dense weights are {w0.dtype}; the MFMA path needs bf16")
+        N, K = w0.shape
+        stream = ops.repack_bf16(w0, _dense_weight(pair) if pair is not None else None, d.R, out=out)
+        del w0
         d.fmt, d.w, d.N, d.K = W_BF16, ptr(stream), N, K
         pw.keep.append(stream)
     pw.stream_bytes = pw.keep[0].numel()

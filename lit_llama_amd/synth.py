@@ -107,11 +107,12 @@ def make_state_dict(
     group_cols: int = 0,
     stats: str = "unit",
 ) -> Dict[str, torch.Tensor]:
-    """Synthetic checkpoint.  mode None / "llm.int8": float weights in `dtype`; "gptq.int4": packed buffers with
+    """Synthetic checkpoint.  mode None / "llm.int8": float weights in `dtype`; "gptq.int4" / "gptq.int8": packed buffers with
     scales / zeros in `dtype` (one pair per row, or per row and group of `group_cols` input columns: the
     ColBlockQuantizedLinear layout with tile_cols = group_cols, lit_llama/quantization.py:350-374).  With `bf16_exact` every float value is rounded to bf16 once at generation time
     (and stored in `dtype`), so a bf16 GPU model and the f32 CPU oracle hold identical parameters."""
-    assert mode in (None, "gptq.int4", "llm.int8") and stats in ("unit", "llama")
+    assert mode in (None, "gptq.int4", "gptq.int8", "llm.int8") and stats in ("unit", "llama")
+    bits = 8 if mode == "gptq.int8" else 4
     plan = llama_stats_plan(cfg) if stats == "llama" else None
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -160,20 +161,20 @@ def make_state_dict(
                 w[:, hu] = 0.0
                 w[ch] *= plan["row_shrink"]
                 w[ch[:, None], hu[None, :]] = plan["w_massive"]
-        if mode == "gptq.int4" and 0 < group_cols < K:
+        if mode in ("gptq.int4", "gptq.int8") and 0 < group_cols < K:
             ng = -(-K // group_cols)
             q = torch.empty((N, K), dtype=torch.uint8, device=device)
             scale, zero = torch.empty((N, ng), device=device), torch.empty((N, ng), device=device)
             for j in range(ng):
                 sl = slice(j * group_cols, (j + 1) * group_cols)
-                q[:, sl], scale[:, j], zero[:, j] = rtn_quantize_rows(w[:, sl], 4)
-            sd[prefix + ".quant_weight"] = pack_colblock(q, 4)
+                q[:, sl], scale[:, j], zero[:, j] = rtn_quantize_rows(w[:, sl], bits)
+            sd[prefix + ".quant_weight"] = pack_colblock(q, bits)
             sd[prefix + ".scales"] = scale.to(torch.bfloat16).float().to(dtype)
             sd[prefix + ".zeros"] = zero.to(dtype)
-        elif mode == "gptq.int4":
-            q, scale, zero = rtn_quantize_rows(w, 4)
+        elif mode in ("gptq.int4", "gptq.int8"):
+            q, scale, zero = rtn_quantize_rows(w, bits)
             scale = scale.to(torch.bfloat16).float()  # rounded once; identical on both sides
-            sd[prefix + ".quant_weight"] = pack_colblock(q, 4)
+            sd[prefix + ".quant_weight"] = pack_colblock(q, bits)
             sd[prefix + ".scales"] = scale[:, None].to(dtype)
             sd[prefix + ".zeros"] = zero[:, None].to(dtype)
         else:
@@ -250,9 +251,10 @@ def fill_model_random_int4(model, seed: int = 0, zero: float = 7.5, gain: float 
                 raw = torch.randint(0, 256, (Kb, N), generator=gen, device=dev, dtype=torch.uint8)
                 mod.quant_weight.copy_(raw.t())
                 K = mod.in_features
-                s = (7.2 / 15.0) * (gain / 2.2) * K**-0.5 * (1.0 + 0.1 * torch.rand((N, 1), generator=gen, device=dev))
+                maxq = 2 ** mod.bits - 1  # (8-bit ColBlock, `gptq.int8`: a byte is one level, the grid is 16 x finer, its centre 127.5)
+                s = (7.2 / maxq) * (gain / 2.2) * K**-0.5 * (1.0 + 0.1 * torch.rand((N, 1), generator=gen, device=dev))
                 mod.scales.copy_(s.to(mod.scales.dtype))
-                mod.zeros.fill_(zero)
+                mod.zeros.fill_(zero if mod.bits == 4 else 16.0 * zero + 7.5)
             elif name.endswith(("rms_1", "rms_2", "ln_f")):
                 mod.scale.copy_((1.0 + 0.1 * _randn(tuple(mod.scale.shape), gen, dev)).to(mod.scale.dtype))
 

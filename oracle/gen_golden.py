@@ -562,6 +562,9 @@ def main():
     cfg1 = dict(n_layer=2, n_head=4, n_embd=256)
     model_case("cfg1_fp32", cfg1, None, prompt_len=8, new_tokens=24)
     model_case("cfg1_int4", cfg1, "gptq.int4", prompt_len=8, new_tokens=24)
+    # `--quantize gptq.int8` (lit_llama/utils.py:100-102, :150-152: ColBlockQuantizedLinear with bits = 8): the reference dequantises
+    # the whole matrix on every forward call (quantization.py:413-423)
+    model_case("cfg1_int8g", cfg1, "gptq.int8", prompt_len=8, new_tokens=24)
     # the cache-roll regime of tests/test_generate.py:26-54 (max_seq_length < T + max_new_tokens)
     tiny = dict(block_size=128, vocab_size=16, n_layer=1, n_head=4, n_embd=8)
     model_case("tiny_roll", tiny, None, prompt_len=5, new_tokens=20, max_seq_length=10)

@@ -488,6 +488,53 @@ def test_bf16_fused_step_matches_launch_per_operator_engine_and_oracle(dev):
     assert err <= 0.05 * std, f"bf16 fused 7B-width logits off the oracle by {err:.4f} (std {std:.3f})"
 
 
+def test_gptq_int8_model_streams_as_bf16_on_the_persistent_step(dev):
+    """`--quantize gptq.int8` at the 7B width (round 5): the reference dequantises an 8-bit ColBlockQuantizedLinear into a matrix of the
+    input's dtype on EVERY forward call and runs a dense linear on it (lit_llama/quantization.py:413-423); the engine builds that bf16
+    matrix once (engine._dense_weight — the same values bit for bit: q - zero exact, one rounding of the product with the scale) and
+    streams it through the BF16 instantiation of the persistent step.  Checked: the weights the engine streams == the module's own
+    get_weight(bf16) == bf16(oracle dequantisation); persistent step vs launch path 0.03 std; vs the f32 oracle the bf16-path bar."""
+    from lit_llama_amd.quantization import ColBlockQuantizedLinear
+
+    cfg = LLaMAConfig(n_layer=2, **W7B)
+    sd = synth.make_state_dict(cfg, seed=5, mode="gptq.int8")
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int8"):
+        model = LLaMA(cfg)
+    model.load_state_dict(sd)
+    model.eval()
+    lin = model.transformer.h[1].mlp.c_proj
+    assert isinstance(lin, ColBlockQuantizedLinear) and lin.bits == 8
+    w_ref = oracle.colblock_get_weight(sd["transformer.h.1.mlp.c_proj.quant_weight"], sd["transformer.h.1.mlp.c_proj.scales"],
+                                       sd["transformer.h.1.mlp.c_proj.zeros"], 8, lin.tile_cols)
+    assert torch.equal(lin.get_weight(torch.bfloat16).float().cpu(), w_ref.to(torch.bfloat16).float())
+    eng = need_fused(model)
+    assert eng.fused.weight_fmt == 1
+    prompt = synth.make_prompt(20).to(dev)
+    outs, logits = {}, {}
+    for fused in (False, True):
+        eng.fused_enabled = fused
+        model.reset_cache()
+        outs[fused] = lit_llama_amd.generate(model, prompt, 16, top_k=1, max_seq_length=64).cpu()
+        logits[fused] = teacher_forced(model, outs[False].to(dev), 20, 64, dev)
+        eng.check_status()
+    eng.fused_enabled = True
+    std = float(logits[False].std(-1).mean())
+    err = (logits[True] - logits[False]).abs().max().item()
+    assert err <= 0.03 * std, f"gptq.int8 fused vs unfused logits: {err:.4f} (std {std:.3f})"
+    om = oracle.Model(oracle.Config(n_layer=2, **W7B), {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()},
+                      mode="gptq.int8")
+    p5 = synth.make_prompt(5)
+    toks = oracle.generate(om, p5, 4, top_k=1)
+    om.reset_cache()
+    ref = oracle.teacher_forced_logits(om, toks, 5)
+    got = teacher_forced(model, toks.to(dev), 5, 16, dev)
+    eng.check_status()
+    std = float(ref.std(-1).mean())
+    err = (got - ref).abs().max().item()
+    print(f"gptq.int8 on BF16 streams, 2 blocks at the 7B width vs the f32 oracle: {err / std:.4f} std")
+    assert err <= 0.05 * std, f"gptq.int8 7B-width logits off the oracle by {err:.4f} (std {std:.3f})"
+
+
 @pytest.mark.parametrize("T", [257, 700])
 def test_bf16_fused_step_attention_over_several_blocks_and_row_split(dev, T):
     """Positions past one cache block and past the row-split threshold (384), fused vs launch path; bit-reproducible."""

@@ -60,7 +60,7 @@ def teacher_forced(model, toks, T, S, dev):
 
 
 # ---------------------------------------------------------------------------------------------- f32 plumbing config
-@pytest.mark.parametrize("name,mode", [("cfg1_fp32", None), ("cfg1_int4", "gptq.int4")])
+@pytest.mark.parametrize("name,mode", [("cfg1_fp32", None), ("cfg1_int4", "gptq.int4"), ("cfg1_int8g", "gptq.int8")])
 def test_cfg1_f32_tokens_equal_reference(dev, golden, name, mode):
     """BASELINE.json configs[0]: LLaMAConfig(n_layer=2, n_head=4, n_embd=256), greedy, on the GPU in f32."""
     g = golden(name)
@@ -80,7 +80,8 @@ def test_cfg1_f32_tokens_equal_reference(dev, golden, name, mode):
     assert np.abs(full[:, PROBES].numpy() - g["nocache_probes"]).max() <= 2e-4 * float(g["std"].mean())
 
 
-@pytest.mark.parametrize("name,mode,dtype", [("cfg1_fp32", None, torch.float32), ("cfg1_int4", "gptq.int4", torch.bfloat16)])
+@pytest.mark.parametrize("name,mode,dtype", [("cfg1_fp32", None, torch.float32), ("cfg1_int4", "gptq.int4", torch.bfloat16),
+                                             ("cfg1_int8g", "gptq.int8", torch.bfloat16)])
 def test_reference_generate_loop_runs_over_the_gpu_model(dev, golden, name, mode, dtype):
     """Drop-in under generate.py: the REFERENCE's sampling loop (restated line by line in oracle.generate, pinned to
     /root/reference generate.py:20-91 by oracle/gen_golden.py) drives `lit_llama_amd.LLaMA` through nothing but the
@@ -204,8 +205,10 @@ def _free_running_check(out, g, tol):
     return None
 
 
-@pytest.mark.parametrize("name,mode", [("cfg1_fp32", None), ("cfg1_int4", "gptq.int4")])
+@pytest.mark.parametrize("name,mode", [("cfg1_fp32", None), ("cfg1_int4", "gptq.int4"), ("cfg1_int8g", "gptq.int8")])
 def test_cfg1_bf16_engine_teacher_forced_parity(dev, golden, name, mode):
+    """(gptq.int8, round 5: the engine streams the 8-bit ColBlock linears as the bf16 matrices the reference builds on every forward
+    call — lit_llama/quantization.py:413-423 — built once, engine._dense_weight.)"""
     g = golden(name)
     model, _, _ = build(CFG1, mode, torch.bfloat16, dev)
     assert model.engine() is not None, model._engine_failed

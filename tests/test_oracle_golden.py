@@ -79,6 +79,15 @@ def test_cfg1_int4_greedy_tokens_and_logits(golden):
     assert np.allclose(logits[:, probes].numpy(), g["probes"], atol=2e-6, rtol=0)
 
 
+def test_cfg1_int8g_greedy_tokens_and_logits(golden):
+    """`--quantize gptq.int8` (ColBlockQuantizedLinear, bits = 8, lit_llama/utils.py:100-102) through the reference itself on the CPU."""
+    g, om, toks, T, S = _run_case(golden, "cfg1_int8g", CFG1, "gptq.int8")
+    logits = oracle.teacher_forced_logits(om, toks, T, S)
+    probes = (np.arange(64) * (32000 // 64) + 7) % 32000
+    assert np.allclose(logits[:, probes].numpy(), g["probes"], atol=2e-6, rtol=0)
+    assert np.array_equal(logits.argmax(-1).numpy().astype(np.int32), g["argmax"])
+
+
 def test_tiny_model_cache_roll_regime(golden):
     _run_case(golden, "tiny_roll", TINY, None)
     _run_case(golden, "tiny_noroll", TINY, None)
