@@ -492,3 +492,31 @@ def test_fp16_centred_operand_statement_and_massive_activations():
     err_off, err_cen = np.sqrt(np.mean((y_off - exact) ** 2)), np.sqrt(np.mean((y_cen - exact) ** 2))
     assert err_off > 0.5 * signal, (err_off, signal)     # the offset form: error of the order of the output itself
     assert err_cen < 0.02 * signal, (err_cen, signal)    # the centred form: two orders of magnitude below it
+
+
+def test_bench_model_weights_are_zero_mean_with_unit_gain():
+    """synth.fill_model_random_int4 (what bench.py times): uniform levels around the zero point 7.5 (4-bit) / 127.5 (8-bit ColBlock,
+    `--quantize gptq.int8`) with scales that give a row a std of ~1 / sqrt(K) — the statistics of make_state_dict's rows.  Round 5: with the
+    zero point at 8 every linear had a common-mode gain of -0.5 scale K and the 7B model's residual stream was one growing constant
+    vector (profiles/r05_bench_model_zero_point.txt); `zero=8.0, gain=2.2` still builds that model for the stress test."""
+    from lit_llama_amd.quantization import ColBlockQuantizedLinear
+
+    for bits in (4, 8):
+        lin = ColBlockQuantizedLinear(512, 256, bias=False, bits=bits, tile_cols=-1)
+
+        class M(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.transformer = torch.nn.Module()
+                self.transformer.wte = torch.nn.Embedding(16, 8)
+                self.lin = lin
+
+        m = M()
+        synth.fill_model_random_int4(m, seed=0)
+        w = lin.get_weight(torch.float32)
+        assert abs(float(w.mean())) * 512 ** 0.5 < 0.02, (bits, float(w.mean()))          # no common-mode term
+        assert 0.85 < float(w.std()) * 512 ** 0.5 < 1.15, (bits, float(w.std()))           # unit gain
+        synth.fill_model_random_int4(m, seed=0, zero=8.0, gain=2.2)
+        w = lin.get_weight(torch.float32)
+        if bits == 4:  # rounds 1-4: mean -0.5 scale, std 4.6 scale with scale = 0.48 / sqrt(K)
+            assert -0.30 < float(w.mean()) * 512 ** 0.5 < -0.18 and 2.0 < float(w.std()) * 512 ** 0.5 < 2.4
