@@ -258,7 +258,22 @@ class DecodeEngine:
             # The LLM.int8 launches (heavier quantising prologue) stay at one per CU throughout.
             i8 = _kind(first.attn.c_attn) == "i8"
             grids = {} if i8 else {"lm_head": 2 * cus}
-            dflt = lambda key: {"grid": grids.get(key, cus), **self.tune.get(key, {})}  # noqa: E731
+            q4 = _kind(first.attn.c_attn) == "q4"
+
+            def dflt(key):
+                # Round 5 (scripts/sweep_gemv.py over the 13B / 65B shapes, profiles/r05_gemv_geometry_13b_65b.txt): a single-matrix
+                # Q4 launch runs TWO workgroups per CU (or one per tile when there are fewer tiles) whenever that does not raise the
+                # largest number of tiles a CU ends up with — 65B c_attn 22.1 -> 20.5 us, attn.c_proj 9.3 -> 8.8, mlp.c_proj 20.2 -> 19.5;
+                # 13B attn.c_proj 7.8 -> 7.3, mlp.c_proj 12.4 -> 11.6.  Every 7B shape keeps what it had (c_attn: 768 tiles = 3 per CU
+                # against 2 x 2; 256-tile linears: one per CU either way; lm_head 2 x CUs).  The c_fc1 / c_fc2 pair stays at one per CU.
+                g = grids.get(key, cus)
+                if q4 and key in ("attn", "proj", "mproj", "lm_head"):
+                    mod = {"attn": first.attn.c_attn, "proj": first.attn.c_proj, "mproj": first.mlp.c_proj, "lm_head": model.lm_head}[key]
+                    n_tiles = -(-mod.out_features // 16)
+                    g2 = min(n_tiles, 2 * cus)
+                    if 2 * -(-n_tiles // (2 * cus)) <= -(-n_tiles // cus) or n_tiles <= 2 * cus:
+                        g = max(g2, 1)
+                return {"grid": g, **self.tune.get(key, {})}
             kinds = {_kind(m_) for blk in model.transformer.h
                      for m_ in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj)}
             kinds.add(_kind(model.lm_head))

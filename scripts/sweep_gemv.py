@@ -31,6 +31,12 @@ SHAPES_7B = {
     "fc13": (13824, 5120, 2, nat.EPI_SWIGLU),
     "mproj13": (5120, 13824, 1, nat.EPI_ACCUM),
     "lm_head13": (32000, 5120, 1, nat.EPI_STORE),
+    # 65B (n_embd 8192, n_hidden 22016): the model behind configs[4] and bench.py's TP = 1 leg
+    "attn65": (24576, 8192, 1, nat.EPI_STORE),
+    "proj65": (8192, 8192, 1, nat.EPI_ACCUM),
+    "fc65": (22016, 8192, 2, nat.EPI_SWIGLU),
+    "mproj65": (8192, 22016, 1, nat.EPI_ACCUM),
+    "lm_head65": (32000, 8192, 1, nat.EPI_STORE),
 }
 
 
