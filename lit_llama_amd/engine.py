@@ -271,7 +271,9 @@ class DecodeEngine:
                     mod = {"attn": first.attn.c_attn, "proj": first.attn.c_proj, "mproj": first.mlp.c_proj, "lm_head": model.lm_head}[key]
                     n_tiles = -(-mod.out_features // 16)
                     g2 = min(n_tiles, 2 * cus)
-                    if 2 * -(-n_tiles // (2 * cus)) <= -(-n_tiles // cus) or n_tiles <= 2 * cus:
+                    # (rows of fewer than 32 units — the K-sharded c_proj / mlp.c_proj of a TP = 8 rank — keep one workgroup per CU:
+                    # 5.2 / 5.7 us against 5.3 / 5.9 with two)
+                    if mod.in_features >= 4096 and (2 * -(-n_tiles // (2 * cus)) <= -(-n_tiles // cus) or n_tiles <= 2 * cus):
                         g = max(g2, 1)
                 return {"grid": g, **self.tune.get(key, {})}
             kinds = {_kind(m_) for blk in model.transformer.h

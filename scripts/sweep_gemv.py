@@ -37,6 +37,11 @@ SHAPES_7B = {
     "fc65": (22016, 8192, 2, nat.EPI_SWIGLU),
     "mproj65": (8192, 22016, 1, nat.EPI_ACCUM),
     "lm_head65": (32000, 8192, 1, nat.EPI_STORE),
+    # one rank's shard of 65B at TP = 8 (scripts/convert_checkpoint.py:57-65: c_attn / c_fc rows, c_proj columns)
+    "attn_tp8": (3072, 8192, 1, nat.EPI_STORE),
+    "proj_tp8": (8192, 1024, 1, nat.EPI_STORE),
+    "fc_tp8": (2752, 8192, 2, nat.EPI_SWIGLU),
+    "mproj_tp8": (8192, 2752, 1, nat.EPI_STORE),
 }
 
 
