@@ -272,6 +272,34 @@ def test_engine_attention_split_variants_agree(dev, golden):
     model._engine = None
 
 
+@pytest.mark.parametrize("width", [dict(n_head=40, n_embd=5120), dict(n_head=64, n_embd=8192)])
+@pytest.mark.parametrize("mode", ["gptq.int4", None])
+def test_wide_models_on_the_launch_path_against_the_oracle(dev, width, mode):
+    """13B / 65B widths on one GPU (the launch-per-operator step: 40 / 64 heads do not map onto the persistent step): one block at full
+    width, engine against the CPU oracle at the bf16-path tolerance, and the three ways through the attention — 4 K / V splits per head
+    with the stand-alone combine kernel (rows past 4096 do not fit attn.c_proj's one-vector combine prologue), 1 split, 8 splits — against
+    each other.  Also what exercises the launch geometry these shapes get since round 5 (engine.py dflt: two workgroups per CU)."""
+    from lit_llama_amd.engine import DecodeEngine
+
+    kw = dict(n_layer=1, **width)
+    model, sd, cfg = build(kw, mode, torch.bfloat16, dev, seed=11)
+    om = oracle.Model(oracle.Config(**kw), {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}, mode=mode)
+    T, n_new = 6, 5
+    toks = oracle.generate(om, synth.make_prompt(T), n_new, top_k=1)
+    om.reset_cache()
+    ref = oracle.teacher_forced_logits(om, toks, T)
+    std = float(ref.std(-1).mean())
+    rows = {}
+    for splits in (4, 1, 8):
+        model._engine = DecodeEngine(model, tune={"attn_splits": splits})
+        rows[splits] = teacher_forced(model, toks.to(dev), T, T + n_new, dev)
+    model._engine = None
+    for splits in (1, 8):
+        assert (rows[splits] - rows[4]).abs().max().item() <= 0.02 * std, f"attn_splits={splits} vs 4 ({width})"
+    err = (rows[4] - ref).abs().max().item()
+    assert err <= 0.05 * std, f"{width} {mode}: engine off the oracle by {err:.4f} (std {std:.3f})"
+
+
 def test_generate_api_sampling_and_eos(dev):
     model, _, cfg = build(CFG1, "gptq.int4", torch.bfloat16, dev)
     prompt = synth.make_prompt(6).to(dev)
