@@ -45,7 +45,7 @@ def f8_limb_round(x, prefix):
     sys.path.insert(0, "/root/repo/tests")
     import layouts
 
-    e = 2 if prefix.endswith("attn.c_proj") else 4 if prefix.endswith("mlp.c_proj") else 0
+    e = 2 if prefix.endswith("attn.c_proj") else F8_EH if prefix.endswith("mlp.c_proj") else 0
     v = x.double().numpy() * 2.0 ** -e
     limbs = layouts.f8_limbs(v)
     rec = layouts.e4m3_decode(limbs[0]) + layouts.e4m3_decode(limbs[1]) / 16.0 + layouts.e4m3_decode(limbs[2]) / 256.0
@@ -57,6 +57,7 @@ def f8_limb_round(x, prefix):
 
 
 LADDER = False
+F8_EH = int(__import__("os").environ.get("SIM_F8_EH", "4"))  # pre-scale exponent of the SwiGLU edge (csrc/fused_step_ring.hip MI355_F8_EH)
 
 
 def rnd(x, kind):
