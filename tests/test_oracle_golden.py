@@ -132,3 +132,42 @@ def test_gptq_restatement_matches_reference(golden, name):
     assert err == float(g["error"])
     packed = oracle.colblock_pack(Q, sc, ze, 4, W.shape[1])
     assert torch.equal(packed.contiguous(), torch.from_numpy(g["quant_weight"]))
+
+
+def test_operand_arithmetic_model_statements():
+    """oracle/sim_operand_arith.py (the CPU model that priced the operand arithmetic of round 5) on one small linear: its `exact` statement is
+    the oracle's dequantise-then-multiply; the offset statement equals it in exact arithmetic (no massive activation -> only f32 rounding);
+    the fp8-limb rounding keeps 12 bits and saturates past 448 x the edge's pre-scale; the ladder variant hands a clipped row to fp16."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("sim_operand_arith", Path(__file__).resolve().parents[1] / "oracle" / "sim_operand_arith.py")
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    cfg = LLaMAConfig(n_layer=1, n_head=4, n_embd=256)
+    sd = synth.make_state_dict(cfg, seed=3, mode="gptq.int4")
+    prefix = "transformer.h.0.mlp.c_proj"
+    K = sd[prefix + ".quant_weight"].shape[1] * 2
+    x = torch.randn((1, 5, K), generator=torch.Generator().manual_seed(0))
+    ref = oracle.linear(sd, prefix, x, "gptq.int4")
+    exact = sim.make_linear("f32", None)(sd, prefix, x, "gptq.int4")
+    assert torch.allclose(exact, ref, atol=1e-5, rtol=0)
+    off = sim.make_linear("f32", 1024.0)(sd, prefix, x, "gptq.int4")
+    assert (off - ref).abs().max() <= 2e-3 * ref.abs().max()     # f32 accumulation of (1024 + q) x: small while x has no massive value
+    xm = x.clone()
+    xm[0, 2, 7] = 3.0e4                                           # ... and not small with one
+    refm = oracle.linear(sd, prefix, xm, "gptq.int4")
+    offm = sim.make_linear("f32", 1024.0)(sd, prefix, xm, "gptq.int4")
+    cen = sim.make_linear("f32", 8.0)(sd, prefix, xm, "gptq.int4")
+    assert (offm - refm)[0, 2].abs().max() > 20 * (cen - refm)[0, 2].abs().max()
+    # limbs: 12 bits inside the range, saturation outside, fp16 for the clipped row under the ladder
+    sim.LADDER = False
+    r = sim.f8_limb_round(x[0], prefix)                           # SwiGLU edge: pre-scale 2^4, exact to 12 bits from 2^-2 up
+    big = x[0].abs() >= 0.25
+    assert ((r - x[0]).abs()[big] <= x[0].abs()[big] * 2.0 ** -11).all()
+    r = sim.f8_limb_round(xm[0], prefix)
+    assert float(r[2, 7]) < 8000.0                                # 3e4 saturates at 477.75 x 16
+    sim.LADDER = True
+    r = sim.f8_limb_round(xm[0], prefix)
+    sim.LADDER = False
+    assert float(r[2, 7]) == float(torch.tensor(3.0e4).to(torch.float16)) and torch.equal(r[2], xm[0, 2].to(torch.float16).float())
