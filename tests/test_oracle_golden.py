@@ -143,7 +143,17 @@ def test_operand_arithmetic_model_statements():
 
     spec = importlib.util.spec_from_file_location("sim_operand_arith", Path(__file__).resolve().parents[1] / "oracle" / "sim_operand_arith.py")
     sim = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(sim)
+    import sys
+
+    saved_path = list(sys.path)  # (the script puts oracle/ itself on sys.path; tests that spawn workers must not inherit that)
+    try:
+        spec.loader.exec_module(sim)
+        _operand_arithmetic_statements(sim)
+    finally:
+        sys.path[:] = saved_path
+
+
+def _operand_arithmetic_statements(sim):
     cfg = LLaMAConfig(n_layer=1, n_head=4, n_embd=256)
     sd = synth.make_state_dict(cfg, seed=3, mode="gptq.int4")
     prefix = "transformer.h.0.mlp.c_proj"
