@@ -47,6 +47,10 @@ ABS_BAR = {"cfg2_7b_int4": 0.03, "cfg2_7b_int4_long": 0.04, "cfg2_7b_int4_p400":
 # the launch-per-operator step stage their operands in bf16 like it.  On top of the absolute bar the fused rungs may not be worse than
 # the launch-per-operator rung by more than 0.015 std (they were, by 0.058, while their fp16 operands still carried a +1024 offset).
 REL_BAR = {"cfg2_7b_int4_real": 1.0}
+# ... and the DECODE steps of the fused rungs (rows 1.. of the teacher-forced run: the persistent step's own arithmetic on top of the bf16
+# prompt pass's cache rows) keep the 0.04 of the other fixtures: measured 0.0355 (fp8 limbs, clipped steps on fp16 operands) / 0.0351 (fp16);
+# the CPU model puts the bf16 K / V rows alone at 0.027-0.034 there (profiles/r05_llama_statistics_operand_arithmetic.txt section 4).
+DECODE_BAR = {"cfg2_7b_int4_real": 0.04}
 FUSED_OVER_LAUNCH = 0.015
 
 
@@ -139,6 +143,9 @@ def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures, record=None):
                        bar_std=round(tol / std, 5), recomputed_steps=[[i, p, to] for i, p, to in demoted],
                        clipped_pairs=int(eng.fused_clipped))
             measured[label] = err / std
+            if fmt is not None and name in DECODE_BAR and float(per_step[1:].max()) > DECODE_BAR[name]:
+                # (the persistent step's own work — every row behind the prompt pass — against the absolute bar of the other fixtures)
+                failures.append(f"{name} {label}: decode steps off by {float(per_step[1:].max()):.4f} std (bar {DECODE_BAR[name]} std)")
             if err > tol:  # (collected: every rung's numbers are recorded before the test fails)
                 failures.append(f"{name} {label}: 7B logits off by {err:.4f} = {err / std:.4f} std (tol {tol / std:.4f} std)")
                 continue
