@@ -9,7 +9,8 @@ activations, `--big-real-aux`).
 
 Through all three rungs of the engine's ladder (persistent step with fp8-limb operands = the default, with fp16 operands, launch-per-
 operator step): every rung at or below the reference's OWN bf16 distance on this fixture (0.0703 logit-std; bf16 operands alone cost
-0.04-0.054 here — test_golden_7b_gpu.REL_BAR says why), the fused rungs within 0.015 of the launch-per-operator rung; the steps
+0.04-0.054 here — test_golden_7b_gpu.REL_BAR says why), the fused rungs within 0.015 of the launch-per-operator rung and within the 0.04 of
+the other fixtures on their decode steps (DECODE_BAR: everything behind the bf16 prompt pass); the steps
 whose SwiGLU output passes the limit are exactly the ones the engine recomputes with fp16 operands, no clipped step's logits or
 tokens reach the caller, and generate() — sticky demotion, replay from the clipped position — follows the reference's tokens.
 First GPU run of this fixture (round 5): launch path 0.050, fp16-operand rung 0.108 — its +1024 operand offset cancelled against
