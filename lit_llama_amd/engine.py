@@ -53,7 +53,12 @@ def _kind(mod: nn.Module) -> str:
         # call and runs a dense linear on it (lit_llama/quantization.py:376-423: get_weight(dtype=inp.dtype), F.linear).  Here that
         # bf16 matrix is built ONCE, at engine build, and streamed like any unquantised bf16 linear (`_dense_weight`): the same weight
         # values bit for bit (q - zero exact in bf16, one rounding of the product with the scale), 2 bytes per weight resident in HBM.
-        return "q4" if mod.bits == 4 else "bf16"
+        if mod.bits == 4:
+            return "q4"
+        if mod.bits == 8:
+            return "bf16"
+        # (the reference constructor also takes bits 1 and 2; mi355_colblock_dequant handles 4 and 8: such models run op by op)
+        raise EngineUnavailable(f"ColBlockQuantizedLinear with bits={mod.bits}: the engine streams 4-bit and (dequantised) 8-bit matrices")
     if isinstance(mod, Linear8bitLt):
         return "i8"
     if type(mod) is nn.Linear or getattr(mod, "_mi355_plain_weight", False):
@@ -258,7 +263,6 @@ class DecodeEngine:
             # The LLM.int8 launches (heavier quantising prologue) stay at one per CU throughout.
             i8 = _kind(first.attn.c_attn) == "i8"
             grids = {} if i8 else {"lm_head": 2 * cus}
-            q4 = _kind(first.attn.c_attn) == "q4"
 
             def dflt(key):
                 # Round 5 (scripts/sweep_gemv.py over the 13B / 65B shapes, profiles/r05_gemv_geometry_13b_65b.txt): a single-matrix
@@ -267,13 +271,13 @@ class DecodeEngine:
                 # 13B attn.c_proj 7.8 -> 7.3, mlp.c_proj 12.4 -> 11.6.  Every 7B shape keeps what it had (c_attn: 768 tiles = 3 per CU
                 # against 2 x 2; 256-tile linears: one per CU either way; lm_head 2 x CUs).  The c_fc1 / c_fc2 pair stays at one per CU.
                 g = grids.get(key, cus)
-                if q4 and key in ("attn", "proj", "mproj", "lm_head"):
-                    mod = {"attn": first.attn.c_attn, "proj": first.attn.c_proj, "mproj": first.mlp.c_proj, "lm_head": model.lm_head}[key]
+                mod = {"attn": first.attn.c_attn, "proj": first.attn.c_proj, "mproj": first.mlp.c_proj, "lm_head": model.lm_head}.get(key)
+                if mod is not None and _kind(mod) == "q4":  # (per module: a bf16 lm_head in a q4 model keeps the generic rule)
                     n_tiles = -(-mod.out_features // 16)
                     g2 = min(n_tiles, 2 * cus)
-                    # (rows of fewer than 32 units — the K-sharded c_proj / mlp.c_proj of a TP = 8 rank — keep one workgroup per CU:
-                    # 5.2 / 5.7 us against 5.3 / 5.9 with two)
-                    if mod.in_features >= 4096 and (2 * -(-n_tiles // (2 * cus)) <= -(-n_tiles // cus) or n_tiles <= 2 * cus):
+                    # (rows of fewer than 32 units of 128 columns — the K-sharded c_proj / mlp.c_proj of a TP = 8 rank — keep one
+                    # workgroup per CU: 5.2 / 5.7 us against 5.3 / 5.9 with two)
+                    if mod.in_features // 128 >= 32 and (2 * -(-n_tiles // (2 * cus)) <= -(-n_tiles // cus) or n_tiles <= 2 * cus):
                         g = max(g2, 1)
                 return {"grid": g, **self.tune.get(key, {})}
             kinds = {_kind(m_) for blk in model.transformer.h
@@ -471,23 +475,52 @@ class DecodeEngine:
         self._fused_warm = False
         self.fused_clipped = 0  # activation pairs clipped by the persistent step so far (check_status)
         self.fused_demotions: List[tuple] = []  # (why, to what, first bad position) every time the hand-off format proved too narrow
+        self.fused_promotions = 0               # times the engine climbed back one rung after a clean run (check_status)
+        # The ladder of hand-off formats, widest last (None = the launch-per-operator step: f32 residual, bf16 staging, no range to
+        # leave).  Round 6: a clip moves the engine ONE rung down for `_hold` steps, not for good — a trained checkpoint's massive
+        # activations fire on a few delimiter tokens, and a sticky ladder turned one of them into a permanent 2.7 % loss.
+        self._full_rungs = [3, 0, None] if int(a.weight_fmt) == 3 else [int(a.weight_fmt), None]
+        self._rungs = list(self._full_rungs)
+        self._rung = 0
+        self._demoted_before = False
+        self._hold = self.HOLD0        # clean steps on a lower rung before the engine climbs back; doubles with every further clip
+        self._steps_on_rung = 0        # decode steps issued since the last demotion / promotion
+
+    HOLD0, HOLD_MAX = 16, 4096
 
     def fused_ready(self) -> bool:
-        return (self.fused is not None and self.fused_enabled and self.fused.kv is not None and self.fused.S == self.S
-                and self.S > 0)
+        return (self.fused is not None and self.fused_enabled and self._rungs[self._rung] is not None and self.fused.kv is not None
+                and self.fused.S == self.S and self.S > 0)
+
+    def status_due(self) -> bool:
+        """Is a periodic `check_status()` worth its device->host read: the persistent step is running (its hand-offs can clip), or the
+        engine sits on a lower rung of the ladder and may climb back."""
+        return self.fused is not None and self.fused_enabled and (self.fused_ready() or self._rung > 0)
+
+    def _set_rung(self, i: int) -> str:
+        """Select rung `i` of the ladder; the hand-off workspace is zeroed when the granule tag width changes (weight_fmt 3 carries
+        16-bit tags: include/mi355_llama.h).  Everything here is enqueued on the engine's stream."""
+        fmt = self._rungs[i]
+        self._rung, self._steps_on_rung = i, 0
+        if fmt is None:
+            return "the launch-per-operator step"
+        if int(self.fused.weight_fmt) != fmt:
+            self.fused.weight_fmt = fmt
+            with torch.cuda.stream(self.stream):
+                self._fused_ws[256:].zero_()
+        return {3: "fp8-limb operands (weight_fmt 3)", 0: "fp16 operands (weight_fmt 0)"}.get(fmt, f"weight_fmt {fmt}")
 
     def _demote_fused(self, why: str, bad: Optional[int] = None) -> str:
-        """The persistent step met a checkpoint (or prompt) its hand-off format is too narrow for — E4M3 limbs clip at +-448 x the
-        edge's pre-scale, fp16 at +-65504, the LLM.int8 outlier list holds 1024 columns.  Move this engine ONE rung down the ladder
+        """The persistent step met a position its hand-off format is too narrow for — E4M3 limbs clip at +-448 x the edge's
+        pre-scale, fp16 at +-65504, the LLM.int8 outlier list holds 1024 columns.  Move this engine ONE rung down the ladder
         fp8-limb operands (weight_fmt 3) -> fp16 operands (weight_fmt 0) -> launch-per-operator step (f32 residual, bf16 staging, no
-        list limit), for good: a checkpoint that clipped once will clip again, and every clip costs a replay."""
-        if self.fused.weight_fmt == 3 and self.fused_enabled:
-            self.fused.weight_fmt = 0
-            self._fused_ws[256:].zero_()  # the granules carried 16-bit tags: include/mi355_llama.h, weight_fmt
-            to = "fp16 operands (weight_fmt 0)"
-        else:
-            self.fused_enabled = False
-            to = "the launch-per-operator step"
+        list limit) for the next `_hold` decode steps; `check_status` climbs back one rung after that many clean steps.  `_hold`
+        starts at 16 and doubles with every further clip (cap 4096): a checkpoint that clips on every token settles on the lower
+        rung by itself, one whose massive activations fire on a few tokens pays one replayed step each."""
+        if self._demoted_before:
+            self._hold = min(2 * self._hold, self.HOLD_MAX)
+        self._demoted_before = True
+        to = self._set_rung(min(self._rung + 1, len(self._rungs) - 1))
         self.fused_demotions.append((why, to, bad))
         return to
 
@@ -495,11 +528,26 @@ class DecodeEngine:
         """Tests / measurements: back to the top rung of the ladder (what `_build_fused` chose), with a clean hand-off workspace."""
         if self.fused is None:
             return
-        top = self._fused_top_fmt
-        if int(self.fused.weight_fmt) != top:
-            self.fused.weight_fmt = top
-            self._fused_ws[256:].zero_()
+        self._rungs = list(self._full_rungs)
+        self._set_rung(0)
+        self._hold, self._demoted_before = self.HOLD0, False
         self.fused_enabled = True
+
+    def use_fused_format(self, fmt: int) -> None:
+        """Tests / measurements: make `fmt` (a rung of this engine's ladder) the top rung — e.g. 0 on an engine whose default is 3
+        times the fp16-operand kernel a clipping checkpoint runs on (bench.py `rungs`, scripts/ab_fused.py --f8)."""
+        self._rungs = self._full_rungs[self._full_rungs.index(fmt):]
+        self._set_rung(0)
+        self._hold, self._demoted_before = self.HOLD0, False
+        self.fused_enabled = True
+
+    def clear_status(self) -> None:
+        """Forget what the status words hold (clip count, lowest clipped position): a caller that starts a NEW sequence must not
+        replay from a position of the previous one (advisor r5: an interrupted generate() or a direct run_step() caller leaves
+        them set; they are sticky by design).  The abort word stays: a timed-out hand-off must still raise."""
+        if self.fused is not None:
+            with torch.cuda.stream(self.stream):
+                self._fused_ws[8:16].zero_()
 
     def check_status(self) -> Optional[int]:
         """One device->host read of the persistent step's status words — call it where the host synchronises anyway (end of
@@ -508,17 +556,25 @@ class DecodeEngine:
         * a hand-off timed out / the step was entered with pos >= S (abort word): raises, the outputs are garbage;
         * activations exceeded the range of the step's hand-off format, or an LLM.int8 vector had more than 1024 outlier columns,
           since the last call: the steps from the returned position on did NOT compute what the reference computes.  The engine
-          has then already demoted itself (`_demote_fused`) and warned; the caller re-runs the generation from that position
+          has then already moved one rung down (`_demote_fused`) and warned; the caller re-runs the generation from that position
           (`generate()` and `forward()` do) — a caller that drives `run_step` itself and ignores the return value keeps tokens
           that are wrong from there on, which is what the RuntimeWarning says;
-        * otherwise returns None."""
+        * otherwise returns None — and, when the engine has spent `_hold` clean steps on a lower rung, climbs back one rung."""
         if self.fused is None:
             return None
         words = self._fused_ws[:16].view(torch.int32).tolist()  # abort code, step counter, clipped pairs, 0x7FFFFFFF - first bad position
         code, clipped, first = words[0], words[2], words[3]
         overflow8 = 0x700 <= code < 0x800
+        if code != 0 and not overflow8:  # (first: a time-out in the same window as a clip must not be cleared by the clip's branch)
+            with torch.cuda.stream(self.stream):
+                self._fused_ws[:4].zero_()
+            raise nat.NativeError(f"fused decode step aborted (code 0x{code:x}): a workgroup hand-off timed out or the "
+                                  "step was entered with pos >= S; the step's outputs are invalid")
         if clipped or overflow8:
-            self._fused_ws[:16].view(torch.int32)[[0, 2, 3]] = 0
+            with torch.cuda.stream(self.stream):
+                if overflow8:
+                    self._fused_ws[:4].zero_()
+                self._fused_ws[8:16].zero_()
             self.fused_clipped += clipped
             bad = 0x7FFFFFFF - first if first else 0
             was = self.fused.weight_fmt
@@ -527,14 +583,13 @@ class DecodeEngine:
             to = self._demote_fused(why, bad)
             import warnings
 
-            warnings.warn(f"fused decode step: {why} — clipped / invalid from position {bad} on; this engine now decodes through {to} "
-                          "and the tokens from that position on must be recomputed (generate() and LLaMA.forward do so themselves)",
-                          RuntimeWarning, stacklevel=2)
+            warnings.warn(f"fused decode step: {why} — clipped / invalid from position {bad} on; this engine decodes the next "
+                          f"{self._hold} steps through {to} and the tokens from that position on must be recomputed (generate() and "
+                          "LLaMA.forward do so themselves)", RuntimeWarning, stacklevel=2)
             return bad
-        if code != 0:
-            self._fused_ws[:4].zero_()
-            raise nat.NativeError(f"fused decode step aborted (code 0x{code:x}): a workgroup hand-off timed out or the "
-                                  "step was entered with pos >= S; the step's outputs are invalid")
+        if self._rung > 0 and self.fused_enabled and self._steps_on_rung >= self._hold:
+            self._set_rung(self._rung - 1)  # `_hold` clean steps behind the last clip: one rung up again
+            self.fused_promotions += 1
         return None
 
     # ---- bookkeeping ---------------------------------------------------------------------------------
@@ -626,6 +681,8 @@ class DecodeEngine:
         logits only, True/1 greedy argmax, 3 chained greedy step (needs `embed_step()` before the first one)."""
         s = self.stream.cuda_stream
         argmax = int(argmax)
+        if self.fused is not None and self._rung > 0:
+            self._steps_on_rung += 1
         while allow_fused and self.fused_ready():
             # one persistent launch per token; launches are asynchronous, so the host runs ahead without a graph
             self.fused.mode = argmax

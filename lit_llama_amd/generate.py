@@ -79,10 +79,18 @@ def generate(
 CHECK_EVERY = 16
 
 
-def _replay_from(eng, bad: int):
+def _replay_from(eng, bad: int, T: int, done: int):
     """The persistent step's activations left the range of its hand-off format at position `bad` (DecodeEngine.check_status: the
     engine has moved to a wider format / the launch-per-operator step by now).  out_tokens[: bad + 1] and the cache rows below
-    `bad` come from unclipped steps: make out_tokens[bad] at position `bad` the step to run next.  The caller recomputes from there."""
+    `bad` come from unclipped steps: make out_tokens[bad] at position `bad` the step to run next.  The caller recomputes from there.
+    `bad` must be a position THIS call decoded (the prompt's last token .. the last step issued): the status words are sticky, and a
+    position left behind by another sequence (an interrupted call, a caller that drove run_step itself) would make the replay
+    overwrite prompt tokens or skip ahead — generate() clears the words when it starts, and refuses anything out of range here."""
+    if not (T - 1 <= bad <= T + done - 1):
+        from ._native import NativeError
+
+        raise NativeError(f"fused decode step: clipped position {bad} is outside this call's decoded range [{T - 1}, {T + done - 1}] "
+                          "(stale status words: was the engine driven by another caller meanwhile?)")
     eng.set_step(eng.out_tokens[bad:bad + 1], 1, bad)
     eng.embed_step()
 
@@ -102,6 +110,7 @@ def _generate_sampled(model, eng, idx, max_new_tokens, max_seq_length, temperatu
     with torch.cuda.stream(eng.stream):
         uniforms = torch.rand(max_seq_length + 1, device=device, dtype=torch.float32)  # indexed by position
         eng._ensure_cache(max_seq_length)
+        eng.clear_status()  # (a clip position of an earlier sequence must not steer this one's replay)
         eng.out_tokens[:T].copy_(idx.to(torch.int32))
         eng.prefill(idx, 0, all_logits=False, argmax=False)  # logits of the last prompt token in row 0
         eng.set_step(idx[-1:], 1, T - 1)                      # position slot = T - 1: the draw lands at out_tokens[T]
@@ -119,7 +128,7 @@ def _generate_sampled(model, eng, idx, max_new_tokens, max_seq_length, temperatu
                 if eos_id is not None and (done % 16 == 0 or done == max_new_tokens):
                     toks = eng.out_tokens[T:T + done].tolist()
                     stop = eos_id in toks
-                if done % CHECK_EVERY == 0 and eng.fused_ready():
+                if done % CHECK_EVERY == 0 and eng.status_due():
                     bad = eng.check_status()
                     if bad is not None:
                         break
@@ -129,7 +138,7 @@ def _generate_sampled(model, eng, idx, max_new_tokens, max_seq_length, temperatu
                 break
             # a step left the range of the persistent step's hand-off format: the draws are per position, so the replay through the
             # wider format continues the very same sample path
-            _replay_from(eng, bad)
+            _replay_from(eng, bad, T, done)
             done, stop = bad + 1 - T, False  # (0 when the clipped step was the prompt's last token, run as a T = 1 chunk)
         out = eng.out_tokens[:T + done].to(dtype).clone()
     cur.wait_stream(eng.stream)
@@ -148,6 +157,7 @@ def _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id):
     eng.stream.wait_stream(cur)
     with torch.cuda.stream(eng.stream):
         eng._ensure_cache(max_seq_length)
+        eng.clear_status()  # (a clip position of an earlier sequence must not steer this one's replay)
         eng.out_tokens[:T].copy_(idx.to(torch.int32))
         # prompt: all but the last token without logits, then the last one with logits + argmax
         eng.prefill(idx, 0, all_logits=False, argmax=True)
@@ -168,7 +178,7 @@ def _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id):
                     # device->host sync for it; here the sync is amortised and the tail is cut off afterwards
                     toks = eng.out_tokens[T:T + done].tolist()
                     stop = eos_id in toks
-                if done % CHECK_EVERY == 0 and eng.fused_ready():
+                if done % CHECK_EVERY == 0 and eng.status_due():
                     bad = eng.check_status()
                     if bad is not None:
                         break
@@ -178,7 +188,7 @@ def _generate_greedy(model, eng, idx, max_new_tokens, max_seq_length, eos_id):
                 bad = eng.check_status()
             if bad is None:
                 break
-            _replay_from(eng, bad)
+            _replay_from(eng, bad, T, done)
             done, stop = bad + 1 - T, False  # out_tokens[T .. bad] stand; the step at `bad` produces out_tokens[bad + 1]
         out = eng.out_tokens[:T + done].to(dtype).clone()
     cur.wait_stream(eng.stream)

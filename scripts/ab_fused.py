@@ -34,9 +34,7 @@ def f8_ab(a):
     S = a.prompt + 8 + 64 * a.blocks * 2 + 80
 
     def set_fmt(f):
-        with torch.cuda.stream(eng.stream):
-            eng.fused.weight_fmt = f
-            eng._fused_ws[256:].zero_()  # granules of the other tag width (include/mi355_llama.h, weight_fmt)
+        eng.use_fused_format(f)  # (zeroes the granules of the other tag width: include/mi355_llama.h, weight_fmt)
         eng.stream.synchronize()
 
     def start():

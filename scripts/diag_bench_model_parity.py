@@ -51,9 +51,8 @@ def main():
             for label, fused, fmt in (("launch", False, None), ("fused/fmt3", True, 3), ("fused/fmt0", True, 0)):
                 eng.reset_fused_format()
                 eng.fused_enabled = fused
-                if fused and int(eng.fused.weight_fmt) != fmt:
-                    eng.fused.weight_fmt = fmt
-                    eng._fused_ws[256:].zero_()
+                if fused:
+                    eng.use_fused_format(fmt)
                 rows[label] = teacher_forced(model, toks, T, S, dev)
                 bad = eng.check_status()
                 print(f"zero {zero} gain {gain} {label}: status {bad}, demotions {eng.fused_demotions}", flush=True)

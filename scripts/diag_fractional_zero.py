@@ -43,9 +43,8 @@ def main():
                 continue
             eng.reset_fused_format()
             eng.fused_enabled = fused
-            if fused and int(eng.fused.weight_fmt) != fmt:
-                eng.fused.weight_fmt = fmt
-                eng._fused_ws[256:].zero_()
+            if fused:
+                eng.use_fused_format(fmt)
             rows[label] = teacher_forced(model, toks, T, S, dev)
             eng.check_status()
         eng.reset_fused_format()

@@ -111,9 +111,8 @@ def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures, record=None):
             eng.reset_fused_format()
             if fmt is None:
                 eng.fused_enabled = False
-            elif int(eng.fused.weight_fmt) != fmt:
-                eng.fused.weight_fmt = fmt
-                eng._fused_ws[256:].zero_()  # (the tag width of the granules changes with the format)
+            else:
+                eng.use_fused_format(fmt)  # (zeroes the hand-off workspace when the tag width of the granules changes)
 
         for label, fmt in rungs:
             set_rung(fmt)
@@ -163,7 +162,7 @@ def _int4_checkpoint_against_its_fixtures(dev, golden, fixtures, record=None):
                 # (one rung down is enough unless a value also passes fp16's +-65504 — 3.3 sigma of the generator's units)
                 assert all(to.startswith("fp16") or a[p] > 60000 for _, p, to in demoted), demoted
                 assert len(must) >= 1, "the LLaMA-statistics fixture no longer exercises the fp8 hand-off's range limit"
-            # free running (generate.py:63-91) on the product's own ladder (sticky demotion, replay from the clipped position):
+            # free running (generate.py:63-91) on the product's own ladder (per-step demotion with hysteresis, replay from the clipped position):
             # equal up to the first near tie
             eng.fused_demotions.clear()
             eng.fused_clipped = 0

@@ -321,10 +321,42 @@ def test_bench_gpus_n_starts_n_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out == {"dry_run": True, "n_gpus": 2, "ranks": [0, 1]}
+    assert {k: out[k] for k in ("dry_run", "n_gpus", "ranks")} == {"dry_run": True, "n_gpus": 2, "ranks": [0, 1]}
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_bench_tp_output_contract_dry_run():
+    """What the first multi-GPU run of bench.py prints for the tensor-parallel part, checked with stub legs over
+    gloo: at world 2 BOTH collectives run — `tp` is the native leg and carries the RCCL leg as `tp["rccl"]` (tokens/s, collective
+    time per token, ranks seen) — and a native leg that fails on ONE rank makes rank 0 report the RCCL leg with
+    `fallback_from_native`, loudly on stderr; at world 1 a single leg."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+    def run(*extra):
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--dry-run", *extra], env=env, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]), r.stderr
+
+    keys = {"tokens_per_s", "ms_per_token", "collective_us_per_token", "ranks_seen", "comm"}
+    out, _ = run("--gpus", "2")
+    assert out["n_gpus"] == 2 and out["tp"]["comm"] == "native" and keys <= set(out["tp"])
+    assert out["tp"]["rccl"]["comm"] == "rccl" and out["tp"]["rccl"]["ranks_seen"] == 2 and keys <= set(out["tp"]["rccl"])
+    out, err = run("--gpus", "2", "--dry-run-fail-native", "1")  # fails on rank 1 only: rank 0 must still fall back
+    why = out["tp"]["fallback_from_native"]
+    assert out["tp"]["comm"] == "rccl" and ("native collective failed" in why or "another rank" in why)
+    assert "FAILED" in err
+    out, _ = run("--gpus", "1")
+    assert out["tp"]["comm"] == "native" and "rccl" not in out["tp"]
 
 
 def test_group_table_layout_of_the_grouped_fused_step():

@@ -440,21 +440,32 @@ def test_7b_width_single_layer_engine_matches_oracle(dev):
     assert err <= 0.05 * std, f"7B-width logits off by {err:.4f} (std {std:.3f})"
 
 
-def test_full_7b_int4_model_size_independent_properties(dev):
+@pytest.mark.parametrize("zero, gain, fused_bar, module_bar, exact_tokens", [
+    (7.5, 1.0, 0.03, None, False),   # the bench model since round 5: zero-mean weights of unit gain (synth.fill_model_random_int4)
+    (8.0, 2.2, 0.02, 0.05, True),    # the bench model of rounds 1-4, at the bars of rounds 1-4 (advisor r5: the bars that guarded the
+                                     # paths which did not change must keep guarding them)
+])
+def test_full_7b_int4_model_size_independent_properties(dev, golden, zero, gain, fused_bar, module_bar, exact_tokens):
     """BASELINE.json configs[2] at FULL size (32 layers, 3.3 GB of int4 weights; the CPU oracle needs minutes per
     token here — the full-depth golden run is tests/test_golden_7b_gpu.py — so these checks are properties):
     (1) greedy decode is reproducible run to run, on the fused persistent step and on the launch-per-operator step;
-    (2) both give the same tokens, and teacher-forced logits within 0.02 logit-std of each other;
+    (2) both give the same tokens (up to the first near tie on the zero-mean model; all of them on the old common-mode model), and
+        teacher-forced logits within `fused_bar` logit-std of each other;
     (3) on the launch-per-operator path the hipGraph replay and eager launches are bit-identical;
     (4) the engine agrees with the op-by-op module path (independent generic kernels, reference arithmetic order)
-    to the bf16-path tolerance on teacher-forced steps."""
+        to the bf16-path tolerance on teacher-forced steps: `module_bar`, or — the zero-mean model, whose logits are not a
+        common-mode term — 1.25 x the LARGEST distance the reference's own bf16 run keeps from its f32 run on the committed
+        unit-statistics full-depth fixtures (tests/golden/cfg2_7b_int4*_bf16ref.npz: the module path IS that arithmetic)."""
     from lit_llama_amd.model import LLaMA, LLaMAConfig
 
+    if module_bar is None:
+        module_bar = 1.25 * max(float(golden(n + "_bf16ref")["max_dist_std"]) for n in ("cfg2_7b_int4", "cfg2_7b_int4_long", "cfg2_7b_int4_s1"))
+        assert 0.08 < module_bar < 0.2, module_bar
     cfg = LLaMAConfig.from_name("7B")
     with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
         model = LLaMA(cfg)
     model.eval()
-    synth.fill_model_random_int4(model, seed=0)
+    synth.fill_model_random_int4(model, seed=0, zero=zero, gain=gain)
     eng = model.engine()
     assert eng is not None and eng.use_graph, model._engine_failed
     prompt = synth.make_prompt(9, vocab=cfg.vocab_size, seed=3).to(dev)
@@ -487,10 +498,10 @@ def test_full_7b_int4_model_size_independent_properties(dev):
             eng.check_status()
         err = (lg_fused - lg_graph).abs().max().item()
         print(f"fused vs launch-per-operator logits at 7B (teacher-forced, zero-mean bench model): {err / std:.4f} std")
-        assert err <= 0.03 * std, f"fused vs launch-per-operator logits at 7B: {err:.4f} (std {std:.3f})"
+        assert err <= fused_bar * std, f"fused vs launch-per-operator logits at 7B (zero {zero}, gain {gain}): {err:.4f} (std {std:.3f})"
         top2 = torch.topk(lg_graph, 2, dim=-1).values
         margins = (top2[:, 0] - top2[:, 1]).tolist()
-        first_tie = next((i for i, m_ in enumerate(margins) if m_ <= 2 * 0.03 * std), len(margins))
+        first_tie = len(margins) if exact_tokens else next((i for i, m_ in enumerate(margins) if m_ <= 2 * fused_bar * std), len(margins))
         n = 9 + first_tie
         assert torch.equal(runs[True][0][:n], a[:n]), \
             f"fused and launch-per-operator steps decode different tokens before the first near tie: {runs[True][0].tolist()} vs {a.tolist()}"
@@ -512,7 +523,7 @@ def test_full_7b_int4_model_size_independent_properties(dev):
     # bf16 run, which sits 0.07-0.12 logit-std from its f32 run on the short full-depth fixtures (tests/golden/*_bf16ref.npz).  Measured
     # here on the zero-mean bench model: 0.095 (round 5; the bar was 0.05 while the bench model's logits were a common-mode term).
     print(f"engine vs module path at 7B (3 teacher-forced steps): {err / std:.4f} std")
-    assert err <= 0.15 * std, f"engine vs module path at 7B: {err:.4f} (std {std:.3f})"
+    assert err <= module_bar * std, f"engine vs module path at 7B (zero {zero}, gain {gain}): {err:.4f} (std {std:.3f}, bar {module_bar:.3f} std)"
 
 
 def test_grouped_int4_model_streams_through_the_engine_and_matches_oracle(dev):

@@ -46,8 +46,7 @@ def build(n_layer, dev, seed=0):
 def set_fmt(eng, fmt):
     """Switch the operand path of a live engine; hand-off granules of the other tag width must not be mistaken for fresh ones."""
     torch.cuda.synchronize()
-    eng.fused.weight_fmt = fmt
-    eng._fused_ws[256:].zero_()
+    eng.use_fused_format(fmt)
     torch.cuda.synchronize()
 
 
