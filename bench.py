@@ -590,6 +590,7 @@ def main():
     tokens = eng.out_tokens[: pos + 1].tolist()
     assert all(0 <= t_ < cfg.padded_vocab_size for t_ in tokens), "decode produced invalid ids"
     fused = eng.fused_ready()
+    eng_fmt = int(eng.fused.weight_fmt) if fused else -1
     f8_operands = fused and int(eng.fused.weight_fmt) == 3  # (the fp8-limb operand path of the int4 step)
     hipgraph_used = bool(eng.use_graph and eng._graphs) and not fused
     if rank == 0:
@@ -769,7 +770,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "fused_step_ring_kernel (the whole decode step, one launch per token)" if fused else
+            "kernel": (("fused_step_wide_kernel" if int(eng_fmt) == 4 else "fused_step_ring_kernel") +
+                       " (the whole decode step, one launch per token)") if fused else
                       {"gptq.int4": "gemv_kernel<Q4,R=2,SwiGLU>", "none": "gemv_kernel<BF16,R=2,SwiGLU>", "gptq.int8": "gemv_kernel<BF16,R=2,SwiGLU>",
                        "llm.int8": "int8_gemv_kernel<R=2>"}[args.quantize] + " (c_fc1/c_fc2 pair)",
             "achieved": round(algo / avg_s / 1e9, 1),

@@ -473,8 +473,8 @@ int mi355_graph_destroy(mi355_graph* g);
 
 /* ------------------------------------------------------------------------------------------
  * The whole T = 1 decode step (LLaMA.forward for one token + greedy sampling, lit_llama/model.py:76-122,
- * generate.py:68-85) as ONE persistent launch: 7B-class gptq.int4 models on a 256-CU device
- * (kernel csrc/fused_step_ring.hip, host entry csrc/fused_step.hip; mi355_fused_step_supported tells).  Everything the launch touches is laid out in
+ * generate.py:68-85) as ONE persistent launch: 7B-class models on a 256-CU device (kernel csrc/fused_step_ring.hip) and, per-row
+ * gptq.int4 only, the 65B shape (csrc/fused_step_wide.hip, weight_fmt 4); host entry csrc/fused_step.hip; mi355_fused_step_supported tells.  Everything the launch touches is laid out in
  * arenas so that a layer is addressed by a stride:
  *   w        Q4 streams (mi355_q4_repack) of layer l at w + l * layer_stride: c_attn (R = 1) at off_attn, attn.c_proj
  *            (R = 1) at off_proj, the interleaved c_fc1 / c_fc2 pair (R = 2) at off_fc, mlp.c_proj (R = 1) at off_mproj;
@@ -540,7 +540,11 @@ typedef struct mi355_fused_step_args {
      * of 0, computed through fp8 operands: one v_mfma_scale_f32_16x16x128_f8f6f4 per 1-KiB piece (an int4 level in a byte is the E4M3
      * code of q * 2^-9), the hand-offs carry three E4M3 limbs per activation under 16-bit tags; per-row scales only, n_hidden <= 11776.
      * A workspace that has carried hand-offs of another weight_fmt must be zeroed (all but its first 256 bytes) before the first step.
-     * Register-ring implementation only. */
+     * Register-ring implementation only.
+     * 4 (round 6): the streams, scales and zeros of 0 through the WIDE-SHAPE kernel (csrc/fused_step_wide.hip): n_embd = 128 n_head with
+     * 64 heads (LLaMA-65B, lit_llama/model.py:47: BASELINE configs[4] on one GPU) or 32 heads (the 7B shape, as a cross-check of the ring
+     * kernel); fp16 operands and hand-offs, per-row scales only, n_hidden <= 22528.  mi355_fused_step_supported returns 2 for the shapes
+     * only this format serves (1: the 7B shape, every format). */
     int32_t weight_fmt;
     const void* gt;
     const void* gt_head;

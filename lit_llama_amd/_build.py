@@ -16,7 +16,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libmi355llama.so"
 OBJ_DIR = PKG / "csrc" / "_obj"
-SOURCES = ["generic.hip", "gemv.hip", "int8.hip", "int8_gemm.hip", "attention.hip", "engine.hip", "gptq.hip", "fused_step.hip", "fused_step_ring.hip", "tp_comm.hip", "gemm.hip", "flash_prefill.hip", "sample.hip"]
+SOURCES = ["generic.hip", "gemv.hip", "int8.hip", "int8_gemm.hip", "attention.hip", "engine.hip", "gptq.hip", "fused_step.hip", "fused_step_ring.hip", "fused_step_wide.hip", "tp_comm.hip", "gemm.hip", "flash_prefill.hip", "sample.hip"]
 ARCH = "gfx950"
 
 

@@ -29,22 +29,114 @@ constexpr int kMaxS = 32768;      // cache rows
 // ------------------------------------------------------------------------------------------------ host side
 extern "C" size_t mi355_fused_step_workspace_bytes(int n_hidden) {
     if (n_hidden <= 0) return 0;
-    return kFsWsGh + (size_t)2 * (kFsGhSums + n_hidden / 2) * 8;
+    // (one size for both kernels: the ring kernel's map and the wide-shape kernel's, fused_step_common.h)
+    const size_t ring = kFsWsGh + (size_t)2 * (kFsGhSums + n_hidden / 2) * 8, wide = kFwGh + (size_t)2 * (n_hidden / 2) * 8;
+    return ring > wide ? ring : wide;
+}
+
+// workgroups per head of the wide-shape kernel (csrc/fused_step_wide.hip) for a shape it handles, else 0: 256 workgroups = n_head
+// heads x GS, n_embd = 128 n_head — LLaMA-65B (8192 / 64 heads: GS 4) and, as a cross-check of the ring kernel, the 7B shape (GS 8)
+static int wide_gs(int n_embd, int n_head, int hs, int n_hidden, int vocab, int S) {
+    if (mi355_num_cus() != kG || hs != kHs || n_head <= 0 || kG % n_head != 0 || n_embd != n_head * kHs) return 0;
+    const int gs = kG / n_head;
+    if (gs != 4 && gs != 8) return 0;
+    const int units_h = n_hidden / 128, mp_steps = gs == 4 ? 24 : 12;  // ring steps of mlp.c_proj per streamer wave
+    if (n_hidden <= 0 || n_hidden % 128 != 0 || units_h > 176 || (units_h + 7) / 8 > mp_steps || n_hidden / 4 > 2 * 6 * 512) return 0;
+    if (vocab <= 0 || vocab % 2 != 0 || S < 1 || S > kMaxS) return 0;
+    return gs;
 }
 
 extern "C" int mi355_fused_step_supported(int n_embd, int n_head, int hs, int n_hidden, int vocab, int S) {
-    if (mi355_num_cus() != kG) return 0;  // one resident workgroup per CU, head groups of 8
-    if (n_embd != kC || n_head != kHeads || hs != kHs) return 0;
-    if (n_hidden <= 0 || n_hidden % 128 != 0 || n_hidden / 16 > kMaxFcTiles * kG || n_hidden / 128 > 96) return 0;
-    if (vocab <= 0 || vocab % 2 != 0 || (vocab + 15) / 16 > kMaxHeadTiles * kG) return 0;
-    if (S < 1 || S > kMaxS) return 0;
-    return 1;
+    if (mi355_num_cus() != kG) return 0;  // one resident workgroup per CU
+    if (n_embd == kC && n_head == kHeads && hs == kHs) {  // the 7B shape: csrc/fused_step_ring.hip, head groups of 8
+        if (n_hidden <= 0 || n_hidden % 128 != 0 || n_hidden / 16 > kMaxFcTiles * kG || n_hidden / 128 > 96) return 0;
+        if (vocab <= 0 || vocab % 2 != 0 || (vocab + 15) / 16 > kMaxHeadTiles * kG) return 0;
+        if (S < 1 || S > kMaxS) return 0;
+        return 1;
+    }
+    // wider shapes (round 6): csrc/fused_step_wide.hip, weight_fmt 4 only
+    return wide_gs(n_embd, n_head, hs, n_hidden, vocab, S) != 0 ? 2 : 0;
 }
 
 
+// weight_fmt 4: the wide-shape kernel (per-row int4 streams, fp16 operands)
+static int fused_step_wide(const mi355_fused_step_args* a, mi355_stream_t stream) {
+    const int gs = wide_gs(a->n_embd, a->n_head, a->hs, a->n_hidden, a->vocab, a->S);
+    MI355_CHECK_ARG(gs != 0, MI355_E_SHAPE,
+                    "fused_step (weight_fmt 4): needs %d CUs, n_embd = 128 n_head with 64 or 32 heads, n_hidden %% 128 == 0 and <= 22528 "
+                    "(11264 for 32 heads), even vocab, S <= %d (got %d CUs, C=%d, heads=%d x %d, H=%d, V=%d, S=%d)",
+                    kG, kMaxS, mi355_num_cus(), a->n_embd, a->n_head, a->hs, a->n_hidden, a->vocab, a->S);
+    MI355_CHECK_ARG(a->group_cols == 0, MI355_E_ARG, "fused_step (weight_fmt 4): per-row scales only");
+    MI355_CHECK_ARG(a->w && a->w_head && a->sz && a->sz_head && a->norms && a->wte && a->rope && a->kv && a->tokens && a->pos && a->logits &&
+                        a->workspace,
+                    MI355_E_ARG, "fused_step: null pointer");
+    MI355_CHECK_ARG(a->n_layer >= 1 && a->n_layer * 6 + 8 < 1024, MI355_E_SHAPE, "fused_step: n_layer %d", a->n_layer);
+    MI355_CHECK_ARG(!(a->mode & 1) || a->next_token != nullptr, MI355_E_ARG, "fused_step: arg-max without next_token");
+    MI355_CHECK_ARG(a->mode >= 0 && a->mode <= 3 && a->mode != 2, MI355_E_ARG, "fused_step: mode must be 0, 1 or 3");
+    MI355_CHECK_ARG(((uintptr_t)a->w | (uintptr_t)a->w_head | (uintptr_t)a->workspace | a->layer_stride | a->off_attn | a->off_proj |
+                     a->off_fc | a->off_mproj) % 16 == 0,
+                    MI355_E_ARG, "fused_step: streams and workspace must be 16-B aligned");
+    MI355_CHECK_ARG((fused_step_wide_occupancy_ok() & (gs == 4 ? 1 : 2)) != 0, MI355_E_STATE,
+                    "fused_step: the device does not admit one %d-thread workgroup of the wide-shape kernel per CU", kThreads);
+    FusedParams p;
+    memset(&p, 0, sizeof(p));
+    p.w = (const uint8_t*)a->w;
+    p.layer_stride = a->layer_stride;
+    p.off_attn = a->off_attn;
+    p.off_proj = a->off_proj;
+    p.off_fc = a->off_fc;
+    p.off_mproj = a->off_mproj;
+    p.layer_bytes = a->layer_bytes;
+    p.head_bytes = a->head_bytes;
+    p.w_head = (const uint8_t*)a->w_head;
+    p.sz = (const bf16_t*)a->sz;
+    p.sz_head = (const bf16_t*)a->sz_head;
+    p.norms = (const bf16_t*)a->norms;
+    p.wte = (const bf16_t*)a->wte;
+    p.rope = a->rope;
+    p.kv = (bf16_t*)a->kv;
+    p.tokens = a->tokens;
+    p.pos = a->pos;
+    p.next_token = a->next_token;
+    p.out_tokens = a->out_tokens;
+    p.logits = a->logits;
+    char* ws = (char*)a->workspace;
+    p.state = (unsigned*)ws;
+    p.gx = (u64*)(ws + kFwGx);
+    p.ga = (u64*)(ws + kFwGa);
+    p.gq = (u64*)(ws + kFwGq);
+    p.gm = (u64*)(ws + kFwGm);
+    p.gp = (u64*)(ws + kFwGp);
+    p.gh = (u64*)(ws + kFwGh);
+    p.dbg = (u64*)a->debug_stamps;
+    p.dbg_layer = a->reserved0;
+    p.sz_layer_stride = (unsigned)(10 * a->n_embd + 4 * a->n_hidden);
+    p.n_layer = a->n_layer;
+    p.H = a->n_hidden;
+    p.V = a->vocab;
+    p.S = a->S;
+    p.units_h = a->n_hidden / 128;
+    p.fc_tiles = a->n_hidden / 16;
+    p.head_tiles = (a->vocab + 15) / 16;
+    p.fmt = 4;
+    p.fc_bodies = ((p.fc_tiles + kG - 1) / kG + 2) / 3;      // bodies of 3 tiles of the busiest workgroup
+    p.head_turns = ((p.head_tiles + kG - 1) / kG + 2) / 3;
+    p.mode = a->mode;
+    p.eps = a->eps;
+    p.scale = 1.0f / sqrtf((float)kHs);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (t_time_start != nullptr) {  // measurement hook: see gemv.hip launch_gemv_m
+        e0 = t_time_start;
+        e1 = t_time_stop;
+        t_time_start = t_time_stop = nullptr;
+    }
+    return fused_step_wide_launch(p, gs, (hipStream_t)stream, e0, e1);
+}
+
 extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t stream) {
     MI355_CHECK_ARG(a != nullptr, MI355_E_ARG, "fused_step: null args");
-    MI355_CHECK_ARG(mi355_fused_step_supported(a->n_embd, a->n_head, a->hs, a->n_hidden, a->vocab, a->S), MI355_E_SHAPE,
+    if (a->weight_fmt == 4) return fused_step_wide(a, stream);
+    MI355_CHECK_ARG(mi355_fused_step_supported(a->n_embd, a->n_head, a->hs, a->n_hidden, a->vocab, a->S) == 1, MI355_E_SHAPE,
                     "fused_step: needs %d CUs, n_embd %d, %d heads of %d, n_hidden %% 128 == 0 and <= %d, vocab <= %d, "
                     "S <= %d (got %d CUs, C=%d, heads=%d x %d, H=%d, V=%d, S=%d)",
                     kG, kC, kHeads, kHs, kMaxFcTiles * kG * 16, kMaxHeadTiles * kG * 16, kMaxS, mi355_num_cus(), a->n_embd,

@@ -45,6 +45,8 @@ struct FusedParams {
     unsigned gt_layer_bytes, gt_head_bytes;
     int grouped, gsh, ngc, ngh;
     int fmt;                 // 0: int4 streams, 1: BF16 streams, 2: LLM.int8 streams, 3: int4 streams through fp8-limb operands
+    int fc_bodies;           // wide-shape kernel (fused_step_wide.hip): bodies of 3 pair tiles the busiest workgroup streams; its
+                             // head_turns counts bodies of 3 lm_head tiles
 };
 
 
@@ -56,5 +58,13 @@ constexpr size_t kFsWsState = 0, kFsWsGx = 256, kFsWsGa = kFsWsGx + 2 * kFsGxStr
                  kFsWsGm = kFsWsGq + 2 * 32 * 256 * 8, kFsWsGp = kFsWsGm + 512 * 8,
                  kFsWsGh = kFsWsGp + 2 * 32 * 8 * 136 * 8;
 
+// workspace map of the wide-shape kernel (csrc/fused_step_wide.hip, weight_fmt 4), sized for its widest shape (n_embd 8192, 64 heads):
+// x edges [2][C / 2 pairs + 512 sums of squares], attention output [2][C / 2], q / k / v of a head [2][n_head][256], arg-max
+// candidates [512], attention partials [2][n_head][workgroups per head][136], MLP hidden [2][H / 2] — granules of 8 bytes
+constexpr size_t kFwGx = 256, kFwGa = kFwGx + (size_t)2 * (4096 + 512) * 8, kFwGq = kFwGa + (size_t)2 * 4096 * 8,
+                 kFwGm = kFwGq + (size_t)2 * 64 * 256 * 8, kFwGp = kFwGm + 512 * 8, kFwGh = kFwGp + (size_t)2 * 256 * 136 * 8;
+
+int fused_step_wide_launch(const FusedParams& p, int gs, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
+int fused_step_wide_occupancy_ok();  // bit 0: the 64-head instantiation fits one workgroup per CU, bit 1: the 32-head one
 int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
 int fused_step_ring_occupancy_ok();  // the device admits one workgroup of the kernel per CU (queried once)

@@ -170,8 +170,12 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
         return None
     if any(hasattr(blk.attn, "adapter_wte") for blk in model.transformer.h):
         return None  # LLaMA-Adapter blocks: the prefix term lives in the launch-per-operator step
-    if not lib().mi355_fused_step_supported(C_, nh, hs, H, V, 1):
+    sup = int(lib().mi355_fused_step_supported(C_, nh, hs, H, V, 1))  # 1: the 7B shape (ring kernel), 2: a wide shape (fused_step_wide.hip)
+    if not sup:
         return None
+    wide = sup == 2 or (_env_int("MI355_FUSED_WIDE", 0) != 0 and kinds == {"q4"})  # (the wide kernel on the 7B shape: a cross-check)
+    if sup == 2 and kinds != {"q4"}:
+        return None  # (the wide-shape kernel streams per-row int4 only)
     first = model.transformer.h[0]
     if kinds in ({"bf16"}, {"i8"}):
         # unquantised models (BASELINE configs[1]) and LLM.int8 models (configs[3]): the BF16 / int8 instantiations of the
@@ -189,6 +193,8 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
     group_cols = 0
     mods = [m_ for blk in model.transformer.h
             for m_ in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj)] + [model.lm_head]
+    if wide and any(m_.scales.shape[1] > 1 for m_ in mods):
+        return None
     if all(m_.scales.shape[1] > 1 for m_ in mods):
         # grouped scales ("groupsize" checkpoints): the GRP instantiation of the register-ring kernel — one group size of
         # 128 * 2^n columns throughout, dividing n_embd and n_hidden, bf16 tables
@@ -208,7 +214,7 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
     layer_bytes = sum(sizes)
     if layer_bytes >= 1 << 32 or any(o % 16 for o in offs) or layer_bytes % 16:
         return None
-    return {"sizes": sizes, "offs": offs, "layer_bytes": layer_bytes, "group_cols": group_cols}
+    return {"sizes": sizes, "offs": offs, "layer_bytes": layer_bytes, "group_cols": group_cols, "fmt": 4 if wide else 0}
 
 
 def group_table(scales: torch.Tensor, zeros: torch.Tensor) -> torch.Tensor:
@@ -439,7 +445,7 @@ class DecodeEngine:
                 sz = torch.empty((cfg.n_layer, 10 * C_ + 4 * H), dtype=torch.bfloat16, device=dev)
                 sz_head = torch.cat([model.lm_head.scales.reshape(-1), model.lm_head.zeros.reshape(-1)]).contiguous()
             for i, blk in enumerate(model.transformer.h):
-                if not gc and fmt == 0:
+                if not gc and fmt in (0, 4):
                     parts = []
                     for mod in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj):
                         parts += [mod.scales.reshape(-1), mod.zeros.reshape(-1)]
@@ -479,6 +485,7 @@ class DecodeEngine:
         # The ladder of hand-off formats, widest last (None = the launch-per-operator step: f32 residual, bf16 staging, no range to
         # leave).  Round 6: a clip moves the engine ONE rung down for `_hold` steps, not for good — a trained checkpoint's massive
         # activations fire on a few delimiter tokens, and a sticky ladder turned one of them into a permanent 2.7 % loss.
+        # (weight_fmt 4, the wide-shape kernel: fp16 hand-offs, then the launch-per-operator step)
         self._full_rungs = [3, 0, None] if int(a.weight_fmt) == 3 else [int(a.weight_fmt), None]
         self._rungs = list(self._full_rungs)
         self._rung = 0

@@ -391,7 +391,31 @@ class TPDecoder:
                     shard.head(n)
                     comm.argmax(shard, False, row=n - 1)  # out_tokens[T] = first generated token
                 pos += n
-            if max_new_tokens > 1:
+            if max_new_tokens > 1 and comm.world == 1 and eng.fused_ready():
+                # world 1 (BASELINE configs[4] on ONE GPU): nothing to exchange, so the whole decode step is the engine's
+                # persistent launch (65B: csrc/fused_step_wide.hip, round 6) — the loop of lit_llama_amd.generate._generate_greedy
+                from .generate import CHECK_EVERY, _replay_from
+
+                eng.clear_status()
+                eng.set_step(None, 1, T, from_next=True)
+                eng.embed_step()
+                done = 1
+                while True:
+                    bad = None
+                    while done < max_new_tokens:
+                        eng.run_step(3)
+                        done += 1
+                        if done % CHECK_EVERY == 0 and eng.status_due():
+                            bad = eng.check_status()
+                            if bad is not None:
+                                break
+                    if bad is None:
+                        bad = eng.check_status()
+                    if bad is None:
+                        break
+                    _replay_from(eng, bad, T, done)
+                    done = bad + 1 - T
+            elif max_new_tokens > 1:
                 eng.set_step(None, 1, T, from_next=True)
                 graph = None
                 if use_graph:

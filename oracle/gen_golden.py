@@ -326,6 +326,17 @@ def big_real_case():
                nocache=False, stats="llama")
 
 
+WIDE = dict(n_layer=2, n_head=64, n_embd=8192)  # two blocks at the LLaMA-65B width (lit_llama/model.py:47; n_hidden 22016)
+
+
+def wide_case():
+    """BASELINE.json configs[4]'s WIDTH (LLaMA-65B: n_embd 8192, 64 heads, n_hidden 22016, vocab 32000) at two layers, gptq.int4, seeded
+    synthetic weights: prompt of 24, 12 greedy tokens from the UNMODIFIED reference on the CPU — the fixture of the wide-shape persistent
+    step (csrc/fused_step_wide.hip, round 6).  `--wide`; bf16 calibration twin: `--big-bf16 --wide`."""
+    torch.set_num_threads(max(8, (torch.get_num_threads() or 8)))
+    model_case("cfg4_65b_w2_int4", WIDE, "gptq.int4", prompt_len=24, new_tokens=12, seed=3, nocache=False)
+
+
 def big_real_aux():
     """Adds `oracle_swiglu_absmax` [positions] to cfg2_7b_int4_real.npz: the largest |silu(c_fc1 x) * c_fc2 x| of the block that holds
     the massive hidden units (synth.llama_stats_plan), per position of the fixture's token sequence, from the ORACLE's activations
@@ -442,7 +453,7 @@ def big_bf16_case(name="cfg2_7b_int4"):
     atol 5e-3 + rtol 1e-3 (tests/test_model.py:133)."""
     torch.set_num_threads(max(8, (torch.get_num_threads() or 8)))
     fx = np.load(OUT / f"{name}.npz")
-    cfg_kwargs = dict(n_layer=32, n_head=32, n_embd=4096)
+    cfg_kwargs = WIDE if name.startswith("cfg4_65b_w2") else dict(n_layer=32, n_head=32, n_embd=4096)
     ref_cfg = ref.LLaMAConfig(**cfg_kwargs)
     sd = synth.make_state_dict(OurConfig(**cfg_kwargs), seed=int(fx["seed"]), mode="gptq.int4",
                                stats=str(fx["stats"]) if "stats" in fx.files else "unit")
@@ -518,6 +529,10 @@ def main():
     if "--big-real-aux" in sys.argv:
         big_real_aux()
         return
+    if "--wide" in sys.argv and "--big-bf16" not in sys.argv:
+        print("generating the two-layer 65B-width fixture from", REF)
+        wide_case()
+        return
     if "--big-real" in sys.argv:
         print("generating the LLaMA-statistics full-depth 7B fixture from", REF)
         big_real_case()
@@ -536,7 +551,7 @@ def main():
         return
     if "--big-bf16" in sys.argv:
         print("running the reference in bf16 on the full-depth fixture from", REF)
-        big_bf16_case("cfg2_7b_int4_real" if "--real" in sys.argv else "cfg2_7b_int4_s1" if "--s1" in sys.argv else "cfg2_7b_int4_p400" if "--p400" in sys.argv else
+        big_bf16_case("cfg4_65b_w2_int4" if "--wide" in sys.argv else "cfg2_7b_int4_real" if "--real" in sys.argv else "cfg2_7b_int4_s1" if "--s1" in sys.argv else "cfg2_7b_int4_p400" if "--p400" in sys.argv else
                       "cfg2_7b_int4_long" if "--long" in sys.argv else "cfg2_7b_int4")
         return
     if "--adapter-v2" in sys.argv:
