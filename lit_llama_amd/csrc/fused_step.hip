@@ -42,6 +42,9 @@ static int wide_gs(int n_embd, int n_head, int hs, int n_hidden, int vocab, int 
     if (gs != 4 && gs != 8) return 0;
     const int units_h = n_hidden / 128, mp_steps = gs == 4 ? 24 : 12;  // ring steps of mlp.c_proj per streamer wave
     if (n_hidden <= 0 || n_hidden % 128 != 0 || units_h > 176 || (units_h + 7) / 8 > mp_steps || n_hidden / 4 > 2 * 6 * 512) return 0;
+    // pair tiles of the busiest workgroup: 4 .. 6 (two unrolled bodies of three) for 64 heads, 1 .. 3 for 32
+    const int fc_max = (n_hidden / 16 + kG - 1) / kG;
+    if (gs == 4 ? (fc_max < 4 || fc_max > 6) : fc_max > 3) return 0;
     if (vocab <= 0 || vocab % 2 != 0 || S < 1 || S > kMaxS) return 0;
     return gs;
 }

@@ -48,9 +48,9 @@ constexpr int kRing = 12;  // ring pieces (1 KiB each) per streamer wave
 #define MI355_WIDE_WINDOW 4
 #endif
 constexpr int kWin = MI355_WIDE_WINDOW;  // pieces per wave in flight while a first ring turn is requested
-#ifndef MI355_WIDE_EARLY
-#define MI355_WIDE_EARLY 1  // request the next phase's first ring turn in front of the publish barrier
-#endif
+// (measured and rejected, profiles/r06_ab_wide_knobs.txt — variants in scripts/patches/r06_*: the second ring turn of a phase parked in LDS
+// by LDS-DMA across the hand-off (-3 %: what it fetches it costs the sweeps), attn.c_proj's first turn in front of the attention
+// (-0.9 %), three instead of two chunks of the hidden edge in flight (-0.7 %), windows of 3 / 6 pieces (0 / +0.5 %))
 constexpr int kHs = 128;
 constexpr unsigned kSpinLimit = 400000u;
 constexpr int kPartStride = 136;  // granules per workgroup partial of the attention: 128 values, max, sum, pad
@@ -173,20 +173,25 @@ struct StreamerCtx {  // per-wave constants of the streamers
     char* smem;
 };
 
-// first ring turn of a phase (12 pieces), consumption order = issue order (VMEM returns in order); at most kWin pieces per wave in
-// flight while it is requested (a deeper queue only stands in front of the gatherers' sweep in the CU's in-order memory pipeline)
-template <int R, int SPT, int MODE, int RTK>
+// A workgroup barrier for the streamer waves: they publish nothing through global memory, what the barrier has to order is their LDS
+// traffic — no fence, no wait for the ring's loads in flight.
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Pieces P0 .. P1 - 1 of a phase's FIRST ring turn (12 pieces), consumption order = issue order (VMEM returns in order).  WAIT: at most
+// kWin pieces per wave in flight while they are requested (a deeper queue only stands in front of the gatherers' sweep in the CU's
+// in-order memory pipeline); the first kWin pieces of a burst go out without it, in front of the publish barrier.
+template <int R, int SPT, int MODE, int RTK, int P0, int P1, bool WAIT>
 __device__ __forceinline__ void burst(u32x4 (&ring)[kRing], const PhaseW& ph, int kstride, __amdgpu_buffer_rsrc_t rs, const StreamerCtx& c) {
     constexpr int STEPS = kRing / R;
+    static_assert(STEPS * R == kRing, "ring turn");
 #pragma unroll
-    for (int pc = 0; pc < kRing; ++pc) {
+    for (int pc = P0; pc < P1; ++pc) {
         const int step = pc / R, r = pc % R;
-        static_assert(STEPS * R == kRing, "ring turn");
         bool ok;
         const unsigned so = piece_off<MODE, RTK>(ph, step / SPT, step % SPT, r, kstride, ok);
         ring[pc] = ring_load(rs, c.rs_null, ok, c.lane_off, so);
         __builtin_amdgcn_sched_barrier(0);
-        if (pc + 1 >= kWin && pc + 1 < kRing) {
+        if constexpr (WAIT) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWin - 1) : "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -196,20 +201,24 @@ __device__ __forceinline__ void burst(u32x4 (&ring)[kRing], const PhaseW& ph, in
 // One phase: `nbodies` bodies of TURNS ring turns of 12 / R steps; a step = R pieces against one activation unit; SPT steps per
 // tile (TURNS * STEPS is a multiple of SPT: bodies hold whole tiles).  Behind every tile the wave parks column 0 of its R partial
 // tiles in LDS and passes the workgroup barrier Bt.
-template <int R, int SPT, int TURNS, int MODE, int RTK>
+// NB: bodies of the phase when known at compile time (the loop is then unrolled: a runtime loop around loads makes hipcc drain the whole
+// ring with vmcnt(0) at every back edge), 0: `nbodies` at run time (lm_head: once per step).
+template <int R, int SPT, int TURNS, int MODE, int RTK, int NB = 1>
 __device__ __forceinline__ void run_phase(u32x4 (&ring)[kRing], const PhaseW& ph, int kstride, int nbodies, __amdgpu_buffer_rsrc_t rs,
-                                          const StreamerCtx& c, int& buf) {
+                                          const StreamerCtx& c, int& buf, u64* stamp, int slot = 0) {
     constexpr int STEPS = kRing / R, BSTEPS = TURNS * STEPS, TPB = BSTEPS / SPT;
     static_assert(BSTEPS % SPT == 0 && R <= kRMax, "bodies hold whole tiles");
     constexpr int NACC = R >= 3 ? 1 : 2;  // accumulators per row group: consecutive MFMAs never share one
     const f16x2 zc1 = {(_Float16)1032.0f, (_Float16)1032.0f}, zc16 = {(_Float16)1152.0f, (_Float16)1152.0f};
+    if constexpr (NB != 0) nbodies = NB;
     const int total = nbodies * BSTEPS;
     f32x4 acc[R][NACC];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int a = 0; a < NACC; ++a) acc[r][a] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();  // B1: the activation vector is staged
+    wg_barrier();  // B1: the activation vector is staged
+    if (stamp != nullptr && threadIdx.x == 0) stamp[slot] = wall_clock64();
     const char* xs = c.smem + kOffXs;
     f16x8 bn[4];  // B operands (activation unit of a step) are read one step ahead
     {
@@ -217,7 +226,9 @@ __device__ __forceinline__ void run_phase(u32x4 (&ring)[kRing], const PhaseW& ph
 #pragma unroll
         for (int d = 0; d < 4; ++d) bn[d] = *(const f16x8*)(xb0 + 16 * d);
     }
-    for (int body = 0; body < nbodies; ++body) {
+    constexpr int kUnrollBodies = NB != 0 ? NB : 1;
+#pragma unroll kUnrollBodies
+    for (int body = 0; body < (NB != 0 ? NB : nbodies); ++body) {
 #pragma unroll
         for (int t = 0; t < TURNS; ++t) {
 #pragma unroll
@@ -255,13 +266,18 @@ __device__ __forceinline__ void run_phase(u32x4 (&ring)[kRing], const PhaseW& ph
                 // refill with the same slots of the next turn of THIS phase (nothing past its end)
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int nls = ls + STEPS;  // (compile time; may run into the next body)
+                    const int nls = ls + STEPS;  // (may run into the next body)
                     const int nti = body * TPB + nls / SPT, nst2 = nls % SPT;
                     bool ok;
                     const unsigned so = piece_off<MODE, RTK>(ph, nti, nst2, r, kstride, ok);
                     ring[s * R + r] = ring_load(rs, c.rs_null, ok && body * BSTEPS + nls < total, c.lane_off, so);
                 }
                 if ((ls + 1) % SPT == 0) {
+                    if (stamp != nullptr && body * BSTEPS + ls + 1 == total) {
+                        if (threadIdx.x == 0) stamp[slot + 1] = wall_clock64();
+                        // (slots 48 / 51 / 52 / 53: when the LAST streamer wave reaches the phase's last tile end — wave skew)
+                        if (c.lane_off == 0u) atomicMax((unsigned long long*)&stamp[48 + (slot - 20) / 2], (unsigned long long)wall_clock64());
+                    }
                     // tile done: column 0 of this wave's partial 16 x 16 tiles (lanes 0, 16, 32, 48 hold rows 4 g .. 4 g + 3 of it)
                     f32x4* pp = (f32x4*)(c.smem + kOffPart + (size_t)((buf * kSW + c.wave) * kRMax) * 64) + (c.lane_off >> 8);
                     const bool col0 = (c.lane_off & 0xF0u) == 0u;
@@ -273,7 +289,7 @@ __device__ __forceinline__ void run_phase(u32x4 (&ring)[kRing], const PhaseW& ph
 #pragma unroll
                         for (int a = 0; a < NACC; ++a) acc[r][a] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                    __syncthreads();  // Bt
+                    wg_barrier();  // Bt
                     buf ^= 1;
                 }
                 // keep a step's conversions next to its MFMAs (hipcc otherwise hoists them to the top of the turn and spills)
@@ -336,6 +352,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
     constexpr int TU_MP = GS == 4 ? 4 : 1;                        // mlp.c_proj: up to TU_MP * ST_PRJ units of the hidden vector per wave
     constexpr int TU_FC = GS == 4 ? 4 : 2, TPB_FC = TU_FC * 6 / SPT_C;     // pair tiles: 6 steps per turn, 3 tiles per body
     constexpr int TU_HD = GS == 4 ? 2 : 1, TPB_HD = TU_HD * 12 / SPT_C;    // lm_head: 12 steps per turn, 3 tiles per body
+    constexpr int NB_FC = GS == 4 ? 2 : 1;  // bodies of the pair phase: 4 .. 6 / 1 .. 3 pair tiles per workgroup (host check)
     static_assert(TPB_FC == 3 && TPB_HD == 3, "tiles per body");
 
     if (wave < kSW) {
@@ -368,23 +385,29 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
         const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_head, 0, (int)p.head_bytes, 0x00020000);
         c.rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
 
-        constexpr bool kEarly = MI355_WIDE_EARLY != 0;
         bool dbg_on = false;
 #define FW_SSTAMP(i)                                                                  \
     do {                                                                              \
         if (dbg_on && threadIdx.x == 0) p.dbg[bid * 64 + (i)] = wall_clock64();        \
     } while (0)
-        burst<R_ATT, TU_ATT * ST_ATT, M_SHARED, RT>(ring, ph_attn, C / 16, rs_l, c);
+        // A phase's first ring turn is requested ACROSS the publish barrier B3 of the phase before it: kWin pieces in front of the
+        // barrier (the streamers must not arrive at it later than the gatherers' epilogue does: the whole burst in front of it cost
+        // ~1.5 us per edge), the rest behind it, while the gatherers sweep the edge
+#define FW_EDGE(R_, SPT_, MODE_, RTK_, PH_, KS_, RS_)                                                  \
+    do {                                                                                              \
+        burst<R_, SPT_, MODE_, RTK_, 0, kWin, false>(ring, PH_, KS_, RS_, c);                          \
+        wg_barrier(); /* B3 */                                                                        \
+        burst<R_, SPT_, MODE_, RTK_, kWin, kRing, true>(ring, PH_, KS_, RS_, c);                       \
+    } while (0)
+        burst<R_ATT, TU_ATT * ST_ATT, M_SHARED, RT, 0, kRing, true>(ring, ph_attn, C / 16, rs_l, c);
         const bf16_t* kv_l = (const bf16_t*)p.kv;
         for (int l = 0; l < p.n_layer; ++l) {
             dbg_on = p.dbg != nullptr && l == p.dbg_layer;
             asm volatile("" : "+v"(c.lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
             // ---------------- c_attn (q, k, v tiles of this workgroup's DH dimensions of its head)
-            FW_SSTAMP(20);
-            run_phase<R_ATT, TU_ATT * ST_ATT, TU_ATT, M_SHARED, RT>(ring, ph_attn, C / 16, 1, rs_l, c, buf);
-            FW_SSTAMP(21);
-            __syncthreads();  // B3
-            // ---------------- attention: this workgroup's chunks of 32 cache rows, all 128 dimensions (the ring's registers hold K / V rows)
+            run_phase<R_ATT, TU_ATT * ST_ATT, TU_ATT, M_SHARED, RT>(ring, ph_attn, C / 16, 1, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 20);
+            wg_barrier();  // B3
+            // ---------------- attention: this workgroup's chunks of 32 cache rows, all 128 dimensions
             {
                 const bf16_t* kc = kv_l + (size_t)head * p.S * kHs;
                 const bf16_t* vc = kc + (size_t)NH * p.S * kHs;
@@ -402,7 +425,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
                     vr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
                 }
-                __syncthreads();  // Ba1: q / new k / new v of the head are in LDS
+                wg_barrier();  // Ba1: q / new k / new v of the head are in LDS
                 FW_SSTAMP(23);
                 float qf[8];
 #pragma unroll
@@ -484,49 +507,30 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     misc[24 + wave] = l_run;
                 }
                 FW_SSTAMP(25);
-                __syncthreads();  // Ba3: partial outputs of the 8 waves
-                __syncthreads();  // Ba4: the attention output is published
+                wg_barrier();  // Ba3: partial outputs of the 8 waves
+                wg_barrier();  // Ba4: the attention output is published
             }
             // ---------------- attn.c_proj, MLP
-            burst<R_PRJ, TU_PRJ * ST_PRJ, M_SHARED, RT>(ring, ph_proj, 0, rs_l, c);
-            FW_SSTAMP(26);
-            run_phase<R_PRJ, TU_PRJ * ST_PRJ, TU_PRJ, M_SHARED, RT>(ring, ph_proj, 0, 1, rs_l, c, buf);
-            FW_SSTAMP(27);
-            if constexpr (kEarly) {
-                burst<2, SPT_C, M_PAIR, 1>(ring, ph_fc, 0, rs_l, c);
-                __syncthreads();  // B3
-            } else {
-                __syncthreads();  // B3
-                burst<2, SPT_C, M_PAIR, 1>(ring, ph_fc, 0, rs_l, c);
-            }
-            FW_SSTAMP(28);
-            run_phase<2, SPT_C, TU_FC, M_PAIR, 1>(ring, ph_fc, 0, p.fc_bodies, rs_l, c, buf);
-            FW_SSTAMP(29);
-            if constexpr (kEarly) {
-                burst<R_PRJ, TU_MP * ST_PRJ, M_SHARED, RT>(ring, ph_mp, 0, rs_l, c);
-                __syncthreads();  // B3
-            } else {
-                __syncthreads();  // B3
-                burst<R_PRJ, TU_MP * ST_PRJ, M_SHARED, RT>(ring, ph_mp, 0, rs_l, c);
-            }
-            FW_SSTAMP(30);
-            run_phase<R_PRJ, TU_MP * ST_PRJ, TU_MP, M_SHARED, RT>(ring, ph_mp, 0, 1, rs_l, c, buf);
-            FW_SSTAMP(31);
-            if constexpr (!kEarly) __syncthreads();  // B3
+            burst<R_PRJ, TU_PRJ * ST_PRJ, M_SHARED, RT, 0, kRing, true>(ring, ph_proj, 0, rs_l, c);
+            run_phase<R_PRJ, TU_PRJ * ST_PRJ, TU_PRJ, M_SHARED, RT>(ring, ph_proj, 0, 1, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 26);
+            FW_EDGE(2, SPT_C, M_PAIR, 1, ph_fc, 0, rs_l);
+            run_phase<2, SPT_C, TU_FC, M_PAIR, 1, NB_FC>(ring, ph_fc, 0, NB_FC, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 28);
+            FW_EDGE(R_PRJ, TU_MP * ST_PRJ, M_SHARED, RT, ph_mp, 0, rs_l);
+            run_phase<R_PRJ, TU_MP * ST_PRJ, TU_MP, M_SHARED, RT>(ring, ph_mp, 0, 1, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 30);
             // next layer (or the head)
             kv_l += (size_t)2 * NH * p.S * kHs;
             if (l + 1 < p.n_layer) {
                 rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (size_t)(l + 1) * p.layer_stride), 0, (int)p.layer_bytes, 0x00020000);
-                burst<R_ATT, TU_ATT * ST_ATT, M_SHARED, RT>(ring, ph_attn, C / 16, rs_l, c);
+                FW_EDGE(R_ATT, TU_ATT * ST_ATT, M_SHARED, RT, ph_attn, C / 16, rs_l);
             } else {
-                burst<1, SPT_C, M_SINGLE, 1>(ring, ph_head, 0, rs_h, c);
+                FW_EDGE(1, SPT_C, M_SINGLE, 1, ph_head, 0, rs_h);
             }
-            if constexpr (kEarly) __syncthreads();  // B3
         }
         dbg_on = false;
-        run_phase<1, SPT_C, TU_HD, M_SINGLE, 1>(ring, ph_head, 0, p.head_turns, rs_h, c, buf);
-        __syncthreads();  // B3
-        if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
+        run_phase<1, SPT_C, TU_HD, M_SINGLE, 1, 0>(ring, ph_head, 0, p.head_turns, rs_h, c, buf, nullptr);
+        wg_barrier();  // B3
+        if (p.mode & 1) wg_barrier();  // the arg-max exchange of the gatherers
+#undef FW_EDGE
 #undef FW_SSTAMP
     } else {
         // =========================================================================================== gatherers
@@ -717,6 +721,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             if (p.dbg != nullptr && l == p.dbg_layer + 1 && gw == 0 && lane == 0) p.dbg[bid * 64 + 46] = wall_clock64();
             __syncthreads();  // B1
             __syncthreads();  // Bt (one virtual tile)
+            FW_GSTAMP(56);
             {
                 const float rinv = x_rinv();
                 if (epi) {
@@ -907,7 +912,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 u64* dst = p.gh + (size_t)hpar * gh_stride;
                 const float rinv = x_rinv();
                 const float s = get_sums();
-                const int tiles_pad = p.fc_bodies * TPB_FC;  // tile ends the streamers pass
+                constexpr int tiles_pad = NB_FC * TPB_FC;  // tile ends the streamers pass
                 for (int t = 0; t < tiles_pad; ++t) {
                     float2 ns1 = fs1, nz1 = fz1, ns2 = fs2, nz2 = fz2;
                     if ((t & 1) == gw) fc_sz(t + 2, ns1, nz1, ns2, nz2);
@@ -948,27 +953,19 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     asm volatile("" : "+v"(lh));  // addresses of this block are computed here, not hoisted and spilled
                     float2 sxp = {0.f, 0.f};
                     constexpr int NCH = 6;  // chunks of 512 loads per gatherer: n_hidden <= 24576
-                    u32x4 va[8], vb[8];
-                    sweep_issue<8>(rs_ws, hbase, first, end, va, lh);
+                    constexpr int ND = 2;  // chunks in flight
+                    u32x4 vv[ND][8];
+#pragma unroll
+                    for (int j = 0; j < ND - 1; ++j) sweep_issue<8>(rs_ws, hbase, first + j * 512, end, vv[j], lh);
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch) {
                         const int c0 = first + ch * 512;
-                        if (ch % 2 == 0) {
-                            if (ch + 1 < NCH) sweep_issue<8>(rs_ws, hbase, c0 + 512, end, vb, lh);
-                            sweep<8>(p, rs_ws, hbase, c0, end, ep, va, 0x500u + edge, lh, true);
+                        if (ch + ND - 1 < NCH) sweep_issue<8>(rs_ws, hbase, c0 + (ND - 1) * 512, end, vv[(ch + ND - 1) % ND], lh);
+                        sweep<8>(p, rs_ws, hbase, c0, end, ep, vv[ch % ND], 0x500u + edge, lh, true);
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                const int i = c0 + k * 64 + lh;
-                                if (i < end) stage(va[k], i, sxp);
-                            }
-                        } else {
-                            if (ch + 1 < NCH) sweep_issue<8>(rs_ws, hbase, c0 + 512, end, va, lh);
-                            sweep<8>(p, rs_ws, hbase, c0, end, ep, vb, 0x500u + edge, lh, true);
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                const int i = c0 + k * 64 + lh;
-                                if (i < end) stage(vb[k], i, sxp);
-                            }
+                        for (int k = 0; k < 8; ++k) {
+                            const int i = c0 + k * 64 + lh;
+                            if (i < end) stage(vv[ch % ND][k], i, sxp);
                         }
                     }
                     put_sums(sxp);
@@ -978,6 +975,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 FW_GSTAMP(11);
                 __syncthreads();  // B1
                 __syncthreads();  // Bt
+                FW_GSTAMP(57);
                 {
                     const float2 d = deq(tile_pair(er), s1, z1, get_sums());
                     xres.x += d.x;

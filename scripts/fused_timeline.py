@@ -72,12 +72,13 @@ def main():
     ap.add_argument("--layer", type=int, default=10)
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--heads", type=int, default=32, help="64: the 65B width (n_embd 8192) on the wide-shape kernel (fused_step_wide.hip)")
     ap.add_argument("--group-cols", type=int, default=0, help="GPTQ groupsize model (GRP instantiation of the kernel)")
     ap.add_argument("--quantize", default="gptq.int4", choices=["gptq.int4", "llm.int8", "none"],
                     help="stream format of the persistent step: int4 (default), LLM.int8 or BF16 (round 4)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    cfg = LLaMAConfig(n_layer=a.layers, n_head=32, n_embd=4096)
+    cfg = LLaMAConfig(n_layer=a.layers, n_head=a.heads, n_embd=128 * a.heads)
     if a.quantize != "gptq.int4":
         import types
 
@@ -134,6 +135,11 @@ def main():
             print(f"  {nm:12s} known landed {raw[:, o + 2].mean():.2f}  requested {raw[:, o + 3].mean():.2f}   "
                   f"requesting took {np.median(st[:, o] - st[:, b1]):.2f} us, waiting for the first group "
                   f"{np.median(st[:, o + 1] - st[:, o]):.2f} us")
+    budget(st)
+    if (st[:, 57] > 0).all() and (st[:, 53] > 0).all():  # wide-shape kernel: gatherer 0 past the Bt of c_attn / mlp.c_proj
+        for nm, last, bt, pub in (("c_attn", 48, 56, 3), ("mlp.c_proj", 53, 57, 12)):
+            print(f"  {nm}: last wave parked -> gatherer 0 past Bt med {np.median(st[:, bt] - st[:, last]):5.2f} us, "
+                  f"past Bt -> published med {np.median(st[:, pub] - st[:, bt]):5.2f} us")
     print("sweep iterations of gatherer 0 per hand-off (a failed sweep costs a memory round trip):")
     for i, nm in ((40, "x edge into c_attn"), (41, "q / k / v head exchange"), (42, "attention out edge"),
                   (43, "x edge into fc"), (44, "hidden edge (first chunk)")):
