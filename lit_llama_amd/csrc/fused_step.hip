@@ -34,19 +34,20 @@ extern "C" size_t mi355_fused_step_workspace_bytes(int n_hidden) {
     return ring > wide ? ring : wide;
 }
 
-// workgroups per head of the wide-shape kernel (csrc/fused_step_wide.hip) for a shape it handles, else 0: 256 workgroups = n_head
-// heads x GS, n_embd = 128 n_head — LLaMA-65B (8192 / 64 heads: GS 4) and, as a cross-check of the ring kernel, the 7B shape (GS 8)
-static int wide_gs(int n_embd, int n_head, int hs, int n_hidden, int vocab, int S) {
-    if (mi355_num_cus() != kG || hs != kHs || n_head <= 0 || kG % n_head != 0 || n_embd != n_head * kHs) return 0;
-    const int gs = kG / n_head;
-    if (gs != 4 && gs != 8) return 0;
-    const int units_h = n_hidden / 128, mp_steps = gs == 4 ? 24 : 12;  // ring steps of mlp.c_proj per streamer wave
+// Does the wide-shape kernel (csrc/fused_step_wide.hip) handle the shape: n_embd = 128 n_head with 40 / 52 / 64 heads (LLaMA-13B / 30B /
+// 65B, lit_llama/model.py:43-48: 4 workgroups per head = 160 / 208 / 256 workgroups) or 32 heads (the 7B shape on 8 workgroups per head,
+// a cross-check of the ring kernel)
+static int wide_ok(int n_embd, int n_head, int hs, int n_hidden, int vocab, int S) {
+    if (mi355_num_cus() != kG || hs != kHs || n_embd != n_head * kHs) return 0;
+    if (n_head != 32 && n_head != 40 && n_head != 52 && n_head != 64) return 0;
+    const int nwg = n_head * (n_head == 32 ? 8 : 4);
+    int tpb_fc, fc_max, tpb_head, mp_steps;
+    fused_step_wide_geometry(n_head, &tpb_fc, &fc_max, &tpb_head, &mp_steps);
+    const int units_h = n_hidden / 128;
     if (n_hidden <= 0 || n_hidden % 128 != 0 || units_h > 176 || (units_h + 7) / 8 > mp_steps || n_hidden / 4 > 2 * 6 * 512) return 0;
-    // pair tiles of the busiest workgroup: 4 .. 6 (two unrolled bodies of three) for 64 heads, 1 .. 3 for 32
-    const int fc_max = (n_hidden / 16 + kG - 1) / kG;
-    if (gs == 4 ? (fc_max < 4 || fc_max > 6) : fc_max > 3) return 0;
+    if ((n_hidden / 16 + nwg - 1) / nwg > fc_max) return 0;  // pair tiles of the busiest workgroup (the kernel unrolls its bodies)
     if (vocab <= 0 || vocab % 2 != 0 || S < 1 || S > kMaxS) return 0;
-    return gs;
+    return 1;
 }
 
 extern "C" int mi355_fused_step_supported(int n_embd, int n_head, int hs, int n_hidden, int vocab, int S) {
@@ -58,16 +59,15 @@ extern "C" int mi355_fused_step_supported(int n_embd, int n_head, int hs, int n_
         return 1;
     }
     // wider shapes (round 6): csrc/fused_step_wide.hip, weight_fmt 4 only
-    return wide_gs(n_embd, n_head, hs, n_hidden, vocab, S) != 0 ? 2 : 0;
+    return wide_ok(n_embd, n_head, hs, n_hidden, vocab, S) ? 2 : 0;
 }
 
 
 // weight_fmt 4: the wide-shape kernel (per-row int4 streams, fp16 operands)
 static int fused_step_wide(const mi355_fused_step_args* a, mi355_stream_t stream) {
-    const int gs = wide_gs(a->n_embd, a->n_head, a->hs, a->n_hidden, a->vocab, a->S);
-    MI355_CHECK_ARG(gs != 0, MI355_E_SHAPE,
-                    "fused_step (weight_fmt 4): needs %d CUs, n_embd = 128 n_head with 64 or 32 heads, n_hidden %% 128 == 0 and <= 22528 "
-                    "(11264 for 32 heads), even vocab, S <= %d (got %d CUs, C=%d, heads=%d x %d, H=%d, V=%d, S=%d)",
+    MI355_CHECK_ARG(wide_ok(a->n_embd, a->n_head, a->hs, a->n_hidden, a->vocab, a->S), MI355_E_SHAPE,
+                    "fused_step (weight_fmt 4): needs %d CUs, n_embd = 128 n_head with 32 / 40 / 52 / 64 heads, n_hidden %% 128 == 0 within the "
+                    "shape's limits (<= 6 pair tiles per workgroup, 3 for 32 heads), even vocab, S <= %d (got %d CUs, C=%d, heads=%d x %d, H=%d, V=%d, S=%d)",
                     kG, kMaxS, mi355_num_cus(), a->n_embd, a->n_head, a->hs, a->n_hidden, a->vocab, a->S);
     MI355_CHECK_ARG(a->group_cols == 0, MI355_E_ARG, "fused_step (weight_fmt 4): per-row scales only");
     MI355_CHECK_ARG(a->w && a->w_head && a->sz && a->sz_head && a->norms && a->wte && a->rope && a->kv && a->tokens && a->pos && a->logits &&
@@ -79,7 +79,8 @@ static int fused_step_wide(const mi355_fused_step_args* a, mi355_stream_t stream
     MI355_CHECK_ARG(((uintptr_t)a->w | (uintptr_t)a->w_head | (uintptr_t)a->workspace | a->layer_stride | a->off_attn | a->off_proj |
                      a->off_fc | a->off_mproj) % 16 == 0,
                     MI355_E_ARG, "fused_step: streams and workspace must be 16-B aligned");
-    MI355_CHECK_ARG((fused_step_wide_occupancy_ok() & (gs == 4 ? 1 : 2)) != 0, MI355_E_STATE,
+    const int widx = a->n_head == 64 ? 0 : a->n_head == 52 ? 1 : a->n_head == 40 ? 2 : 3;
+    MI355_CHECK_ARG((fused_step_wide_occupancy_ok() & (1 << widx)) != 0, MI355_E_STATE,
                     "fused_step: the device does not admit one %d-thread workgroup of the wide-shape kernel per CU", kThreads);
     FusedParams p;
     memset(&p, 0, sizeof(p));
@@ -122,8 +123,13 @@ static int fused_step_wide(const mi355_fused_step_args* a, mi355_stream_t stream
     p.fc_tiles = a->n_hidden / 16;
     p.head_tiles = (a->vocab + 15) / 16;
     p.fmt = 4;
-    p.fc_bodies = ((p.fc_tiles + kG - 1) / kG + 2) / 3;      // bodies of 3 tiles of the busiest workgroup
-    p.head_turns = ((p.head_tiles + kG - 1) / kG + 2) / 3;
+    {
+        const int nwg = a->n_head * (a->n_head == 32 ? 8 : 4);
+        int tpb_fc, fc_max, tpb_head, mp_steps;
+        fused_step_wide_geometry(a->n_head, &tpb_fc, &fc_max, &tpb_head, &mp_steps);
+        p.fc_bodies = ((p.fc_tiles + nwg - 1) / nwg + tpb_fc - 1) / tpb_fc;          // (the kernel unrolls them: informational)
+        p.head_turns = ((p.head_tiles + nwg - 1) / nwg + tpb_head - 1) / tpb_head;   // bodies of lm_head tiles of the busiest workgroup
+    }
     p.mode = a->mode;
     p.eps = a->eps;
     p.scale = 1.0f / sqrtf((float)kHs);
@@ -133,7 +139,7 @@ static int fused_step_wide(const mi355_fused_step_args* a, mi355_stream_t stream
         e1 = t_time_stop;
         t_time_start = t_time_stop = nullptr;
     }
-    return fused_step_wide_launch(p, gs, (hipStream_t)stream, e0, e1);
+    return fused_step_wide_launch(p, a->n_head, (hipStream_t)stream, e0, e1);
 }
 
 extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t stream) {

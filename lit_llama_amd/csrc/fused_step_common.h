@@ -64,7 +64,8 @@ constexpr size_t kFsWsState = 0, kFsWsGx = 256, kFsWsGa = kFsWsGx + 2 * kFsGxStr
 constexpr size_t kFwGx = 256, kFwGa = kFwGx + (size_t)2 * (4096 + 512) * 8, kFwGq = kFwGa + (size_t)2 * 4096 * 8,
                  kFwGm = kFwGq + (size_t)2 * 64 * 256 * 8, kFwGp = kFwGm + 512 * 8, kFwGh = kFwGp + (size_t)2 * 256 * 136 * 8;
 
-int fused_step_wide_launch(const FusedParams& p, int gs, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
-int fused_step_wide_occupancy_ok();  // bit 0: the 64-head instantiation fits one workgroup per CU, bit 1: the 32-head one
+int fused_step_wide_launch(const FusedParams& p, int n_head, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
+int fused_step_wide_occupancy_ok();  // bit i: instantiation i (64 / 52 / 40 heads x 4 workgroups, 32 heads x 8) fits one workgroup per CU
+void fused_step_wide_geometry(int n_head, int* tpb_fc, int* fc_max, int* tpb_head, int* mp_steps);
 int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
 int fused_step_ring_occupancy_ok();  // the device admits one workgroup of the kernel per CU (queried once)

@@ -39,7 +39,7 @@
 
 namespace {
 
-constexpr int kG = 256;   // workgroups
+constexpr int kG = 256;   // workgroups, at most (= CUs)
 constexpr int kSW = 8;    // streamer waves
 constexpr int kGW = 2;    // gatherer waves
 constexpr int kThreads = 64 * (kSW + kGW);
@@ -68,16 +68,30 @@ constexpr int kOffO2 = kOffQ + 3 * 512;                     // [8 waves][128] f3
 constexpr int kLdsBytes = kOffO2 + kSW * 128 * 4;
 static_assert(kLdsBytes <= 160 * 1024, "LDS map");
 
-template <int GS>
+// smallest number of ring turns of `steps` steps that holds whole tiles of `spt` steps
+constexpr int turns_for(int steps, int spt) {
+    int t = 1;
+    while ((t * steps) % spt != 0) ++t;
+    return t;
+}
+
+// NH heads of 128 dims on NH x GS workgroups (one per CU, <= 256): GS = 4 for the 13B / 30B / 65B shapes of lit_llama/model.py:43-48
+// (40 / 52 / 64 heads: 160 / 208 / 256 workgroups), GS = 8 for the 7B shape (32 heads).
+template <int NH_, int GS>
 struct Shape {
-    static_assert(GS == 4 || GS == 8, "workgroups per head");
-    static constexpr int NH = kG / GS;       // heads
+    static_assert((GS == 4 && (NH_ == 40 || NH_ == 52 || NH_ == 64)) || (GS == 8 && NH_ == 32), "heads x workgroups per head");
+    static constexpr int NH = NH_;           // heads
+    static constexpr int NWG = NH * GS;      // workgroups
+    static_assert(NWG <= kG, "one workgroup per CU");
     static constexpr int C = NH * kHs;       // n_embd
-    static constexpr int UC = C / 128;       // units of a C-wide input
+    static constexpr int UC = C / 128;       // units of a C-wide input (= NH)
     static constexpr int RT = 8 / GS;        // 16-row tiles per workgroup (residual rows / head dims)
     static constexpr int DH = 16 * RT;       // dims of its head a workgroup owns
-    static constexpr int NUW = UC / kSW;     // units per streamer wave of a C-wide input (8 / 4)
-    static constexpr int GXS = C / 2 + 2 * kG;  // granules per parity of an x edge: pairs, then RT (<= 2) sums of squares per workgroup
+    static constexpr int NUW = (UC + kSW - 1) / kSW;  // units per streamer wave of a C-wide input, at most (8 / 7 / 5 / 4)
+    static constexpr int GXS = C / 2 + 2 * NWG;       // granules per parity of an x edge: pairs, then RT (<= 2) sums of squares per workgroup
+    // ring steps of mlp.c_proj per streamer wave, at most (n_hidden <= 22528 / 18432 / 18432 / 11264: the host checks)
+    static constexpr int MP_STEPS = NH == 64 ? 22 : NH == 32 ? 11 : 18;
+    static constexpr int FC_MAX = GS == 4 ? 6 : 3;    // pair tiles of the busiest workgroup, at most (the host checks)
 };
 
 // ------------------------------------------------------------------------------------------------ granules
@@ -131,6 +145,7 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 struct PhaseW {  // one phase as a streamer wave sees it (all wave-uniform)
     unsigned base;  // byte offset of the stream inside the layer's descriptor
     int tile0, units, u0, nu, ntiles;
+    int tstride;    // M_PAIR / M_SINGLE: tile of the phase's ti-th tile = tile0 + ti * tstride (the number of workgroups)
 };
 // how the R pieces of a ring step relate: M_SHARED — R row tiles against one activation unit, ONE virtual tile per phase (tile of
 // piece r = tile0 + (r / RTK) * kstride + r % RTK: the q / k / v thirds of c_attn, or the RT residual tiles of a projection);
@@ -146,11 +161,11 @@ __device__ __forceinline__ unsigned piece_off(const PhaseW& ph, int ti, int st, 
         ok = ti == 0 && st < ph.nu;
         return ph.base + (unsigned)(tile * ph.units + ph.u0 + st) * 1024u;
     } else if constexpr (MODE == M_PAIR) {
-        const int tile = ph.tile0 + ti * kG;
+        const int tile = ph.tile0 + ti * ph.tstride;
         ok = ti < ph.ntiles && st < ph.nu;
         return ph.base + (unsigned)((tile * ph.units + ph.u0 + st) * 2 + r) * 1024u;
     } else {
-        const int tile = ph.tile0 + ti * kG;
+        const int tile = ph.tile0 + ti * ph.tstride;
         ok = ti < ph.ntiles && st < ph.nu;
         return ph.base + (unsigned)(tile * ph.units + ph.u0 + st) * 1024u;
     }
@@ -306,10 +321,10 @@ __device__ __forceinline__ void run_phase(u32x4 (&ring)[kRing], const PhaseW& ph
 
 }  // namespace
 
-template <int GS>
+template <int NH_, int GS>
 __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedParams p) {
-    using SH = Shape<GS>;
-    constexpr int C = SH::C, UC = SH::UC, RT = SH::RT, DH = SH::DH, NH = SH::NH, NUW = SH::NUW;
+    using SH = Shape<NH_, GS>;
+    constexpr int C = SH::C, UC = SH::UC, RT = SH::RT, DH = SH::DH, NH = SH::NH, NUW = SH::NUW, NWG = SH::NWG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -324,15 +339,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
     // workgroup -> head group: the GS workgroups of a head sit on one XCD (blocks are dealt round-robin to the 8 XCDs; a speed
     // matter only — the protocol does not depend on placement)
     const int xcd = bid & 7, slot = bid >> 3;
-    const int head = xcd * (NH / 8) + slot / GS;
-    const int hj = slot % GS;  // which DH dimensions of the head
+    const int head = NH % 8 == 0 ? xcd * (NH / 8) + slot / GS : bid / GS;  // (52 heads: a head group spans XCDs)
+    const int hj = NH % 8 == 0 ? slot % GS : bid % GS;                     // which DH dimensions of the head
 
     const int pos = p.pos[0];
     const int token = p.tokens[0];
     const unsigned step_id = p.state[1];
     const unsigned ebase = step_id * 1024u + 1u;
-    const int n_fc = (p.fc_tiles - bid + kG - 1) / kG;        // this workgroup's pair tiles
-    const int n_head_t = (p.head_tiles - bid + kG - 1) / kG;  // lm_head tiles
+    const int n_fc = (p.fc_tiles - bid + NWG - 1) / NWG;        // this workgroup's pair tiles
+    const int n_head_t = (p.head_tiles - bid + NWG - 1) / NWG;  // lm_head tiles
 
     // entered outside the cache (the host takes the cache-roll regime of model.py:214-218 elsewhere) or with a token id outside
     // the embedding table: refuse before anything is written.  Uniform over the grid, so no hand-off hangs.
@@ -344,16 +359,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
     FW_STAMP(0);
 
     // phase geometry (compile time): steps per tile / ring turns per body
-    constexpr int SPT_C = NUW;                                    // tiles over a C-wide input: NUW steps per wave
+    constexpr int SPT_C = NUW;                                    // tiles over a C-wide input: NUW steps per wave (idle ones where a wave has fewer)
     constexpr int R_ATT = 3 * RT, ST_ATT = kRing / R_ATT;         // c_attn: q / k / v x RT tiles share the operand
     constexpr int TU_ATT = (NUW + ST_ATT - 1) / ST_ATT;
     constexpr int R_PRJ = RT, ST_PRJ = kRing / R_PRJ;             // attn.c_proj, mlp.c_proj: RT residual tiles share the operand
     constexpr int TU_PRJ = (NUW + ST_PRJ - 1) / ST_PRJ;
-    constexpr int TU_MP = GS == 4 ? 4 : 1;                        // mlp.c_proj: up to TU_MP * ST_PRJ units of the hidden vector per wave
-    constexpr int TU_FC = GS == 4 ? 4 : 2, TPB_FC = TU_FC * 6 / SPT_C;     // pair tiles: 6 steps per turn, 3 tiles per body
-    constexpr int TU_HD = GS == 4 ? 2 : 1, TPB_HD = TU_HD * 12 / SPT_C;    // lm_head: 12 steps per turn, 3 tiles per body
-    constexpr int NB_FC = GS == 4 ? 2 : 1;  // bodies of the pair phase: 4 .. 6 / 1 .. 3 pair tiles per workgroup (host check)
-    static_assert(TPB_FC == 3 && TPB_HD == 3, "tiles per body");
+    constexpr int TU_MP = (SH::MP_STEPS + ST_PRJ - 1) / ST_PRJ;   // mlp.c_proj: up to TU_MP * ST_PRJ units of the hidden vector per wave
+    constexpr int TU_FC = turns_for(6, SPT_C), TPB_FC = TU_FC * 6 / SPT_C;      // pair tiles: 6 steps per turn, whole tiles per body
+    constexpr int NB_FC = (SH::FC_MAX + TPB_FC - 1) / TPB_FC;                   // bodies of the pair phase (unrolled)
+    constexpr int TU_HD = turns_for(12, SPT_C), TPB_HD = TU_HD * 12 / SPT_C;    // lm_head: 12 steps per turn
 
     if (wave < kSW) {
         // =========================================================================================== streamers
@@ -372,14 +386,16 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
         int buf = 0;
 
         PhaseW ph_attn, ph_proj, ph_fc, ph_mp, ph_head;
-        ph_attn = {p.off_attn, head * 8 + hj * RT, UC, wave * NUW, NUW, 1};
-        ph_proj = {p.off_proj, bid * RT, UC, wave * NUW, NUW, 1};
-        ph_fc = {p.off_fc, bid, UC, wave * NUW, NUW, n_fc};
+        // this wave's units of a C-wide input (52 heads: 6 or 7) and of the hidden vector
+        const int cu0 = wave * (UC / kSW) + (wave < UC % kSW ? wave : UC % kSW), cnu = UC / kSW + (wave < UC % kSW ? 1 : 0);
+        ph_attn = {p.off_attn, head * 8 + hj * RT, UC, cu0, cnu, 1, 0};
+        ph_proj = {p.off_proj, bid * RT, UC, cu0, cnu, 1, 0};
+        ph_fc = {p.off_fc, bid, UC, cu0, cnu, n_fc, NWG};
         {
             const int uq = p.units_h / kSW, ur = p.units_h % kSW;
-            ph_mp = {p.off_mproj, bid * RT, p.units_h, wave * uq + (wave < ur ? wave : ur), uq + (wave < ur ? 1 : 0), 1};
+            ph_mp = {p.off_mproj, bid * RT, p.units_h, wave * uq + (wave < ur ? wave : ur), uq + (wave < ur ? 1 : 0), 1, 0};
         }
-        ph_head = {0u, bid, UC, wave * NUW, NUW, n_head_t};
+        ph_head = {0u, bid, UC, cu0, cnu, n_head_t, NWG};
 
         __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.layer_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_head, 0, (int)p.head_bytes, 0x00020000);
@@ -632,9 +648,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
         auto gather_x = [&]() {
             const unsigned ep = ebase + edge;
             const unsigned base = (unsigned)xpar * (unsigned)SH::GXS * 8u;
-            constexpr int NPL = C / 4 / 64;          // pair loads per lane over both gatherers (32 / 16)
+            constexpr int NPL = C / 4 / 64;          // pair loads per lane over both gatherers (32 / 26 / 20 / 16)
             constexpr int NP0 = NPL / 2 - 2;         // gatherer 0's share
-            constexpr int NS = 2 * RT;               // loads of the per-tile sums of squares (two each)
+            constexpr int NSL = NWG * RT / 2;        // loads of the per-tile sums of squares (two each)
+            constexpr int NS = (NSL + 63) / 64;      // ... per lane
             float2 sx = {0.f, 0.f};
             if (gw == 0) {
                 u32x4 v[NP0 + NS];
@@ -642,12 +659,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     bool ok = true;
 #pragma unroll
                     for (int k = 0; k < NP0 + NS; ++k) {
+                        const int is = (k - NP0) * 64 + lane_v;  // (k >= NP0: load `is` of the sums; none past NSL)
                         const unsigned off = k < NP0 ? base + (unsigned)(k * 64 + lane_v) * 16u
-                                                     : base + (unsigned)(C / 2) * 8u + (unsigned)((k - NP0) * 64 + lane_v) * 16u;
+                                                     : (is < NSL ? base + (unsigned)(C / 2) * 8u + (unsigned)is * 16u : 0xFFFFFFF0u);
                         v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, off, 0, 16));
                     }
 #pragma unroll
-                    for (int k = 0; k < NP0 + NS; ++k) ok &= v[k][1] == ep && v[k][3] == ep;
+                    for (int k = 0; k < NP0 + NS; ++k) ok &= (k >= NP0 && (k - NP0) * 64 + lane_v >= NSL) || (v[k][1] == ep && v[k][3] == ep);
                     if (__all(ok)) break;
                     if (spins > kSpinLimit || aborted(p)) {
                         if (lane == 0) raise_abort(p, 0x100u + edge);
@@ -659,7 +677,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 for (int k = 0; k < NP0; ++k) stage(v[k], k * 64 + lane_v, sx);
                 float ss = 0.f;
 #pragma unroll
-                for (int k = 0; k < NS; ++k) ss += __uint_as_float(v[NP0 + k][0]) + __uint_as_float(v[NP0 + k][2]);
+                for (int k = 0; k < NS; ++k)  // (loads past the end returned zeros)
+                    ss += __uint_as_float(v[NP0 + k][0]) + __uint_as_float(v[NP0 + k][2]);
                 ss = group_sum(ss, 64);
                 put_sums(sx);
                 if (lane == 0) {
@@ -897,7 +916,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 const bf16_t* s_fc = sz_l + 8 * C;
                 // scales / zeros of the pair tile this gatherer handles next (requested one of its tiles ahead)
                 auto fc_sz = [&](int t, float2& a1, float2& b1, float2& a2, float2& b2) {
-                    const int n = (bid + (t < n_fc ? t : 0) * kG) * 16 + 2 * pg;
+                    const int n = (bid + (t < n_fc ? t : 0) * NWG) * 16 + 2 * pg;
                     a1 = ldpair(s_fc + n);
                     b1 = ldpair(s_fc + p.H + n);
                     a2 = ldpair(s_fc + 2 * p.H + n);
@@ -921,7 +940,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                         const float2 a = deq(tile_pair(0), fs1, fz1, s);
                         const float2 b = deq(tile_pair(1), fs2, fz2, s);
                         if (w8 == 0)
-                            gr_store(dst + (bid + t * kG) * 8 + pg, ep,
+                            gr_store(dst + (bid + t * NWG) * 8 + pg, ep,
                                      hpair(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv), (pg & 1) != 0));
                     }
                     fs1 = ns1;
@@ -994,7 +1013,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
         // ================= ln_f + lm_head (+ greedy arg-max, generate.py:68-85 with top_k = 1): gatherer 0
         {
             auto head_sz = [&](int t, float2& sc_, float2& z_) {  // scale / zero of a tile's rows, requested one tile ahead
-                const int n = (bid + t * kG) * 16 + 2 * pg;
+                const int n = (bid + t * NWG) * 16 + 2 * pg;
                 const bool ok = t < n_head_t && n + 1 < p.V;
                 sc_ = ok ? ldpair(p.sz_head + n) : float2{0.f, 0.f};
                 z_ = ok ? ldpair(p.sz_head + p.V + n) : float2{0.f, 0.f};
@@ -1013,7 +1032,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 if (gw == 0) head_sz(t + 1, scn, zn);
                 __syncthreads();  // Bt
                 if (gw == 0 && t < n_head_t) {
-                    const int n = (bid + t * kG) * 16 + 2 * pg;
+                    const int n = (bid + t * NWG) * 16 + 2 * pg;
                     float2 y = deq(tile_pair(0), sct, zt, s);
                     y.x *= rinv;
                     y.y *= rinv;
@@ -1053,11 +1072,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     }
                     if (bid == 0) {
                         u32x4 v[4];
-                        const bool ok = sweep<4>(p, rs_ws, kOGm, 0, 256, ep, v, 0x600u + edge, lane_v);
+                        const bool ok = sweep<4>(p, rs_ws, kOGm, 0, NWG, ep, v, 0x600u + edge, lane_v);
                         float bv = -INFINITY;
                         int bx = 0x7fffffff;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
+                            if (k * 64 + lane_v >= NWG) continue;  // (fewer than 256 workgroups: loads past the end returned zeros)
                             const float cv = __uint_as_float(v[k][0]);
                             const int ci = (int)v[k][2];
                             if (cv > bv || (cv == bv && ci < bx)) {
@@ -1096,43 +1116,59 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
 
 // ------------------------------------------------------------------------------------------------ host side
 // (residency: see fused_step_ring.hip — the occupancy query is made once, a kernel that does not fit one workgroup per CU is refused)
+namespace {
+const void* const kWideFn[4] = {(const void*)fused_step_wide_kernel<64, 4>, (const void*)fused_step_wide_kernel<52, 4>,
+                                (const void*)fused_step_wide_kernel<40, 4>, (const void*)fused_step_wide_kernel<32, 8>};
+int wide_index(int n_head) { return n_head == 64 ? 0 : n_head == 52 ? 1 : n_head == 40 ? 2 : n_head == 32 ? 3 : -1; }
+}  // namespace
+
 int fused_step_wide_occupancy_ok() {
     static int ok = -1;
     static std::once_flag once;
     std::call_once(once, [] {
-        const void* fn[2] = {(const void*)fused_step_wide_kernel<4>, (const void*)fused_step_wide_kernel<8>};
         ok = 0;
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             int per_cu = 0;
-            (void)hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn[i], kThreads, kLdsBytes) == hipSuccess && per_cu >= 1) ok |= 1 << i;
+            (void)hipFuncSetAttribute(kWideFn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kWideFn[i], kThreads, kLdsBytes) == hipSuccess && per_cu >= 1) ok |= 1 << i;
         }
     });
-    return ok;  // bit 0: the 64-head instantiation fits one workgroup per CU, bit 1: the 32-head one
+    return ok;  // bit i: instantiation i (64 / 52 / 40 heads x 4 workgroups, 32 heads x 8) fits one workgroup per CU
 }
 
-// launched by mi355_fused_step (fused_step.hip) for weight_fmt 4; gs = workgroups per head (4: n_embd 8192 / 64 heads, 8: 4096 / 32)
-int fused_step_wide_launch(const FusedParams& p, int gs, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+// tiles per body of the pair phase / of lm_head and the ring steps mlp.c_proj may take per wave, for the host's checks and body counts
+void fused_step_wide_geometry(int n_head, int* tpb_fc, int* fc_max, int* tpb_head, int* mp_steps) {
+    const int spt = (n_head + kSW - 1) / kSW;
+    *tpb_fc = turns_for(6, spt) * 6 / spt;
+    *tpb_head = turns_for(12, spt) * 12 / spt;
+    *fc_max = n_head == 32 ? 3 : 6;
+    *mp_steps = n_head == 64 ? 22 : n_head == 32 ? 11 : 18;
+}
+
+// launched by mi355_fused_step (fused_step.hip) for weight_fmt 4; n_head selects the instantiation, the grid is n_head x (4 or 8) workgroups
+int fused_step_wide_launch(const FusedParams& p, int n_head, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        const void* fn[2] = {(const void*)fused_step_wide_kernel<4>, (const void*)fused_step_wide_kernel<8>};
-        for (int i = 0; i < 2 && attr_err == hipSuccess; ++i)
-            attr_err = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        for (int i = 0; i < 4 && attr_err == hipSuccess; ++i)
+            attr_err = hipFuncSetAttribute(kWideFn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     });
     MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "fused_step: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+    const int grid = n_head * (n_head == 32 ? 8 : 4);
 #define FW_LAUNCH(K_)                                                                                                  \
     do {                                                                                                              \
         if (e0 != nullptr) {                                                                                          \
-            hipExtLaunchKernelGGL((K_), dim3(kG), dim3(kThreads), (uint32_t)kLdsBytes, stream, e0, e1, 0, p);          \
+            hipExtLaunchKernelGGL((K_), dim3(grid), dim3(kThreads), (uint32_t)kLdsBytes, stream, e0, e1, 0, p);        \
         } else {                                                                                                      \
-            hipLaunchKernelGGL((K_), dim3(kG), dim3(kThreads), kLdsBytes, stream, p);                                  \
+            hipLaunchKernelGGL((K_), dim3(grid), dim3(kThreads), kLdsBytes, stream, p);                                \
         }                                                                                                             \
     } while (0)
-    if (gs == 4) {
-        FW_LAUNCH((fused_step_wide_kernel<4>));
-    } else {
-        FW_LAUNCH((fused_step_wide_kernel<8>));
+    switch (wide_index(n_head)) {
+        case 0: FW_LAUNCH((fused_step_wide_kernel<64, 4>)); break;
+        case 1: FW_LAUNCH((fused_step_wide_kernel<52, 4>)); break;
+        case 2: FW_LAUNCH((fused_step_wide_kernel<40, 4>)); break;
+        case 3: FW_LAUNCH((fused_step_wide_kernel<32, 8>)); break;
+        default: MI355_CHECK_ARG(false, MI355_E_SHAPE, "fused_step (weight_fmt 4): %d heads", n_head);
     }
 #undef FW_LAUNCH
     MI355_LAUNCH_CHECK();
