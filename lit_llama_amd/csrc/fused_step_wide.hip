@@ -1,31 +1,36 @@
-// The persistent decode step for the WIDE shapes (round 6): mi355_fused_step with weight_fmt 4 — per-row gptq.int4 models whose
-// heads do not map 8 workgroups to a head of 32, i.e. LLaMA-65B on one GPU (n_embd 8192, 64 heads: BASELINE.json configs[4] at TP = 1).
-// csrc/fused_step_ring.hip is the same protocol written for n_embd 4096 / 32 heads with five operand formats; this file carries ONE
-// format (int4 streams -> fp16 operands, its weight_fmt 0) and ONE shape parameter:
+// The persistent decode step for the WIDE shapes (round 6): mi355_fused_step with weight_fmt 4 — per-row gptq.int4 models whose heads
+// do not map 8 workgroups to a head of 32, i.e. every LLaMA size above 7B of /root/reference lit_llama/model.py:43-48: 13B (40 heads,
+// n_embd 5120), 30B (52, 6656) and 65B (64, 8192: BASELINE.json configs[4] at TP = 1).  csrc/fused_step_ring.hip is the same protocol
+// written for n_embd 4096 / 32 heads with five operand formats; this file carries ONE format (int4 streams -> fp16 operands, its
+// weight_fmt 0) and the shape as template parameters:
 //
-//   GS = workgroups per head (256 workgroups = 256 / GS heads of 128 dims), RT = 8 / GS = 16-row tiles per workgroup
-//        GS = 4: 64 heads, n_embd 8192 (65B);  GS = 8: 32 heads, n_embd 4096 (the 7B shape, kept as the cross-check against
+//   NH = heads of 128 dims, GS = workgroups per head, NH x GS workgroups (one per CU), RT = 8 / GS = 16-row tiles per workgroup
+//        GS = 4: 40 / 52 / 64 heads = 160 / 208 / 256 workgroups;  GS = 8: 32 heads (the 7B shape, kept as the cross-check against
 //        fused_step_ring.hip: MI355_FUSED_WIDE=1 in lit_llama_amd/engine.py)
 //
-// Replaces, per generated token, the 161 x (n_layer / 32) operator calls of /root/reference lit_llama/model.py:76-122 (Block.forward
-// :165-168, CausalSelfAttention.forward :194-237, MLP.forward :251-254, RMSNorm :274-277, apply_rope :306-323), the greedy sampling of
-// generate.py:68-85 and this repository's launch-per-operator step (80 x 7 launches for 65B: 138.6 tok/s = 0.56 of the int4-weight
-// roofline in round 5, against 0.76 for the 404-MB bf16 7B layer on the persistent skeleton).
+// Replaces, per generated token, the 161 x (n_layer / 32) operator calls of lit_llama/model.py:76-122 (Block.forward :165-168,
+// CausalSelfAttention.forward :194-237, MLP.forward :251-254, RMSNorm :274-277, apply_rope :306-323), the greedy sampling of
+// generate.py:68-85 and this repository's launch-per-operator step (80 x 7 launches for 65B).  Measured (round 6, bench.py --model):
+// 65B 161-163 tok/s = 0.66 of the int4-weight roofline against 133 = 0.54 on launches, 30B 265 against 209, 13B 509 against 394.
 //
-// What is shared with fused_step_ring.hip (read its header first): 256 resident workgroups of 8 streamer + 2 gatherer waves; weights in
+// What is shared with fused_step_ring.hip (read its header first): resident workgroups of 8 streamer waves + gatherer waves; weights in
 // a 12-piece register ring per streamer wave (1-KiB non-temporal wave loads); activations between phases as 8-byte {tag, value}
 // granules (one sc1 store, swept with sc1 loads until every tag equals the edge's epoch); the residual stream in registers for the
 // whole step; head-local q / k / v exchange.  What differs:
 //   * a workgroup owns 16 RT residual rows and 16 RT dims of its head: c_attn is 3 RT row tiles against one activation operand
-//     (R = 6 for 65B), attn.c_proj / mlp.c_proj RT tiles; with RT = 2 BOTH gatherer waves run epilogues (tile r belongs to gatherer
-//     r) and both publish; the c_fc1 / c_fc2 pair tiles alternate between them;
+//     (R = 6), attn.c_proj / mlp.c_proj RT tiles; FOUR gatherer waves sweep the (twice as large) edges, the first RT of them run the
+//     epilogues of the residual / head tiles (tile r belongs to gatherer r) and publish; the c_fc1 / c_fc2 pair tiles alternate between
+//     gatherers 0 and 1;
 //   * the attention splits cache ROWS over the GS workgroups of a head at every position (the ring kernel does so from position
 //     384 on): chunk c of 32 rows belongs to workgroup c % GS, wave (c / GS) % 8; a second head-local exchange of (128 weighted
 //     values, max, sum) partials;
-//   * the phases of these shapes stream many ring turns in-phase (a 65B layer is 405 MB: 65 us at the 6.2 TB/s a plain stream
-//     reaches), so the next phase's first ring turn is requested in FRONT of the publish barrier (the ring kernel's
-//     MI355_FUSED_EARLY_BURST rule for its bf16 / int8 streams), and partial tiles are parked as column 0 only (LDS: the hidden
-//     vector alone is 44 KB).
+//   * a phase's first ring turn is requested ACROSS the publish barrier of the phase before it (kWin pieces in front of it, the rest
+//     behind), partial tiles are parked as column 0 only (LDS: the hidden vector alone is 44 KB), the bodies of the pair phase are
+//     unrolled (a runtime loop around loads makes hipcc drain the ring at every back edge).
+// Where a 65B layer's 77 us go (profiles/r06_wide_65b_first_timeline.txt): the four phases stream 306 MB in 53 us (5.8 TB/s, 7.0 between a
+// phase's B1 and wave 0's last tile), the hand-offs take 23 us (x edges 4.2-5.3, attention output 4.2, hidden 7.8: every CU reads every
+// edge) during which only the 96 KiB per CU of a first ring turn are in flight.  More in flight across a hand-off costs the sweeps what it
+// fetches (LDS-DMA extension ring: -3 %), so does requesting earlier (profiles/r06_ab_wide_knobs.txt).
 // Hand-offs are fp16 pairs: the +-65504 range rule, the clip bookkeeping (state[2], state[3]) and the abort word are the ring kernel's.
 #include <math.h>
 
@@ -41,7 +46,8 @@ namespace {
 
 constexpr int kG = 256;   // workgroups, at most (= CUs)
 constexpr int kSW = 8;    // streamer waves
-constexpr int kGW = 2;    // gatherer waves
+constexpr int kGW = 4;    // gatherer waves: the first RT of them also run the epilogues of the residual / head tiles (two gatherers, the
+                          // ring kernel's count, cost 1.3 % at the 65B width, where every edge is twice as large: profiles/r06_ab_wide_knobs.txt)
 constexpr int kThreads = 64 * (kSW + kGW);
 constexpr int kRing = 12;  // ring pieces (1 KiB each) per streamer wave
 #ifndef MI355_WIDE_WINDOW
@@ -552,9 +558,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
         // =========================================================================================== gatherers
         const int gw = wave - kSW;
         // with RT = 2 both gatherer waves own a residual / head tile (tile `er`) and run its epilogues; with RT = 1 gatherer 0 does
-        constexpr bool kBoth = RT == 2;
-        const bool epi = kBoth || gw == 0;
-        const int er = kBoth ? gw : 0;
+        const bool epi = gw < RT;
+        const int er = gw < RT ? gw : 0;
         unsigned edge = 0;  // edges published so far in this step (the epoch of the next one is ebase + edge)
         int xpar = 0, apar = 0, hpar = 0, qpar = 0, ppar = 0;
         int buf = 0;
@@ -603,15 +608,23 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             sx.x = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, even), ones2, sx.x, false);
             sx.y = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, odd), ones2, sx.y, false);
         };
-        auto put_sums = [&](float2 sx) {  // misc[4 + gw] / misc[6 + gw]: this gatherer wave's S_even / S_odd
+        auto put_sums = [&](float2 sx) {  // misc[4 + gw] / misc[8 + gw]: this gatherer wave's S_even / S_odd
             sx.x = group_sum(sx.x, 64);
             sx.y = group_sum(sx.y, 64);
             if (lane == 0) {
                 misc[4 + gw] = sx.x;
-                misc[6 + gw] = sx.y;
+                misc[8 + gw] = sx.y;
             }
         };
-        auto get_sums = [&]() { return (misc[4] + misc[5]) + 16.f * (misc[6] + misc[7]); };
+        auto get_sums = [&]() {
+            float se = misc[4], so = misc[8];
+#pragma unroll
+            for (int g2 = 1; g2 < kGW; ++g2) {
+                se += misc[4 + g2];
+                so += misc[8 + g2];
+            }
+            return se + 16.f * so;
+        };
         auto deq = [&](float2 t, float2 sc_, float2 z_, float s) {  // the streamers' operands are q - 8
             return float2{sc_.x * (t.x - (z_.x - 8.f) * s), sc_.y * (t.y - (z_.y - 8.f) * s)};
         };
@@ -649,7 +662,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             const unsigned ep = ebase + edge;
             const unsigned base = (unsigned)xpar * (unsigned)SH::GXS * 8u;
             constexpr int NPL = C / 4 / 64;          // pair loads per lane over both gatherers (32 / 26 / 20 / 16)
-            constexpr int NP0 = NPL / 2 - 2;         // gatherer 0's share
+            // gatherer 0's share (it also takes the sums of squares and the serial tail behind them)
+            constexpr int NP0 = (NPL + (NWG * RT / 2 + 63) / 64 + kGW - 1) / kGW - (NWG * RT / 2 + 63) / 64;
             constexpr int NSL = NWG * RT / 2;        // loads of the per-tile sums of squares (two each)
             constexpr int NS = (NSL + 63) / 64;      // ... per lane
             float2 sx = {0.f, 0.f};
@@ -686,17 +700,31 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     misc[0] = rv;
                 }
             } else {
-                constexpr int N1 = NPL - NP0;  // 18 / 10 loads per lane: two chunks in flight, only the first waits for producers
-                constexpr int NA = 8, NB = N1 - NA;
-                u32x4 va[NA], vb[NB];
-                sweep_issue<NA>(rs_ws, base, NP0 * 64, C / 4, va, lane_v);
-                sweep_issue<NB>(rs_ws, base, (NP0 + NA) * 64, C / 4, vb, lane_v);
-                sweep<NA>(p, rs_ws, base, NP0 * 64, C / 4, ep, va, 0x200u + edge, lane_v, true);
+                // the other gatherers share the rest: N1 loads per lane each, two chunks in flight, only the first waits for producers
+                constexpr int N1 = (NPL - NP0 + kGW - 2) / (kGW - 1);
+                constexpr int NA = N1 < 8 ? N1 : 8, NB = N1 - NA;
+                constexpr bool EX = (NP0 + (kGW - 1) * N1) * 64 == C / 4;  // the shares tile the edge exactly: no bounds to test
+                const int first = (NP0 + (gw - 1) * N1) * 64;
+                const int end = first + N1 * 64 < C / 4 ? first + N1 * 64 : C / 4;
+                u32x4 va[NA];
+                sweep_issue<NA>(rs_ws, base, first, end, va, lane_v);
+                if constexpr (NB > 0) {
+                    u32x4 vb[NB];
+                    sweep_issue<NB>(rs_ws, base, first + NA * 64, end, vb, lane_v);
+                    sweep<NA>(p, rs_ws, base, first, end, ep, va, 0x200u + edge, lane_v, true);
 #pragma unroll
-                for (int k = 0; k < NA; ++k) stage(va[k], (NP0 + k) * 64 + lane_v, sx);
-                sweep<NB>(p, rs_ws, base, (NP0 + NA) * 64, C / 4, ep, vb, 0x200u + edge, lane_v, true);
+                    for (int k = 0; k < NA; ++k)
+                        if (EX || first + k * 64 + lane_v < end) stage(va[k], first + k * 64 + lane_v, sx);
+                    sweep<NB>(p, rs_ws, base, first + NA * 64, end, ep, vb, 0x200u + edge, lane_v, true);
 #pragma unroll
-                for (int k = 0; k < NB; ++k) stage(vb[k], (NP0 + NA + k) * 64 + lane_v, sx);
+                    for (int k = 0; k < NB; ++k)
+                        if (EX || first + (NA + k) * 64 + lane_v < end) stage(vb[k], first + (NA + k) * 64 + lane_v, sx);
+                } else {
+                    sweep<NA>(p, rs_ws, base, first, end, ep, va, 0x200u + edge, lane_v, true);
+#pragma unroll
+                    for (int k = 0; k < NA; ++k)
+                        if (EX || first + k * 64 + lane_v < end) stage(va[k], first + k * 64 + lane_v, sx);
+                }
                 put_sums(sx);
             }
             xpar ^= 1;
@@ -872,11 +900,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 }
                 const unsigned ep = ebase + edge;
                 {
-                    // C / 4 loads of pair granules, half per gatherer, two chunks in flight
-                    constexpr int NL = C / 4 / 64 / 2;  // 16 / 8 per lane
+                    // C / 4 loads of pair granules, an equal share per gatherer, two chunks in flight
+                    constexpr int NL = (C / 4 / 64 + kGW - 1) / kGW;  // per lane
                     constexpr int NA = NL < 8 ? NL : 8, NB = NL - NA;
+                    constexpr bool EX = NL * kGW * 64 == C / 4;
                     const unsigned base = kOGa + (unsigned)apar * (unsigned)(C / 2) * 8u;
-                    const int first = gw * NL * 64, end = first + NL * 64;
+                    const int first = gw * NL * 64, end = first + NL * 64 < C / 4 ? first + NL * 64 : C / 4;
                     float2 sxp = {0.f, 0.f};
                     u32x4 va[NA];
                     sweep_issue<NA>(rs_ws, base, first, end, va, lane_v);
@@ -885,14 +914,17 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                         sweep_issue<NB>(rs_ws, base, first + NA * 64, end, vb, lane_v);
                         sweep<NA>(p, rs_ws, base, first, end, ep, va, 0x400u + edge, lane_v, true);
 #pragma unroll
-                        for (int k = 0; k < NA; ++k) stage(va[k], first + k * 64 + lane_v, sxp);
+                        for (int k = 0; k < NA; ++k)
+                            if (EX || first + k * 64 + lane_v < end) stage(va[k], first + k * 64 + lane_v, sxp);
                         sweep<NB>(p, rs_ws, base, first + NA * 64, end, ep, vb, 0x400u + edge, lane_v, true);
 #pragma unroll
-                        for (int k = 0; k < NB; ++k) stage(vb[k], first + (NA + k) * 64 + lane_v, sxp);
+                        for (int k = 0; k < NB; ++k)
+                            if (EX || first + (NA + k) * 64 + lane_v < end) stage(vb[k], first + (NA + k) * 64 + lane_v, sxp);
                     } else {
                         sweep<NA>(p, rs_ws, base, first, end, ep, va, 0x400u + edge, lane_v, true);
 #pragma unroll
-                        for (int k = 0; k < NA; ++k) stage(va[k], first + k * 64 + lane_v, sxp);
+                        for (int k = 0; k < NA; ++k)
+                            if (EX || first + k * 64 + lane_v < end) stage(va[k], first + k * 64 + lane_v, sxp);
                     }
                     put_sums(sxp);
                 }
@@ -963,15 +995,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 }
                 const unsigned ep = ebase + edge;
                 {
-                    // H / 4 loads of pair granules, half per gatherer, in chunks of 8 per lane, TWO in flight: only the first one waits
+                    // H / 4 loads of pair granules, an equal share per gatherer, in chunks of 8 per lane, TWO in flight: only the first one waits
                     // for producers (issued one after the other each later chunk costs its own memory round trip)
-                    const int n_loads = p.H / 4, half_l = (n_loads + 1) / 2;
-                    const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
+                    const int n_loads = p.H / 4, part_l = (n_loads + kGW - 1) / kGW;
+                    const int first = gw * part_l, end = first + part_l < n_loads ? first + part_l : n_loads;
                     const unsigned hbase = kOGh + (unsigned)hpar * (unsigned)gh_stride * 8u;
                     int lh = lane_v;
                     asm volatile("" : "+v"(lh));  // addresses of this block are computed here, not hoisted and spilled
                     float2 sxp = {0.f, 0.f};
-                    constexpr int NCH = 6;  // chunks of 512 loads per gatherer: n_hidden <= 24576
+                    constexpr int NCH = 12 / kGW;  // chunks of 512 loads per gatherer: n_hidden <= 24576
                     constexpr int ND = 2;  // chunks in flight
                     u32x4 vv[ND][8];
 #pragma unroll
