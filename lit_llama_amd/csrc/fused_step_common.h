@@ -50,8 +50,8 @@ struct FusedParams {
 };
 
 
-// granules per parity of the x / attention-output edges and in front of the hidden edge's pairs (round 5: with fp8-limb operands every
-// PUBLISHER also sends the sum of the operand values it publishes, so that no consumer has to take it: see fused_step_ring.hip)
+// granules per parity of the x / attention-output edges and in front of the hidden edge's pairs (the 256 granules in front of the
+// attention-output / hidden pairs carried per-publisher operand sums in round 5's rejected variant; the map keeps the room)
 constexpr int kFsGxStride = 2048 + 512, kFsGaSums = 256, kFsGaStride = kFsGaSums + 2048, kFsGhSums = 256;
 // workspace map (bytes), see mi355_fused_step_workspace_bytes
 constexpr size_t kFsWsState = 0, kFsWsGx = 256, kFsWsGa = kFsWsGx + 2 * kFsGxStride * 8, kFsWsGq = kFsWsGa + 2 * kFsGaStride * 8,

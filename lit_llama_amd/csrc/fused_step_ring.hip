@@ -1,7 +1,8 @@
-// THE DEFAULT implementation of the persistent decode step (mi355_fused_step, host side in fused_step.hip): weights in a
-// 12-piece REGISTER ring per streamer wave, requested per phase after the previous phase's publish.  fused_step.hip holds
-// the round-3 alternative (LDS-DMA rings that stream across phase boundaries, MI355_FUSED_IMPL=lds), which keeps every
-// phase's weights landed before its hand-off completes and is still slower end to end: see DESIGN.md section 5.
+// The persistent decode step of the 7B shape (mi355_fused_step, host side in fused_step.hip; weight_fmt 0 .. 3): weights in a 12-piece
+// REGISTER ring per streamer wave, requested per phase after the previous phase's publish.  Round 3's alternative (LDS-DMA rings that
+// stream across phase boundaries: every phase's weights landed before its hand-off completes, and still slower end to end — DESIGN.md
+// section 5) lives in scripts/patches/r03_fused_step_lds_dma_kernel.hip.txt.gz; the wider LLaMA shapes (13B / 30B / 65B) run
+// fused_step_wide.hip, the same protocol with the shape as a template parameter.
 //
 // The whole T = 1 decode step of a 7B-class gptq.int4 LLaMA as ONE persistent launch on gfx950.
 //
@@ -48,13 +49,7 @@ constexpr int kSW = 8;          // streamer waves
 constexpr int kGW = 2;          // gatherer waves
 constexpr int kThreads = 64 * (kSW + kGW);
 constexpr int kRing = 12;       // ring pieces (1 KiB each) per streamer wave
-#ifndef MI355_FUSED_HSWEEP
-#define MI355_FUSED_HSWEEP 2  // chunks of the hidden edge in flight per gatherer wave (2: 8 + 4 loads per lane, 3: 3 x 8)
-#endif
-#ifndef MI355_FUSED_WINDOW
-#define MI355_FUSED_WINDOW 4
-#endif
-constexpr int kWin = MI355_FUSED_WINDOW;  // pieces per wave in flight while a first ring turn is requested
+constexpr int kWin = 4;         // pieces per wave in flight while a first ring turn is requested (2, 3, 5, 6, 8: within +-1 % except 2 and 6)
 constexpr int kC = 4096;        // n_embd
 constexpr int kHeads = 32;
 constexpr int kHs = 128;
@@ -63,49 +58,21 @@ constexpr int kUnitsC = kC / 128;
 constexpr int kMaxFcTiles = 3;    // c_fc1/c_fc2 pair tiles per workgroup (n_hidden <= 12288)
 [[maybe_unused]] constexpr int kMaxHeadTiles = 8;  // lm_head tiles per workgroup (vocab <= 32768)
 constexpr unsigned kSpinLimit = 400000u;
-#ifndef MI355_FUSED_G0_PAIRS
-#define MI355_FUSED_G0_PAIRS 6
-#endif
-#ifndef MI355_FUSED_PROXY_NOB
-#define MI355_FUSED_PROXY_NOB 0  // MEASUREMENT ONLY (wrong results): the int4 streamers read their B operands once per phase — what do the LDS reads cost?
-#endif
-#ifndef MI355_FUSED_VSPLIT
-#define MI355_FUSED_VSPLIT 2  // c_attn epilogue (int4 streams): 1 = gatherer 1 dequantises and publishes the v rows, 2 = the k rows (RoPE) as well —
-                              // gatherer 0 keeps q.  Round 4, fp16 operands, 1: 926 vs 935 us per step on one box, 928.5 vs 921.4 on another (off).
-                              // Round 5, fp8 operands (the epilogue is a larger share of a shorter phase), profiles/r05_ab5_*.txt: 1 against 0:
-                              // 900.9 / 899.0 vs 904.7 / 908.3 and 902.7 / 897.0 / 896.3 vs 906.4 / 904.8 / 906.8; 2 against 1: 902.5 / 904.1 /
-                              // 904.2 vs 904.3 / 909.2 / 910.2 (alternating rounds on one box each)
-#endif
-#ifndef MI355_FUSED_EARLY_BURST
-#define MI355_FUSED_EARLY_BURST 1  // (same box, two rounds, profiles/r05_early_burst_ab.txt: bf16 454.8 -> 459.5 tok/s, llm.int8 719.7 -> 727.4)
-                                   // BF16 / LLM.int8 streams: request a phase's first ring turn in front of the previous phase's publish barrier
-#endif
-#ifndef MI355_FUSED_POW2RCP
-#define MI355_FUSED_POW2RCP 1  // x_scale is a power of two: 1 / x_scale = the float with the mirrored exponent (exact; saves an IEEE division per epilogue)
-#endif
-#ifndef MI355_FUSED_GPRIO
-#define MI355_FUSED_GPRIO 0
-#endif
-#ifndef MI355_FUSED_SPLIT_POS
-#define MI355_FUSED_SPLIT_POS 384
-#endif
-constexpr int kSplitPos = MI355_FUSED_SPLIT_POS;  // from this position on the attention splits rows, not dimensions
+// Round 6: the compile-time knobs of rounds 2-5 are gone (28 of them; the kernel text that carried them all is
+// scripts/patches/r05_fused_step_ring_with_all_knobs.hip.txt.gz, the measurements that decided each one are quoted where its winner lives
+// and in HISTORY.md / NOTES.md): what is left is the template (GRP, FMT) and these constants.
+constexpr int kG0Pairs = 6;     // gatherer 0's share of an x edge's 16 pair loads per lane (6 : 10 -> 918 us per step, 7 : 9 -> 935 us)
+constexpr int kSplitPos = 384;  // from this position on the attention splits rows, not dimensions (profiles/r03_attention_row_split_crossover.txt)
 constexpr int kPartStride = 136;  // granules per workgroup partial of the row-split attention: 128 values, max, sum, pad
 
 // LDS map (bytes)
 constexpr int kOffMisc = 0;                       // [0] 1/rms, [4..7] operand sums, [16..23] / [24..31] per-wave softmax max / sum
 constexpr int kOffZero = 256;                     // one all-zero unit (idle ring steps read it)
 constexpr int kOffXs = 512;                       // activation vector, 16-bit values, <= 96 units
-// [2][8 waves][4 row tiles] partial 16 x 16 tiles of the streamer waves (f32; int8 streams: int32): whole tiles (1 KiB each), or column 0
-// only (64 B) with MI355_FUSED_PART_FULL = 0.  The row-split attention parks its per-wave partial outputs here ([8 waves][128] f32).
-// 1 (default): a wave parks its whole 16 x 16 partial tiles (64 KiB of LDS in all); 0: COLUMN 0 only (4 KiB; at M = 1 the other
-// columns are copies).  The small form measured SLOWER on the int4 step (profiles/r04_ab6_*.txt, us per step: box A small 934.9 against
-// 918.7 for the round-3 object; box B small 942.2, whole 936.2, round-3 object 933.3) although it moves 1/16 of the LDS bytes — the
-// masked store sits on the tile-end path of every phase — and nothing needs the LDS it frees.
-#ifndef MI355_FUSED_PART_FULL
-#define MI355_FUSED_PART_FULL 1
-#endif
-constexpr int kPartTile = MI355_FUSED_PART_FULL ? 1024 : 64;  // bytes of one partial tile in LDS
+// [2][8 waves][4 row tiles] partial 16 x 16 tiles of the streamer waves (f32; int8 streams: int32), whole tiles of 1 KiB each (64 KiB of LDS
+// in all; parking column 0 only — at M = 1 the other columns are copies — measured SLOWER, profiles/r04_ab6_*.txt).  The row-split attention
+// parks its per-wave partial outputs here ([8 waves][128] f32).
+constexpr int kPartTile = 1024;  // bytes of one partial tile in LDS
 constexpr int kPartBytes = 2 * kSW * 4 * kPartTile;
 constexpr int kOffPart = kOffXs + 96 * 256;
 constexpr int kOffQ = kOffPart + kPartBytes;      // q[128] knew[128] vnew[128] f32
@@ -126,54 +93,16 @@ constexpr int kF8P0 = kOffXs, kF8P1 = kOffXs + kF8Units * 128 + 192, kF8P2 = kOf
 static_assert(kF8P1 + kF8Units * 128 <= kOffPart && (kF8P1 - kF8P0) % 256 == 64 && (kF8P2 - kF8P0) % 256 == 128, "fp8 limb planes");
 // power-of-two pre-scales of the three kinds of edge (published value = x * 2^-E; the consumer's block scale undoes it): an E4M3 limb
 // holds |v| <= 448 and is exact to 12 bits from 2^-6 up
-#ifndef MI355_F8_EX
-#define MI355_F8_EX 0  // x edges: norm_scale * x / ~rms
-#endif
-#ifndef MI355_F8_EA
-#define MI355_F8_EA 2  // attention output
-#endif
-#ifndef MI355_F8_EH
-#define MI355_F8_EH 4  // SwiGLU output
-#endif
-#ifndef MI355_F8_XSCALE0
-#define MI355_F8_XSCALE0 0  // scale of a step's FIRST x edge from the token's embedding row (see the gatherers' entry)
-#endif
-// fp8-limb operands (FMT 3), round 5: the zero-point term of y = scale (acc - zero S) needs S = the sum of the operand values that were
-// multiplied.  Round 4 took it in every streamer wave — one more MFMA with an all-ones A operand per step of a phase's first tile (mlp.c_proj:
-// 11 on top of its 11), a DPP sum, an LDS word per wave, eight LDS reads in the gatherer's epilogue: all of it on the consumers' chain.  1: every
-// PUBLISHER adds up the decoded limbs of the 16 values it publishes (it holds them in registers anyway) and sends the partial sum along — per
-// workgroup one more granule next to the sum of squares (x edges), one in front of the pair granules (attention output, MLP hidden) — and the
-// gatherer that sweeps the edge adds the 256 partials: S is known BEFORE the phase starts, and the streamers issue weights x activations only.
-// MEASURED (profiles/r05_ab1..3_*.txt, three boxes): the phases do get shorter (mlp.c_proj B1 -> parked 1.04 -> 0.80 us, its epilogue 0.76 -> 0.64,
-// c_attn's 1.80 -> 1.56, attn.c_proj's 0.84 -> 0.72: ~0.8 us per layer) and the STEP does not: 897 vs 898 us on one box, 911 vs 898 on another —
-// a workgroup that finishes a phase earlier sends its first sweep earlier, misses the slowest publishers and pays a whole memory round trip
-// for the retry (the row "x hand-off into the next layer": 3.7 -> 4.6 us).  Default off; the code stays as the measured alternative.
-#ifndef MI355_F8_PUBSUM
-#define MI355_F8_PUBSUM 0
-#endif
-// 1: a streamer wave parks its raw partial tiles (limb columns 0 / 1 / 2 side by side) and gatherer 0's read adds the three columns; 0:
-// the streamers add them up at the tile end (two DPP adds per register: round 4)
-#ifndef MI355_F8_COLSUM_G
-#define MI355_F8_COLSUM_G 1  // (same box, two rounds, profiles/r05_ab2_*.txt: 896.7 / 897.9 us per step against 906.8 / 904.8 with 0)
-#endif
-// fp8-limb operands: how the two gatherer waves sweep the hidden edge.  1 (round 5): what is published LATE — the third pair tiles of the
-// 176 workgroups that have one (pair loads from 2048 on) and the operand-sum partials, which follow a workgroup's last tile — is split
-// between the two gatherers and requested as each one's LAST chunk, behind its share of the early loads: when the slowest publisher's
-// granules land, ONE retry of one chunk is all that is left.  0: round 4's contiguous halves (gatherer 1 held every late load in three
-// of its four chunks; the chunk that was requested last only went out after an earlier one had seen the late data: one more memory round
-// trip behind the slowest publisher)
-#ifndef MI355_F8_HLATE
-#define MI355_F8_HLATE 1
-#endif
-#ifndef MI355_FUSED_G0_PAIRS_F8
-#define MI355_FUSED_G0_PAIRS_F8 6  // gatherer 0's share of an x edge's 16 pair loads per lane with MI355_F8_PUBSUM
-#endif
+constexpr int kF8Ex = 0;  // x edges: norm_scale * x / ~rms
+constexpr int kF8Ea = 2;  // attention output
+constexpr int kF8Eh = 4;  // SwiGLU output
+// (measured and rejected for fp8-limb operands, round 5: the publishers sending the operand sums — every phase shorter, the step not,
+// profiles/r05_ab1..3_*.txt; the streamers adding the three limb columns up at the tile end instead of gatherer 0's read — +1 %,
+// profiles/r05_ab2_*.txt; the first x edge of a step scaled by the embedding row's own rms — no gain on the LLaMA-statistics fixture at
+// +1.2 % per step, profiles/r05_f8_xscale0_llama_statistics.txt)
 [[maybe_unused]] constexpr int kMaxS = 32768;     // cache rows (the attention keeps no per-row state in LDS)
-#ifndef MI355_FUSED_LDS_PAD
-#define MI355_FUSED_LDS_PAD 0  // (A / B knob: bytes of LDS requested on top of the map)
-#endif
-constexpr int kLdsBytes = kOffOlist + kMaxOut * 2 + MI355_FUSED_LDS_PAD;
-static_assert(kLdsBytes <= 160 * 1024 && kPartBytes >= kSW * 128 * 4 && kF8P2 + kF8Units * 128 <= kLdsBytes - MI355_FUSED_LDS_PAD, "LDS map");
+constexpr int kLdsBytes = kOffOlist + kMaxOut * 2;
+static_assert(kLdsBytes <= 160 * 1024 && kPartBytes >= kSW * 128 * 4 && kF8P2 + kF8Units * 128 <= kLdsBytes, "LDS map");
 
 // ------------------------------------------------------------------------------------------------ granules
 __device__ __forceinline__ void gr_store(u64* p, unsigned tag, unsigned val) {
@@ -192,8 +121,7 @@ __device__ __forceinline__ void gr_store16(u64* p, unsigned tag, unsigned lo32, 
 // x -> three OCP E4M3 limbs, x ~ l0 + l1 / 16 + l2 / 256 (residual splitting: every difference below is exact in f32, the conversions
 // round to nearest even; past +-448 v_cvt_pk_fp8_f32 returns NaN, hence the clamps).  12 significant bits for 2^-6 <= |x| <= 448, an
 // absolute error of ~2^-19 below (scripts/micro/mx_fp8.hip checks the instruction semantics and prints the error per binade).
-// dsum: a~ + b~, the sum of the two values the limbs DECODE to (what the consumers' MFMAs multiply by)
-__device__ __forceinline__ void f8_limbs(float a, float b, unsigned& lo32, unsigned& hi16, float& dsum) {
+__device__ __forceinline__ void f8_limbs(float a, float b, unsigned& lo32, unsigned& hi16) {
     const int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.f, 448.f), __builtin_amdgcn_fmed3f(b, -448.f, 448.f), 0, false);
     const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false);
     float ra = a - f0[0], rb = b - f0[1];
@@ -206,8 +134,6 @@ __device__ __forceinline__ void f8_limbs(float a, float b, unsigned& lo32, unsig
                                                    __builtin_amdgcn_fmed3f(rb * 256.f, -448.f, 448.f), 0, false);
     lo32 = ((unsigned)w0 & 0xFFFFu) | ((unsigned)w1 << 16);
     hi16 = (unsigned)w2 & 0xFFFFu;
-    const auto f2 = __builtin_amdgcn_cvt_pk_f32_fp8(w2, false);
-    dsum = (f0[0] + f0[1]) + ((f1[0] + f1[1]) * 0.0625f + (f2[0] + f2[1]) * 0.00390625f);
 }
 __device__ __forceinline__ bool aborted(const FusedParams& p) {
     return __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
@@ -234,14 +160,10 @@ __device__ __forceinline__ void sweep_issue(__amdgpu_buffer_rsrc_t rs, unsigned 
 // T16: granules with 16-bit tags in the top half of their second dword (fp8-limb operands, gr_store16); `epoch` is then 16 bits wide
 template <int NL, bool T16 = false>
 __device__ __forceinline__ bool sweep(const FusedParams& p, __amdgpu_buffer_rsrc_t rs, unsigned base, int first, int end,
-                                      unsigned epoch, u32x4 (&v)[NL], unsigned code, int lane, unsigned* iters = nullptr,
-                                      bool preissued = false) {
+                                      unsigned epoch, u32x4 (&v)[NL], unsigned code, int lane, bool preissued = false) {
     // (lane: the caller's per-layer opaque copy of the lane id — from threadIdx the offsets of every sweep site are
     // loop invariants, which hipcc computes once in the kernel prologue and then spills)
     for (unsigned spins = 0;; ++spins) {
-#ifdef MI355_FUSED_COUNT_SWEEPS
-        if (iters != nullptr) *iters = spins + 1;
-#endif
         bool ok = true;
         if (!(preissued && spins == 0)) sweep_issue<NL>(rs, base, first, end, v, lane);
 #pragma unroll
@@ -319,11 +241,7 @@ __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_b
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rs : rs_null, lane_off, ok ? soff : 0u, 2));
 }
 
-#if MI355_FUSED_PART_FULL
 #define FS_PART_LANE (lane_off >> 4)   /* every lane parks its 4 rows x 1 column */
-#else
-#define FS_PART_LANE (lane_off >> 8)   /* column 0 only: lanes 0, 16, 32, 48 = row groups 0..3 */
-#endif
 #define FS_STAMP(i)                                                                   \
     do {                                                                              \
         if (p.dbg != nullptr && (threadIdx.x & 63) == 0) p.dbg[bid * 64 + (i)] = wall_clock64(); \
@@ -533,9 +451,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         const int nun__ = (PH_).u0 + (nst__ < (PH_).nu ? nst__ : 0);                                  \
                         const bool mine__ = !GRP || cc__ == (nun__ >> p.gsh) - gfirst__;                              \
                         const char* xbn__ = (mine__ ? xs + nun__ * 256 : smem + kOffZero) + g * 64;                   \
-                        if (!MI355_FUSED_PROXY_NOB) {                                                                 \
-                            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const f16x8*)(xbn__ + 16 * d__); \
-                        }                                                                                             \
+                        _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) bn__[d__] = *(const f16x8*)(xbn__ + 16 * d__); \
                     }                                                                                                 \
                     if constexpr (GRP) {                                                                              \
                         /* first step of a tile: request its table entries (consumed at the tile's last step) */      \
@@ -578,9 +494,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if ((t__ * STEPS__ + s__ + 1) % SPT__ == 0) {                                                     \
                         /* tile done: publish this wave's partial 16x16 tiles */                                      \
                         if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
-                        /* column 0 only: lanes 0, 16, 32, 48 hold rows 4 g .. 4 g + 3 of it */                       \
                         f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
-                        const bool col0__ = MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u;                       \
                         if constexpr (GRP) {                                                                          \
                             /* column c holds group gfirst + c: y = s (acc - (z - 8) (Se + 16 So)) with                */ \
                             /* the group's operand sums (units of the group), then the 16 columns are added up        */ \
@@ -594,12 +508,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                                     const float sc__ = __uint_as_float(w__ << 16), zp__ = __uint_as_float(w__ & 0xffff0000u); \
                                     y4__[e__] = group_sum(sc__ * (a4__[e__] - (zp__ - 8.f) * gb__), 16);              \
                                 }                                                                                     \
-                                if (col0__) pp__[r__ * (kPartTile / 16)] = y4__;                                                     \
+                                pp__[r__ * (kPartTile / 16)] = y4__;                                                                 \
                                 acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                            \
                             }                                                                                         \
                         } else {                                                                                      \
                         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
-                            if (col0__) pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1];                                \
+                            pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1];                                            \
                             acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                                \
                         }                                                                                             \
                         }                                                                                             \
@@ -652,9 +566,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if ((gstep__ + 1) % SPT__ == 0) { /* (bodies of 12 steps need not hold whole tiles) */         \
                         FS_SSTAMP((STAMP_) + 1); /* (the last tile end is what stays) */                               \
                         f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
-                        if (MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u) {                                      \
-                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1]; \
-                        }                                                                                             \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1]; \
                         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f}; \
                         __syncthreads(); /* Bt */                                                                     \
                         buf ^= 1;                                                                                     \
@@ -770,9 +682,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if ((gstep__ + 1) % SPT__ == 0) { /* (bodies of 12 steps need not hold whole tiles) */         \
                         FS_SSTAMP((STAMP_) + 1); /* (the last tile end is what stays) */                               \
                         i32x4* pp__ = (i32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
-                        if (MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u) {                                      \
-                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1]; \
-                        }                                                                                             \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1]; \
                         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = i32x4{0, 0, 0, 0}; \
                         __syncthreads(); /* Bt */                                                                     \
                         buf ^= 1;                                                                                     \
@@ -790,8 +700,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
         f32x4 acc__[R__][2];                                                                                          \
         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f}; \
-        [[maybe_unused]] f32x4 accs__ = f32x4{0.f, 0.f, 0.f, 0.f}; /* all-ones rows: the operand sums of this wave's units, per limb column */ \
-        [[maybe_unused]] i32x8 ones__;                                                                                \
+        f32x4 accs__ = f32x4{0.f, 0.f, 0.f, 0.f}; /* all-ones rows: the operand sums of this wave's units, per limb column */ \
+        i32x8 ones__;                                                                                                 \
         _Pragma("unroll") for (int e__ = 0; e__ < 8; ++e__) ones__[e__] = 0x38383838; /* E4M3 1.0 */                  \
         const int sb__ = 127 + (E8_) - f8_dsb; /* E8M0 block scale of this lane's 32 operand bytes */                 \
         __syncthreads(); /* B1: the limb planes are staged */                                                        \
@@ -821,7 +731,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                             acc__[r__][s__ & 1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                   \
                                 a__, b__, acc__[r__][s__ & 1], 0, 0, 0, 136, 0, sb__);                                \
                         }                                                                                             \
-                        if (!MI355_F8_PUBSUM && ti__ == 0)                                                            \
+                        if (ti__ == 0)                                                                                \
                             accs__ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones__, b__, accs__, 0, 0, 0, 127, 0, sb__); \
                     }                                                                                                 \
                     _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                           \
@@ -837,7 +747,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                             if (dbg_on && lane_off == 0u)                                                             \
                                 atomicMax((unsigned long long*)&p.dbg[bid * 64 + 48 + ((STAMP_) - 20) / 2], (unsigned long long)wall_clock64()); \
                         }                                                                                             \
-                        if (!MI355_F8_PUBSUM && ti__ == 0) {                                                          \
+                        if (ti__ == 0) {                                                                              \
                             /* S of this wave's units: limb columns 0 + 1 + 2 of any row (quad broadcasts of lanes 1 / 2) */ \
                             float ssum__ = accs__[0];                                                                 \
                             ssum__ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, accs__[0]), 0x55, 0xF, 0xF, false)) + \
@@ -845,16 +755,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                             if (lane_off == 0u) misc[32 + wave] = ssum__;                                             \
                         }                                                                                             \
                         f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
-                        const bool col0__ = MI355_FUSED_PART_FULL || (lane_off & 0xF0u) == 0u;                       \
+                        /* (the wave parks its raw tiles, limb columns 0 / 1 / 2 side by side: gatherer 0's read adds them up) */ \
                         _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
-                            f32x4 t4__ = acc__[r__][0] + acc__[r__][1];                                               \
-                            _Pragma("unroll") for (int e__ = 0; e__ < (MI355_F8_COLSUM_G && MI355_FUSED_PART_FULL ? 0 : 4); ++e__) { \
-                                const float c0__ = t4__[e__];                                                         \
-                                t4__[e__] = c0__ +                                                                    \
-                                    (__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c0__), 0x55, 0xF, 0xF, false)) + \
-                                     __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c0__), 0xAA, 0xF, 0xF, false))); \
-                            }                                                                                         \
-                            if (col0__) pp__[r__ * (kPartTile / 16)] = t4__;                                          \
+                            const f32x4 t4__ = acc__[r__][0] + acc__[r__][1];                                         \
+                            pp__[r__ * (kPartTile / 16)] = t4__;                                                      \
                             acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                                \
                         }                                                                                             \
                         __syncthreads(); /* Bt */                                                                     \
@@ -889,10 +793,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
 
         // B3 of a phase: the gatherers have issued its publish stores.  The next phase's first ring turn is requested BEHIND it (int4
         // streams: a refill queued in front of the publish in the CU's in-order memory pipeline delays every consumer of the edge) or, for
-        // the wide formats whose chain is shorter than their stream (BF16, LLM.int8; MI355_FUSED_EARLY_BURST), in FRONT of it: their
+        // the wide formats whose chain is shorter than their stream (BF16, LLM.int8), in FRONT of it: their
         // phases stream two to sixteen ring turns in-phase, and the gap between a phase's last tile and the next request is HBM idle time
 #define FS_B3() __syncthreads()
-        constexpr bool kEarly = (FMT == 1 || FMT == 2) && MI355_FUSED_EARLY_BURST;
+        constexpr bool kEarly = FMT == 1 || FMT == 2;  // (+1.0 / +1.1 %, profiles/r05_early_burst_ab.txt)
         FS_PBURST(rs_l, 3, 4, 4 * kSub, false, true, ph_attn);
         const bf16_t* kv_l = (const bf16_t*)p.kv;
         bool dbg_on = false;
@@ -904,7 +808,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             dbg_on = p.dbg != nullptr && l == p.dbg_layer;
             asm volatile("" : "+v"(lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
             // ---------------- c_attn (q, k, v tiles of this workgroup's 16 dimensions of its head)
-            FS_PHASE(rs_l, 3, 4, 1, 4 * kSub, kSub, false, true, ph_attn, 1, 20, rs_t, true, MI355_F8_EX);
+            FS_PHASE(rs_l, 3, 4, 1, 4 * kSub, kSub, false, true, ph_attn, 1, 20, rs_t, true, kF8Ex);
             FS_B3();
             // ---------------- attention: scores over the whole context, then this workgroup's 16 output dims
             {
@@ -1127,7 +1031,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }
             // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows)
             FS_PBURST(rs_l, 1, 12, 4 * kSub, false, false, ph_proj);
-            FS_PHASE(rs_l, 1, 12, 1, 4 * kSub, (4 * kSub + 11) / 12, false, false, ph_proj, 1, 26, rs_t, false, MI355_F8_EA);
+            FS_PHASE(rs_l, 1, 12, 1, 4 * kSub, (4 * kSub + 11) / 12, false, false, ph_proj, 1, 26, rs_t, false, kF8Ea);
             if constexpr (kEarly) {
                 FS_PBURST(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
                 FS_B3();
@@ -1135,7 +1039,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 FS_B3();
                 FS_PBURST(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
             }
-            FS_PHASE(rs_l, 2, 4, 2, 4 * kSub, 2 * kSub, true, false, ph_fc, 1, 28, rs_t, true, MI355_F8_EX);
+            FS_PHASE(rs_l, 2, 4, 2, 4 * kSub, 2 * kSub, true, false, ph_fc, 1, 28, rs_t, true, kF8Ex);
             if constexpr (kEarly) {
                 FS_PBURST(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
                 FS_B3();
@@ -1143,7 +1047,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 FS_B3();
                 FS_PBURST(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
             }
-            FS_PHASE(rs_l, 1, 12, 1, 12 * kSub, kSub, false, false, ph_mp, 1, 30, rs_t, false, MI355_F8_EH);
+            FS_PHASE(rs_l, 1, 12, 1, 12 * kSub, kSub, false, false, ph_mp, 1, 30, rs_t, false, kF8Eh);
             if constexpr (!kEarly) FS_B3();
             // next layer (or the head)
             kv_l += (size_t)2 * kHeads * p.S * kHs;
@@ -1160,7 +1064,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             if constexpr (kEarly) FS_B3();
         }
         dbg_on = false;
-        FS_PHASE(rs_h, 1, 4, 1, 4 * kSub, 1, false, false, ph_head, p.head_turns, 32, rs_th, true, MI355_F8_EX);
+        FS_PHASE(rs_h, 1, 4, 1, 4 * kSub, 1, false, false, ph_head, p.head_turns, 32, rs_th, true, kF8Ex);
         FS_B3();
         if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
 #undef FS_B3
@@ -1175,9 +1079,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
     } else {
         // =========================================================================================== gatherers
         const int gw = wave - kSW;  // 0: combines / publishes, 1: helps with the sweeps
-#if MI355_FUSED_GPRIO
-        __builtin_amdgcn_s_setprio(MI355_FUSED_GPRIO);  // (A / B knob: the gatherers' instructions issue ahead of the streamers')
-#endif
         unsigned edge = 0;   // edges published so far in this step (the epoch of the next one is ebase + edge)
         int xpar = 0, apar = 0, hpar = 0, qpar = 0, ppar = 0;
         int buf = 0;
@@ -1187,9 +1088,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             (void*)p.gx, 0, (int)(kFsWsGh - kFsWsGx) + 2 * (kFsGhSums + p.H / 2) * 8, 0x00020000);
         constexpr unsigned kOGa = (unsigned)(kFsWsGa - kFsWsGx), kOGq = (unsigned)(kFsWsGq - kFsWsGx), kOGm = (unsigned)(kFsWsGm - kFsWsGx),
                            kOGp = (unsigned)(kFsWsGp - kFsWsGx), kOGh = (unsigned)(kFsWsGh - kFsWsGx);
-        constexpr bool PUBSUM = FMT == 3 && MI355_F8_PUBSUM;  // the publishers send the operand sums (see MI355_F8_PUBSUM)
         const int gh_stride = kFsGhSums + p.H / 2;           // granules per parity of the hidden edge
-        [[maybe_unused]] float s_edge = 0.f;                  // PUBSUM: operand sum of the edge gathered last (gatherer 0)
 
         // ---- epilogue mapping of gatherer 0: lane = (pair pg = lane >> 3, streamer wave w8 = lane & 7).  A lane reads
         // rows 2 pg, 2 pg + 1 of ONE wave's partial tile (8 B), the 8 lanes of a pair are summed with DPP (fixed
@@ -1198,11 +1097,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         int lane_v = lane;  // made opaque once per layer: per-lane pointers are otherwise hoisted out of the layer loop
                             // (a few dozen 64-bit addresses) and spilled to scratch, i.e. to VMEM on the hand-off path
         int pg = lane >> 3, w8 = lane & 7;
-        // float index of D[2 pg][0] in a wave's partial tile (column 0 is lane 16 g: 4 floats per row group, or per lane with whole tiles)
-        int psrc = (pg >> 1) * (MI355_FUSED_PART_FULL ? 64 : 4) + ((2 * pg) & 3);
+        // float index of D[2 pg][0] in a wave's partial tile (column 0 is lane 16 g: 4 floats per lane)
+        int psrc = (pg >> 1) * 64 + ((2 * pg) & 3);
         auto tile_pair = [&](int r) {
             float2 t = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc);
-            if constexpr (FMT == 3 && MI355_F8_COLSUM_G && MI355_FUSED_PART_FULL) {
+            if constexpr (FMT == 3) {
                 // limb columns 1 / 2 of the same rows sit 4 / 8 floats on (lane 16 g + n holds D[4 g .. 4 g + 3][n])
                 const float2 t1 = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc + 4);
                 const float2 t2 = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc + 8);
@@ -1255,9 +1154,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         // one (rows j, j + 1 with j = 0 or 2) publishes (j, j + 4), the upper one (rows j + 4, j + 5) publishes (j + 1, j + 5).  Granule
         // index inside the tile's 8: 4 (octet) + j.  `e8`: the edge's pre-scale exponent.  Every lane of the wave must call it.
         [[maybe_unused]] auto f8_slot = [&]() { return 4 * (pg >> 2) + 2 * (pg & 1) + ((pg >> 1) & 1); };
-        // Returns a~ + b~ of the granule this lane built, in the CONSUMER's units (pre-scale undone): the same number in the 8 lanes of
-        // a pair; `pair8_sum` of it is the sum of the 16 values of the tile as the consumers' MFMAs will see them.
-        [[maybe_unused]] auto f8_publish = [&](u64* tile_dst, unsigned ep, float a, float b, int e8, bool store) -> float {
+        [[maybe_unused]] auto f8_publish = [&](u64* tile_dst, unsigned ep, float a, float b, int e8, bool store) {
             const float pre = __uint_as_float((unsigned)(127 - e8) << 23);
             a *= pre;
             b *= pre;
@@ -1266,17 +1163,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             const float va = up ? got : a, vb = up ? b : got;
             if (store && fmaxf(fabsf(va), fabsf(vb)) > 448.f) note_clip();  // clipped: counted like the fp16 clips
             unsigned lo32, hi16;
-            float dsum;
-            f8_limbs(va, vb, lo32, hi16, dsum);
+            f8_limbs(va, vb, lo32, hi16);
             if (store) gr_store16(tile_dst + f8_slot(), ep, lo32, hi16);
-            return dsum * __uint_as_float((unsigned)(127 + e8) << 23);
-        };
-        // sum over the 8 pairs of a wave of a value that is the same in the 8 lanes of a pair (two pairs per 16-lane row)
-        [[maybe_unused]] auto pair8_sum = [&](float v) {
-            v = MI355_DPP_ADD(v, 0x140);
-            v += lane_xor16(v);
-            v += lane_xor32(v);
-            return v;
         };
         // FMT 3: stage one 16-B sweep load (two granules) = dword `i` of each limb plane
         [[maybe_unused]] auto f8_stage = [&](const u32x4& v, int i) {
@@ -1307,7 +1195,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }
         };
         auto get_sums = [&]() {
-            if constexpr (PUBSUM) return float2{0.f, s_edge};  // gathered with the edge: y = scale (acc - zero S)
             if constexpr (FMT == 3) {
                 // the streamer waves' operand sums (all-ones MFMAs of the phase's first tile: valid behind its Bt); the A block scale
                 // made the products q x~ themselves, so there is no offset term: y = scale (acc - zero S)
@@ -1335,9 +1222,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             const unsigned ep = ebase + edge;
             u64* dst = p.gx + (size_t)xpar * kFsGxStride;
             x_scale = __uint_as_float((__float_as_uint(rinv_seen) + 0x00400000u) & 0x7F800000u);
-            [[maybe_unused]] float sxp = 0.f;
             if constexpr (FMT == 3) {
-                sxp = f8_publish(dst + bid * 8, ep, x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y, MI355_F8_EX, w8 == 0);
+                f8_publish(dst + bid * 8, ep, x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y, kF8Ex, w8 == 0);
             } else {
                 if (w8 == 0) gr_store(dst + bid * 8 + pg, ep, hpair(x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y));
             }
@@ -1345,32 +1231,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             ss = MI355_DPP_ADD(ss, 0x140);
             ss += lane_xor16(ss);
             ss += lane_xor32(ss);
-            if constexpr (PUBSUM) {
-                // {sum of squares, operand sum} of this workgroup's rows in ONE granule under a 16-bit tag — no more sweep loads than the
-                // sum of squares alone took (a first version with two granules per workgroup: 4 instead of 2 loads per lane for gatherer
-                // 0, and the x hand-offs paid for it): 24 bits each, rounded — ss >= 0 keeps exponent + 16 mantissa bits, the operand sum
-                // sign + exponent + 15 (2^-16 relative on partials that are added up 256 at a time: far below the limbs' own 2^-12)
-                sxp = pair8_sum(sxp);
-                const unsigned sb = ((__float_as_uint(ss) + 0x40u) >> 7) & 0xFFFFFFu, xb = (__float_as_uint(sxp) + 0x80u) >> 8;
-                if (lane == 0) gr_store16(dst + 2048 + bid, ep, sb | (xb << 24), (xb >> 8) & 0xFFFFu);
-            } else {
-                if (lane == 0) gr_store(dst + 2048 + bid, ep, __float_as_uint(ss));
-            }
+            if (lane == 0) gr_store(dst + 2048 + bid, ep, __float_as_uint(ss));
         };
         // gather an x-type edge into xs (fp16), 1/rms into misc[0], the operand sums into misc[4 .. 7]
-        // profiling aid (-DMI355_FUSED_COUNT_SWEEPS, scripts/fused_timeline.py): sweep iterations of gatherer 0 per hand-off.
-        // Measured (profiles/r02_fused_step_sweep_iterations.txt): the x edges ALWAYS succeed on the first sweep — a
-        // loaded hand-off is one slow memory round trip behind the ring turn, not a retry.  Off by default: the counter
-        // costs registers on the hand-off path (56 spill instructions, 925 -> 988 us per step).
-        unsigned n_sweeps = 0;
-#ifdef MI355_FUSED_COUNT_SWEEPS
-#define FS_GCOUNT(i)                                                                              \
-    do {                                                                                          \
-        if (dbg_on && gw == 0 && lane == 0) p.dbg[bid * 64 + (i)] = n_sweeps;                     \
-    } while (0)
-#else
-#define FS_GCOUNT(i) do { } while (0)
-#endif
         [[maybe_unused]] auto zero_obits = [&]() {  // (one gatherer wave; the streamers set bits behind the next B1)
 #pragma unroll
             for (int i = 0; i < 96 * 4; i += 64) ((unsigned*)(smem + kOffObits))[i + lane_v] = 0u;
@@ -1381,14 +1244,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             // the 1024 16-B loads of the pair region are split kG0 : 16 - kG0 between the two gatherer waves, the 128 loads of
             // the sums of squares go to gatherer 0, which also has the serial tail (sums, 1/rms).  Measured (same box,
             // alternating runs): 6 : 10 -> 918 us per step, 7 : 9 (equal load counts) -> 935 us.
-            constexpr int kG0 = PUBSUM ? MI355_FUSED_G0_PAIRS_F8 : MI355_FUSED_G0_PAIRS;
+            constexpr int kG0 = kG0Pairs;
             constexpr int kNS = 2;  // loads of the per-workgroup sums (two workgroups each)
             if (gw == 0) {
                 u32x4 v[kG0 + kNS];
                 for (unsigned spins = 0;; ++spins) {
-#ifdef MI355_FUSED_COUNT_SWEEPS
-                    n_sweeps = spins + 1;
-#endif
                     bool ok = true;
 #pragma unroll
                     for (int k = 0; k < kG0 + kNS; ++k) {
@@ -1398,7 +1258,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     }
 #pragma unroll
                     for (int k = 0; k < kG0 + kNS; ++k) {
-                        if (FMT == 3 && (k < kG0 || PUBSUM)) ok &= (v[k][1] >> 16) == (ep & 0xFFFFu) && (v[k][3] >> 16) == (ep & 0xFFFFu);
+                        if (FMT == 3 && k < kG0) ok &= (v[k][1] >> 16) == (ep & 0xFFFFu) && (v[k][3] >> 16) == (ep & 0xFFFFu);
                         else ok &= v[k][1] == ep && v[k][3] == ep;
                     }
                     if (__all(ok)) break;
@@ -1418,26 +1278,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         pair_sums(sx, v[k][0], v[k][2]);
                     }
                 }
-                float ss;
-                if constexpr (PUBSUM) {
-                    auto ss24 = [](unsigned d0) { return __uint_as_float((d0 & 0xFFFFFFu) << 7); };
-                    auto sx24 = [](unsigned d0, unsigned d1) { return __uint_as_float(((d0 >> 24) | ((d1 & 0xFFFFu) << 8)) << 8); };
-                    ss = (ss24(v[kG0][0]) + ss24(v[kG0][2])) + (ss24(v[kG0 + 1][0]) + ss24(v[kG0 + 1][2]));
-                    const float sx4 = (sx24(v[kG0][0], v[kG0][1]) + sx24(v[kG0][2], v[kG0][3])) +
-                                      (sx24(v[kG0 + 1][0], v[kG0 + 1][1]) + sx24(v[kG0 + 1][2], v[kG0 + 1][3]));
-                    s_edge = group_sum(sx4, 64);
-                } else {
-                    ss = ((__uint_as_float(v[kG0][0]) + __uint_as_float(v[kG0][2])) + __uint_as_float(v[kG0 + 1][0])) +
-                         __uint_as_float(v[kG0 + 1][2]);
-                }
+                float ss = ((__uint_as_float(v[kG0][0]) + __uint_as_float(v[kG0][2])) + __uint_as_float(v[kG0 + 1][0])) +
+                           __uint_as_float(v[kG0 + 1][2]);
                 ss = group_sum(ss, 64);
                 put_sums(sx);
                 if (lane == 0) {
                     const float rv = rsqrtf(ss / (float)kC + p.eps);
                     misc[0] = rv;
-#if !defined(MI355_FUSED_NO_MISC1)
                     misc[1] = rv / x_scale;  // (int8 streams: what the streamers multiply the staged values by before their f16 cast)
-#endif
                 }
             } else {
                 if constexpr (FMT == 2) zero_obits();
@@ -1569,28 +1417,20 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         const bf16_t* sz_l = p.sz;
         bf16_t* kv_l = p.kv;
         const float2 cs = *(const float2*)(p.rope + ((size_t)pos * (kHs / 2) + hj * 8 + pg) * 2);
-#if MI355_F8_XSCALE0
-        if constexpr (FMT == 3) {
-            // (knob, default off — written after round 4's GPU budget, to be measured in round 5)  The first edge of a step is published
-            // before any 1/rms is known, i.e. with scale 1: the embedding row times rms_1's scale.  An E4M3 limb triple is exact to 12
-            // bits only from 2^-6 up, and a trained checkpoint's embeddings are ~2^-6..2^-12.  1/rms of the row's first 64 values — the
-            // same number in every workgroup — stands in for the edge's 1/rms (publish_x rounds it to a power of two).
-            const float e0 = bf16_to_f32(p.wte[(size_t)token * kC + lane]);
-            rinv_seen = rsqrtf(group_sum(e0 * e0, 64) * (1.0f / 64.0f) + 1.0e-30f);
-        }
-#endif
         if (gw == 0) publish_x(xres, ldpair(norms_l + r0));
         for (int l = 0; l < p.n_layer; ++l) {
             dbg_on = p.dbg != nullptr && l == p.dbg_layer;
             asm volatile("" : "+v"(lane_v));
             pg = lane_v >> 3;
             w8 = lane_v & 7;
-            psrc = (pg >> 1) * (MI355_FUSED_PART_FULL ? 64 : 4) + ((2 * pg) & 3);
+            psrc = (pg >> 1) * 64 + ((2 * pg) & 3);
             r0 = bid * 16 + 2 * pg;
             // ================= c_attn
             const int nq = (head * 8 + hj) * 16 + 2 * pg;  // q rows of this lane's pair; k at + C, v at + 2 C
             float2 sc[3], zr[3];
-            constexpr bool VSPLIT = MI355_FUSED_VSPLIT && (FMT == 0 || FMT == 3);
+            // int4 streams: gatherer 1 dequantises and publishes the k (RoPE) and v rows, gatherer 0 keeps q (round 5, fp8 operands:
+            // 902.5 / 904.1 / 904.2 against 904.3 / 909.2 / 910.2 us per step with v alone, 906.4 / 904.8 / 906.8 with neither: profiles/r05_ab5_*.txt)
+            constexpr bool VSPLIT = FMT == 0 || FMT == 3;
             if (gw == 0 || VSPLIT) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
@@ -1608,7 +1448,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             // (slot 46: the same event of the NEXT layer — a stamped layer's edges then add up to its period in every workgroup,
             // scripts/fused_timeline.py budget(); VERDICT r4 weak 2: the round-4 table compared medians against the minimum of one event)
             if (p.dbg != nullptr && l == p.dbg_layer + 1 && gw == 0 && lane == 0) p.dbg[bid * 64 + 46] = wall_clock64();
-            FS_GCOUNT(40);
             __syncthreads();  // B1
             post_b1();
             if constexpr (FMT == 2) {
@@ -1628,7 +1467,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 bf16_t* vrow = kv_l + ((size_t)head * p.S + pos) * kHs + hj * 16 + (size_t)kHeads * p.S * kHs;
                 if (w8 == 3) gr_store(dst + 24 + pg, ebase + edge, vp);
                 if (w8 == 5) ((unsigned*)vrow)[pg] = vp;
-                if constexpr (MI355_FUSED_VSPLIT == 2) {  // ... and the k rows (RoPE, model.py:306-323): gatherer 0 keeps q only
+                {  // ... and the k rows (RoPE, model.py:306-323): gatherer 0 keeps q only
                     const float2 yk = deq(tile_pair(1), sc[1], zr[1], sx);
                     const float kx = yk.x * rinv1, ky = yk.y * rinv1;
                     const unsigned kp = bfpair(kx * cs.x - ky * cs.y, ky * cs.x + kx * cs.y);
@@ -1636,35 +1475,27 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if (w8 == 4) ((unsigned*)(vrow - (size_t)kHeads * p.S * kHs))[pg] = kp;
                 }
             }
-#ifdef MI355_FUSED_FINE_STAMPS
-#define FS_FSTAMP(i) FS_GSTAMP(i)  /* diagnostic build: where the c_attn epilogue's time goes (slots 56..59) */
-#else
-#define FS_FSTAMP(i) do { } while (0)
-#endif
-            FS_FSTAMP(56);
             if (gw == 0) {
                 rinv_seen = misc[0];
-                const float rinv = FMT == 2 ? 1.f : MI355_FUSED_POW2RCP ? rinv_seen * __uint_as_float(0x7F000000u - __float_as_uint(x_scale)) : rinv_seen / x_scale;  // (int8 streams: 1/rms is inside the quantised operand)
+                const float rinv = FMT == 2 ? 1.f : rinv_seen * __uint_as_float(0x7F000000u - __float_as_uint(x_scale));  // (int8 streams: 1/rms is inside the quantised operand)
                 const float2 sx = get_sums();
                 float2 y[3];
 #pragma unroll
-                for (int r = 0; r < (VSPLIT ? (MI355_FUSED_VSPLIT == 2 ? 1 : 2) : 3); ++r) {
+                for (int r = 0; r < (VSPLIT ? 1 : 3); ++r) {
                     if constexpr (FMT == 2) y[r] = tile_deq8(r, sc[r], wl8 + p.off_attn, kUnitsC, 1, 0, nq + r * kC, pb0[r], pb1[r]);
                     else y[r] = deq(tile_pair(r), sc[r], zr[r], sx);
                     y[r].x *= rinv;
                     y[r].y *= rinv;
                 }
-                FS_FSTAMP(57);
                 // RoPE (model.py:306-323) of the q / k pair, publish to the head group, write the cache row
                 const unsigned ep = ebase + edge;
                 u64* dst = p.gq + ((size_t)qpar * kHeads + head) * 256 + hj * 32;
                 bf16_t* krow = kv_l + ((size_t)head * p.S + pos) * kHs + hj * 16;
                 bf16_t* vrow = krow + (size_t)kHeads * p.S * kHs;
                 const float qa = y[0].x * cs.x - y[0].y * cs.y, qb = y[0].y * cs.x + y[0].x * cs.y;
-                FS_FSTAMP(58);
                 if (w8 == 0) gr_store(dst + 2 * pg, ep, __float_as_uint(qa));
                 if (w8 == 1) gr_store(dst + 2 * pg + 1, ep, __float_as_uint(qb));
-                if constexpr (!(VSPLIT && MI355_FUSED_VSPLIT == 2)) {
+                if constexpr (!VSPLIT) {
                     const unsigned kp = bfpair(y[1].x * cs.x - y[1].y * cs.y, y[1].y * cs.x + y[1].x * cs.y);
                     if (w8 == 2) gr_store(dst + 16 + pg, ep, kp);
                     if (w8 == 4) ((unsigned*)krow)[pg] = kp;
@@ -1683,8 +1514,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 const unsigned ep = ebase + edge;
                 if (gw == 0) {
                     u32x4 v[2];
-                    sweep<2>(p, rs_ws, kOGq + (unsigned)((qpar * kHeads + head) * 256) * 8u, 0, 128, ep, v, 0x300u + edge, lane_v, &n_sweeps);
-                    FS_GCOUNT(41);
+                    sweep<2>(p, rs_ws, kOGq + (unsigned)((qpar * kHeads + head) * 256) * 8u, 0, 128, ep, v, 0x300u + edge, lane_v);
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
 #pragma unroll
@@ -1724,11 +1554,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     // attention output elements head * 128 + hj * 16 + 2 pg, + 1 -> one pair granule
                     u64* ga_t = p.ga + (size_t)apar * kFsGaStride + kFsGaSums + head * 64 + hj * 8;  // this workgroup's 8 pair granules
                     if constexpr (FMT == 3) {
-                        const float sa = f8_publish(ga_t, ebase + edge, o.x * inv, o.y * inv, MI355_F8_EA, w8 == 0);
-                        if constexpr (PUBSUM) {
-                            const float st = pair8_sum(sa);
-                            if (lane == 0) gr_store16(p.ga + (size_t)apar * kFsGaStride + bid, ebase + edge, __float_as_uint(st), 0u);
-                        }
+                        f8_publish(ga_t, ebase + edge, o.x * inv, o.y * inv, kF8Ea, w8 == 0);
                     } else {
                         if (w8 == 0) gr_store(ga_t + pg, ebase + edge, hpair_b(o.x * inv, o.y * inv));
                     }
@@ -1788,11 +1614,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         const float inv = 1.0f / group_sum(lj * wsc, 8);
                         u64* ga_t = p.ga + (size_t)apar * kFsGaStride + kFsGaSums + head * 64 + hj * 8;
                         if constexpr (FMT == 3) {
-                            const float sa = f8_publish(ga_t, ebase + edge, ox * inv, oy * inv, MI355_F8_EA, w8 == 0);
-                            if constexpr (PUBSUM) {
-                                const float st = pair8_sum(sa);
-                                if (lane == 0) gr_store16(p.ga + (size_t)apar * kFsGaStride + bid, ebase + edge, __float_as_uint(st), 0u);
-                            }
+                            f8_publish(ga_t, ebase + edge, ox * inv, oy * inv, kF8Ea, w8 == 0);
                         } else {
                             if (w8 == 0) gr_store(ga_t + pg, ebase + edge, hpair_b(ox * inv, oy * inv));
                         }
@@ -1819,24 +1641,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if (gw == 1) zero_obits();
                 }
                 float2 sxp = {0.f, 0.f};
-                if constexpr (PUBSUM) {
-                    // 128 loads of operand-sum partials (two workgroups each) in front of the 1024 pair loads: 9 loads per lane and gatherer
-                    u32x4 v[9];
-                    sweep<9, true>(p, rs_ws, kOGa + (unsigned)apar * (unsigned)kFsGaStride * 8u, gw * 576, gw * 576 + 576, ep & 0xFFFFu, v,
-                                   0x400u + edge, lane_v, &n_sweeps);
-                    FS_GCOUNT(42);
-                    float sa = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        if (gw == 0 && k < 2) sa += __uint_as_float(v[k][0]) + __uint_as_float(v[k][2]);
-                        else f8_stage(v[k], gw * 576 + k * 64 + lane_v - 128);
-                    }
-                    if (gw == 0) s_edge = group_sum(sa, 64);
-                } else {
+                {
                     u32x4 v[8];
                     sweep<8, FMT == 3>(p, rs_ws, kOGa + (unsigned)(apar * kFsGaStride + kFsGaSums) * 8u, gw * 512, gw * 512 + 512,
-                                       FMT == 3 ? (ep & 0xFFFFu) : ep, v, 0x400u + edge, lane_v, &n_sweeps);
-                    FS_GCOUNT(42);
+                                       FMT == 3 ? (ep & 0xFFFFu) : ep, v, 0x400u + edge, lane_v);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         if constexpr (FMT == 3) {
@@ -1891,7 +1699,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 }
                 gather_x();
                 FS_GSTAMP(9);
-                FS_GCOUNT(43);
                 __syncthreads();  // B1
                 post_b1();
                 if constexpr (FMT == 2) {
@@ -1906,9 +1713,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 }
                 const unsigned ep = ebase + edge;
                 u64* dst = p.gh + (size_t)hpar * gh_stride;  // the pair granules of this parity (the operand-sum partials sit behind them)
-                [[maybe_unused]] float hsum = 0.f;
                 rinv_seen = misc[0];
-                const float rinv = FMT == 2 ? 1.f : MI355_FUSED_POW2RCP ? rinv_seen * __uint_as_float(0x7F000000u - __float_as_uint(x_scale)) : rinv_seen / x_scale;
+                const float rinv = FMT == 2 ? 1.f : rinv_seen * __uint_as_float(0x7F000000u - __float_as_uint(x_scale));
                 float2 sx = {0.f, 0.f};
                 if constexpr (FMT != 3) sx = get_sums();
 #pragma unroll
@@ -1928,8 +1734,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                             b = deq(tile_pair(1), fs2[t], fz2[t], sx);
                         }
                         if constexpr (FMT == 3) {
-                            hsum += f8_publish(dst + (bid + t * kG) * 8, ep, swiglu_f32(a.x * rinv, b.x * rinv),
-                                               swiglu_f32(a.y * rinv, b.y * rinv), MI355_F8_EH, w8 == 0);
+                            f8_publish(dst + (bid + t * kG) * 8, ep, swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv), kF8Eh,
+                                       w8 == 0);
                         } else {
                             if (w8 == 0)
                                 gr_store(dst + (bid + t * kG) * 8 + pg, ep,
@@ -1937,12 +1743,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         }
                     }
                     buf ^= 1;
-                }
-                if constexpr (PUBSUM) {
-                    if (gw == 0) {  // the operand sum of this workgroup's 2 or 3 tiles, behind its last tile
-                        const float st = pair8_sum(hsum);
-                        if (lane == 0) gr_store16(p.gh + (size_t)hpar * gh_stride + p.H / 2 + bid, ep, __float_as_uint(st), 0u);
-                    }
                 }
                 FS_GSTAMP(10);
                 __syncthreads();  // B3
@@ -1965,21 +1765,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     if (gw == 1) zero_obits();
                 }
                 [[maybe_unused]] const unsigned eph = FMT == 3 ? (ep & 0xFFFFu) : ep;
-                // 16-B loads of the edge: the H / 4 pair loads, then (PUBSUM) 128 loads of operand-sum partials (two workgroups each).  BEHIND
-                // the pairs, i.e. in gatherer 1's last chunk: a partial is published behind its workgroup's LAST tile, and a first version
-                // that swept them in gatherer 0's first chunk kept that chunk spinning until the slowest workgroup was done — and only
-                // then requested the later chunks: the hidden hand-off 4.96 -> 5.9-6.5 us (profiles/r05_ab1_*.txt)
-                constexpr int kHS = PUBSUM ? kFsGhSums / 2 : 0;
+                // 16-B loads of the edge: the H / 4 pair loads
                 const int n_pairs = p.H / 4;
-                const int n_loads = n_pairs + kHS, half_l = (n_loads + 1) / 2;
+                const int n_loads = n_pairs, half_l = (n_loads + 1) / 2;
                 const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
                 float2 sxp = {0.f, 0.f};
-                [[maybe_unused]] float hs = 0.f;
-                // stage load i of the edge (i >= n_pairs: two partial sums)
-                auto stage_h = [&](const u32x4& v, int i) {
+                auto stage_h = [&](const u32x4& v, int i) {  // stage load i of the edge
                     if constexpr (FMT == 3) {
-                        if (PUBSUM && i >= n_pairs) hs += __uint_as_float(v[0]) + __uint_as_float(v[2]);
-                        else f8_stage(v, i);
+                        f8_stage(v, i);
                     } else {
                         *(u64*)(xs + (size_t)i * 8) = ((u64)v[2] << 32) | v[0];
                         pair_sums(sxp, v[0], v[2]);
@@ -1992,11 +1785,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     const unsigned hbase = kOGh + (unsigned)hpar * (unsigned)gh_stride * 8u;
                     int lh = lane_v;
                     asm volatile("" : "+v"(lh));  // addresses of this block are computed here, not hoisted and spilled
-                if constexpr (FMT == 3 && MI355_F8_HLATE) {
+                if constexpr (FMT == 3) {
                     // per gatherer: its half of the early loads (first and second tiles of every workgroup: pair loads below 2048) in
-                    // chunks of 8 / 4 / 4 per lane, its half of the late loads (third tiles from load 2048 on, then the operand-sum
-                    // partials: contiguous) as ONE chunk of <= 8, requested as soon as the first early chunk has landed (see
-                    // MI355_F8_HLATE); buffers as in round 4 (8 + 4 loads per lane)
+                    // chunks of 8 / 4 / 4 per lane, its half of the late loads (third tiles of the 176 workgroups that have one: from load
+                    // 2048 on) as ONE chunk of <= 8, requested as soon as the first early chunk has landed — when the slowest publisher's
+                    // granules land, ONE retry of one chunk is all that is left (round 5: +0 .. 0.5 % over contiguous halves, profiles/r05_ab3_*.txt)
                     const int n_early = n_pairs < 2048 ? n_pairs : 2048, he = (n_early + 1) / 2;
                     const int hl = (n_loads - n_early + 1) / 2;  // <= 512: host check (n_hidden <= 11776)
                     const int e0 = gw * he, e_end = gw == 0 ? he : n_early;
@@ -2013,41 +1806,17 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     u32x4 va[8], vb[4];
                     sweep_issue<8>(rs_ws, hbase, e0, e_end, va, lh);
                     sweep_issue<4>(rs_ws, hbase, e0 + 512, e_end, vb, lh);
-                    sweep<8, true>(p, rs_ws, hbase, e0, e_end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
-                    FS_GCOUNT(44);
+                    sweep<8, true>(p, rs_ws, hbase, e0, e_end, eph, va, 0x500u + edge, lh, true);
                     stage_c(va, n8, e0, e_end);
                     sweep_issue<8>(rs_ws, hbase, l0, l_end, va, lh);  // (waits below, behind the early chunks)
-                    sweep<4, true>(p, rs_ws, hbase, e0 + 512, e_end, eph, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep<4, true>(p, rs_ws, hbase, e0 + 512, e_end, eph, vb, 0x500u + edge, lh, true);
                     stage_c(vb, n4, e0 + 512, e_end);
                     sweep_issue<4>(rs_ws, hbase, e0 + 768, e_end, vb, lh);
-                    sweep<4, true>(p, rs_ws, hbase, e0 + 768, e_end, eph, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep<4, true>(p, rs_ws, hbase, e0 + 768, e_end, eph, vb, 0x500u + edge, lh, true);
                     stage_c(vb, n4, e0 + 768, e_end);
-                    sweep<8, true>(p, rs_ws, hbase, l0, l_end, eph, va, 0x500u + edge, lh, nullptr, true);
+                    sweep<8, true>(p, rs_ws, hbase, l0, l_end, eph, va, 0x500u + edge, lh, true);
                     stage_c(va, n8, l0, l_end);
                 } else {
-#if MI355_FUSED_HSWEEP == 3
-                    // all three chunks of 8 loads per lane (24 >= 12288 / 4 / 2 / 64) in flight at once
-                    u32x4 va[8], vb[8], vc[8];
-                    auto stage8 = [&](const u32x4 (&v)[8], int c0) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int i = c0 + k * 64 + lh;
-                            if (i < end) stage_h(v[k], i);
-                        }
-                    };
-                    const int c1 = first + 512, c2 = first + 1024;
-                    sweep_issue<8>(rs_ws, hbase, first, end, va, lh);
-                    sweep_issue<8>(rs_ws, hbase, c1, end, vb, lh);
-                    sweep_issue<8>(rs_ws, hbase, c2, end, vc, lh);
-                    sweep<8, FMT == 3>(p, rs_ws, hbase, first, end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
-                    FS_GCOUNT(44);
-                    stage8(va, first);
-                    sweep<8, FMT == 3>(p, rs_ws, hbase, c1, end, eph, vb, 0x500u + edge, lh, nullptr, true);
-                    stage8(vb, c1);
-                    sweep<8, FMT == 3>(p, rs_ws, hbase, c2, end, eph, vc, 0x500u + edge, lh, nullptr, true);
-                    stage8(vc, c2);
-                }
-#else
                     // chunks of 8, 4, 8, 4 loads per lane (24 >= 12288 / 4 / 2 / 64), two in flight
                     u32x4 va[8], vb[4];
                     auto stage_a = [&](int c0) {
@@ -2067,29 +1836,19 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     const int c1 = first + 512, c2 = first + 768, c3 = first + 1280;
                     sweep_issue<8>(rs_ws, hbase, first, end, va, lh);
                     sweep_issue<4>(rs_ws, hbase, c1, end, vb, lh);
-                    sweep<8, FMT == 3>(p, rs_ws, hbase, first, end, eph, va, 0x500u + edge, lh, &n_sweeps, true);
-                    FS_GCOUNT(44);
+                    sweep<8, FMT == 3>(p, rs_ws, hbase, first, end, eph, va, 0x500u + edge, lh, true);
                     stage_a(first);
                     sweep_issue<8>(rs_ws, hbase, c2, end, va, lh);
-                    sweep<4, FMT == 3>(p, rs_ws, hbase, c1, end, eph, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep<4, FMT == 3>(p, rs_ws, hbase, c1, end, eph, vb, 0x500u + edge, lh, true);
                     stage_b(c1);
                     sweep_issue<4>(rs_ws, hbase, c3, end, vb, lh);
-                    sweep<8, FMT == 3>(p, rs_ws, hbase, c2, end, eph, va, 0x500u + edge, lh, nullptr, true);
+                    sweep<8, FMT == 3>(p, rs_ws, hbase, c2, end, eph, va, 0x500u + edge, lh, true);
                     stage_a(c2);
-                    sweep<4, FMT == 3>(p, rs_ws, hbase, c3, end, eph, vb, 0x500u + edge, lh, nullptr, true);
+                    sweep<4, FMT == 3>(p, rs_ws, hbase, c3, end, eph, vb, 0x500u + edge, lh, true);
                     stage_b(c3);
                 }
-#endif
                 }
                 put_sums(sxp);
-                if constexpr (PUBSUM) {
-                    hs = group_sum(hs, 64);  // (each gatherer has summed the partials among ITS loads)
-                    if (gw == 1) {  // -> gatherer 0's epilogue, through LDS (two workgroup barriers in between)
-                        if (lane == 0) misc[33] = hs;
-                    } else {
-                        s_edge = hs;
-                    }
-                }
                 hpar ^= 1;
                 ++edge;
                 FS_GSTAMP(11);
@@ -2101,7 +1860,6 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 __syncthreads();  // Bt
                 if (gw == 0) {
                     float2 d;
-                    if constexpr (PUBSUM) s_edge += misc[33];
                     if constexpr (FMT == 2) d = tile_deq8(0, s1, wl8 + p.off_mproj, p.units_h, 1, 0, r0, pb0[0], pb1[0]);
                     else d = deq(tile_pair(0), s1, z1, get_sums());
                     xres.x += d.x;
@@ -2141,7 +1899,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             __syncthreads();  // B1
             post_b1();
             rinv_seen = misc[0];
-            const float rinv = FMT == 2 ? 1.f : MI355_FUSED_POW2RCP ? rinv_seen * __uint_as_float(0x7F000000u - __float_as_uint(x_scale)) : rinv_seen / x_scale;
+            const float rinv = FMT == 2 ? 1.f : rinv_seen * __uint_as_float(0x7F000000u - __float_as_uint(x_scale));
             float2 sx = {0.f, 0.f};
             if constexpr (FMT != 3) sx = get_sums();
             float best = -INFINITY;

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Build lit_llama_amd/_variants/libmi355llama_<tag>.so with extra defines for one source of csrc/ (A / B of tuning knobs on
 # one box: MI355_LLAMA_LIB=<path> selects the library).
-#   bash scripts/build_variant.sh w8 [-s fused_step_ring.hip] -DMI355_FUSED_SPLIT_POS=256 ...     (default source: fused_step_ring.hip)
+#   bash scripts/build_variant.sh x [-s fused_step_wide.hip] -DSOME_EXPERIMENT=1 ...     (default source: fused_step_ring.hip; round 6: the
+#   kernels carry no standing knobs any more — an experiment adds its own #ifdef for the duration of its A / B and leaves with its evidence)
 set -e
 cd "$(dirname "$0")/.."
 tag=$1; shift

@@ -54,11 +54,6 @@ def budget(st, out=print):
             d1, d2 = st[:, slot] - st[:, first], st[:, pub] - st[:, slot]
             rows.append((f"  [{nm}: wave 0 parked -> LAST wave parked]", float(np.median(d1)), float(d1.min()), float(d1.max())))
             rows.append((f"  [{nm}: last wave parked -> published]", float(np.median(d2)), float(d2.min()), float(d2.max())))
-    if (st[:, 56] > 0).all():  # -DMI355_FUSED_FINE_STAMPS: inside the c_attn epilogue of gatherer 0
-        for a, b, nm in ((48, 56, "last wave parked -> gatherer 0 past Bt"), (56, 57, "partial tiles read, summed, dequantised"),
-                         (57, 58, "RoPE + bf16 pairs"), (58, 3, "six masked stores (+ the stamps themselves)")):
-            d = st[:, b] - st[:, a]
-            rows.append((f"  [c_attn epilogue: {nm}]", float(np.median(d)), float(d.min()), float(d.max())))
     hand = sum(m for w, m, _, _ in rows if "hand-off" in w)
     out(f"  layer period (x gathered -> x gathered of the next layer, per workgroup): median {np.median(period):6.2f} us, "
         f"min {period.min():6.2f}, max {period.max():6.2f}; sum of the row medians {tot:6.2f}; hand-off rows {hand:5.2f}")
@@ -140,12 +135,6 @@ def main():
         for nm, last, bt, pub in (("c_attn", 48, 56, 3), ("mlp.c_proj", 53, 57, 12)):
             print(f"  {nm}: last wave parked -> gatherer 0 past Bt med {np.median(st[:, bt] - st[:, last]):5.2f} us, "
                   f"past Bt -> published med {np.median(st[:, pub] - st[:, bt]):5.2f} us")
-    print("sweep iterations of gatherer 0 per hand-off (a failed sweep costs a memory round trip):")
-    for i, nm in ((40, "x edge into c_attn"), (41, "q / k / v head exchange"), (42, "attention out edge"),
-                  (43, "x edge into fc"), (44, "hidden edge (first chunk)")):
-        c = raw[:, i]
-        hist = np.bincount(np.clip(c, 0, 8).astype(np.int64), minlength=9)
-        print(f"  {nm:28s} mean {c.mean():5.2f}  max {c.max():3d}   histogram 1..8+: {hist[1:].tolist()}")
 
 
 if __name__ == "__main__":
