@@ -1120,7 +1120,16 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             if constexpr (GRP || FMT == 1 || FMT == 2) return float2{0.f, 0.f};
             return ldpair(q);
         };
-        auto bfpair = [&](float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); };
+        // Epilogue arithmetic on an instruction diet (round 6, profiles/r06_ab1_epilogue_diet.txt: 902 -> 894 us per step, three alternating
+        // rounds on one box): the epilogues are a serial chain of ONE wave, so every instruction counts — bf16 pairs by the hardware
+        // conversion (v_cvt_pk_bf16_f32: round to nearest even, the bits of f32_to_bf16 for every finite value), SiLU through v_exp_f32 /
+        // v_rcp_f32 instead of expf and an IEEE division (1 ulp: far below the fp8-limb / fp16 rounding the value gets next), the
+        // softmax normalisation by v_rcp_f32.  (LLM.int8 keeps its correctly rounded divisions: they are part of the oracle's arithmetic.)
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        auto bfpair = [&](float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t)); };
+        auto swiglu_e = [&](float a, float b) { return a * __builtin_amdgcn_rcpf(1.0f + __expf(-a)) * b; };
+        auto recip_e = [&](float v) { return __builtin_amdgcn_rcpf(v); };
         // activation pair granule: fp16 (a, b); ODD pairs of a vector carry a / 16, b / 16 (see nib2f16).  pg is the
         // pair's index inside its 8-pair row, the rows start at even pair indices.
         // fp16 has 5 exponent bits: the conversion saturates (a finite, if clipped, operand instead of an inf that the
@@ -1283,9 +1292,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 ss = group_sum(ss, 64);
                 put_sums(sx);
                 if (lane == 0) {
-                    const float rv = rsqrtf(ss / (float)kC + p.eps);
+                    // (lane 0's tail sits between the sweep and B1: v_rsq_f32 without rsqrtf's denormal guard — the argument is >= eps — and
+                    // the exact reciprocal of the power of two x_scale instead of an IEEE division: -0.4 %, profiles/r06_ab1_epilogue_diet.txt)
+                    const float rv = __builtin_amdgcn_rsqf(ss * (1.0f / (float)kC) + p.eps);
                     misc[0] = rv;
-                    misc[1] = rv / x_scale;  // (int8 streams: what the streamers multiply the staged values by before their f16 cast)
+                    misc[1] = rv * __uint_as_float(0x7F000000u - __float_as_uint(x_scale));  // (int8 streams: what the streamers multiply the staged values by before their f16 cast)
                 }
             } else {
                 if constexpr (FMT == 2) zero_obits();
@@ -1550,7 +1561,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     const float wsc = __expf(mw - mall);
                     o.x = group_sum(o.x * wsc, 8);
                     o.y = group_sum(o.y * wsc, 8);
-                    const float inv = 1.0f / group_sum(misc[24 + w8] * wsc, 8);
+                    const float inv = recip_e(group_sum(misc[24 + w8] * wsc, 8));
                     // attention output elements head * 128 + hj * 16 + 2 pg, + 1 -> one pair granule
                     u64* ga_t = p.ga + (size_t)apar * kFsGaStride + kFsGaSums + head * 64 + hj * 8;  // this workgroup's 8 pair granules
                     if constexpr (FMT == 3) {
@@ -1611,7 +1622,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         const float wsc = __expf(mj - mall);
                         const float ox = group_sum(__uint_as_float(v1[0]) * wsc, 8);
                         const float oy = group_sum(__uint_as_float(v1[2]) * wsc, 8);
-                        const float inv = 1.0f / group_sum(lj * wsc, 8);
+                        const float inv = recip_e(group_sum(lj * wsc, 8));
                         u64* ga_t = p.ga + (size_t)apar * kFsGaStride + kFsGaSums + head * 64 + hj * 8;
                         if constexpr (FMT == 3) {
                             f8_publish(ga_t, ebase + edge, ox * inv, oy * inv, kF8Ea, w8 == 0);
@@ -1734,12 +1745,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                             b = deq(tile_pair(1), fs2[t], fz2[t], sx);
                         }
                         if constexpr (FMT == 3) {
-                            f8_publish(dst + (bid + t * kG) * 8, ep, swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv), kF8Eh,
+                            f8_publish(dst + (bid + t * kG) * 8, ep, swiglu_e(a.x * rinv, b.x * rinv), swiglu_e(a.y * rinv, b.y * rinv), kF8Eh,
                                        w8 == 0);
                         } else {
                             if (w8 == 0)
                                 gr_store(dst + (bid + t * kG) * 8 + pg, ep,
-                                         hpair_b(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv)));
+                                         hpair_b(swiglu_e(a.x * rinv, b.x * rinv), swiglu_e(a.y * rinv, b.y * rinv)));
                         }
                     }
                     buf ^= 1;

@@ -586,7 +586,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             const unsigned v = *(const unsigned*)q;
             return float2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
         };
-        auto bfpair = [&](float a, float b) { return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16); };
+        // (the epilogues' arithmetic on the ring kernel's instruction diet: hardware bf16 pairs, SiLU and the softmax normalisation through
+        // v_exp_f32 / v_rcp_f32, v_rsq_f32 without the denormal guard — profiles/r06_ab1_epilogue_diet.txt)
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        auto bfpair = [&](float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t)); };
+        auto swiglu_e = [&](float a, float b) { return a * __builtin_amdgcn_rcpf(1.0f + __expf(-a)) * b; };
         // state[2] counts the clipped pairs, state[3] keeps 0x7FFFFFFF - (the LOWEST position whose step clipped): the host replays
         // from there on the launch-per-operator step (DecodeEngine.check_status)
         auto note_clip = [&]() {
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 ss = group_sum(ss, 64);
                 put_sums(sx);
                 if (lane == 0) {
-                    const float rv = rsqrtf(ss / (float)C + p.eps);
+                    const float rv = __builtin_amdgcn_rsqf(ss * (1.0f / (float)C) + p.eps);  // (the argument is >= eps: no denormal guard)
                     misc[0] = rv;
                 }
             } else {
@@ -881,7 +886,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     const float wsc = __expf(mj - mall);
                     const float ox = group_sum(__uint_as_float(v1[0]) * wsc, GS);
                     const float oy = group_sum(__uint_as_float(v1[2]) * wsc, GS);
-                    const float inv = 1.0f / group_sum(lj * wsc, GS);
+                    const float inv = __builtin_amdgcn_rcpf(group_sum(lj * wsc, GS));
                     // attention output elements head * 128 + hj * DH + 2 px, + 1 -> one pair granule
                     u64* ga_t = p.ga + (size_t)apar * (C / 2) + head * 64 + hj * (DH / 2);
                     if (wq == 0) gr_store(ga_t + px, ebase + edge, hpair(ox * inv, oy * inv, (px & 1) != 0));
@@ -973,7 +978,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                         const float2 b = deq(tile_pair(1), fs2, fz2, s);
                         if (w8 == 0)
                             gr_store(dst + (bid + t * NWG) * 8 + pg, ep,
-                                     hpair(swiglu_f32(a.x * rinv, b.x * rinv), swiglu_f32(a.y * rinv, b.y * rinv), (pg & 1) != 0));
+                                     hpair(swiglu_e(a.x * rinv, b.x * rinv), swiglu_e(a.y * rinv, b.y * rinv), (pg & 1) != 0));
                     }
                     fs1 = ns1;
                     fz1 = nz1;
