@@ -373,23 +373,25 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0, 0x00020000);
 
         // ---- first ring turn of a phase (12 pieces), requested right after the previous phase's publish
-#define FS_BURST(RS_, R_, SPT_, PAIR_, QKV_, PH_)                                                             \
+        // (pieces P0_ .. P1_ - 1 of it)
+#define FS_BURST_RANGE(RS_, R_, SPT_, PAIR_, QKV_, PH_, P0_, P1_)                                             \
     do {                                                                                                     \
-        _Pragma("unroll") for (int pc__ = 0; pc__ < kRing; ++pc__) {                                         \
-            bool ok__;                                                                                       \
-            const unsigned so__ = piece_off<SPT_, PAIR_, QKV_, kSub>(PH_, pc__ / (R_), pc__ % (R_), ok__);    \
-            ring[pc__] = ring_load(RS_, rs_null, ok__, lane_off, so__);                                      \
-            __builtin_amdgcn_sched_barrier(0); /* issue order = consumption order (VMEM returns in order) */ \
+        _Pragma("unroll") for (int pc__ = (P0_); pc__ < (P1_); ++pc__) {                                     \
             /* sliding window: at most kWin pieces per wave (8 kWin KiB per CU) are in flight; a deeper     */ \
             /* queue only stands in front of the gatherers' sweep in the CU's in-order memory pipeline (the */ \
             /* hand-offs into fc / mlp.c_proj took 5.5 / 5.0 us instead of ~3), and whole chunks separated  */ \
             /* by vmcnt(0) serialise the memory latency (3 x 2 us for 96 KiB)                               */ \
-            if (pc__ + 1 >= kWin && pc__ + 1 < kRing) {                                                      \
+            if (pc__ >= kWin) {                                                                              \
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWin - 1) : "memory");                               \
                 __builtin_amdgcn_sched_barrier(0);                                                           \
             }                                                                                                \
+            bool ok__;                                                                                       \
+            const unsigned so__ = piece_off<SPT_, PAIR_, QKV_, kSub>(PH_, pc__ / (R_), pc__ % (R_), ok__);    \
+            ring[pc__] = ring_load(RS_, rs_null, ok__, lane_off, so__);                                      \
+            __builtin_amdgcn_sched_barrier(0); /* issue order = consumption order (VMEM returns in order) */ \
         }                                                                                                    \
     } while (0)
+#define FS_BURST(RS_, R_, SPT_, PAIR_, QKV_, PH_) FS_BURST_RANGE(RS_, R_, SPT_, PAIR_, QKV_, PH_, 0, kRing)
 
         // ---- one phase: BODIES x TURNS ring turns of 12 / R steps; a step = R pieces against one activation unit
 #define FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_)                                       \
@@ -782,13 +784,21 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             FS_RUN_8(RS_, R_, SPTW_, PAIR_, QKV_, TURNSW_, PH_, NBODIES_, STAMP_, XEDGE_);                            \
         }                                                                                                            \
     } while (0)
-#define FS_PBURST(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_)                                                             \
+#define FS_PBURST_RANGE(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_, P0_, P1_)                                              \
     do {                                                                                                             \
-        if constexpr (FMT == 0 || FMT == 3) {                                                                                  \
-            FS_BURST(RS_, R_, SPT_, PAIR_, QKV_, PH_);                                                                \
+        if constexpr (FMT == 0 || FMT == 3) {                                                                        \
+            FS_BURST_RANGE(RS_, R_, SPT_, PAIR_, QKV_, PH_, P0_, P1_);                                                \
         } else {                                                                                                     \
-            FS_BURST(RS_, R_, SPTW_, PAIR_, QKV_, PH_);                                                               \
+            FS_BURST_RANGE(RS_, R_, SPTW_, PAIR_, QKV_, PH_, P0_, P1_);                                               \
         }                                                                                                            \
+    } while (0)
+#define FS_PBURST(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_) FS_PBURST_RANGE(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_, 0, kRing)
+        // the wide formats' early request: the whole windowed burst in front of the publish barrier (split across it — kWin pieces in front,
+        // the rest behind — cost 4 % / 7 %: profiles/r06_ab2_ring_split_burst_bf16_int8.txt)
+#define FS_EARLY_EDGE(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_)                        \
+    do {                                                                            \
+        FS_PBURST(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_);                           \
+        FS_B3();                                                                    \
     } while (0)
 
         // B3 of a phase: the gatherers have issued its publish stores.  The next phase's first ring turn is requested BEHIND it (int4
@@ -1033,16 +1043,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             FS_PBURST(rs_l, 1, 12, 4 * kSub, false, false, ph_proj);
             FS_PHASE(rs_l, 1, 12, 1, 4 * kSub, (4 * kSub + 11) / 12, false, false, ph_proj, 1, 26, rs_t, false, kF8Ea);
             if constexpr (kEarly) {
-                FS_PBURST(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
-                FS_B3();
+                FS_EARLY_EDGE(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
             } else {
                 FS_B3();
                 FS_PBURST(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
             }
             FS_PHASE(rs_l, 2, 4, 2, 4 * kSub, 2 * kSub, true, false, ph_fc, 1, 28, rs_t, true, kF8Ex);
             if constexpr (kEarly) {
-                FS_PBURST(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
-                FS_B3();
+                FS_EARLY_EDGE(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
             } else {
                 FS_B3();
                 FS_PBURST(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
@@ -1057,17 +1065,20 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if constexpr (GRP)
                     rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gt + (size_t)(l + 1) * p.gt_layer_stride), 0,
                                                              (int)p.gt_layer_bytes, 0x00020000);
-                FS_PBURST(rs_l, 3, 4, 4 * kSub, false, true, ph_attn);
+                if constexpr (kEarly) FS_EARLY_EDGE(rs_l, 3, 4, 4 * kSub, false, true, ph_attn);
+                else FS_PBURST(rs_l, 3, 4, 4 * kSub, false, true, ph_attn);
             } else {
-                FS_PBURST(rs_h, 1, 4, 4 * kSub, false, false, ph_head);
+                if constexpr (kEarly) FS_EARLY_EDGE(rs_h, 1, 4, 4 * kSub, false, false, ph_head);
+                else FS_PBURST(rs_h, 1, 4, 4 * kSub, false, false, ph_head);
             }
-            if constexpr (kEarly) FS_B3();
         }
         dbg_on = false;
         FS_PHASE(rs_h, 1, 4, 1, 4 * kSub, 1, false, false, ph_head, p.head_turns, 32, rs_th, true, kF8Ex);
         FS_B3();
         if (p.mode & 1) __syncthreads();  // the arg-max exchange of the gatherers
 #undef FS_B3
+#undef FS_EARLY_EDGE
+#undef FS_PBURST_RANGE
 #undef FS_PBURST
 #undef FS_PHASE
 #undef FS_RUN_F
@@ -1075,6 +1086,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
 #undef FS_RUN_W
 #undef FS_RUN
 #undef FS_BURST
+#undef FS_BURST_RANGE
 #undef FS_SSTAMP
     } else {
         // =========================================================================================== gatherers

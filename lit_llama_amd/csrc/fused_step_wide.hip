@@ -24,8 +24,8 @@
 //   * the attention splits cache ROWS over the GS workgroups of a head at every position (the ring kernel does so from position
 //     384 on): chunk c of 32 rows belongs to workgroup c % GS, wave (c / GS) % 8; a second head-local exchange of (128 weighted
 //     values, max, sum) partials;
-//   * a phase's first ring turn is requested ACROSS the publish barrier of the phase before it (kWin pieces in front of it, the rest
-//     behind), partial tiles are parked as column 0 only (LDS: the hidden vector alone is 44 KB), the bodies of the pair phase are
+//   * a phase's first ring turn is requested in FRONT of the publish barrier of the phase before it (the ring kernel's rule for its
+//     bf16 / int8 streams), partial tiles are parked as column 0 only (LDS: the hidden vector alone is 44 KB), the bodies of the pair phase are
 //     unrolled (a runtime loop around loads makes hipcc drain the ring at every back edge).
 // Where a 65B layer's 77 us go (profiles/r06_wide_65b_first_timeline.txt): the four phases stream 306 MB in 53 us (5.8 TB/s, 7.0 between a
 // phase's B1 and wave 0's last tile), the hand-offs take 23 us (x edges 4.2-5.3, attention output 4.2, hidden 7.8: every CU reads every
@@ -200,7 +200,7 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 // Pieces P0 .. P1 - 1 of a phase's FIRST ring turn (12 pieces), consumption order = issue order (VMEM returns in order).  WAIT: at most
 // kWin pieces per wave in flight while they are requested (a deeper queue only stands in front of the gatherers' sweep in the CU's
-// in-order memory pipeline); the first kWin pieces of a burst go out without it, in front of the publish barrier.
+// in-order memory pipeline).
 template <int R, int SPT, int MODE, int RTK, int P0, int P1, bool WAIT>
 __device__ __forceinline__ void burst(u32x4 (&ring)[kRing], const PhaseW& ph, int kstride, __amdgpu_buffer_rsrc_t rs, const StreamerCtx& c) {
     constexpr int STEPS = kRing / R;
@@ -412,14 +412,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
     do {                                                                              \
         if (dbg_on && threadIdx.x == 0) p.dbg[bid * 64 + (i)] = wall_clock64();        \
     } while (0)
-        // A phase's first ring turn is requested ACROSS the publish barrier B3 of the phase before it: kWin pieces in front of the
-        // barrier (the streamers must not arrive at it later than the gatherers' epilogue does: the whole burst in front of it cost
-        // ~1.5 us per edge), the rest behind it, while the gatherers sweep the edge
+        // A phase's first ring turn is requested in FRONT of the publish barrier B3 of the phase before it, windowed (kWin pieces per wave in
+        // flight): the stream runs through the epilogue, and when the gatherers sweep the edge most of the turn has landed.  Measured
+        // against it at the 65B width (profiles/r06_ab_wide_knobs.txt): kWin pieces in front of B3 and the rest behind it -1.6 %; no burst
+        // at all but the turn CHAINED to the last turn of the phase before (a consumed slot refilled with the next phase's piece: up to
+        // 96 KiB per CU in front of the publish store) -1.2 %; the same two on the ring kernel's bf16 / int8 streams -4 % / -7 %.
 #define FW_EDGE(R_, SPT_, MODE_, RTK_, PH_, KS_, RS_)                                                  \
     do {                                                                                              \
-        burst<R_, SPT_, MODE_, RTK_, 0, kWin, false>(ring, PH_, KS_, RS_, c);                          \
+        burst<R_, SPT_, MODE_, RTK_, 0, kRing, true>(ring, PH_, KS_, RS_, c);                          \
         wg_barrier(); /* B3 */                                                                        \
-        burst<R_, SPT_, MODE_, RTK_, kWin, kRing, true>(ring, PH_, KS_, RS_, c);                       \
     } while (0)
         burst<R_ATT, TU_ATT * ST_ATT, M_SHARED, RT, 0, kRing, true>(ring, ph_attn, C / 16, rs_l, c);
         const bf16_t* kv_l = (const bf16_t*)p.kv;
