@@ -20,10 +20,10 @@
 //    (write-through) store and swept with sc1 loads until every tag equals the phase's epoch: the data is the
 //    flag, there is no fence and no barrier between workgroups.  Tags are unique per (step, edge) — the step
 //    counter lives in device memory — so nothing needs zeroing between launches or graph replays.
-//  * The weights of phase k + 1 do not depend on activations: the streamers request its first ring turn right
-//    AFTER the gatherers have issued phase k's publish stores (a refill queued in front of the publish in the CU's
-//    in-order memory pipeline delays the whole chip: 6.2 -> 4.2 us per 96-KiB phase) and BEFORE the all-gather, so
-//    the HBM stream runs through the hand-off.
+//  * The weights of phase k + 1 do not depend on activations: the streamers request its first ring turn behind phase k's last
+//    tile, in front of its publish barrier, at most 4 pieces per wave in flight (a whole ring turn queued in front of the
+//    publish in the CU's in-order memory pipeline delays the whole chip: 6.2 -> 4.2 us per 96-KiB phase; the windowed one
+//    does not, and runs through the epilogue: round 6), so the HBM stream runs through the hand-off.
 //  * c_attn, RoPE, the KV-cache row write and the attention of a head are local to the 8 workgroups of that head
 //    (same XCD): they exchange q and the new k / v row (2 KiB) among themselves; each workgroup then computes the
 //    softmax over the whole context and its own 16 dimensions of the head's output.
@@ -49,7 +49,8 @@ constexpr int kSW = 8;          // streamer waves
 constexpr int kGW = 2;          // gatherer waves
 constexpr int kThreads = 64 * (kSW + kGW);
 constexpr int kRing = 12;       // ring pieces (1 KiB each) per streamer wave
-constexpr int kWin = 4;         // pieces per wave in flight while a first ring turn is requested (2, 3, 5, 6, 8: within +-1 % except 2 and 6)
+constexpr int kWin = 4;         // pieces per wave in flight while a first ring turn is requested (round 6, with the burst in front of the publish
+                                // barrier: 3 -> +1.0 %, 5 -> +0.8 %, 6 -> +4 %, 8 -> +15 % per step: profiles/r06_ab3_early_burst_int4.txt)
 constexpr int kC = 4096;        // n_embd
 constexpr int kHeads = 32;
 constexpr int kHs = 128;
@@ -793,20 +794,21 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         }                                                                                                            \
     } while (0)
 #define FS_PBURST(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_) FS_PBURST_RANGE(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_, 0, kRing)
-        // the wide formats' early request: the whole windowed burst in front of the publish barrier (split across it — kWin pieces in front,
-        // the rest behind — cost 4 % / 7 %: profiles/r06_ab2_ring_split_burst_bf16_int8.txt)
+        // (split across the barrier — kWin pieces in front, the rest behind — cost the BF16 / LLM.int8 streams 4 % / 7 %:
+        // profiles/r06_ab2_ring_split_burst_bf16_int8.txt)
 #define FS_EARLY_EDGE(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_)                        \
     do {                                                                            \
         FS_PBURST(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_);                           \
         FS_B3();                                                                    \
     } while (0)
 
-        // B3 of a phase: the gatherers have issued its publish stores.  The next phase's first ring turn is requested BEHIND it (int4
-        // streams: a refill queued in front of the publish in the CU's in-order memory pipeline delays every consumer of the edge) or, for
-        // the wide formats whose chain is shorter than their stream (BF16, LLM.int8), in FRONT of it: their
-        // phases stream two to sixteen ring turns in-phase, and the gap between a phase's last tile and the next request is HBM idle time
+        // B3 of a phase: the gatherers have issued its publish stores.  The next phase's first ring turn is requested in FRONT of it, windowed
+        // (kWin pieces per wave in flight): the stream runs through the epilogue, and most of the turn has landed when the gatherers sweep the
+        // edge.  Rounds 2-5 requested it BEHIND the barrier for the int4 streams ("publish, then refill": an UNwindowed ring turn queued in front of
+        // the publish stores delays every consumer of the edge, 6.2 -> 4.2 us per 96-KiB phase in scripts/micro/allgather.hip) and in front of it for
+        // the BF16 / LLM.int8 streams only (round 5, +1 %); round 6 measured the windowed burst in front of it on the int4 streams as well:
+        // 891 -> 875 us per step (profiles/r06_ab3_early_burst_int4.txt).
 #define FS_B3() __syncthreads()
-        constexpr bool kEarly = FMT == 1 || FMT == 2;  // (+1.0 / +1.1 %, profiles/r05_early_burst_ab.txt)
         FS_PBURST(rs_l, 3, 4, 4 * kSub, false, true, ph_attn);
         const bf16_t* kv_l = (const bf16_t*)p.kv;
         bool dbg_on = false;
@@ -1039,24 +1041,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 __syncthreads();  // Ba3: partial outputs of the 8 waves
                 __syncthreads();  // Ba4: the attention output is published
             }
-            // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows)
+            // ---------------- attn.c_proj, MLP (the ring is free during the attention: its registers hold K / V rows; attn.c_proj's turn
+            // in front of the attention output's publish barrier Ba4 as well: +1.4 % per step, profiles/r06_ab3_early_burst_int4.txt)
             FS_PBURST(rs_l, 1, 12, 4 * kSub, false, false, ph_proj);
             FS_PHASE(rs_l, 1, 12, 1, 4 * kSub, (4 * kSub + 11) / 12, false, false, ph_proj, 1, 26, rs_t, false, kF8Ea);
-            if constexpr (kEarly) {
-                FS_EARLY_EDGE(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
-            } else {
-                FS_B3();
-                FS_PBURST(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
-            }
+            FS_EARLY_EDGE(rs_l, 2, 4, 4 * kSub, true, false, ph_fc);
             FS_PHASE(rs_l, 2, 4, 2, 4 * kSub, 2 * kSub, true, false, ph_fc, 1, 28, rs_t, true, kF8Ex);
-            if constexpr (kEarly) {
-                FS_EARLY_EDGE(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
-            } else {
-                FS_B3();
-                FS_PBURST(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
-            }
+            FS_EARLY_EDGE(rs_l, 1, 12, 12 * kSub, false, false, ph_mp);
             FS_PHASE(rs_l, 1, 12, 1, 12 * kSub, kSub, false, false, ph_mp, 1, 30, rs_t, false, kF8Eh);
-            if constexpr (!kEarly) FS_B3();
             // next layer (or the head)
             kv_l += (size_t)2 * kHeads * p.S * kHs;
             if (l + 1 < p.n_layer) {
@@ -1065,11 +1057,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if constexpr (GRP)
                     rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gt + (size_t)(l + 1) * p.gt_layer_stride), 0,
                                                              (int)p.gt_layer_bytes, 0x00020000);
-                if constexpr (kEarly) FS_EARLY_EDGE(rs_l, 3, 4, 4 * kSub, false, true, ph_attn);
-                else FS_PBURST(rs_l, 3, 4, 4 * kSub, false, true, ph_attn);
+                FS_EARLY_EDGE(rs_l, 3, 4, 4 * kSub, false, true, ph_attn);
             } else {
-                if constexpr (kEarly) FS_EARLY_EDGE(rs_h, 1, 4, 4 * kSub, false, false, ph_head);
-                else FS_PBURST(rs_h, 1, 4, 4 * kSub, false, false, ph_head);
+                FS_EARLY_EDGE(rs_h, 1, 4, 4 * kSub, false, false, ph_head);
             }
         }
         dbg_on = false;
