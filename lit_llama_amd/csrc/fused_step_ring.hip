@@ -62,7 +62,8 @@ constexpr unsigned kSpinLimit = 400000u;
 // Round 6: the compile-time knobs of rounds 2-5 are gone (28 of them; the kernel text that carried them all is
 // scripts/patches/r05_fused_step_ring_with_all_knobs.hip.txt.gz, the measurements that decided each one are quoted where its winner lives
 // and in HISTORY.md / NOTES.md): what is left is the template (GRP, FMT) and these constants.
-constexpr int kG0Pairs = 6;     // gatherer 0's share of an x edge's 16 pair loads per lane (6 : 10 -> 918 us per step, 7 : 9 -> 935 us)
+constexpr int kG0Pairs = 7;     // gatherer 0's share of an x edge's 16 pair loads per lane (rounds 2-5: 6 : 10 -> 918 us per step, 7 : 9 -> 935;
+                                // round 6, with the burst in front of the publish barrier: 5 / 6 / 7 / 8 -> 879 / 878 / 873 / 879, profiles/r06_ab3_*.txt)
 constexpr int kSplitPos = 384;  // from this position on the attention splits rows, not dimensions (profiles/r03_attention_row_split_crossover.txt)
 constexpr int kPartStride = 136;  // granules per workgroup partial of the row-split attention: 128 values, max, sum, pad
 
