@@ -60,6 +60,7 @@ constexpr int kWin = MI355_WIDE_WINDOW;  // pieces per wave in flight while a fi
 constexpr int kHs = 128;
 constexpr unsigned kSpinLimit = 400000u;
 constexpr int kPartStride = 136;  // granules per workgroup partial of the attention: 128 values, max, sum, pad
+constexpr int kSoloPos = 256;     // up to this position every workgroup of a head covers ALL cache rows itself (see the attention phase)
 constexpr int kMaxUnits = 176;    // units of 128 columns of the widest activation vector (n_hidden <= 22528)
 constexpr int kRMax = 6;          // row tiles of a step (c_attn of the 64-head shape)
 
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
     const unsigned ebase = step_id * 1024u + 1u;
     const int n_fc = (p.fc_tiles - bid + NWG - 1) / NWG;        // this workgroup's pair tiles
     const int n_head_t = (p.head_tiles - bid + NWG - 1) / NWG;  // lm_head tiles
+    int solo_i = pos <= kSoloPos ? 1 : 0;  // short context: no row split, no second head-local exchange (attention phase)
 
     // entered outside the cache (the host takes the cache-roll regime of model.py:214-218 elsewhere) or with a token id outside
     // the embedding table: refuse before anything is written.  Uniform over the grid, so no hand-off hangs.
@@ -439,11 +441,19 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, pos * (kHs * 2), 0x00020000);
                 int n_chunks = (pos + 31) >> 5;
                 n_chunks = n_chunks < 1 ? 1 : n_chunks;  // (position 0: chunk 0 carries the new token's own row only)
-                const int c0 = wave * GS + hj;
+                // Up to position 256 (eight chunks: at most ONE per wave either way) every workgroup of the head takes ALL rows — chunk c belongs
+                // to wave c % 8 of each of them — and so holds the whole head's output: its gatherer publishes its own DH dimensions at once,
+                // the exchange of partials (one hand-off, ~1.5 us per layer) is not needed.  The head's GS workgroups sit on one XCD: the rows
+                // are read from HBM once and from its L2 GS - 1 times.  Beyond, the rows are split: chunk c -> workgroup c % GS, wave (c / GS) % 8.
+                // (written with the loop's compile-time stride: the loop variable counts chunks x GS in that mode — a run-time stride cost 30 VGPRs
+                // and scratch)
+                const int csh = solo_i ? (GS == 4 ? 2 : 3) : 0, hsel = solo_i ? 0 : hj;
+                const int c0 = wave * GS + hsel;          // loop variable: chunk << csh
+                const int n_loop = n_chunks << csh;
                 u32x4 kr[8], vr[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int t = c0 * 32 + u * 4 + lr;
+                    const int t = (c0 >> csh) * 32 + u * 4 + lr;
                     const unsigned off = t < pos ? (unsigned)t * 256u + li * 16u : 0xFFFFFFF0u;
                     kr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
                     vr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
@@ -457,8 +467,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 float of[8];                           // dims li * 8 .. + 7, over this lane group's rows
 #pragma unroll
                 for (int j = 0; j < 8; ++j) of[j] = 0.f;
-                for (int ch = c0; ch < n_chunks; ch += kSW * GS) {
-                    if (ch != c0) {
+                for (int chl = c0; chl < n_loop; chl += kSW * GS) {
+                    const int ch = chl >> csh;  // the chunk
+                    if (chl != c0) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int t = ch * 32 + u * 4 + lr;
@@ -484,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     bm = fmaxf(bm, lane_xor16(bm));  // over the 4 row groups lr: the maximum of the wave's 32 rows
                     bm = fmaxf(bm, lane_xor32(bm));
                     float s_new = -1.0e30f;
-                    const bool own = ch == 0 && wave == 0 && hj == 0;  // the new token's own row rides with chunk 0
+                    const bool own = ch == 0 && wave == 0 && hsel == 0;  // the new token's own row rides with chunk 0
                     if (own) {
                         float dot = qs[lane] * knew[lane] + qs[lane + 64] * knew[lane + 64];
                         s_new = group_sum(dot, 64) * p.scale;
@@ -760,9 +771,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             psrc = (pg >> 1) * 4 + ((2 * pg) & 3);
             r0 = (bid * RT + er) * 16 + 2 * pg;
             // ================= c_attn
-            const int nq = head * kHs + hj * DH + er * 16 + 2 * pg;  // q rows of this lane's pair; k at + C, v at + 2 C
+            // (c_attn's epilogue spread over all four gatherers — q rows on gatherers 0 / 1, k and v rows on 2 / 3 — measured flat at the 65B
+            // width, profiles/r06_ab_wide_knobs.txt: the tile's owner does all three)
+            const int crole = epi ? 3 : 2, cer = er;   // 3: q, k and v; 2: nothing
+            const int nq = head * kHs + hj * DH + cer * 16 + 2 * pg;  // q rows of this lane's pair; k at + C, v at + 2 C
             float2 sc[3], zr[3];
-            if (epi) {
+            if (crole != 2) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     sc[r] = ldpair(sz_l + nq + r * C);
@@ -777,29 +791,32 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             FW_GSTAMP(56);
             {
                 const float rinv = x_rinv();
-                if (epi) {
+                if (crole != 2) {
                     const float s = get_sums();
-                    float2 y[3];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        y[r] = deq(tile_pair(r * RT + er), sc[r], zr[r], s);
-                        y[r].x *= rinv;
-                        y[r].y *= rinv;
-                    }
                     // RoPE (model.py:306-323) of the q / k pair, publish to the head group, write the cache rows
                     const unsigned ep = ebase + edge;
                     u64* dst = p.gq + ((size_t)qpar * NH + head) * 256 + hj * (2 * DH);
-                    bf16_t* krow = kv_l + ((size_t)head * p.S + pos) * kHs + hj * DH + er * 16;
-                    bf16_t* vrow = krow + (size_t)NH * p.S * kHs;
-                    const float qa = y[0].x * cs.x - y[0].y * cs.y, qb = y[0].y * cs.x + y[0].x * cs.y;
-                    const unsigned kp = bfpair(y[1].x * cs.x - y[1].y * cs.y, y[1].y * cs.x + y[1].x * cs.y);
-                    const unsigned vp = bfpair(y[2].x, y[2].y);
-                    if (w8 == 0) gr_store(dst + er * 16 + 2 * pg, ep, __float_as_uint(qa));
-                    if (w8 == 1) gr_store(dst + er * 16 + 2 * pg + 1, ep, __float_as_uint(qb));
-                    if (w8 == 2) gr_store(dst + DH + er * 8 + pg, ep, kp);
-                    if (w8 == 3) gr_store(dst + DH + DH / 2 + er * 8 + pg, ep, vp);
-                    if (w8 == 4) ((unsigned*)krow)[pg] = kp;
-                    if (w8 == 5) ((unsigned*)vrow)[pg] = vp;
+                    if (crole == 0 || crole == 3) {
+                        float2 y = deq(tile_pair(cer), sc[0], zr[0], s);
+                        y.x *= rinv;
+                        y.y *= rinv;
+                        const float qa = y.x * cs.x - y.y * cs.y, qb = y.y * cs.x + y.x * cs.y;
+                        if (w8 == 0) gr_store(dst + cer * 16 + 2 * pg, ep, __float_as_uint(qa));
+                        if (w8 == 1) gr_store(dst + cer * 16 + 2 * pg + 1, ep, __float_as_uint(qb));
+                    }
+                    if (crole == 1 || crole == 3) {
+                        float2 yk = deq(tile_pair(RT + cer), sc[1], zr[1], s), yv = deq(tile_pair(2 * RT + cer), sc[2], zr[2], s);
+                        yk.x *= rinv;
+                        yk.y *= rinv;
+                        bf16_t* krow = kv_l + ((size_t)head * p.S + pos) * kHs + hj * DH + cer * 16;
+                        bf16_t* vrow = krow + (size_t)NH * p.S * kHs;
+                        const unsigned kp = bfpair(yk.x * cs.x - yk.y * cs.y, yk.y * cs.x + yk.x * cs.y);
+                        const unsigned vp = bfpair(yv.x * rinv, yv.y * rinv);
+                        if (w8 == 2) gr_store(dst + DH + cer * 8 + pg, ep, kp);
+                        if (w8 == 3) gr_store(dst + DH + DH / 2 + cer * 8 + pg, ep, vp);
+                        if (w8 == 4) ((unsigned*)krow)[pg] = kp;
+                        if (w8 == 5) ((unsigned*)vrow)[pg] = vp;
+                    }
                 }
             }
             FW_GSTAMP(3);
@@ -836,8 +853,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 __syncthreads();  // Ba1
                 __syncthreads();  // Ba3
                 FW_GSTAMP(5);
-                // this workgroup's partial over ITS rows (all 128 dimensions) goes to the head group, every workgroup then merges
-                // the GS partials for its own DH output dimensions
+                solo_i = __builtin_amdgcn_readfirstlane(solo_i);
+                asm volatile("" : "+s"(solo_i));  // (see the streamers)
+                const bool solo = solo_i != 0;
+                // the 8 waves' partials merged: over ALL rows of the head (solo: this workgroup's DH dimensions of it are the attention
+                // output — published at once), or over this workgroup's rows (all 128 dimensions of them go to the head group, every
+                // workgroup then merges the GS partials for its own DH output dimensions)
                 const unsigned ep1 = ebase + edge;
                 if (gw == 0) {
                     float mall = misc[16];
@@ -853,16 +874,24 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                         o.y += wsc * t.y;
                         lsum += wsc * misc[24 + w];
                     }
-                    u64* dstp = p.gp + (((size_t)ppar * NH + head) * GS + hj) * kPartStride;
-                    gr_store(dstp + 2 * lane_v, ep1, __float_as_uint(o.x));
-                    gr_store(dstp + 2 * lane_v + 1, ep1, __float_as_uint(o.y));
-                    if (lane_v == 0) {
-                        gr_store(dstp + 128, ep1, __float_as_uint(mall));
-                        gr_store(dstp + 129, ep1, __float_as_uint(lsum));
+                    if (solo) {
+                        // lane holds dimensions 2 lane, 2 lane + 1 of the head: pair lane % (DH / 2) of workgroup lane / (DH / 2)
+                        const float inv = __builtin_amdgcn_rcpf(lsum);
+                        const int px = lane_v % (DH / 2);
+                        u64* ga_t = p.ga + (size_t)apar * (C / 2) + head * 64 + hj * (DH / 2);
+                        if (lane_v / (DH / 2) == hj) gr_store(ga_t + px, ep1, hpair(o.x * inv, o.y * inv, (px & 1) != 0));
+                    } else {
+                        u64* dstp = p.gp + (((size_t)ppar * NH + head) * GS + hj) * kPartStride;
+                        gr_store(dstp + 2 * lane_v, ep1, __float_as_uint(o.x));
+                        gr_store(dstp + 2 * lane_v + 1, ep1, __float_as_uint(o.y));
+                        if (lane_v == 0) {
+                            gr_store(dstp + 128, ep1, __float_as_uint(mall));
+                            gr_store(dstp + 129, ep1, __float_as_uint(lsum));
+                        }
                     }
                 }
-                ++edge;
-                if (gw == 0) {
+                if (!solo) ++edge;
+                if (gw == 0 && !solo) {
                     // lane = (pair px of this workgroup's DH output dimensions, partial wq of the head group)
                     const int px = lane_v / GS, wq = lane_v % GS;
                     const unsigned hbase = kOGp + (unsigned)(((ppar * NH + head) * GS) * kPartStride) * 8u;
@@ -892,7 +921,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     u64* ga_t = p.ga + (size_t)apar * (C / 2) + head * 64 + hj * (DH / 2);
                     if (wq == 0) gr_store(ga_t + px, ebase + edge, hpair(ox * inv, oy * inv, (px & 1) != 0));
                 }
-                ppar ^= 1;
+                if (!solo) ppar ^= 1;
                 FW_GSTAMP(6);
                 __syncthreads();  // Ba4
             }
