@@ -11,7 +11,7 @@
 // Replaces, per generated token, the 161 x (n_layer / 32) operator calls of lit_llama/model.py:76-122 (Block.forward :165-168,
 // CausalSelfAttention.forward :194-237, MLP.forward :251-254, RMSNorm :274-277, apply_rope :306-323), the greedy sampling of
 // generate.py:68-85 and this repository's launch-per-operator step (80 x 7 launches for 65B).  Measured (round 6, bench.py --model):
-// 65B 161-163 tok/s = 0.66 of the int4-weight roofline against 133 = 0.54 on launches, 30B 265 against 209, 13B 509 against 394.
+// 65B 168-170 tok/s = 0.68-0.69 of the int4-weight roofline against 133-138 = 0.54-0.56 on launches, 30B 265 against 209, 13B 565 against 394.
 //
 // What is shared with fused_step_ring.hip (read its header first): resident workgroups of 8 streamer waves + gatherer waves; weights in
 // a 12-piece register ring per streamer wave (1-KiB non-temporal wave loads); activations between phases as 8-byte {tag, value}
@@ -21,9 +21,10 @@
 //     (R = 6), attn.c_proj / mlp.c_proj RT tiles; FOUR gatherer waves sweep the (twice as large) edges, the first RT of them run the
 //     epilogues of the residual / head tiles (tile r belongs to gatherer r) and publish; the c_fc1 / c_fc2 pair tiles alternate between
 //     gatherers 0 and 1;
-//   * the attention splits cache ROWS over the GS workgroups of a head at every position (the ring kernel does so from position
-//     384 on): chunk c of 32 rows belongs to workgroup c % GS, wave (c / GS) % 8; a second head-local exchange of (128 weighted
-//     values, max, sum) partials;
+//   * the attention splits cache ROWS over the GS workgroups of a head (the ring kernel does so from position 384 on): chunk c of 32
+//     rows belongs to workgroup c % GS, wave (c / GS) % 8, and a second head-local exchange carries (128 weighted values, max, sum)
+//     partials — except up to position 256, where every workgroup of the head covers all rows itself (at most one chunk per wave
+//     either way; the head group shares an L2) and publishes its own dimensions without that exchange;
 //   * a phase's first ring turn is requested in FRONT of the publish barrier of the phase before it (the ring kernel's rule for its
 //     bf16 / int8 streams), partial tiles are parked as column 0 only (LDS: the hidden vector alone is 44 KB), the bodies of the pair phase are
 //     unrolled (a runtime loop around loads makes hipcc drain the ring at every back edge).
