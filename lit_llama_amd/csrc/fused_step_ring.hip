@@ -797,6 +797,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
 #define FS_PBURST(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_) FS_PBURST_RANGE(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_, 0, kRing)
         // (split across the barrier — kWin pieces in front, the rest behind — cost the BF16 / LLM.int8 streams 4 % / 7 %:
         // profiles/r06_ab2_ring_split_burst_bf16_int8.txt)
+        // (waiting for the whole burst to land in front of the barrier — the sweeps then run with this CU's memory pipeline empty — costs more than
+        // the sweeps gain: +2.3 % per step, +1.6 % with two pieces left in flight: profiles/r06_ab3_early_burst_int4.txt)
 #define FS_EARLY_EDGE(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_)                        \
     do {                                                                            \
         FS_PBURST(RS_, R_, SPT_, SPTW_, PAIR_, QKV_, PH_);                           \
