@@ -591,7 +591,7 @@ def main():
     assert all(0 <= t_ < cfg.padded_vocab_size for t_ in tokens), "decode produced invalid ids"
     fused = eng.fused_ready()
     eng_fmt = int(eng.fused.weight_fmt) if fused else -1
-    f8_operands = fused and int(eng.fused.weight_fmt) == 3  # (the fp8-limb operand path of the int4 step)
+    f8_operands = fused and int(eng.fused.weight_fmt) in (3, 5)  # (the fp8-limb operand path of the int4 step)
     hipgraph_used = bool(eng.use_graph and eng._graphs) and not fused
     if rank == 0:
         bpt = bytes_per_token(cfg, args.quantize)
@@ -621,7 +621,7 @@ def main():
                 kname = None
                 if fused:
                     # the entry of the kernel that was TIMED: fused_step_ring_kernel<GRP, FMT> with FMT = the engine's weight_fmt
-                    kname = f"fused_step_ring_kernel<false, {int(eng.fused.weight_fmt)}>"
+                    kname = f"fused_step_ring_kernel<false, {eng_fmt}>"
                     ent = doc.get("kernels", {}).get(kname)
                     traffic = round(ent["corrected_bytes_per_launch"]) if ent else None
                 traffic_source = (f"profiles/pmc_traffic.json: committed rocprofv3 --pmc FETCH_SIZE pass over this command"
@@ -630,11 +630,12 @@ def main():
             except Exception:
                 traffic = None
         # what a checkpoint that leaves the fp8 hand-off's range gets: the SAME K steps over the same positions on
-        # the next rung of the engine's ladder — fp16 operands, `fused_step_ring_kernel<false, 0>` — one block, same engine, same box
+        # the next rung of the engine's ladder — fp16 operands, `fused_step_ring_kernel<false, 0>` (wide shapes: weight_fmt 4) — one block,
+        # same engine, same box
         rungs = None
         if f8_operands:
             with torch.cuda.stream(eng.stream):
-                eng.use_fused_format(0)
+                eng.use_fused_format(0 if eng_fmt == 3 else 4)
                 eng.set_step(eng.out_tokens[p0:p0 + 1], 1, p0)
                 eng.embed_step()
                 for _ in range(4):
@@ -747,7 +748,7 @@ def main():
         "dtype": ("fp8x3" if f8_operands else
                   "fp16" if fused and args.quantize == "gptq.int4" else "int8" if args.quantize == "llm.int8" else "bf16"),
         "dtype_detail": ("int4 weights as exact E4M3 bytes x activations as THREE E4M3 limbs (12 significant bits) on the MX-scaled fp8 MFMA "
-                         "(weight_fmt 3, the default since round 4; MI355_FUSED_F8=0: fp16 operands), f32 accumulate, bf16 KV cache" if f8_operands else
+                         f"(weight_fmt {eng_fmt}, the default; MI355_FUSED_F8=0: fp16 operands), f32 accumulate, bf16 KV cache" if f8_operands else
                          "int4 weights -> fp16 MFMA operands x fp16 activations, f32 accumulate, bf16 KV cache"
                          if fused and args.quantize == "gptq.int4" else
                          "int8 x int8 -> int32 MFMA + f16 outlier columns, bf16 KV cache" if args.quantize == "llm.int8" else
@@ -770,7 +771,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": (("fused_step_wide_kernel" if int(eng_fmt) == 4 else "fused_step_ring_kernel") +
+            "kernel": (("fused_step_wide_kernel" if int(eng_fmt) in (4, 5) else "fused_step_ring_kernel") +
                        " (the whole decode step, one launch per token)") if fused else
                       {"gptq.int4": "gemv_kernel<Q4,R=2,SwiGLU>", "none": "gemv_kernel<BF16,R=2,SwiGLU>", "gptq.int8": "gemv_kernel<BF16,R=2,SwiGLU>",
                        "llm.int8": "int8_gemv_kernel<R=2>"}[args.quantize] + " (c_fc1/c_fc2 pair)",

@@ -474,7 +474,7 @@ int mi355_graph_destroy(mi355_graph* g);
 /* ------------------------------------------------------------------------------------------
  * The whole T = 1 decode step (LLaMA.forward for one token + greedy sampling, lit_llama/model.py:76-122,
  * generate.py:68-85) as ONE persistent launch: 7B-class models on a 256-CU device (kernel csrc/fused_step_ring.hip) and, per-row
- * gptq.int4 only, the 65B shape (csrc/fused_step_wide.hip, weight_fmt 4); host entry csrc/fused_step.hip; mi355_fused_step_supported tells.  Everything the launch touches is laid out in
+ * gptq.int4 only, the 13B / 30B / 65B shapes (csrc/fused_step_wide.hip, weight_fmt 4 / 5); host entry csrc/fused_step.hip; mi355_fused_step_supported tells.  Everything the launch touches is laid out in
  * arenas so that a layer is addressed by a stride:
  *   w        Q4 streams (mi355_q4_repack) of layer l at w + l * layer_stride: c_attn (R = 1) at off_attn, attn.c_proj
  *            (R = 1) at off_proj, the interleaved c_fc1 / c_fc2 pair (R = 2) at off_fc, mlp.c_proj (R = 1) at off_mproj;
@@ -544,7 +544,10 @@ typedef struct mi355_fused_step_args {
      * 4 (round 6): the streams, scales and zeros of 0 through the WIDE-SHAPE kernel (csrc/fused_step_wide.hip): n_embd = 128 n_head with
      * 64 heads (LLaMA-65B, lit_llama/model.py:47: BASELINE configs[4] on one GPU) or 32 heads (the 7B shape, as a cross-check of the ring
      * kernel); fp16 operands and hand-offs, per-row scales only, n_hidden <= 22528.  mi355_fused_step_supported returns 2 for the shapes
-     * only this format serves (1: the 7B shape, every format). */
+     * only this format and 5 serve (1: the 7B shape, every format).
+     * 5 (round 6; what lit_llama_amd's engine selects on those shapes unless MI355_FUSED_F8=0): the wide-shape kernel with the operands of 3
+     * — one scaled fp8 MFMA per 1-KiB piece, three E4M3 limbs per activation under 16-bit tags; same shapes and limits as 4, the workspace
+     * rule of 3 (zero it when the format changes). */
     int32_t weight_fmt;
     const void* gt;
     const void* gt_head;

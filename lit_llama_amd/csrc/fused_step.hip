@@ -58,18 +58,18 @@ extern "C" int mi355_fused_step_supported(int n_embd, int n_head, int hs, int n_
         if (S < 1 || S > kMaxS) return 0;
         return 1;
     }
-    // wider shapes (round 6): csrc/fused_step_wide.hip, weight_fmt 4 only
+    // wider shapes (round 6): csrc/fused_step_wide.hip, weight_fmt 4 / 5 only
     return wide_ok(n_embd, n_head, hs, n_hidden, vocab, S) ? 2 : 0;
 }
 
 
-// weight_fmt 4: the wide-shape kernel (per-row int4 streams, fp16 operands)
+// weight_fmt 4 / 5: the wide-shape kernel (per-row int4 streams; fp16 operands / E4M3 limb operands)
 static int fused_step_wide(const mi355_fused_step_args* a, mi355_stream_t stream) {
     MI355_CHECK_ARG(wide_ok(a->n_embd, a->n_head, a->hs, a->n_hidden, a->vocab, a->S), MI355_E_SHAPE,
-                    "fused_step (weight_fmt 4): needs %d CUs, n_embd = 128 n_head with 32 / 40 / 52 / 64 heads, n_hidden %% 128 == 0 within the "
+                    "fused_step (weight_fmt 4 / 5): needs %d CUs, n_embd = 128 n_head with 32 / 40 / 52 / 64 heads, n_hidden %% 128 == 0 within the "
                     "shape's limits (<= 6 pair tiles per workgroup, 3 for 32 heads), even vocab, S <= %d (got %d CUs, C=%d, heads=%d x %d, H=%d, V=%d, S=%d)",
                     kG, kMaxS, mi355_num_cus(), a->n_embd, a->n_head, a->hs, a->n_hidden, a->vocab, a->S);
-    MI355_CHECK_ARG(a->group_cols == 0, MI355_E_ARG, "fused_step (weight_fmt 4): per-row scales only");
+    MI355_CHECK_ARG(a->group_cols == 0, MI355_E_ARG, "fused_step (weight_fmt 4 / 5): per-row scales only");
     MI355_CHECK_ARG(a->w && a->w_head && a->sz && a->sz_head && a->norms && a->wte && a->rope && a->kv && a->tokens && a->pos && a->logits &&
                         a->workspace,
                     MI355_E_ARG, "fused_step: null pointer");
@@ -80,7 +80,7 @@ static int fused_step_wide(const mi355_fused_step_args* a, mi355_stream_t stream
                      a->off_fc | a->off_mproj) % 16 == 0,
                     MI355_E_ARG, "fused_step: streams and workspace must be 16-B aligned");
     const int widx = a->n_head == 64 ? 0 : a->n_head == 52 ? 1 : a->n_head == 40 ? 2 : 3;
-    MI355_CHECK_ARG((fused_step_wide_occupancy_ok() & (1 << widx)) != 0, MI355_E_STATE,
+    MI355_CHECK_ARG((fused_step_wide_occupancy_ok() & (1 << (widx + (a->weight_fmt == 5 ? 4 : 0)))) != 0, MI355_E_STATE,
                     "fused_step: the device does not admit one %d-thread workgroup of the wide-shape kernel per CU", kThreads);
     FusedParams p;
     memset(&p, 0, sizeof(p));
@@ -122,7 +122,7 @@ static int fused_step_wide(const mi355_fused_step_args* a, mi355_stream_t stream
     p.units_h = a->n_hidden / 128;
     p.fc_tiles = a->n_hidden / 16;
     p.head_tiles = (a->vocab + 15) / 16;
-    p.fmt = 4;
+    p.fmt = a->weight_fmt;
     {
         const int nwg = a->n_head * (a->n_head == 32 ? 8 : 4);
         int tpb_fc, fc_max, tpb_head, mp_steps;
@@ -144,7 +144,7 @@ static int fused_step_wide(const mi355_fused_step_args* a, mi355_stream_t stream
 
 extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t stream) {
     MI355_CHECK_ARG(a != nullptr, MI355_E_ARG, "fused_step: null args");
-    if (a->weight_fmt == 4) return fused_step_wide(a, stream);
+    if (a->weight_fmt == 4 || a->weight_fmt == 5) return fused_step_wide(a, stream);
     MI355_CHECK_ARG(mi355_fused_step_supported(a->n_embd, a->n_head, a->hs, a->n_hidden, a->vocab, a->S) == 1, MI355_E_SHAPE,
                     "fused_step: needs %d CUs, n_embd %d, %d heads of %d, n_hidden %% 128 == 0 and <= %d, vocab <= %d, "
                     "S <= %d (got %d CUs, C=%d, heads=%d x %d, H=%d, V=%d, S=%d)",
@@ -153,7 +153,8 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     const bool grouped = a->group_cols > 0;
     const int fmt = a->weight_fmt;
     MI355_CHECK_ARG(fmt >= 0 && fmt <= 3, MI355_E_ARG,
-                    "fused_step: weight_fmt %d (0 = int4 streams, 1 = BF16, 2 = LLM.int8, 3 = int4 streams through fp8 operands)", fmt);
+                    "fused_step: weight_fmt %d (0 = int4 streams, 1 = BF16, 2 = LLM.int8, 3 = int4 streams through fp8 operands; 4 / 5 = the wide-shape "
+                    "kernel's fp16 / fp8 operands)", fmt);
     // fp8-limb operands keep three byte planes of the activation vector in LDS: 95 units of 128 columns
     // (and its gatherers sweep the hidden edge — n_hidden / 4 loads of two granules + 128 of operand-sum partials — in at most 24 loads per lane)
     MI355_CHECK_ARG(fmt != 3 || a->n_hidden / 128 <= 92, MI355_E_SHAPE, "fused_step: weight_fmt 3 needs n_hidden <= %d (got %d)", 92 * 128,

@@ -66,11 +66,19 @@ constexpr int kMaxUnits = 176;    // units of 128 columns of the widest activati
 constexpr int kRMax = 6;          // row tiles of a step (c_attn of the 64-head shape)
 
 // LDS map (bytes)
-constexpr int kOffMisc = 0;      // [0] 1/rms, [1] 1/rms over x_scale, [4..7] operand sums, [16..23] / [24..31] per-wave softmax max / sum
+constexpr int kOffMisc = 0;      // [0] 1/rms, [4..11] operand sums (fp16), [16..23] / [24..31] per-wave softmax max / sum, [32..39] the waves' operand sums (F8)
 constexpr int kOffZero = 256;    // one all-zero unit (idle ring steps read it)
-constexpr int kOffXs = 512;      // activation vector, fp16
-constexpr int kOffPart = kOffXs + kMaxUnits * 256;          // [2][8 waves][kRMax][4 row groups x f32x4]: column 0 of the waves' partial tiles
-constexpr int kPartBytes = 2 * kSW * kRMax * 64;
+constexpr int kOffXs = 512;      // activation vector: fp16 (F8 = false), or three E4M3 limb planes in MFMA-B byte order (F8)
+// F8: limb plane p of the vector at kF8P0 + p * kF8Plane, one 128-byte unit per 128 values; the planes start 64 B (16 banks) apart modulo
+// 256 so that the lanes of MFMA columns 0 / 1 / 2 of one lane group read different banks (fused_step_ring.hip kF8P0 .. kF8P2)
+constexpr int kF8Plane = kMaxUnits * 128 + 64, kF8P0 = kOffXs;
+constexpr int kXsBytes = 3 * kF8Plane > kMaxUnits * 256 ? 3 * kF8Plane : kMaxUnits * 256;
+static_assert(kF8Plane % 256 == 64 && kXsBytes % 16 == 0, "limb planes");
+// [2][8 waves][kRMax][3 columns][4 row groups x f32x4]: the first columns of the waves' partial tiles (fp16 operands: column 0 only — at M = 1
+// the others are copies; fp8-limb operands: the limb columns 0 / 1 / 2, added up by the gatherer's read)
+constexpr int kPartTile = 192;
+constexpr int kOffPart = kOffXs + kXsBytes;
+constexpr int kPartBytes = 2 * kSW * kRMax * kPartTile;
 constexpr int kOffQ = kOffPart + kPartBytes;                // q[128] knew[128] vnew[128] f32
 constexpr int kOffO2 = kOffQ + 3 * 512;                     // [8 waves][128] f32: per-wave attention partials
 constexpr int kLdsBytes = kOffO2 + kSW * 128 * 4;
@@ -106,6 +114,28 @@ struct Shape {
 __device__ __forceinline__ void gr_store(u64* p, unsigned tag, unsigned val) {
     __hip_atomic_store(p, ((u64)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // one 8-B sc1 store
 }
+// fp8-limb operands: a granule is {tag: 16 bits, payload: 48 bits} = limb 0 / 1 / 2 of TWO values (fused_step_ring.hip gr_store16, f8_limbs:
+// the format, its 16-bit tags and its arithmetic are that kernel's; pre-scale exponents per edge: x 0, attention output 2, SwiGLU output 4)
+__device__ __forceinline__ void gr_store16(u64* p, unsigned tag, unsigned lo32, unsigned hi16) {
+    __hip_atomic_store(p, ((u64)(((tag & 0xFFFFu) << 16) | hi16) << 32) | lo32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// x -> three OCP E4M3 limbs, x ~ l0 + l1 / 16 + l2 / 256 (every difference is exact in f32, the conversions round to nearest even; past +-448
+// v_cvt_pk_fp8_f32 returns NaN, hence the clamps): 12 significant bits for 2^-6 <= |x| <= 448
+__device__ __forceinline__ void f8_limbs(float a, float b, unsigned& lo32, unsigned& hi16) {
+    const int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.f, 448.f), __builtin_amdgcn_fmed3f(b, -448.f, 448.f), 0, false);
+    const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false);
+    float ra = a - f0[0], rb = b - f0[1];
+    const int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(ra * 16.f, -448.f, 448.f),
+                                                   __builtin_amdgcn_fmed3f(rb * 16.f, -448.f, 448.f), 0, false);
+    const auto f1 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false);
+    ra -= f1[0] * 0.0625f;
+    rb -= f1[1] * 0.0625f;
+    const int w2 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(ra * 256.f, -448.f, 448.f),
+                                                   __builtin_amdgcn_fmed3f(rb * 256.f, -448.f, 448.f), 0, false);
+    lo32 = ((unsigned)w0 & 0xFFFFu) | ((unsigned)w1 << 16);
+    hi16 = (unsigned)w2 & 0xFFFFu;
+}
+constexpr int kF8Ex = 0, kF8Ea = 2, kF8Eh = 4;
 __device__ __forceinline__ bool aborted(const FusedParams& p) {
     return __hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 }
@@ -126,16 +156,19 @@ __device__ __forceinline__ void sweep_issue(__amdgpu_buffer_rsrc_t rs, unsigned 
 }
 // ... and repeats them until every tag equals `epoch`.  Returns false after a time-out / abort (the values are then garbage, the
 // caller keeps going so that the barrier counts of the workgroup stay balanced).  `preissued`: v was requested already.
-template <int NL>
+// T16: granules with 16-bit tags in the top half of their second dword (gr_store16); `epoch` is then taken modulo 2^16
+template <int NL, bool T16 = false>
 __device__ __forceinline__ bool sweep(const FusedParams& p, __amdgpu_buffer_rsrc_t rs, unsigned base, int first, int end, unsigned epoch,
                                       u32x4 (&v)[NL], unsigned code, int lane, bool preissued = false) {
+    if constexpr (T16) epoch &= 0xFFFFu;
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
         if (!(preissued && spins == 0)) sweep_issue<NL>(rs, base, first, end, v, lane);
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             const int i = first + k * 64 + lane;
-            ok &= i >= end || (v[k][1] == epoch && v[k][3] == epoch);
+            if constexpr (T16) ok &= i >= end || ((v[k][1] >> 16) == epoch && (v[k][3] >> 16) == epoch);
+            else ok &= i >= end || (v[k][1] == epoch && v[k][3] == epoch);
         }
         if (__all(ok)) return true;
         if (spins > kSpinLimit || aborted(p)) {
@@ -149,6 +182,7 @@ __device__ __forceinline__ bool sweep(const FusedParams& p, __amdgpu_buffer_rsrc
 // ------------------------------------------------------------------------------------------------ streamers
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 struct PhaseW {  // one phase as a streamer wave sees it (all wave-uniform)
     unsigned base;  // byte offset of the stream inside the layer's descriptor
@@ -194,6 +228,10 @@ struct StreamerCtx {  // per-wave constants of the streamers
     int g, wave;
     uint32_t magic, nmask, nmask16;
     char* smem;
+    // fp8-limb operands: nibble mask, this lane's limb plane (+ its lane group's 32 bytes of a unit), the step of its block scale
+    uint32_t nib8;
+    unsigned f8_plane;
+    int f8_dsb;
 };
 
 // A workgroup barrier for the streamer waves: they publish nothing through global memory, what the barrier has to order is their LDS
@@ -226,9 +264,13 @@ __device__ __forceinline__ void burst(u32x4 (&ring)[kRing], const PhaseW& ph, in
 // tiles in LDS and passes the workgroup barrier Bt.
 // NB: bodies of the phase when known at compile time (the loop is then unrolled: a runtime loop around loads makes hipcc drain the whole
 // ring with vmcnt(0) at every back edge), 0: `nbodies` at run time (lm_head: once per step).
-template <int R, int SPT, int TURNS, int MODE, int RTK, int NB = 1>
+// F8: the int4 stream through fp8 operands (fused_step_ring.hip FMT 3): a byte holding an int4 level IS the E4M3 code of q x 2^-9, ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 per 1-KiB piece (A block scale 2^9), the activation's three limbs in MFMA columns 0 / 1 / 2 under the
+// per-lane B block scales 2^(E8 - 0 / 4 / 8), E8 = the pre-scale exponent of the phase's input edge; during a phase's first tile one more
+// MFMA per step with an all-ones A operand takes the operand sums (misc[32 + wave]).
+template <int R, int SPT, int TURNS, int MODE, int RTK, bool F8, int NB = 1>
 __device__ __forceinline__ void run_phase(u32x4 (&ring)[kRing], const PhaseW& ph, int kstride, int nbodies, __amdgpu_buffer_rsrc_t rs,
-                                          const StreamerCtx& c, int& buf, u64* stamp, int slot = 0) {
+                                          const StreamerCtx& c, int& buf, u64* stamp, int slot = 0, int e8 = 0) {
     constexpr int STEPS = kRing / R, BSTEPS = TURNS * STEPS, TPB = BSTEPS / SPT;
     static_assert(BSTEPS % SPT == 0 && R <= kRMax, "bodies hold whole tiles");
     constexpr int NACC = R >= 3 ? 1 : 2;  // accumulators per row group: consecutive MFMAs never share one
@@ -240,11 +282,21 @@ __device__ __forceinline__ void run_phase(u32x4 (&ring)[kRing], const PhaseW& ph
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int a = 0; a < NACC; ++a) acc[r][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] f32x4 accs = f32x4{0.f, 0.f, 0.f, 0.f};  // F8: all-ones rows = the operand sums of this wave's units, per limb column
+    [[maybe_unused]] i32x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = 0x38383838;  // E4M3 1.0
+    [[maybe_unused]] const int sb = 127 + e8 - c.f8_dsb;  // E8M0 block scale of this lane's 32 operand bytes
     wg_barrier();  // B1: the activation vector is staged
     if (stamp != nullptr && threadIdx.x == 0) stamp[slot] = wall_clock64();
     const char* xs = c.smem + kOffXs;
-    f16x8 bn[4];  // B operands (activation unit of a step) are read one step ahead
-    {
+    [[maybe_unused]] const char* xl = c.smem + c.f8_plane;
+    // B operands (activation unit of a step) are read one step ahead
+    [[maybe_unused]] f16x8 bn[4];
+    [[maybe_unused]] i32x8 bn8;
+    if constexpr (F8) {
+        bn8 = *(const i32x8*)(xl + ph.u0 * 128);
+    } else {
         const char* xb0 = xs + ph.u0 * 256 + c.g * 64;
 #pragma unroll
         for (int d = 0; d < 4; ++d) bn[d] = *(const f16x8*)(xb0 + 16 * d);
@@ -258,18 +310,45 @@ __device__ __forceinline__ void run_phase(u32x4 (&ring)[kRing], const PhaseW& ph
             for (int s = 0; s < STEPS; ++s) {
                 const int ls = t * STEPS + s;              // step inside the body (compile time)
                 const int ti = body * TPB + ls / SPT, st = ls % SPT;
-                f16x8 b[4];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) b[d] = bn[d];
+                [[maybe_unused]] f16x8 b[4];
+                [[maybe_unused]] i32x8 b8;
                 {
                     const int nst = (st + 1 == SPT) ? 0 : st + 1;
                     const int nun = ph.u0 + (nst < ph.nu ? nst : 0);
-                    const char* xbn = xs + nun * 256 + c.g * 64;
+                    if constexpr (F8) {
+                        b8 = bn8;
+                        bn8 = *(const i32x8*)(xl + nun * 128);
+                    } else {
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) bn[d] = *(const f16x8*)(xbn + 16 * d);
+                        for (int d = 0; d < 4; ++d) b[d] = bn[d];
+                        const char* xbn = xs + nun * 256 + c.g * 64;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) bn[d] = *(const f16x8*)(xbn + 16 * d);
+                    }
                 }
                 // idle steps (padding of the ring turn) carry no data: skip their MFMAs (wave-uniform)
-                if (st < ph.nu && (MODE == M_SHARED || ti < ph.ntiles)) {
+                if constexpr (F8) {
+                    if (st < ph.nu && (MODE == M_SHARED || ti < ph.ntiles)) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const u32x4 v = ring[s * R + r];
+                            i32x8 a;
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                a[2 * d] = (int)(v[d] & c.nib8);
+                                a[2 * d + 1] = (int)((v[d] >> 4) & c.nib8);
+                            }
+                            acc[r][s % NACC] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b8, acc[r][s % NACC], 0, 0, 0, 136, 0, sb);
+                            // (pinned here: the partial tile's only reader is the `if (colp)` store at the tile end, and hipcc otherwise SINKS
+                            // the phase's whole MFMA chain into that divergent branch, behind all of the phase's loads — the ring in scratch)
+                            asm volatile("" : "+v"(acc[r][s % NACC]));
+                        }
+                        if (ti == 0) {
+                            accs = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, b8, accs, 0, 0, 0, 127, 0, sb);
+                            asm volatile("" : "+v"(accs));
+                        }
+                    }
+                } else if (st < ph.nu && (MODE == M_SHARED || ti < ph.ntiles)) {
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
 #pragma unroll
@@ -301,14 +380,24 @@ __device__ __forceinline__ void run_phase(u32x4 (&ring)[kRing], const PhaseW& ph
                         // (slots 48 / 51 / 52 / 53: when the LAST streamer wave reaches the phase's last tile end — wave skew)
                         if (c.lane_off == 0u) atomicMax((unsigned long long*)&stamp[48 + (slot - 20) / 2], (unsigned long long)wall_clock64());
                     }
-                    // tile done: column 0 of this wave's partial 16 x 16 tiles (lanes 0, 16, 32, 48 hold rows 4 g .. 4 g + 3 of it)
-                    f32x4* pp = (f32x4*)(c.smem + kOffPart + (size_t)((buf * kSW + c.wave) * kRMax) * 64) + (c.lane_off >> 8);
-                    const bool col0 = (c.lane_off & 0xF0u) == 0u;
+                    if constexpr (F8) {
+                        if (ti == 0) {
+                            // S of this wave's units: limb columns 0 + 1 + 2 of any row (quad broadcasts of lanes 1 / 2)
+                            float ssum = accs[0];
+                            ssum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, accs[0]), 0x55, 0xF, 0xF, false)) +
+                                    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, accs[0]), 0xAA, 0xF, 0xF, false));
+                            if (c.lane_off == 0u) ((float*)(c.smem + kOffMisc))[32 + c.wave] = ssum;
+                        }
+                    }
+                    // tile done: the first column(s) of this wave's partial 16 x 16 tiles (lane 16 g + n holds rows 4 g .. 4 g + 3 of column n)
+                    const unsigned col = (c.lane_off >> 4) & 15u;
+                    f32x4* pp = (f32x4*)(c.smem + kOffPart + (size_t)((buf * kSW + c.wave) * kRMax) * kPartTile + col * 64) + (c.lane_off >> 8);
+                    const bool colp = col < (F8 ? 3u : 1u);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         f32x4 t4 = acc[r][0];
                         if constexpr (NACC == 2) t4 += acc[r][1];
-                        if (col0) pp[r * 4] = t4;
+                        if (colp) pp[r * (kPartTile / 16)] = t4;
 #pragma unroll
                         for (int a = 0; a < NACC; ++a) acc[r][a] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
@@ -329,7 +418,9 @@ __device__ __forceinline__ void run_phase(u32x4 (&ring)[kRing], const PhaseW& ph
 
 }  // namespace
 
-template <int NH_, int GS>
+// F8: activations travel as three E4M3 limbs and the int4 levels go to the matrix pipe as E4M3 codes (weight_fmt 5; the ring kernel's FMT 3,
+// its default for per-row int4); else fp16 pairs and int4 -> fp16 operands (weight_fmt 4; the rung below, fp16's range)
+template <int NH_, int GS, bool F8>
 __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedParams p) {
     using SH = Shape<NH_, GS>;
     constexpr int C = SH::C, UC = SH::UC, RT = SH::RT, DH = SH::DH, NH = SH::NH, NUW = SH::NUW, NWG = SH::NWG;
@@ -391,6 +482,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
         asm volatile("" : "+v"(c.magic));  // opaque register values (fused_step_ring.hip nib2f16: hipcc then selects v_and_or_b32)
         asm volatile("" : "+s"(c.nmask));
         asm volatile("" : "+s"(c.nmask16));
+        c.nib8 = 0x0F0F0F0Fu;
+        if constexpr (F8) asm volatile("" : "+s"(c.nib8));  // (opaque: hipcc then keeps the mask in an SGPR operand)
+        {
+            const int f8_col = lane & 15;  // MFMA token column of this lane: limb plane 0 / 1 / 2 (columns >= 2 read plane 2: unused copies)
+            c.f8_plane = (unsigned)(kF8P0 + (f8_col == 0 ? 0 : f8_col == 1 ? 1 : 2) * kF8Plane) + (unsigned)c.g * 32u;
+            c.f8_dsb = f8_col == 0 ? 0 : f8_col == 1 ? 4 : 8;
+        }
         u32x4 ring[kRing];
         int buf = 0;
 
@@ -431,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             dbg_on = p.dbg != nullptr && l == p.dbg_layer;
             asm volatile("" : "+v"(c.lane_off));  // per-lane addresses are recomputed per layer, not hoisted and spilled
             // ---------------- c_attn (q, k, v tiles of this workgroup's DH dimensions of its head)
-            run_phase<R_ATT, TU_ATT * ST_ATT, TU_ATT, M_SHARED, RT>(ring, ph_attn, C / 16, 1, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 20);
+            run_phase<R_ATT, TU_ATT * ST_ATT, TU_ATT, M_SHARED, RT, F8>(ring, ph_attn, C / 16, 1, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 20, kF8Ex);
             wg_barrier();  // B3
             // ---------------- attention: this workgroup's chunks of 32 cache rows, all 128 dimensions
             {
@@ -547,11 +645,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             }
             // ---------------- attn.c_proj, MLP
             burst<R_PRJ, TU_PRJ * ST_PRJ, M_SHARED, RT, 0, kRing, true>(ring, ph_proj, 0, rs_l, c);
-            run_phase<R_PRJ, TU_PRJ * ST_PRJ, TU_PRJ, M_SHARED, RT>(ring, ph_proj, 0, 1, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 26);
+            run_phase<R_PRJ, TU_PRJ * ST_PRJ, TU_PRJ, M_SHARED, RT, F8>(ring, ph_proj, 0, 1, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 26, kF8Ea);
             FW_EDGE(2, SPT_C, M_PAIR, 1, ph_fc, 0, rs_l);
-            run_phase<2, SPT_C, TU_FC, M_PAIR, 1, NB_FC>(ring, ph_fc, 0, NB_FC, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 28);
+            run_phase<2, SPT_C, TU_FC, M_PAIR, 1, F8, NB_FC>(ring, ph_fc, 0, NB_FC, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 28, kF8Ex);
             FW_EDGE(R_PRJ, TU_MP * ST_PRJ, M_SHARED, RT, ph_mp, 0, rs_l);
-            run_phase<R_PRJ, TU_MP * ST_PRJ, TU_MP, M_SHARED, RT>(ring, ph_mp, 0, 1, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 30);
+            run_phase<R_PRJ, TU_MP * ST_PRJ, TU_MP, M_SHARED, RT, F8>(ring, ph_mp, 0, 1, rs_l, c, buf, dbg_on ? p.dbg + bid * 64 : nullptr, 30, kF8Eh);
             // next layer (or the head)
             kv_l += (size_t)2 * NH * p.S * kHs;
             if (l + 1 < p.n_layer) {
@@ -562,7 +660,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             }
         }
         dbg_on = false;
-        run_phase<1, SPT_C, TU_HD, M_SINGLE, 1, 0>(ring, ph_head, 0, p.head_turns, rs_h, c, buf, nullptr);
+        run_phase<1, SPT_C, TU_HD, M_SINGLE, 1, F8, 0>(ring, ph_head, 0, p.head_turns, rs_h, c, buf, nullptr, 0, kF8Ex);
         wg_barrier();  // B3
         if (p.mode & 1) wg_barrier();  // the arg-max exchange of the gatherers
 #undef FW_EDGE
@@ -590,7 +688,13 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
         int pg = lane >> 3, w8 = lane & 7;
         int psrc = (pg >> 1) * 4 + ((2 * pg) & 3);  // float index of D[2 pg][0] in a parked tile column
         auto tile_pair = [&](int r) {
-            float2 t = *(const float2*)((const float*)(smem + kOffPart + (size_t)((buf * kSW + w8) * kRMax + r) * 64) + psrc);
+            const float* tp = (const float*)(smem + kOffPart + (size_t)((buf * kSW + w8) * kRMax + r) * kPartTile) + psrc;
+            float2 t = *(const float2*)tp;
+            if constexpr (F8) {  // limb columns 1 / 2 of the same rows sit 16 / 32 floats on
+                const float2 t1 = *(const float2*)(tp + 16), t2 = *(const float2*)(tp + 32);
+                t.x += t1.x + t2.x;
+                t.y += t1.y + t2.y;
+            }
             t.x = group_sum(t.x, 8);
             t.y = group_sum(t.y, 8);
             return t;
@@ -620,6 +724,34 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             const f16x2 h = {(_Float16)__builtin_amdgcn_fmed3f(ak, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(bk, -65504.f, 65504.f)};
             return __builtin_bit_cast(unsigned, h);
         };
+        // Publish the pair (a, b) = rows 2 q, 2 q + 1 of a 16-row tile whose 8 granules start at `tile` (q = 0 .. 7), epoch `ep`; every lane of the
+        // wave must call it, `store`: this lane is the one that writes.  fp16: one {tag, pair} granule at slot q.  fp8 limbs (`e8`: the edge's
+        // pre-scale exponent): a granule carries the values at offsets (j, j + 4) of an octet of rows, so the lanes of pairs q and q ^ 2 — XD lanes
+        // apart — exchange one value: the lower one publishes (j, j + 4) at slot 4 (octet) + j, the upper one (j + 1, j + 5) (fused_step_ring.hip
+        // f8_publish); values past +-448 x 2^e8 are clipped and counted.
+        auto xchg = [&](float v, auto xd) {
+            constexpr int XD = decltype(xd)::value;
+            if constexpr (XD == 16) return lane_xor16(v);
+            else if constexpr (XD == 8) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));  // row_ror:8
+            else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+        };
+        auto publish_pair = [&](u64* tile, int q, unsigned ep, float a, float b, int e8, bool store, auto xd) {
+            if constexpr (F8) {
+                const float pre = __uint_as_float((unsigned)(127 - e8) << 23);
+                a *= pre;
+                b *= pre;
+                const bool up = (q & 2) != 0;
+                const float got = xchg(up ? a : b, xd);
+                const float va = up ? got : a, vb = up ? b : got;
+                if (store && fmaxf(fabsf(va), fabsf(vb)) > 448.f) note_clip();
+                unsigned lo32, hi16;
+                f8_limbs(va, vb, lo32, hi16);
+                if (store) gr_store16(tile + 4 * (q >> 2) + 2 * (q & 1) + ((q >> 1) & 1), ep, lo32, hi16);
+            } else {
+                if (store) gr_store(tile + q, ep, hpair(a, b, (q & 1) != 0));
+            }
+        };
+        constexpr std::integral_constant<int, 16> xd16{};
         // sums of the staged operands, even pairs in .x and odd pairs in .y: y = scale (acc - (zero - 8) (S_even + 16 S_odd))
         const f16x2 ones2 = {(_Float16)1.0f, (_Float16)1.0f};
         auto pair_sums = [&](float2& sx, unsigned even, unsigned odd) {
@@ -627,6 +759,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             sx.y = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, odd), ones2, sx.y, false);
         };
         auto put_sums = [&](float2 sx) {  // misc[4 + gw] / misc[8 + gw]: this gatherer wave's S_even / S_odd
+            if constexpr (F8) return;      // (fp8 operands: the streamers take the operand sums with all-ones MFMAs)
             sx.x = group_sum(sx.x, 64);
             sx.y = group_sum(sx.y, 64);
             if (lane == 0) {
@@ -635,6 +768,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             }
         };
         auto get_sums = [&]() {
+            if constexpr (F8) {
+                // the streamer waves' operand sums (valid behind the phase's first tile end); the A block scale made the products q x~
+                // themselves, so there is no offset term: y = scale (acc - zero S)
+                const f32x4 sa = *(const f32x4*)(misc + 32), sb2 = *(const f32x4*)(misc + 36);
+                return ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sb2[0] + sb2[1]) + (sb2[2] + sb2[3]));
+            }
             float se = misc[4], so = misc[8];
 #pragma unroll
             for (int g2 = 1; g2 < kGW; ++g2) {
@@ -643,11 +782,18 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             }
             return se + 16.f * so;
         };
-        auto deq = [&](float2 t, float2 sc_, float2 z_, float s) {  // the streamers' operands are q - 8
-            return float2{sc_.x * (t.x - (z_.x - 8.f) * s), sc_.y * (t.y - (z_.y - 8.f) * s)};
+        auto deq = [&](float2 t, float2 sc_, float2 z_, float s) {  // the streamers' operands are q - 8 (fp16) / q itself (fp8)
+            constexpr float zc = F8 ? 0.f : 8.f;
+            return float2{sc_.x * (t.x - (z_.x - zc) * s), sc_.y * (t.y - (z_.y - zc) * s)};
         };
         // stage one 16-B load (two granules = 4 fp16 values) of an edge into xs and add its operand sums
         auto stage = [&](const u32x4& v, int i, float2& sx) {
+            if constexpr (F8) {  // two granules = dword `i` of each limb plane (fused_step_ring.hip f8_stage)
+                *(unsigned*)(smem + kF8P0 + (size_t)i * 4) = __builtin_amdgcn_perm(v[2], v[0], 0x05040100u);                 // l0: low halves of dwords 0 / 2
+                *(unsigned*)(smem + kF8P0 + kF8Plane + (size_t)i * 4) = __builtin_amdgcn_perm(v[2], v[0], 0x07060302u);      // l1: high halves of dwords 0 / 2
+                *(unsigned*)(smem + kF8P0 + 2 * kF8Plane + (size_t)i * 4) = __builtin_amdgcn_perm(v[3], v[1], 0x05040100u);  // l2: low halves of dwords 1 / 3
+                return;
+            }
             *(u64*)(xs + (size_t)i * 8) = ((u64)v[2] << 32) | v[0];
             pair_sums(sx, v[0], v[2]);
         };
@@ -666,7 +812,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             u64* dst = p.gx + (size_t)xpar * SH::GXS;
             x_scale = __uint_as_float((__float_as_uint(rinv_seen) + 0x00400000u) & 0x7F800000u);
             if (!epi) return;  // (RT = 1: gatherer 1 owns no residual tile — it only keeps x_scale in step for its c_fc epilogues)
-            if (w8 == 0) gr_store(dst + (bid * RT + er) * 8 + pg, ep, hpair(x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y, (pg & 1) != 0));
+            publish_pair(dst + (bid * RT + er) * 8, pg, ep, x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y, kF8Ex, w8 == 0, xd16);
             float ss = xv.x * xv.x + xv.y * xv.y;  // the same in the 8 lanes of a pair: sum over the 8 pairs
             ss = MI355_DPP_ADD(ss, 0x140);
             ss += lane_xor16(ss);
@@ -697,7 +843,10 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                         v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, off, 0, 16));
                     }
 #pragma unroll
-                    for (int k = 0; k < NP0 + NS; ++k) ok &= (k >= NP0 && (k - NP0) * 64 + lane_v >= NSL) || (v[k][1] == ep && v[k][3] == ep);
+                    for (int k = 0; k < NP0 + NS; ++k) {
+                        if (F8 && k < NP0) ok &= (v[k][1] >> 16) == (ep & 0xFFFFu) && (v[k][3] >> 16) == (ep & 0xFFFFu);  // (pair granules: 16-bit tags)
+                        else ok &= (k >= NP0 && (k - NP0) * 64 + lane_v >= NSL) || (v[k][1] == ep && v[k][3] == ep);
+                    }
                     if (__all(ok)) break;
                     if (spins > kSpinLimit || aborted(p)) {
                         if (lane == 0) raise_abort(p, 0x100u + edge);
@@ -729,16 +878,16 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 if constexpr (NB > 0) {
                     u32x4 vb[NB];
                     sweep_issue<NB>(rs_ws, base, first + NA * 64, end, vb, lane_v);
-                    sweep<NA>(p, rs_ws, base, first, end, ep, va, 0x200u + edge, lane_v, true);
+                    sweep<NA, F8>(p, rs_ws, base, first, end, ep, va, 0x200u + edge, lane_v, true);
 #pragma unroll
                     for (int k = 0; k < NA; ++k)
                         if (EX || first + k * 64 + lane_v < end) stage(va[k], first + k * 64 + lane_v, sx);
-                    sweep<NB>(p, rs_ws, base, first + NA * 64, end, ep, vb, 0x200u + edge, lane_v, true);
+                    sweep<NB, F8>(p, rs_ws, base, first + NA * 64, end, ep, vb, 0x200u + edge, lane_v, true);
 #pragma unroll
                     for (int k = 0; k < NB; ++k)
                         if (EX || first + (NA + k) * 64 + lane_v < end) stage(vb[k], first + (NA + k) * 64 + lane_v, sx);
                 } else {
-                    sweep<NA>(p, rs_ws, base, first, end, ep, va, 0x200u + edge, lane_v, true);
+                    sweep<NA, F8>(p, rs_ws, base, first, end, ep, va, 0x200u + edge, lane_v, true);
 #pragma unroll
                     for (int k = 0; k < NA; ++k)
                         if (EX || first + k * 64 + lane_v < end) stage(va[k], first + k * 64 + lane_v, sx);
@@ -880,7 +1029,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                         const float inv = __builtin_amdgcn_rcpf(lsum);
                         const int px = lane_v % (DH / 2);
                         u64* ga_t = p.ga + (size_t)apar * (C / 2) + head * 64 + hj * (DH / 2);
-                        if (lane_v / (DH / 2) == hj) gr_store(ga_t + px, ep1, hpair(o.x * inv, o.y * inv, (px & 1) != 0));
+                        // (the pairs of this workgroup sit in DH / 2 consecutive lanes: pair px ^ 2 is 2 lanes away)
+                        publish_pair(ga_t + (px >> 3) * 8, px & 7, ep1, o.x * inv, o.y * inv, kF8Ea, lane_v / (DH / 2) == hj, std::integral_constant<int, 2>{});
                     } else {
                         u64* dstp = p.gp + (((size_t)ppar * NH + head) * GS + hj) * kPartStride;
                         gr_store(dstp + 2 * lane_v, ep1, __float_as_uint(o.x));
@@ -920,7 +1070,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     const float inv = __builtin_amdgcn_rcpf(group_sum(lj * wsc, GS));
                     // attention output elements head * 128 + hj * DH + 2 px, + 1 -> one pair granule
                     u64* ga_t = p.ga + (size_t)apar * (C / 2) + head * 64 + hj * (DH / 2);
-                    if (wq == 0) gr_store(ga_t + px, ebase + edge, hpair(ox * inv, oy * inv, (px & 1) != 0));
+                    // (lane = px GS + wq: pair px ^ 2 is 2 GS lanes away)
+                    publish_pair(ga_t + (px >> 3) * 8, px & 7, ebase + edge, ox * inv, oy * inv, kF8Ea, wq == 0, std::integral_constant<int, 2 * GS>{});
                 }
                 if (!solo) ppar ^= 1;
                 FW_GSTAMP(6);
@@ -948,16 +1099,16 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     if constexpr (NB > 0) {
                         u32x4 vb[NB];
                         sweep_issue<NB>(rs_ws, base, first + NA * 64, end, vb, lane_v);
-                        sweep<NA>(p, rs_ws, base, first, end, ep, va, 0x400u + edge, lane_v, true);
+                        sweep<NA, F8>(p, rs_ws, base, first, end, ep, va, 0x400u + edge, lane_v, true);
 #pragma unroll
                         for (int k = 0; k < NA; ++k)
                             if (EX || first + k * 64 + lane_v < end) stage(va[k], first + k * 64 + lane_v, sxp);
-                        sweep<NB>(p, rs_ws, base, first + NA * 64, end, ep, vb, 0x400u + edge, lane_v, true);
+                        sweep<NB, F8>(p, rs_ws, base, first + NA * 64, end, ep, vb, 0x400u + edge, lane_v, true);
 #pragma unroll
                         for (int k = 0; k < NB; ++k)
                             if (EX || first + (NA + k) * 64 + lane_v < end) stage(vb[k], first + (NA + k) * 64 + lane_v, sxp);
                     } else {
-                        sweep<NA>(p, rs_ws, base, first, end, ep, va, 0x400u + edge, lane_v, true);
+                        sweep<NA, F8>(p, rs_ws, base, first, end, ep, va, 0x400u + edge, lane_v, true);
 #pragma unroll
                         for (int k = 0; k < NA; ++k)
                             if (EX || first + k * 64 + lane_v < end) stage(va[k], first + k * 64 + lane_v, sxp);
@@ -998,18 +1149,20 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 const unsigned ep = ebase + edge;
                 u64* dst = p.gh + (size_t)hpar * gh_stride;
                 const float rinv = x_rinv();
-                const float s = get_sums();
+                float s = 0.f;
+                if constexpr (!F8) s = get_sums();
                 constexpr int tiles_pad = NB_FC * TPB_FC;  // tile ends the streamers pass
                 for (int t = 0; t < tiles_pad; ++t) {
                     float2 ns1 = fs1, nz1 = fz1, ns2 = fs2, nz2 = fz2;
                     if ((t & 1) == gw) fc_sz(t + 2, ns1, nz1, ns2, nz2);
                     __syncthreads();  // Bt
+                    if constexpr (F8) {
+                        if (t == 0) s = get_sums();  // (the streamers' operand sums exist behind the first tile end)
+                    }
                     if ((t & 1) == gw && t < n_fc) {
                         const float2 a = deq(tile_pair(0), fs1, fz1, s);
                         const float2 b = deq(tile_pair(1), fs2, fz2, s);
-                        if (w8 == 0)
-                            gr_store(dst + (bid + t * NWG) * 8 + pg, ep,
-                                     hpair(swiglu_e(a.x * rinv, b.x * rinv), swiglu_e(a.y * rinv, b.y * rinv), (pg & 1) != 0));
+                        publish_pair(dst + (bid + t * NWG) * 8, pg, ep, swiglu_e(a.x * rinv, b.x * rinv), swiglu_e(a.y * rinv, b.y * rinv), kF8Eh, w8 == 0, xd16);
                     }
                     fs1 = ns1;
                     fz1 = nz1;
@@ -1048,7 +1201,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                     for (int ch = 0; ch < NCH; ++ch) {
                         const int c0 = first + ch * 512;
                         if (ch + ND - 1 < NCH) sweep_issue<8>(rs_ws, hbase, c0 + (ND - 1) * 512, end, vv[(ch + ND - 1) % ND], lh);
-                        sweep<8>(p, rs_ws, hbase, c0, end, ep, vv[ch % ND], 0x500u + edge, lh, true);
+                        sweep<8, F8>(p, rs_ws, hbase, c0, end, ep, vv[ch % ND], 0x500u + edge, lh, true);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             const int i = c0 + k * 64 + lh;
@@ -1091,7 +1244,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
             gather_x();
             __syncthreads();  // B1
             const float rinv = x_rinv();
-            const float s = get_sums();
+            float s = 0.f;
+            if constexpr (!F8) s = get_sums();
             float best = -INFINITY;
             int bi = 0x7fffffff;
             const int tiles_pad = p.head_turns * TPB_HD;  // tile ends the streamers pass
@@ -1099,6 +1253,9 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
                 float2 scn = {0.f, 0.f}, zn = {0.f, 0.f};
                 if (gw == 0) head_sz(t + 1, scn, zn);
                 __syncthreads();  // Bt
+                if constexpr (F8) {
+                    if (t == 0) s = get_sums();
+                }
                 if (gw == 0 && t < n_head_t) {
                     const int n = (bid + t * NWG) * 16 + 2 * pg;
                     float2 y = deq(tile_pair(0), sct, zt, s);
@@ -1185,8 +1342,12 @@ __global__ __launch_bounds__(kThreads) void fused_step_wide_kernel(const FusedPa
 // ------------------------------------------------------------------------------------------------ host side
 // (residency: see fused_step_ring.hip — the occupancy query is made once, a kernel that does not fit one workgroup per CU is refused)
 namespace {
-const void* const kWideFn[4] = {(const void*)fused_step_wide_kernel<64, 4>, (const void*)fused_step_wide_kernel<52, 4>,
-                                (const void*)fused_step_wide_kernel<40, 4>, (const void*)fused_step_wide_kernel<32, 8>};
+// [0..3]: fp16 operands (weight_fmt 4), [4..7]: E4M3 limb operands (weight_fmt 5)
+const void* const kWideFn[8] = {
+    (const void*)fused_step_wide_kernel<64, 4, false>, (const void*)fused_step_wide_kernel<52, 4, false>,
+    (const void*)fused_step_wide_kernel<40, 4, false>, (const void*)fused_step_wide_kernel<32, 8, false>,
+    (const void*)fused_step_wide_kernel<64, 4, true>,  (const void*)fused_step_wide_kernel<52, 4, true>,
+    (const void*)fused_step_wide_kernel<40, 4, true>,  (const void*)fused_step_wide_kernel<32, 8, true>};
 int wide_index(int n_head) { return n_head == 64 ? 0 : n_head == 52 ? 1 : n_head == 40 ? 2 : n_head == 32 ? 3 : -1; }
 }  // namespace
 
@@ -1195,13 +1356,14 @@ int fused_step_wide_occupancy_ok() {
     static std::once_flag once;
     std::call_once(once, [] {
         ok = 0;
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             int per_cu = 0;
             (void)hipFuncSetAttribute(kWideFn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kWideFn[i], kThreads, kLdsBytes) == hipSuccess && per_cu >= 1) ok |= 1 << i;
         }
     });
-    return ok;  // bit i: instantiation i (64 / 52 / 40 heads x 4 workgroups, 32 heads x 8) fits one workgroup per CU
+    // bit i: instantiation i (64 / 52 / 40 heads x 4 workgroups, 32 heads x 8; + 4: the E4M3-operand twin) fits one workgroup per CU
+    return ok;
 }
 
 // tiles per body of the pair phase / of lm_head and the ring steps mlp.c_proj may take per wave, for the host's checks and body counts
@@ -1213,12 +1375,13 @@ void fused_step_wide_geometry(int n_head, int* tpb_fc, int* fc_max, int* tpb_hea
     *mp_steps = n_head == 64 ? 22 : n_head == 32 ? 11 : 18;
 }
 
-// launched by mi355_fused_step (fused_step.hip) for weight_fmt 4; n_head selects the instantiation, the grid is n_head x (4 or 8) workgroups
+// launched by mi355_fused_step (fused_step.hip) for weight_fmt 4 / 5 (p.fmt); n_head selects the instantiation, the grid is
+// n_head x (4 or 8) workgroups
 int fused_step_wide_launch(const FusedParams& p, int n_head, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        for (int i = 0; i < 4 && attr_err == hipSuccess; ++i)
+        for (int i = 0; i < 8 && attr_err == hipSuccess; ++i)
             attr_err = hipFuncSetAttribute(kWideFn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     });
     MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "fused_step: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
@@ -1231,12 +1394,17 @@ int fused_step_wide_launch(const FusedParams& p, int n_head, hipStream_t stream,
             hipLaunchKernelGGL((K_), dim3(grid), dim3(kThreads), kLdsBytes, stream, p);                                \
         }                                                                                                             \
     } while (0)
-    switch (wide_index(n_head)) {
-        case 0: FW_LAUNCH((fused_step_wide_kernel<64, 4>)); break;
-        case 1: FW_LAUNCH((fused_step_wide_kernel<52, 4>)); break;
-        case 2: FW_LAUNCH((fused_step_wide_kernel<40, 4>)); break;
-        case 3: FW_LAUNCH((fused_step_wide_kernel<32, 8>)); break;
-        default: MI355_CHECK_ARG(false, MI355_E_SHAPE, "fused_step (weight_fmt 4): %d heads", n_head);
+    const int idx = wide_index(n_head);
+    switch (idx < 0 ? -1 : idx + (p.fmt == 5 ? 4 : 0)) {
+        case 0: FW_LAUNCH((fused_step_wide_kernel<64, 4, false>)); break;
+        case 1: FW_LAUNCH((fused_step_wide_kernel<52, 4, false>)); break;
+        case 2: FW_LAUNCH((fused_step_wide_kernel<40, 4, false>)); break;
+        case 3: FW_LAUNCH((fused_step_wide_kernel<32, 8, false>)); break;
+        case 4: FW_LAUNCH((fused_step_wide_kernel<64, 4, true>)); break;
+        case 5: FW_LAUNCH((fused_step_wide_kernel<52, 4, true>)); break;
+        case 6: FW_LAUNCH((fused_step_wide_kernel<40, 4, true>)); break;
+        case 7: FW_LAUNCH((fused_step_wide_kernel<32, 8, true>)); break;
+        default: MI355_CHECK_ARG(false, MI355_E_SHAPE, "fused_step (weight_fmt 4 / 5): %d heads", n_head);
     }
 #undef FW_LAUNCH
     MI355_LAUNCH_CHECK();

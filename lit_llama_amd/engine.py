@@ -467,6 +467,8 @@ class DecodeEngine:
             # the headline, the same distance from the reference's run as the fp16 operands).  MI355_FUSED_F8=0 keeps weight_fmt 0;
             # tests/test_zz_fused_f8_gpu.py and scripts/ab_fused.py --f8 toggle `fused.weight_fmt` on a live engine.
             a.weight_fmt = 3
+        if fmt == 4 and _env_int("MI355_FUSED_F8", 1) != 0:
+            a.weight_fmt = 5  # round 6: the same operands in the wide-shape kernel (csrc/fused_step_wide.hip F8)
         if gc:
             a.group_cols, a.gt, a.gt_head, a.gt_layer_stride = gc, ptr(gt), ptr(gt_head), gt.shape[1] * 4
         a.wte, a.rope = self.m.wte, self.m.rope
@@ -485,8 +487,8 @@ class DecodeEngine:
         # The ladder of hand-off formats, widest last (None = the launch-per-operator step: f32 residual, bf16 staging, no range to
         # leave).  Round 6: a clip moves the engine ONE rung down for `_hold` steps, not for good — a trained checkpoint's massive
         # activations fire on a few delimiter tokens, and a sticky ladder turned one of them into a permanent 2.7 % loss.
-        # (weight_fmt 4, the wide-shape kernel: fp16 hand-offs, then the launch-per-operator step)
-        self._full_rungs = [3, 0, None] if int(a.weight_fmt) == 3 else [int(a.weight_fmt), None]
+        # (the wide-shape kernel: weight_fmt 5 -> 4 -> the launch-per-operator step)
+        self._full_rungs = {3: [3, 0, None], 5: [5, 4, None]}.get(int(a.weight_fmt), [int(a.weight_fmt), None])
         self._rungs = list(self._full_rungs)
         self._rung = 0
         self._demoted_before = False
@@ -515,12 +517,13 @@ class DecodeEngine:
             self.fused.weight_fmt = fmt
             with torch.cuda.stream(self.stream):
                 self._fused_ws[256:].zero_()
-        return {3: "fp8-limb operands (weight_fmt 3)", 0: "fp16 operands (weight_fmt 0)"}.get(fmt, f"weight_fmt {fmt}")
+        return {3: "fp8-limb operands (weight_fmt 3)", 0: "fp16 operands (weight_fmt 0)", 5: "fp8-limb operands (weight_fmt 5)",
+                4: "fp16 operands (weight_fmt 4)"}.get(fmt, f"weight_fmt {fmt}")
 
     def _demote_fused(self, why: str, bad: Optional[int] = None) -> str:
         """The persistent step met a position its hand-off format is too narrow for — E4M3 limbs clip at +-448 x the edge's
         pre-scale, fp16 at +-65504, the LLM.int8 outlier list holds 1024 columns.  Move this engine ONE rung down the ladder
-        fp8-limb operands (weight_fmt 3) -> fp16 operands (weight_fmt 0) -> launch-per-operator step (f32 residual, bf16 staging, no
+        fp8-limb operands (weight_fmt 3 / 5) -> fp16 operands (weight_fmt 0 / 4) -> launch-per-operator step (f32 residual, bf16 staging, no
         list limit) for the next `_hold` decode steps; `check_status` climbs back one rung after that many clean steps.  `_hold`
         starts at 16 and doubles with every further clip (cap 4096): a checkpoint that clips on every token settles on the lower
         rung by itself, one whose massive activations fire on a few tokens pays one replayed step each."""

@@ -35,7 +35,8 @@ def main():
     synth.fill_model_random_int4(model, seed=0)
     model.eval()
     eng = model.engine()
-    assert eng is not None and eng.fused is not None and int(eng.fused.weight_fmt) == 4, model._engine_failed
+    assert eng is not None and eng.fused is not None and int(eng.fused.weight_fmt) in (4, 5), model._engine_failed
+    a.tag = f"{a.tag}/fmt{int(eng.fused.weight_fmt)}"
     prompt = synth.make_prompt(a.prompt).to(dev)
     S = a.prompt + 8 + 4 * a.steps + 16
 
