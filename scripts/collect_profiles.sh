@@ -12,11 +12,11 @@ cp $O/prof_summary.txt profiles/${R}_rocprofv3_kernel_trace_summary.txt
 cp $O/pmc_summary.txt profiles/${R}_rocprofv3_pmc_fetch_size.txt
 [ -s $O/int8_timeline.txt ] && grep -v amdgpu $O/int8_timeline.txt > profiles/${R}_int8_phase_timeline.txt
 [ -s $O/timeline.txt ] && grep -v amdgpu $O/timeline.txt > profiles/${R}_gemv_phase_timeline.txt
-for f in none llm.int8 13B 65B; do [ -s $O/bench_cfg_$f.json ] && cp $O/bench_cfg_$f.json profiles/${R}_bench_cfg_$f.json; done
+for f in none llm.int8 13B 30B 65B; do [ -s $O/bench_cfg_$f.json ] && cp $O/bench_cfg_$f.json profiles/${R}_bench_cfg_$f.json; done
 [ -s $O/bench_longctx.json ] && cp $O/bench_longctx.json profiles/${R}_bench_longctx.json
 python - <<PY
 import json
-for f in ["${R}_bench","${R}_bench_cfg_none","${R}_bench_cfg_llm.int8","${R}_bench_cfg_13B","${R}_bench_cfg_65B","${R}_bench_longctx"]:
+for f in ["${R}_bench","${R}_bench_cfg_none","${R}_bench_cfg_llm.int8","${R}_bench_cfg_13B","${R}_bench_cfg_30B","${R}_bench_cfg_65B","${R}_bench_longctx"]:
     try:
         d=json.load(open(f"profiles/{f}.json"))
     except Exception as e:

@@ -13,7 +13,7 @@ for st in $STAGES; do
   echo "=== $st $(date +%T)" | tee -a $OUT/session.log
   case $st in
     tests)
-      timeout 1500 python -m pytest tests -m gpu -q -rA -p no:cacheprovider --timeout=900 > $OUT/pytest_gpu.log 2>&1
+      timeout 2700 python -m pytest tests -m gpu -q -rA -p no:cacheprovider --timeout=900 > $OUT/pytest_gpu.log 2>&1
       echo "pytest exit $?" | tee -a $OUT/session.log; tail -60 $OUT/pytest_gpu.log ;;
     smoke)
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
@@ -45,9 +45,10 @@ for st in $STAGES; do
       timeout 400 python bench.py --quantize none --steps 64 --no-cpu-baseline --no-tp > $OUT/bench_cfg_none.json 2>> $OUT/bench.err
       timeout 400 python bench.py --quantize llm.int8 --steps 64 --no-cpu-baseline --no-tp > $OUT/bench_cfg_llm.int8.json 2>> $OUT/bench.err
       timeout 500 python bench.py --model 13B --steps 64 --no-cpu-baseline --no-tp > $OUT/bench_cfg_13B.json 2>> $OUT/bench.err
+      timeout 700 python bench.py --model 30B --steps 48 --no-cpu-baseline --no-tp > $OUT/bench_cfg_30B.json 2>> $OUT/bench.err
       timeout 900 python bench.py --model 65B --steps 32 --no-cpu-baseline --no-tp > $OUT/bench_cfg_65B.json 2>> $OUT/bench.err
       timeout 400 python bench.py --prompt-len 1900 --steps 64 --warmup 16 --no-cpu-baseline --no-tp > $OUT/bench_longctx.json 2>> $OUT/bench.err
-      for f in none llm.int8 13B 65B; do tail -1 $OUT/bench_cfg_$f.json | cut -c1-200; done; tail -1 $OUT/bench_longctx.json | cut -c1-200
+      for f in none llm.int8 13B 30B 65B; do tail -1 $OUT/bench_cfg_$f.json | cut -c1-200; done; tail -1 $OUT/bench_longctx.json | cut -c1-200
       echo "cfgs done" | tee -a $OUT/session.log ;;
     mfma)
       rm -rf $OUT/mfma
