@@ -103,12 +103,7 @@ constexpr int kF8Eh = 4;  // SwiGLU output
 // profiles/r05_ab2_*.txt; the first x edge of a step scaled by the embedding row's own rms — no gain on the LLaMA-statistics fixture at
 // +1.2 % per step, profiles/r05_f8_xscale0_llama_statistics.txt)
 [[maybe_unused]] constexpr int kMaxS = 32768;     // cache rows (the attention keeps no per-row state in LDS)
-#ifdef FS_PROBE_PARK
-constexpr int kOffPark = kOffOlist + kMaxOut * 2;
-constexpr int kLdsBytes = kOffPark + kSW * FS_PROBE_PARK * 1024;
-#else
 constexpr int kLdsBytes = kOffOlist + kMaxOut * 2;
-#endif
 static_assert(kLdsBytes <= 160 * 1024 && kPartBytes >= kSW * 128 * 4 && kF8P2 + kF8Units * 128 <= kLdsBytes, "LDS map");
 
 // ------------------------------------------------------------------------------------------------ granules
@@ -859,16 +854,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         vr = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                            rv, t < pos ? (unsigned)t * 256u + hj * 32u + half * 16u : 0xFFFFFFF0u, 0, 0));
                     }
-#ifdef FS_PROBE_PARK
-                    // PROBE: FS_PROBE_PARK pieces per wave of this layer's c_fc1/c_fc2 stream requested into LDS by LDS-DMA while the attention runs
-#pragma unroll
-                    for (int i = 0; i < FS_PROBE_PARK; ++i)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_l, (__attribute__((address_space(3))) void*)(smem + kOffPark + (wave * FS_PROBE_PARK + i) * 1024),
-                                                                 16, lane_off, (unsigned)p.off_fc + (unsigned)(((bid * kSW + wave) * FS_PROBE_PARK + i) * 1024), 0, 2);
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // Ba1 without the fence's vmcnt(0)
-#else
                     __syncthreads();  // Ba1: q / new k / new v of the head are in LDS
-#endif
                     FS_SSTAMP(23);
                     float qf[8];
 #pragma unroll
