@@ -528,7 +528,7 @@ typedef struct mi355_fused_step_args {
      * per (scale, zero) pair, dividing n_embd and n_hidden (0: one pair per output row, `sz` / `sz_head` above).  Then `sz` and
      * `sz_head` are not read; `gt` holds per layer (stride gt_layer_stride bytes) the tables of c_attn, attn.c_proj, c_fc1,
      * c_fc2, mlp.c_proj in this order, `gt_head` lm_head's, each [N / 16 tiles][K / group_cols groups][16 rows] uint32 =
-     * bf16 scale | bf16 zero << 16.  Register-ring implementation only. */
+     * bf16 scale | bf16 zero << 16.  Register-ring implementation only; weight_fmt 0 or 3. */
     int32_t group_cols;
     /* 0: `w` / `w_head` hold int4 streams (mi355_q4_repack) as described above; 1 (round 4): BF16 streams of an unquantised model
      * (mi355_bf16_repack, same R / pair arguments: lit_llama/model.py with plain nn.Linear, BASELINE configs[1]) — `sz`, `sz_head`
@@ -538,7 +538,8 @@ typedef struct mi355_fused_step_args {
      * at most 1024 outlier columns per gathered vector (more raise the abort word: such a step belongs on mi355_forward).
      * 3 (round 4; what lit_llama_amd's engine selects for per-row int4 models unless MI355_FUSED_F8=0): the streams, scales and zeros
      * of 0, computed through fp8 operands: one v_mfma_scale_f32_16x16x128_f8f6f4 per 1-KiB piece (an int4 level in a byte is the E4M3
-     * code of q * 2^-9), the hand-offs carry three E4M3 limbs per activation under 16-bit tags; per-row scales only, n_hidden <= 11776.
+     * code of q * 2^-9), the hand-offs carry three E4M3 limbs per activation under 16-bit tags; n_hidden <= 11776; per-row scales or (round 6) group
+     * tables with at most 15 groups per streamer wave (group_cols >= 128: three MFMA columns per group).
      * A workspace that has carried hand-offs of another weight_fmt must be zeroed (all but its first 256 bytes) before the first step.
      * Register-ring implementation only.
      * 4 (round 6): the streams, scales and zeros of 0 through the WIDE-SHAPE kernel (csrc/fused_step_wide.hip): n_embd = 128 n_head with

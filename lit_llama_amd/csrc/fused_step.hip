@@ -159,7 +159,7 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     // (and its gatherers sweep the hidden edge — n_hidden / 4 loads of two granules + 128 of operand-sum partials — in at most 24 loads per lane)
     MI355_CHECK_ARG(fmt != 3 || a->n_hidden / 128 <= 92, MI355_E_SHAPE, "fused_step: weight_fmt 3 needs n_hidden <= %d (got %d)", 92 * 128,
                     a->n_hidden);
-    MI355_CHECK_ARG(!(grouped && fmt != 0), MI355_E_ARG, "fused_step: grouped scales exist for int4 streams only");
+    MI355_CHECK_ARG(!(grouped && fmt != 0 && fmt != 3), MI355_E_ARG, "fused_step: grouped scales exist for int4 streams only (weight_fmt 0 / 3)");
     MI355_CHECK_ARG(a->w && a->w_head && (grouped || fmt == 1 || (a->sz && a->sz_head)) && a->norms && a->wte && a->rope && a->kv && a->tokens &&
                         a->pos && a->logits && a->workspace,
                     MI355_E_ARG, "fused_step: null pointer");
@@ -172,7 +172,7 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
         MI355_CHECK_ARG(a->gt && a->gt_head && ((uintptr_t)a->gt | (uintptr_t)a->gt_head | a->gt_layer_stride) % 16 == 0, MI355_E_ARG,
                         "fused_step: grouped scales need the 16-B aligned group tables gt / gt_head");
         // a streamer wave keeps its groups side by side in the 16 MFMA token columns
-        MI355_CHECK_ARG(((a->n_hidden / 128 + 7) / 8 >> gsh) + 1 <= 16, MI355_E_SHAPE, "fused_step: too many groups per wave");
+        MI355_CHECK_ARG(((a->n_hidden / 128 + 7) / 8 >> gsh) + 1 <= (fmt == 3 ? 15 : 16), MI355_E_SHAPE, "fused_step: too many groups per wave");
     }
     MI355_CHECK_ARG(a->n_layer >= 1 && a->n_layer * 6 + 8 < 1024, MI355_E_SHAPE, "fused_step: n_layer %d", a->n_layer);
     MI355_CHECK_ARG(!(a->mode & 1) || a->next_token != nullptr, MI355_E_ARG, "fused_step: arg-max without next_token");
@@ -180,7 +180,7 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     MI355_CHECK_ARG(((uintptr_t)a->w | (uintptr_t)a->w_head | (uintptr_t)a->workspace | a->layer_stride | a->off_attn |
                      a->off_proj | a->off_fc | a->off_mproj) % 16 == 0,
                     MI355_E_ARG, "fused_step: streams and workspace must be 16-B aligned");
-    MI355_CHECK_ARG((fused_step_ring_occupancy_ok() & (fmt == 3 ? 16 : fmt == 2 ? 8 : fmt == 1 ? 4 : grouped ? 2 : 1)) != 0, MI355_E_STATE,
+    MI355_CHECK_ARG((fused_step_ring_occupancy_ok() & (fmt == 3 ? (grouped ? 32 : 16) : fmt == 2 ? 8 : fmt == 1 ? 4 : grouped ? 2 : 1)) != 0, MI355_E_STATE,
                     "fused_step: the device does not admit one %d-thread workgroup of the kernel per CU", kThreads);
     FusedParams p;
     memset(&p, 0, sizeof(p));

@@ -286,7 +286,7 @@ __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_b
 // the size of the fp16 operand rounding this replaces.
 template <bool GRP, int FMT>
 __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedParams p) {
-    static_assert(!(GRP && FMT != 0), "grouped scales exist for the fp16-operand int4 kernel only");
+    static_assert(!(GRP && FMT != 0 && FMT != 3), "grouped scales exist for the int4 streams only (fp16 or fp8 operands)");
     constexpr int kSub = FMT == 1 ? 4 : FMT == 2 ? 2 : 1;  // ring steps per 128-column unit (FMT 3 reads FMT 0's streams)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         // FMT 3: nibble mask, this lane's limb plane (+ its lane group's 32 bytes of a unit) and block-scale step, the all-ones operand
         [[maybe_unused]] uint32_t nib8 = 0x0F0F0F0Fu;
         if constexpr (FMT == 3) asm volatile("" : "+s"(nib8));  // (opaque: hipcc then keeps the mask in an SGPR operand)
-        [[maybe_unused]] const int f8_col = lane & 15;
+        // (GRP: columns 3 j .. 3 j + 2 carry the three limbs of group slot j, five slots per accumulator; column 15 idles)
+        [[maybe_unused]] const int f8_col = GRP ? (lane & 15) % 3 : lane & 15;
         [[maybe_unused]] const unsigned f8_plane = (f8_col == 0 ? (unsigned)kF8P0 : f8_col == 1 ? (unsigned)kF8P1 : (unsigned)kF8P2) + (unsigned)g * 32u;
         [[maybe_unused]] const int f8_dsb = f8_col == 0 ? 0 : f8_col == 1 ? 4 : 8;
 
@@ -773,11 +774,127 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
+        // ---- FMT 3 with group tables (round 6): FS_RUN_F's operands, FS_RUN's way with the groups.  A unit of 128 columns is one group's
+        // (or a part of one); the three limb planes of a unit go to MFMA columns 3 j .. 3 j + 2 of group slot j = (group - the wave's
+        // first) % 5 (the other columns read the all-zero unit), slots 0 .. 4 share an accumulator, a wave with more than five groups
+        // (mlp.c_proj: 11 units) takes a second and a third one (NS_).  The all-ones MFMAs of the first tile leave every column its own
+        // operand sum; at a tile's end lane (g, c) applies its group's (scale, zero) pairs of rows 4 g .. 4 g + 3 to its column and the 16
+        // columns are added up: y = sum_groups s (acc - z S).  The tile is parked finished (column 0), as FS_RUN's.
+#define FS_RUN_FG(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_, E8_)                               \
+    do {                                                                                                             \
+        constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
+        constexpr int NS__ = (SPT__ + 4) / 5, NA__ = NS__ == 1 ? 2 : NS__; /* accumulators: slots of five groups (one set: even / odd steps) */ \
+        const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
+        f32x4 acc__[R__][NA__];                                                                                       \
+        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__)                                                         \
+            _Pragma("unroll") for (int a__ = 0; a__ < NA__; ++a__) acc__[r__][a__] = f32x4{0.f, 0.f, 0.f, 0.f};       \
+        f32x4 accs__[NS__];                                                                                           \
+        _Pragma("unroll") for (int a__ = 0; a__ < NS__; ++a__) accs__[a__] = f32x4{0.f, 0.f, 0.f, 0.f};               \
+        float sg__[NS__]; /* this column's operand sum per accumulator (from the first tile on) */                    \
+        _Pragma("unroll") for (int a__ = 0; a__ < NS__; ++a__) sg__[a__] = 0.f;                                       \
+        i32x8 ones__;                                                                                                 \
+        _Pragma("unroll") for (int e__ = 0; e__ < 8; ++e__) ones__[e__] = 0x38383838; /* E4M3 1.0 */                  \
+        const int sb__ = 127 + (E8_) - f8_dsb;                                                                        \
+        const int cc__ = (int)(lane_off >> 4) & 15, slot__ = cc__ / 3; /* (slot 5 = column 15: never a group's) */    \
+        const int gfirst__ = (PH_).u0 >> p.gsh;                                                                       \
+        u32x4 tab__[R__][NS__];                                                                                       \
+        __syncthreads(); /* B1: the limb planes are staged */                                                        \
+        FS_SSTAMP(STAMP_);                                                                                            \
+        const char* xl__ = smem + f8_plane;                                                                           \
+        const char* xz__ = smem + kOffZero + g * 32;                                                                  \
+        i32x8 bn__ = *(const i32x8*)(slot__ == 0 ? xl__ + (PH_).u0 * 128 : xz__);                                     \
+        for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
+            _Pragma("unroll") for (int t__ = 0; t__ < (TURNS_); ++t__) {                                              \
+                _Pragma("unroll") for (int s__ = 0; s__ < STEPS__; ++s__) {                                           \
+                    const int gstep__ = (body__ * (TURNS_) + t__) * STEPS__ + s__;                                    \
+                    const int ti__ = gstep__ / SPT__, st__ = gstep__ - ti__ * SPT__;                                  \
+                    const i32x8 b__ = bn__;                                                                           \
+                    const int rel__ = (((PH_).u0 + st__) >> p.gsh) - gfirst__; /* this step's group, from the wave's first */ \
+                    [[maybe_unused]] const int set__ = NS__ == 1 ? 0 : rel__ / 5;                                     \
+                    {                                                                                                 \
+                        const int nst__ = (st__ + 1 == SPT__) ? 0 : st__ + 1;                                         \
+                        const int nun__ = (PH_).u0 + (nst__ < (PH_).nu ? nst__ : 0);                                  \
+                        const int nrel__ = (nun__ >> p.gsh) - gfirst__;                                               \
+                        bn__ = *(const i32x8*)(slot__ == nrel__ % 5 ? xl__ + nun__ * 128 : xz__);                     \
+                    }                                                                                                 \
+                    /* first step of a tile: request its table entries (consumed at the tile's last step) */          \
+                    if ((t__ * STEPS__ + s__) % SPT__ == 0) {                                                         \
+                        _Pragma("unroll") for (int a__ = 0; a__ < NS__; ++a__) {                                      \
+                            int grp__ = gfirst__ + a__ * 5 + slot__;                                                  \
+                            grp__ = grp__ < (PH_).ng ? grp__ : (PH_).ng - 1;                                          \
+                            const unsigned voff__ = (unsigned)(grp__ * 16 + 4 * g) * 4u;                              \
+                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                   \
+                                const int tile__ = (QKV_) ? (PH_).tile0 + r__ * (PH_).tstride : (PH_).tile0 + ti__ * (PH_).tstride; \
+                                const bool okt__ = (QKV_) || ti__ < (PH_).ntiles;                                     \
+                                const unsigned tb__ = ((PAIR_) && r__ == 1) ? (PH_).tab2 : (PH_).tab;                 \
+                                tab__[r__][a__] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(    \
+                                    okt__ ? (RST_) : rs_null, voff__, okt__ ? tb__ + (unsigned)(tile__ * (PH_).ng) * 64u : 0u, 0)); \
+                            }                                                                                         \
+                        }                                                                                             \
+                    }                                                                                                 \
+                    if (st__ < (PH_).nu && ((QKV_) || ti__ < (PH_).ntiles)) {                                         \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
+                            const u32x4 v__ = ring[s__ * R__ + r__];                                                  \
+                            i32x8 a__;                                                                                \
+                            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                     \
+                                a__[2 * d__] = (int)(v__[d__] & nib8);                                                \
+                                a__[2 * d__ + 1] = (int)((v__[d__] >> 4) & nib8);                                     \
+                            }                                                                                         \
+                            if constexpr (NS__ == 1) {                                                                \
+                                acc__[r__][s__ & 1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a__, b__, acc__[r__][s__ & 1], 0, 0, 0, 136, 0, sb__); \
+                            } else {                                                                                  \
+                                _Pragma("unroll") for (int q__ = 0; q__ < NS__; ++q__)                                \
+                                    if (set__ == q__) /* (wave-uniform) */                                            \
+                                        acc__[r__][q__] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a__, b__, acc__[r__][q__], 0, 0, 0, 136, 0, sb__); \
+                            }                                                                                         \
+                        }                                                                                             \
+                        if (ti__ == 0) {                                                                              \
+                            _Pragma("unroll") for (int q__ = 0; q__ < NS__; ++q__)                                    \
+                                if (set__ == q__)                                                                     \
+                                    accs__[q__] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones__, b__, accs__[q__], 0, 0, 0, 127, 0, sb__); \
+                        }                                                                                             \
+                    }                                                                                                 \
+                    _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                           \
+                        const int nstep__ = gstep__ + STEPS__;                                                        \
+                        bool ok__;                                                                                    \
+                        const unsigned so__ = piece_off<SPT__, PAIR_, QKV_, kSub>(PH_, nstep__, r__, ok__);           \
+                        ring[s__ * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__);   \
+                    }                                                                                                 \
+                    if ((t__ * STEPS__ + s__ + 1) % SPT__ == 0) {                                                     \
+                        if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
+                        if (ti__ == 0) {                                                                              \
+                            _Pragma("unroll") for (int q__ = 0; q__ < NS__; ++q__) sg__[q__] = accs__[q__][0]; /* (all rows of a column are equal) */ \
+                        }                                                                                             \
+                        f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
+                            f32x4 y4__ = f32x4{0.f, 0.f, 0.f, 0.f};                                                   \
+                            _Pragma("unroll") for (int q__ = 0; q__ < NS__; ++q__) {                                  \
+                                const f32x4 a4__ = NS__ == 1 ? acc__[r__][0] + acc__[r__][1] : acc__[r__][q__];       \
+                                _Pragma("unroll") for (int e__ = 0; e__ < 4; ++e__) {                                 \
+                                    const uint32_t w__ = tab__[r__][q__][e__];                                        \
+                                    const float sc__ = __uint_as_float(w__ << 16), zp__ = __uint_as_float(w__ & 0xffff0000u); \
+                                    y4__[e__] += sc__ * (a4__[e__] - zp__ * sg__[q__]);                               \
+                                }                                                                                     \
+                            }                                                                                         \
+                            _Pragma("unroll") for (int e__ = 0; e__ < 4; ++e__) y4__[e__] = group_sum(y4__[e__], 16); \
+                            pp__[r__ * (kPartTile / 16)] = y4__;                                                      \
+                            _Pragma("unroll") for (int a__ = 0; a__ < NA__; ++a__) acc__[r__][a__] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+                        }                                                                                             \
+                        __syncthreads(); /* Bt */                                                                     \
+                        buf ^= 1;                                                                                     \
+                    }                                                                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                                \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
         // a phase: (int4 SPT / TURNS, wide-format SPT / TURNS) — steps per tile and ring turns differ with the piece width
 #define FS_PHASE(RS_, R_, SPT_, TURNS_, SPTW_, TURNSW_, PAIR_, QKV_, PH_, NBODIES_, STAMP_, RST_, XEDGE_, E8_)        \
     do {                                                                                                             \
         if constexpr (FMT == 0) {                                                                                    \
             FS_RUN(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_);                                  \
+        } else if constexpr (FMT == 3 && GRP) {                                                                      \
+            FS_RUN_FG(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_, E8_);                          \
         } else if constexpr (FMT == 3) {                                                                             \
             FS_RUN_F(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, E8_);                                 \
         } else if constexpr (FMT == 1) {                                                                             \
@@ -1106,7 +1223,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         int psrc = (pg >> 1) * 64 + ((2 * pg) & 3);
         auto tile_pair = [&](int r) {
             float2 t = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc);
-            if constexpr (FMT == 3) {
+            if constexpr (FMT == 3 && !GRP) {
                 // limb columns 1 / 2 of the same rows sit 4 / 8 floats on (lane 16 g + n holds D[4 g .. 4 g + 3][n])
                 const float2 t1 = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc + 4);
                 const float2 t2 = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc + 8);
@@ -2022,11 +2139,11 @@ int fused_step_ring_occupancy_ok() {
     static int ok = -1;
     static std::once_flag once;
     std::call_once(once, [] {
-        const void* fn[5] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
+        const void* fn[6] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
                              (const void*)fused_step_ring_kernel<false, 1>, (const void*)fused_step_ring_kernel<false, 2>,
-                             (const void*)fused_step_ring_kernel<false, 3>};
+                             (const void*)fused_step_ring_kernel<false, 3>, (const void*)fused_step_ring_kernel<true, 3>};
         ok = 0;
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < 6; ++i) {
             int per_cu = 0;
             (void)hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn[i], kThreads, kLdsBytes) == hipSuccess && per_cu >= 1)
@@ -2034,7 +2151,7 @@ int fused_step_ring_occupancy_ok() {
         }
     });
     return ok;  // bit 0: the per-row int4 kernel fits one workgroup per CU, bit 1: the grouped-scale kernel, bit 2: BF16, bit 3: LLM.int8,
-                // bit 4: int4 streams through fp8 operands
+                // bit 4: int4 streams through fp8 operands, bit 5: the same with group tables
 }
 
 // launched by mi355_fused_step (fused_step.hip)
@@ -2042,10 +2159,10 @@ int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t 
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        const void* fn[5] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
+        const void* fn[6] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
                              (const void*)fused_step_ring_kernel<false, 1>, (const void*)fused_step_ring_kernel<false, 2>,
-                             (const void*)fused_step_ring_kernel<false, 3>};
-        for (int i = 0; i < 5 && attr_err == hipSuccess; ++i)
+                             (const void*)fused_step_ring_kernel<false, 3>, (const void*)fused_step_ring_kernel<true, 3>};
+        for (int i = 0; i < 6 && attr_err == hipSuccess; ++i)
             attr_err = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     });
     MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "fused_step: hipFuncSetAttribute failed: %s",
@@ -2058,7 +2175,9 @@ int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t 
             hipLaunchKernelGGL((K_), dim3(kG), dim3(kThreads), kLdsBytes, stream, p);                                  \
         }                                                                                                             \
     } while (0)
-    if (p.fmt == 3) {
+    if (p.fmt == 3 && p.grouped) {
+        FS_LAUNCH((fused_step_ring_kernel<true, 3>));
+    } else if (p.fmt == 3) {
         FS_LAUNCH((fused_step_ring_kernel<false, 3>));
     } else if (p.fmt == 2) {
         FS_LAUNCH((fused_step_ring_kernel<false, 2>));

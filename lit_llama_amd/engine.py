@@ -461,7 +461,9 @@ class DecodeEngine:
         a.w_head = head.desc.w
         a.sz, a.sz_head, a.norms = ptr(sz), ptr(sz_head), ptr(norms)
         a.weight_fmt = fmt
-        if fmt == 0 and not gc and H // 128 <= 92 and _env_int("MI355_FUSED_F8", 1) != 0:
+        # (round 6: group tables too — csrc/fused_step_ring.hip FS_RUN_FG: three MFMA columns per group, at most 15 groups per streamer wave)
+        gc_f8_ok = not gc or ((H // 128 + 7) // 8 >> (gc // 128).bit_length() - 1) + 1 <= 15
+        if fmt == 0 and gc_f8_ok and H // 128 <= 92 and _env_int("MI355_FUSED_F8", 1) != 0:
             # round 4: the same int4 streams through fp8 operands — one scaled K = 128 MFMA per 1-KiB piece instead of four f16 ones, the
             # publishers split the activations into three E4M3 limbs (csrc/fused_step_ring.hip FMT 3; DESIGN.md section 5: +2.4..2.8 % on
             # the headline, the same distance from the reference's run as the fp16 operands).  MI355_FUSED_F8=0 keeps weight_fmt 0;

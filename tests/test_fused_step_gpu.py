@@ -132,33 +132,39 @@ def build_grouped(n_layer, dev, g, seed=0):
 
 @pytest.mark.parametrize("g", [128, 256])
 def test_fused_step_with_grouped_scales(dev, g):
-    """GPTQ groupsize checkpoints on the persistent step (GRP instantiation of the register-ring kernel: 16 groups side by
-    side in the MFMA token columns, scales applied by the streamers): against the launch-per-operator engine on the same
-    weights (tokens equal up to the first near tie, logits within 0.03 std) and against the CPU oracle (0.05 std)."""
+    """GPTQ groupsize checkpoints on the persistent step, both operand formats of the GRP instantiations of the register-ring kernel —
+    weight_fmt 3 (round 6: three MFMA columns per group for the E4M3 limbs, up to three accumulators of five groups) and weight_fmt 0
+    (16 groups side by side in the MFMA token columns); scales applied by the streamers: against the launch-per-operator engine on
+    the same weights (tokens equal up to the first near tie, logits within 0.03 std) and against the CPU oracle (0.05 std)."""
     model, sd, cfg = build_grouped(2, dev, g)
     eng = need_fused(model)
-    assert eng.fused.group_cols == g
+    assert eng.fused.group_cols == g and eng._full_rungs == [3, 0, None], eng._full_rungs
     prompt = synth.make_prompt(12, seed=3).to(dev)
     outs, logits = {}, {}
-    for fused in (False, True):
-        eng.fused_enabled = fused
+    for fused in (None, 3, 0):
+        eng.fused_enabled = fused is not None
+        if fused is not None:
+            eng.use_fused_format(fused)
+            assert int(eng.fused.weight_fmt) == fused
         model.reset_cache()
         outs[fused] = lit_llama_amd.generate(model, prompt, 12, top_k=1, max_seq_length=32).cpu()
-        logits[fused] = teacher_forced(model, outs[False].to(dev), 12, 32, dev)
-        eng.check_status()
-    eng.fused_enabled = True
-    std = float(logits[False].std(-1).mean())
-    err = (logits[True] - logits[False]).abs().max().item()
-    assert err <= 0.03 * std, f"grouped fused vs unfused logits: {err:.4f} (std {std:.3f})"
-    top2 = torch.topk(logits[False], 2, dim=-1).values
+        logits[fused] = teacher_forced(model, outs[None].to(dev), 12, 32, dev)
+        assert eng.check_status() is None and not eng.fused_demotions
+    eng.reset_fused_format()
+    std = float(logits[None].std(-1).mean())
+    top2 = torch.topk(logits[None], 2, dim=-1).values
     margins = (top2[:, 0] - top2[:, 1]).tolist()
     first_tie = next((i for i, m_ in enumerate(margins) if m_ <= 2 * 0.03 * std), len(margins))
-    n = 12 + first_tie + 1
-    assert torch.equal(outs[True][:n], outs[False][:n]), f"{outs[True].tolist()} vs {outs[False].tolist()}"
+    n = 12 + first_tie
     om = oracle.Model(oracle.Config(n_layer=2, **W7B), {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()},
                       mode="gptq.int4")
-    ref = oracle.teacher_forced_logits(om, outs[False], 12)
-    assert (logits[True] - ref).abs().max().item() <= 0.05 * float(ref.std(-1).mean())
+    ref = oracle.teacher_forced_logits(om, outs[None], 12)
+    for fmt in (3, 0):
+        err = (logits[fmt] - logits[None]).abs().max().item()
+        print(f"grouped g{g} weight_fmt {fmt}: fused vs launch path {err / std:.4f} std")
+        assert err <= 0.03 * std, f"grouped fused (weight_fmt {fmt}) vs unfused logits: {err:.4f} (std {std:.3f})"
+        assert torch.equal(outs[fmt][:n], outs[None][:n]), f"weight_fmt {fmt}: {outs[fmt].tolist()} vs {outs[None].tolist()}"
+        assert (logits[fmt] - ref).abs().max().item() <= 0.05 * float(ref.std(-1).mean())
 
 
 def test_fused_step_is_reproducible_and_modes_agree(dev):
