@@ -72,7 +72,7 @@ def parse():
     return ap.parse_args()
 
 
-def bytes_per_token(cfg, mode: str):
+def bytes_per_token(cfg, mode: str, u8_stream: bool = False):
     """Algorithmic HBM bytes of one decode step: every linear weight once + its per-row
     scale/zero + norm scales + one embedding row; KV traffic is reported separately (position dependent)."""
     C_, H, V, L = cfg.n_embd, cfg.n_hidden, cfg.padded_vocab_size, cfg.n_layer
@@ -80,8 +80,9 @@ def bytes_per_token(cfg, mode: str):
     rows = L * (3 * C_ + C_ + 2 * H + C_) + V
     # (gptq.int8: the reference dequantises an 8-bit ColBlock matrix into a bf16 one on every forward call, quantization.py:413-423;
     # the engine builds it once and streams it — 2 bytes per weight is what a decode step reads)
-    wbytes = {"gptq.int4": params // 2, "llm.int8": params, "none": params * 2, "gptq.int8": params * 2}[mode]
-    side = {"gptq.int4": rows * 4, "llm.int8": rows * 4, "none": 0, "gptq.int8": 0}[mode]
+    # (round 6: the persistent step reads the 8-bit levels themselves, weight_fmt 6 — 1 byte per weight + the per-row scale / zero pairs)
+    wbytes = {"gptq.int4": params // 2, "llm.int8": params, "none": params * 2, "gptq.int8": params if u8_stream else params * 2}[mode]
+    side = {"gptq.int4": rows * 4, "llm.int8": rows * 4, "none": 0, "gptq.int8": rows * 4 if u8_stream else 0}[mode]
     other = (2 * L + 1) * C_ * 2 + C_ * 2
     return dict(weights=wbytes, total=wbytes + side + other, kv_per_pos=2 * L * C_ * 2)
 
@@ -591,10 +592,10 @@ def main():
     assert all(0 <= t_ < cfg.padded_vocab_size for t_ in tokens), "decode produced invalid ids"
     fused = eng.fused_ready()
     eng_fmt = int(eng.fused.weight_fmt) if fused else -1
-    f8_operands = fused and int(eng.fused.weight_fmt) in (3, 5)  # (the fp8-limb operand path of the int4 step)
+    f8_operands = fused and int(eng.fused.weight_fmt) in (3, 5, 6)  # (the fp8-limb operand path of the int4 / 8-bit steps)
     hipgraph_used = bool(eng.use_graph and eng._graphs) and not fused
     if rank == 0:
-        bpt = bytes_per_token(cfg, args.quantize)
+        bpt = bytes_per_token(cfg, args.quantize, u8_stream=eng_fmt == 6)
         tok_s_gpu = K / elapsed
         mean_pos = T + W + K / 2
         # ---- dominant kernel roofline (c_fc1/c_fc2 + SwiGLU)
@@ -633,7 +634,7 @@ def main():
         # the next rung of the engine's ladder — fp16 operands, `fused_step_ring_kernel<false, 0>` (wide shapes: weight_fmt 4) — one block,
         # same engine, same box
         rungs = None
-        if f8_operands:
+        if f8_operands and eng_fmt in (3, 5):
             with torch.cuda.stream(eng.stream):
                 eng.use_fused_format(0 if eng_fmt == 3 else 4)
                 eng.set_step(eng.out_tokens[p0:p0 + 1], 1, p0)
@@ -725,7 +726,8 @@ def main():
     variant = args.adapter or args.group_cols > 0
     default_cfg = args.model == "7B" and args.quantize == "gptq.int4" and not variant
     cfg_idx = {"none": 1, "gptq.int4": 2, "llm.int8": 3}.get(args.quantize) if args.model == "7B" and not variant else None
-    wname = {"gptq.int4": "int4", "llm.int8": "int8", "none": "bf16", "gptq.int8": "bf16"}[args.quantize]  # (gptq.int8 streams bf16 matrices: engine._dense_weight)
+    # (gptq.int8: the persistent step streams the 8-bit levels, weight_fmt 6; with MI355_FUSED_U8=0 the dequantised bf16 matrices: engine._dense_weight)
+    wname = {"gptq.int4": "int4", "llm.int8": "int8", "none": "bf16", "gptq.int8": "int8" if eng_fmt == 6 else "bf16"}[args.quantize]
     out = {
         "metric": METRIC if default_cfg else f"decode tokens/sec/GPU LLaMA-{args.model}{' + LLaMA-Adapter' if args.adapter else ''} "
                                              f"{args.quantize}{' groupsize %d' % args.group_cols if args.group_cols else ''} bs=1; % HBM roofline",

@@ -548,7 +548,14 @@ typedef struct mi355_fused_step_args {
      * only this format and 5 serve (1: the 7B shape, every format).
      * 5 (round 6; what lit_llama_amd's engine selects on those shapes unless MI355_FUSED_F8=0): the wide-shape kernel with the operands of 3
      * — one scaled fp8 MFMA per 1-KiB piece, three E4M3 limbs per activation under 16-bit tags; same shapes and limits as 4, the workspace
-     * rule of 3 (zero it when the format changes). */
+     * rule of 3 (zero it when the format changes).
+     * 6 (round 6; what lit_llama_amd's engine selects for `gptq.int8` models unless MI355_FUSED_U8=0): 8-bit ColBlockQuantizedLinear levels
+     * (lit_llama/quantization.py:340-423 with bits = 8, one (scale, zero) pair per row: `sz` / `sz_head` as for 0) at the 7B shape, streamed as they
+     * are: `w` / `w_head` hold, per linear, [tile of 16 rows][unit of 128 columns][r][piece e = 0, 1][lane = 16 g + row][16 bytes] with byte b of
+     * lane (g, row) of piece e = the level of column 128 u + 32 g + 16 e + 8 (b >> 3) + (0 4 1 5 2 6 3 7)[b & 7] (r = 0, 1: c_fc1, c_fc2 of the pair
+     * stream; a linear takes N x K bytes).  A byte is two int4 levels: the low nibbles of a unit's two pieces are one fp8 A operand (block scale
+     * 2^9), the high nibbles another (2^13), both against the unit's three E4M3 limb planes; y = scale (acc - zero S) in f32.  Hand-offs,
+     * tags, workspace rule and n_hidden limit of 3. */
     int32_t weight_fmt;
     const void* gt;
     const void* gt_head;

@@ -152,12 +152,12 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
                     a->n_head, a->hs, a->n_hidden, a->vocab, a->S);
     const bool grouped = a->group_cols > 0;
     const int fmt = a->weight_fmt;
-    MI355_CHECK_ARG(fmt >= 0 && fmt <= 3, MI355_E_ARG,
+    MI355_CHECK_ARG((fmt >= 0 && fmt <= 3) || fmt == 6, MI355_E_ARG,
                     "fused_step: weight_fmt %d (0 = int4 streams, 1 = BF16, 2 = LLM.int8, 3 = int4 streams through fp8 operands; 4 / 5 = the wide-shape "
-                    "kernel's fp16 / fp8 operands)", fmt);
+                    "kernel's fp16 / fp8 operands, 6 = 8-bit ColBlock streams through fp8 operands)", fmt);
     // fp8-limb operands keep three byte planes of the activation vector in LDS: 95 units of 128 columns
     // (and its gatherers sweep the hidden edge — n_hidden / 4 loads of two granules + 128 of operand-sum partials — in at most 24 loads per lane)
-    MI355_CHECK_ARG(fmt != 3 || a->n_hidden / 128 <= 92, MI355_E_SHAPE, "fused_step: weight_fmt 3 needs n_hidden <= %d (got %d)", 92 * 128,
+    MI355_CHECK_ARG((fmt != 3 && fmt != 6) || a->n_hidden / 128 <= 92, MI355_E_SHAPE, "fused_step: weight_fmt 3 / 6 needs n_hidden <= %d (got %d)", 92 * 128,
                     a->n_hidden);
     MI355_CHECK_ARG(!(grouped && fmt != 0 && fmt != 3), MI355_E_ARG, "fused_step: grouped scales exist for int4 streams only (weight_fmt 0 / 3)");
     MI355_CHECK_ARG(a->w && a->w_head && (grouped || fmt == 1 || (a->sz && a->sz_head)) && a->norms && a->wte && a->rope && a->kv && a->tokens &&
@@ -180,7 +180,7 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     MI355_CHECK_ARG(((uintptr_t)a->w | (uintptr_t)a->w_head | (uintptr_t)a->workspace | a->layer_stride | a->off_attn |
                      a->off_proj | a->off_fc | a->off_mproj) % 16 == 0,
                     MI355_E_ARG, "fused_step: streams and workspace must be 16-B aligned");
-    MI355_CHECK_ARG((fused_step_ring_occupancy_ok() & (fmt == 3 ? (grouped ? 32 : 16) : fmt == 2 ? 8 : fmt == 1 ? 4 : grouped ? 2 : 1)) != 0, MI355_E_STATE,
+    MI355_CHECK_ARG((fused_step_ring_occupancy_ok() & (fmt == 6 ? 64 : fmt == 3 ? (grouped ? 32 : 16) : fmt == 2 ? 8 : fmt == 1 ? 4 : grouped ? 2 : 1)) != 0, MI355_E_STATE,
                     "fused_step: the device does not admit one %d-thread workgroup of the kernel per CU", kThreads);
     FusedParams p;
     memset(&p, 0, sizeof(p));
@@ -226,7 +226,7 @@ extern "C" int mi355_fused_step(const mi355_fused_step_args* a, mi355_stream_t s
     p.fmt = fmt;
     {
         const int per_wg = (p.head_tiles + kG - 1) / kG;  // tiles of the busiest workgroup (ring version)
-        const int steps = per_wg * 4 * (fmt == 1 ? 4 : fmt == 2 ? 2 : 1);  // ring steps per tile and wave: 4 (int4), 16 (BF16), 8 (int8)
+        const int steps = per_wg * 4 * (fmt == 1 ? 4 : (fmt == 2 || fmt == 6) ? 2 : 1);  // ring steps per tile and wave: 4 (int4), 16 (BF16), 8 (8-bit)
         p.head_turns = (steps + 12 - 1) / 12;
     }
     p.mode = a->mode;

@@ -287,7 +287,9 @@ __device__ __forceinline__ u32x4 ring_load(__amdgpu_buffer_rsrc_t rs, __amdgpu_b
 template <bool GRP, int FMT>
 __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedParams p) {
     static_assert(!(GRP && FMT != 0 && FMT != 3), "grouped scales exist for the int4 streams only (fp16 or fp8 operands)");
-    constexpr int kSub = FMT == 1 ? 4 : FMT == 2 ? 2 : 1;  // ring steps per 128-column unit (FMT 3 reads FMT 0's streams)
+    constexpr int kSub = FMT == 1 ? 4 : (FMT == 2 || FMT == 4) ? 2 : 1;  // ring steps per 128-column unit (FMT 3 reads FMT 0's streams)
+    // fp8-limb operands and hand-offs: the int4 streams (FMT 3) and the 8-bit ColBlock streams (FMT 4, round 6: `gptq.int8`)
+    constexpr bool kF8 = FMT == 3 || FMT == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         int buf = 0;
         // FMT 3: nibble mask, this lane's limb plane (+ its lane group's 32 bytes of a unit) and block-scale step, the all-ones operand
         [[maybe_unused]] uint32_t nib8 = 0x0F0F0F0Fu;
-        if constexpr (FMT == 3) asm volatile("" : "+s"(nib8));  // (opaque: hipcc then keeps the mask in an SGPR operand)
+        if constexpr (kF8) asm volatile("" : "+s"(nib8));  // (opaque: hipcc then keeps the mask in an SGPR operand)
         // (GRP: columns 3 j .. 3 j + 2 carry the three limbs of group slot j, five slots per accumulator; column 15 idles)
         [[maybe_unused]] const int f8_col = GRP ? (lane & 15) % 3 : lane & 15;
         [[maybe_unused]] const unsigned f8_plane = (f8_col == 0 ? (unsigned)kF8P0 : f8_col == 1 ? (unsigned)kF8P1 : (unsigned)kF8P2) + (unsigned)g * 32u;
@@ -888,6 +890,88 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
+        // ---- FMT 4 (round 6): 8-bit ColBlock streams (`gptq.int8`, lit_llama/quantization.py:340-423 with bits = 8) through the fp8 pipe.  A byte
+        // q = 16 h + l is TWO int4 levels: a unit of 128 columns is two 1-KiB pieces (FS_RUN_8's geometry: a ring step = one piece of 64
+        // columns); at the unit's second piece the low nibbles of both pieces are one A operand (block scale 2^9: the products are l x),
+        // the high nibbles another (block scale 2^13: 16 h x), both against the unit's limb planes — two scaled MFMAs per 2 KiB, FS_RUN_F's
+        // rate per byte.  The stream's byte order makes the nibble planes read the limb planes' octet order (tests/layouts.py u8_to_stream).
+#define FS_RUN_U(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, E8_)                                      \
+    do {                                                                                                             \
+        constexpr int SPT__ = (SPT_), R__ = (R_), STEPS__ = kRing / R__;                                              \
+        static_assert(SPT__ % 2 == 0 && STEPS__ % 2 == 0, "a unit is two ring steps");                                \
+        const int total__ = (NBODIES_) * (TURNS_) * STEPS__;                                                          \
+        f32x4 acc__[R__][2];                                                                                          \
+        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+        f32x4 accs__ = f32x4{0.f, 0.f, 0.f, 0.f};                                                                     \
+        i32x8 ones__;                                                                                                 \
+        _Pragma("unroll") for (int e__ = 0; e__ < 8; ++e__) ones__[e__] = 0x38383838; /* E4M3 1.0 */                  \
+        const int sb__ = 127 + (E8_) - f8_dsb;                                                                        \
+        __syncthreads(); /* B1: the limb planes are staged */                                                        \
+        FS_SSTAMP(STAMP_);                                                                                            \
+        const char* xl__ = smem + f8_plane;                                                                           \
+        const int nsub__ = (PH_).nu * 2;                                                                              \
+        i32x8 b__ = *(const i32x8*)(xl__ + (PH_).u0 * 128);                                                           \
+        for (int body__ = 0; body__ < (NBODIES_); ++body__) {                                                         \
+            _Pragma("unroll") for (int t__ = 0; t__ < (TURNS_); ++t__) {                                              \
+                _Pragma("unroll") for (int s__ = 0; s__ < STEPS__; ++s__) {                                           \
+                    const int gstep__ = (body__ * (TURNS_) + t__) * STEPS__ + s__;                                    \
+                    const int ti__ = gstep__ / SPT__, st__ = gstep__ - ti__ * SPT__;                                  \
+                    const bool act__ = st__ < nsub__ && ((QKV_) || ti__ < (PH_).ntiles);                              \
+                    if ((s__ & 1) == 0) { /* (compile time once unrolled) */                                          \
+                        /* first piece of a unit: its B operand (read a step ahead of its MFMAs), the piece set aside */ \
+                        b__ = *(const i32x8*)(xl__ + ((PH_).u0 + (st__ < nsub__ ? st__ >> 1 : 0)) * 128);             \
+                    } else if (act__) {                                                                               \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
+                            const u32x4 v0__ = ring[(s__ - 1) * R__ + r__], v1__ = ring[s__ * R__ + r__];                 \
+                            i32x8 lo__, hi__;                                                                         \
+                            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                     \
+                                lo__[d__] = (int)(v0__[d__] & nib8);                                                  \
+                                lo__[4 + d__] = (int)(v1__[d__] & nib8);                                              \
+                            }                                                                                         \
+                            acc__[r__][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(lo__, b__, acc__[r__][0], 0, 0, 0, 136, 0, sb__); \
+                            __builtin_amdgcn_sched_barrier(0);                                                        \
+                            _Pragma("unroll") for (int d__ = 0; d__ < 4; ++d__) {                                     \
+                                hi__[d__] = (int)((v0__[d__] >> 4) & nib8);                                           \
+                                hi__[4 + d__] = (int)((v1__[d__] >> 4) & nib8);                                       \
+                            }                                                                                         \
+                            acc__[r__][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(hi__, b__, acc__[r__][1], 0, 0, 0, 140, 0, sb__); \
+                            __builtin_amdgcn_sched_barrier(0); /* (one row group's nibble planes at a time) */        \
+                        }                                                                                             \
+                        if (ti__ == 0)                                                                                \
+                            accs__ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones__, b__, accs__, 0, 0, 0, 127, 0, sb__); \
+                    }                                                                                                 \
+                    /* both pieces of the unit are refilled behind its MFMAs (the first one stays in its ring slot until then) */ \
+                    if ((s__ & 1) == 1) {                                                                             \
+                        _Pragma("unroll") for (int q__ = 1; q__ >= 0; --q__) {                                        \
+                            _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                   \
+                                const int nstep__ = gstep__ - q__ + STEPS__;                                          \
+                                bool ok__;                                                                            \
+                                const unsigned so__ = piece_off<SPT__, PAIR_, QKV_, kSub>(PH_, nstep__, r__, ok__);   \
+                                ring[(s__ - q__) * R__ + r__] = ring_load(RS_, rs_null, ok__ && nstep__ < total__, lane_off, so__); \
+                            }                                                                                         \
+                        }                                                                                             \
+                    }                                                                                                 \
+                    if ((gstep__ + 1) % SPT__ == 0) {                                                                 \
+                        if (gstep__ + 1 == total__) FS_SSTAMP((STAMP_) + 1);                                          \
+                        if (ti__ == 0) {                                                                              \
+                            float ssum__ = accs__[0];                                                                 \
+                            ssum__ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, accs__[0]), 0x55, 0xF, 0xF, false)) + \
+                                      __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, accs__[0]), 0xAA, 0xF, 0xF, false)); \
+                            if (lane_off == 0u) misc[32 + wave] = ssum__;                                             \
+                        }                                                                                             \
+                        f32x4* pp__ = (f32x4*)(part + (size_t)((buf * kSW + wave) * 4) * kPartTile) + FS_PART_LANE;   \
+                        _Pragma("unroll") for (int r__ = 0; r__ < R__; ++r__) {                                       \
+                            pp__[r__ * (kPartTile / 16)] = acc__[r__][0] + acc__[r__][1];                             \
+                            acc__[r__][0] = acc__[r__][1] = f32x4{0.f, 0.f, 0.f, 0.f};                                \
+                        }                                                                                             \
+                        __syncthreads(); /* Bt */                                                                     \
+                        buf ^= 1;                                                                                     \
+                    }                                                                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                                \
+                }                                                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
         // a phase: (int4 SPT / TURNS, wide-format SPT / TURNS) — steps per tile and ring turns differ with the piece width
 #define FS_PHASE(RS_, R_, SPT_, TURNS_, SPTW_, TURNSW_, PAIR_, QKV_, PH_, NBODIES_, STAMP_, RST_, XEDGE_, E8_)        \
     do {                                                                                                             \
@@ -897,6 +981,8 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             FS_RUN_FG(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, RST_, E8_);                          \
         } else if constexpr (FMT == 3) {                                                                             \
             FS_RUN_F(RS_, R_, SPT_, PAIR_, QKV_, TURNS_, PH_, NBODIES_, STAMP_, E8_);                                 \
+        } else if constexpr (FMT == 4) {                                                                             \
+            FS_RUN_U(RS_, R_, SPTW_, PAIR_, QKV_, TURNSW_, PH_, NBODIES_, STAMP_, E8_);                               \
         } else if constexpr (FMT == 1) {                                                                             \
             FS_RUN_W(RS_, R_, SPTW_, PAIR_, QKV_, TURNSW_, PH_, NBODIES_, STAMP_);                                    \
         } else {                                                                                                     \
@@ -1223,7 +1309,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
         int psrc = (pg >> 1) * 64 + ((2 * pg) & 3);
         auto tile_pair = [&](int r) {
             float2 t = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc);
-            if constexpr (FMT == 3 && !GRP) {
+            if constexpr (kF8 && !GRP) {
                 // limb columns 1 / 2 of the same rows sit 4 / 8 floats on (lane 16 g + n holds D[4 g .. 4 g + 3][n])
                 const float2 t1 = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc + 4);
                 const float2 t2 = *(const float2*)((const float*)(part + (size_t)((buf * kSW + w8) * 4 + r) * kPartTile) + psrc + 8);
@@ -1326,7 +1412,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             }
         };
         auto get_sums = [&]() {
-            if constexpr (FMT == 3) {
+            if constexpr (kF8) {
                 // the streamer waves' operand sums (all-ones MFMAs of the phase's first tile: valid behind its Bt); the A block scale
                 // made the products q x~ themselves, so there is no offset term: y = scale (acc - zero S)
                 const f32x4 sa = *(const f32x4*)(misc + 32), sb = *(const f32x4*)(misc + 36);
@@ -1353,7 +1439,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             const unsigned ep = ebase + edge;
             u64* dst = p.gx + (size_t)xpar * kFsGxStride;
             x_scale = __uint_as_float((__float_as_uint(rinv_seen) + 0x00400000u) & 0x7F800000u);
-            if constexpr (FMT == 3) {
+            if constexpr (kF8) {
                 f8_publish(dst + bid * 8, ep, x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y, kF8Ex, w8 == 0);
             } else {
                 if (w8 == 0) gr_store(dst + bid * 8 + pg, ep, hpair(x_scale * gsc.x * xv.x, x_scale * gsc.y * xv.y));
@@ -1389,7 +1475,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     }
 #pragma unroll
                     for (int k = 0; k < kG0 + kNS; ++k) {
-                        if (FMT == 3 && k < kG0) ok &= (v[k][1] >> 16) == (ep & 0xFFFFu) && (v[k][3] >> 16) == (ep & 0xFFFFu);
+                        if (kF8 && k < kG0) ok &= (v[k][1] >> 16) == (ep & 0xFFFFu) && (v[k][3] >> 16) == (ep & 0xFFFFu);
                         else ok &= v[k][1] == ep && v[k][3] == ep;
                     }
                     if (__all(ok)) break;
@@ -1402,7 +1488,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 float2 sx = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < kG0; ++k) {
-                    if constexpr (FMT == 3) {
+                    if constexpr (kF8) {
                         f8_stage(v[k], k * 64 + lane_v);
                     } else {
                         *(u64*)(xs + (size_t)(k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
@@ -1423,11 +1509,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             } else {
                 if constexpr (FMT == 2) zero_obits();
                 u32x4 v[16 - kG0];
-                sweep<16 - kG0, FMT == 3>(p, rs_ws, base, kG0 * 64, 1024, FMT == 3 ? (ep & 0xFFFFu) : ep, v, 0x200u + edge, lane_v);
+                sweep<16 - kG0, kF8>(p, rs_ws, base, kG0 * 64, 1024, kF8 ? (ep & 0xFFFFu) : ep, v, 0x200u + edge, lane_v);
                 float2 sx = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 16 - kG0; ++k) {
-                    if constexpr (FMT == 3) {
+                    if constexpr (kF8) {
                         f8_stage(v[k], kG0 * 64 + k * 64 + lane_v);
                     } else {
                         *(u64*)(xs + (size_t)(kG0 * 64 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
@@ -1563,7 +1649,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             float2 sc[3], zr[3];
             // int4 streams: gatherer 1 dequantises and publishes the k (RoPE) and v rows, gatherer 0 keeps q (round 5, fp8 operands:
             // 902.5 / 904.1 / 904.2 against 904.3 / 909.2 / 910.2 us per step with v alone, 906.4 / 904.8 / 906.8 with neither: profiles/r05_ab5_*.txt)
-            constexpr bool VSPLIT = FMT == 0 || FMT == 3;
+            constexpr bool VSPLIT = FMT == 0 || kF8;
             if (gw == 0 || VSPLIT) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
@@ -1686,7 +1772,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     const float inv = recip_e(group_sum(misc[24 + w8] * wsc, 8));
                     // attention output elements head * 128 + hj * 16 + 2 pg, + 1 -> one pair granule
                     u64* ga_t = p.ga + (size_t)apar * kFsGaStride + kFsGaSums + head * 64 + hj * 8;  // this workgroup's 8 pair granules
-                    if constexpr (FMT == 3) {
+                    if constexpr (kF8) {
                         f8_publish(ga_t, ebase + edge, o.x * inv, o.y * inv, kF8Ea, w8 == 0);
                     } else {
                         if (w8 == 0) gr_store(ga_t + pg, ebase + edge, hpair_b(o.x * inv, o.y * inv));
@@ -1746,7 +1832,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                         const float oy = group_sum(__uint_as_float(v1[2]) * wsc, 8);
                         const float inv = recip_e(group_sum(lj * wsc, 8));
                         u64* ga_t = p.ga + (size_t)apar * kFsGaStride + kFsGaSums + head * 64 + hj * 8;
-                        if constexpr (FMT == 3) {
+                        if constexpr (kF8) {
                             f8_publish(ga_t, ebase + edge, ox * inv, oy * inv, kF8Ea, w8 == 0);
                         } else {
                             if (w8 == 0) gr_store(ga_t + pg, ebase + edge, hpair_b(ox * inv, oy * inv));
@@ -1776,11 +1862,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 float2 sxp = {0.f, 0.f};
                 {
                     u32x4 v[8];
-                    sweep<8, FMT == 3>(p, rs_ws, kOGa + (unsigned)(apar * kFsGaStride + kFsGaSums) * 8u, gw * 512, gw * 512 + 512,
-                                       FMT == 3 ? (ep & 0xFFFFu) : ep, v, 0x400u + edge, lane_v);
+                    sweep<8, kF8>(p, rs_ws, kOGa + (unsigned)(apar * kFsGaStride + kFsGaSums) * 8u, gw * 512, gw * 512 + 512,
+                                       kF8 ? (ep & 0xFFFFu) : ep, v, 0x400u + edge, lane_v);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        if constexpr (FMT == 3) {
+                        if constexpr (kF8) {
                             f8_stage(v[k], gw * 512 + k * 64 + lane_v);
                         } else {
                             *(u64*)(xs + (size_t)(gw * 512 + k * 64 + lane_v) * 8) = ((u64)v[k][2] << 32) | v[k][0];
@@ -1849,11 +1935,11 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 rinv_seen = misc[0];
                 const float rinv = FMT == 2 ? 1.f : rinv_seen * __uint_as_float(0x7F000000u - __float_as_uint(x_scale));
                 float2 sx = {0.f, 0.f};
-                if constexpr (FMT != 3) sx = get_sums();
+                if constexpr (!kF8) sx = get_sums();
 #pragma unroll
                 for (int t = 0; t < kMaxFcTiles; ++t) {
                     __syncthreads();  // Bt
-                    if constexpr (FMT == 3) {
+                    if constexpr (kF8) {
                         if (t == 0) sx = get_sums();  // (the streamers' operand sums exist behind the first tile end)
                     }
                     if (gw == 0 && t < n_fc) {
@@ -1866,7 +1952,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                             a = deq(tile_pair(0), fs1[t], fz1[t], sx);
                             b = deq(tile_pair(1), fs2[t], fz2[t], sx);
                         }
-                        if constexpr (FMT == 3) {
+                        if constexpr (kF8) {
                             f8_publish(dst + (bid + t * kG) * 8, ep, swiglu_e(a.x * rinv, b.x * rinv), swiglu_e(a.y * rinv, b.y * rinv), kF8Eh,
                                        w8 == 0);
                         } else {
@@ -1897,14 +1983,14 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 if constexpr (FMT == 2) {
                     if (gw == 1) zero_obits();
                 }
-                [[maybe_unused]] const unsigned eph = FMT == 3 ? (ep & 0xFFFFu) : ep;
+                [[maybe_unused]] const unsigned eph = kF8 ? (ep & 0xFFFFu) : ep;
                 // 16-B loads of the edge: the H / 4 pair loads
                 const int n_pairs = p.H / 4;
                 const int n_loads = n_pairs, half_l = (n_loads + 1) / 2;
                 const int first = gw * half_l, end = gw == 0 ? half_l : n_loads;
                 float2 sxp = {0.f, 0.f};
                 auto stage_h = [&](const u32x4& v, int i) {  // stage load i of the edge
-                    if constexpr (FMT == 3) {
+                    if constexpr (kF8) {
                         f8_stage(v, i);
                     } else {
                         *(u64*)(xs + (size_t)i * 8) = ((u64)v[2] << 32) | v[0];
@@ -1918,7 +2004,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     const unsigned hbase = kOGh + (unsigned)hpar * (unsigned)gh_stride * 8u;
                     int lh = lane_v;
                     asm volatile("" : "+v"(lh));  // addresses of this block are computed here, not hoisted and spilled
-                if constexpr (FMT == 3) {
+                if constexpr (kF8) {
                     // per gatherer: its half of the early loads (first and second tiles of every workgroup: pair loads below 2048) in
                     // chunks of 8 / 4 / 4 per lane, its half of the late loads (third tiles of the 176 workgroups that have one: from load
                     // 2048 on) as ONE chunk of <= 8, requested as soon as the first early chunk has landed — when the slowest publisher's
@@ -1969,15 +2055,15 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                     const int c1 = first + 512, c2 = first + 768, c3 = first + 1280;
                     sweep_issue<8>(rs_ws, hbase, first, end, va, lh);
                     sweep_issue<4>(rs_ws, hbase, c1, end, vb, lh);
-                    sweep<8, FMT == 3>(p, rs_ws, hbase, first, end, eph, va, 0x500u + edge, lh, true);
+                    sweep<8, kF8>(p, rs_ws, hbase, first, end, eph, va, 0x500u + edge, lh, true);
                     stage_a(first);
                     sweep_issue<8>(rs_ws, hbase, c2, end, va, lh);
-                    sweep<4, FMT == 3>(p, rs_ws, hbase, c1, end, eph, vb, 0x500u + edge, lh, true);
+                    sweep<4, kF8>(p, rs_ws, hbase, c1, end, eph, vb, 0x500u + edge, lh, true);
                     stage_b(c1);
                     sweep_issue<4>(rs_ws, hbase, c3, end, vb, lh);
-                    sweep<8, FMT == 3>(p, rs_ws, hbase, c2, end, eph, va, 0x500u + edge, lh, true);
+                    sweep<8, kF8>(p, rs_ws, hbase, c2, end, eph, va, 0x500u + edge, lh, true);
                     stage_a(c2);
-                    sweep<4, FMT == 3>(p, rs_ws, hbase, c3, end, eph, vb, 0x500u + edge, lh, true);
+                    sweep<4, kF8>(p, rs_ws, hbase, c3, end, eph, vb, 0x500u + edge, lh, true);
                     stage_b(c3);
                 }
                 }
@@ -2034,7 +2120,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
             rinv_seen = misc[0];
             const float rinv = FMT == 2 ? 1.f : rinv_seen * __uint_as_float(0x7F000000u - __float_as_uint(x_scale));
             float2 sx = {0.f, 0.f};
-            if constexpr (FMT != 3) sx = get_sums();
+            if constexpr (!kF8) sx = get_sums();
             float best = -INFINITY;
             int bi = 0x7fffffff;
             const int tiles_pad = p.head_turns * 12 / (4 * kSub);  // tile ends the streamers pass (4 kSub ring steps per tile and wave)
@@ -2042,7 +2128,7 @@ __global__ __launch_bounds__(kThreads) void fused_step_ring_kernel(const FusedPa
                 float2 scn = {0.f, 0.f}, zn = {0.f, 0.f};
                 if (gw == 0) head_sz(t + 1, scn, zn);
                 __syncthreads();  // Bt
-                if constexpr (FMT == 3) {
+                if constexpr (kF8) {
                     if (t == 0) sx = get_sums();
                 }
                 if (gw == 0 && t < n_head_t) {
@@ -2139,11 +2225,12 @@ int fused_step_ring_occupancy_ok() {
     static int ok = -1;
     static std::once_flag once;
     std::call_once(once, [] {
-        const void* fn[6] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
+        const void* fn[7] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
                              (const void*)fused_step_ring_kernel<false, 1>, (const void*)fused_step_ring_kernel<false, 2>,
-                             (const void*)fused_step_ring_kernel<false, 3>, (const void*)fused_step_ring_kernel<true, 3>};
+                             (const void*)fused_step_ring_kernel<false, 3>, (const void*)fused_step_ring_kernel<true, 3>,
+                             (const void*)fused_step_ring_kernel<false, 4>};
         ok = 0;
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 7; ++i) {
             int per_cu = 0;
             (void)hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn[i], kThreads, kLdsBytes) == hipSuccess && per_cu >= 1)
@@ -2151,7 +2238,7 @@ int fused_step_ring_occupancy_ok() {
         }
     });
     return ok;  // bit 0: the per-row int4 kernel fits one workgroup per CU, bit 1: the grouped-scale kernel, bit 2: BF16, bit 3: LLM.int8,
-                // bit 4: int4 streams through fp8 operands, bit 5: the same with group tables
+                // bit 4: int4 streams through fp8 operands, bit 5: the same with group tables, bit 6: 8-bit ColBlock streams through fp8 operands
 }
 
 // launched by mi355_fused_step (fused_step.hip)
@@ -2159,10 +2246,11 @@ int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t 
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        const void* fn[6] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
+        const void* fn[7] = {(const void*)fused_step_ring_kernel<false, 0>, (const void*)fused_step_ring_kernel<true, 0>,
                              (const void*)fused_step_ring_kernel<false, 1>, (const void*)fused_step_ring_kernel<false, 2>,
-                             (const void*)fused_step_ring_kernel<false, 3>, (const void*)fused_step_ring_kernel<true, 3>};
-        for (int i = 0; i < 6 && attr_err == hipSuccess; ++i)
+                             (const void*)fused_step_ring_kernel<false, 3>, (const void*)fused_step_ring_kernel<true, 3>,
+                             (const void*)fused_step_ring_kernel<false, 4>};
+        for (int i = 0; i < 7 && attr_err == hipSuccess; ++i)
             attr_err = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     });
     MI355_CHECK_ARG(attr_err == hipSuccess, (int)attr_err, "fused_step: hipFuncSetAttribute failed: %s",
@@ -2175,7 +2263,9 @@ int fused_step_ring_launch(const FusedParams& p, hipStream_t stream, hipEvent_t 
             hipLaunchKernelGGL((K_), dim3(kG), dim3(kThreads), kLdsBytes, stream, p);                                  \
         }                                                                                                             \
     } while (0)
-    if (p.fmt == 3 && p.grouped) {
+    if (p.fmt == 6) {
+        FS_LAUNCH((fused_step_ring_kernel<false, 4>));
+    } else if (p.fmt == 3 && p.grouped) {
         FS_LAUNCH((fused_step_ring_kernel<true, 3>));
     } else if (p.fmt == 3) {
         FS_LAUNCH((fused_step_ring_kernel<false, 3>));

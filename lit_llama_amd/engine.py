@@ -189,7 +189,18 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
         layer_bytes = sum(sizes)
         if layer_bytes >= 1 << 31 or ops.packed_bytes(wfmt, V, C_, 1, False) >= 1 << 31:
             return None  # (a layer is addressed through one 32-bit buffer descriptor)
-        return {"sizes": sizes, "offs": offs, "layer_bytes": layer_bytes, "group_cols": 0, "fmt": fmt}
+        plan = {"sizes": sizes, "offs": offs, "layer_bytes": layer_bytes, "group_cols": 0, "fmt": fmt}
+        if fmt == 1 and _env_int("MI355_FUSED_U8", 1) != 0 and H // 128 <= 92:
+            # round 6: `gptq.int8` (8-bit ColBlockQuantizedLinear everywhere, one (scale, zero) pair per row): the persistent step reads
+            # the 8-bit levels themselves (weight_fmt 6, half the bytes of the dequantised bf16 matrices the launch path keeps streaming)
+            from .quantization import ColBlockQuantizedLinear
+
+            mods = [m_ for blk in model.transformer.h
+                    for m_ in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj)] + [model.lm_head]
+            if all(isinstance(m_, ColBlockQuantizedLinear) and m_.bits == 8 and m_.scales.shape[1] == 1 and m_.scales.dtype == torch.bfloat16
+                   and m_.out_features % 16 == 0 and m_.in_features % 128 == 0 for m_ in mods):
+                plan["u8"] = True
+        return plan
     group_cols = 0
     mods = [m_ for blk in model.transformer.h
             for m_ in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj)] + [model.lm_head]
@@ -215,6 +226,29 @@ def _fused_plan(model, kinds, C_, nh, hs, H, V) -> Optional[dict]:
     if layer_bytes >= 1 << 32 or any(o % 16 for o in offs) or layer_bytes % 16:
         return None
     return {"sizes": sizes, "offs": offs, "layer_bytes": layer_bytes, "group_cols": group_cols, "fmt": 4 if wide else 0}
+
+
+_U8_PERM = (0, 4, 1, 5, 2, 6, 3, 7)
+
+
+def u8_stream(mats: List[torch.Tensor]) -> torch.Tensor:
+    """uint8 [N, K] levels of an 8-bit ColBlockQuantizedLinear (one matrix: R = 1; the c_fc1 / c_fc2 pair: R = 2) -> the stream
+    `mi355_fused_step` reads with weight_fmt 6: [tile of 16 rows][unit of 128 columns][r][piece e = 0, 1][lane = 16 g + row][16 B],
+    byte b of lane (g, row) of piece e = column 128 u + 32 g + 16 e + 8 (b >> 3) + (0 4 1 5 2 6 3 7)[b & 7] — the octet order of
+    the fp8 step's limb planes (tests/layouts.py f8_planes), so that `v & 0x0F0F0F0F` / `(v >> 4) & 0x0F0F0F0F` of the two pieces of
+    a unit are the low- / high-nibble A operands against one B operand (csrc/fused_step_ring.hip FS_RUN_U)."""
+    N, K = mats[0].shape
+    assert N % 16 == 0 and K % 128 == 0 and all(m_.shape == (N, K) and m_.dtype == torch.uint8 for m_ in mats)
+    dev = mats[0].device
+    u, e, g, b = torch.meshgrid(torch.arange(K // 128, device=dev), torch.arange(2, device=dev), torch.arange(4, device=dev),
+                                torch.arange(16, device=dev), indexing="ij")
+    perm = torch.tensor(_U8_PERM, device=dev)
+    col = (128 * u + 32 * g + 16 * e + 8 * (b >> 3) + perm[b & 7]).reshape(-1)
+    outs = []
+    for m_ in mats:
+        t = m_.index_select(1, col).view(N // 16, 16, K // 128, 2, 4, 16)  # [tile, row, unit, e, g, b]
+        outs.append(t.permute(0, 2, 3, 4, 1, 5))                               # [tile, unit, e, g, row, b]
+    return torch.stack(outs, dim=2).contiguous().reshape(-1)                   # [tile, unit, r, e, lane, b]
 
 
 def group_table(scales: torch.Tensor, zeros: torch.Tensor) -> torch.Tensor:
@@ -459,6 +493,30 @@ class DecodeEngine:
         a.off_attn, a.off_proj, a.off_fc, a.off_mproj = plan["offs"]
         a.layer_bytes, a.head_bytes = plan["layer_bytes"], head.stream_bytes
         a.w_head = head.desc.w
+        u8_arena = u8_head = None
+        if plan.get("u8"):
+            # 8-bit levels as their own arena (the bf16 arena stays what the launch-per-operator path and the prompt pass stream)
+            with torch.cuda.device(dev):
+                per_layer = []
+                for blk in model.transformer.h:
+                    per_layer.append(torch.cat([u8_stream([blk.attn.c_attn.quant_weight]), u8_stream([blk.attn.c_proj.quant_weight]),
+                                                u8_stream([blk.mlp.c_fc1.quant_weight, blk.mlp.c_fc2.quant_weight]),
+                                                u8_stream([blk.mlp.c_proj.quant_weight])]))
+                u8_arena = torch.stack(per_layer).contiguous()
+                u8_head = u8_stream([model.lm_head.quant_weight])
+                sz = torch.empty((cfg.n_layer, 10 * C_ + 4 * H), dtype=torch.bfloat16, device=dev)
+                for i, blk in enumerate(model.transformer.h):
+                    parts = []
+                    for mod in (blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc1, blk.mlp.c_fc2, blk.mlp.c_proj):
+                        parts += [mod.scales.reshape(-1), mod.zeros.reshape(-1)]
+                    sz[i].copy_(torch.cat(parts))
+                sz_head = torch.cat([model.lm_head.scales.reshape(-1), model.lm_head.zeros.reshape(-1)]).contiguous()
+            lb = u8_arena.shape[1]
+            assert lb == 3 * C_ * C_ + C_ * C_ + 2 * H * C_ + C_ * H and lb < 1 << 31
+            a.w, a.layer_stride, a.layer_bytes = ptr(u8_arena), lb, lb
+            a.off_attn, a.off_proj, a.off_fc, a.off_mproj = 0, 3 * C_ * C_, 4 * C_ * C_, 4 * C_ * C_ + 2 * H * C_
+            a.w_head, a.head_bytes = ptr(u8_head), u8_head.numel()
+            fmt = 6
         a.sz, a.sz_head, a.norms = ptr(sz), ptr(sz_head), ptr(norms)
         a.weight_fmt = fmt
         # (round 6: group tables too — csrc/fused_step_ring.hip FS_RUN_FG: three MFMA columns per group, at most 15 groups per streamer wave)
@@ -480,7 +538,7 @@ class DecodeEngine:
         a.n_hidden, a.vocab, a.eps = H, V, self.m.eps
         self.fused = a
         self._fused_top_fmt = int(a.weight_fmt)
-        self._fused_keep = [sz, sz_head, norms, ws, gt, gt_head]
+        self._fused_keep = [sz, sz_head, norms, ws, gt, gt_head, u8_arena, u8_head]
         self._fused_ws = ws
         self._fused_warm = False
         self.fused_clipped = 0  # activation pairs clipped by the persistent step so far (check_status)
@@ -520,7 +578,7 @@ class DecodeEngine:
             with torch.cuda.stream(self.stream):
                 self._fused_ws[256:].zero_()
         return {3: "fp8-limb operands (weight_fmt 3)", 0: "fp16 operands (weight_fmt 0)", 5: "fp8-limb operands (weight_fmt 5)",
-                4: "fp16 operands (weight_fmt 4)"}.get(fmt, f"weight_fmt {fmt}")
+                4: "fp16 operands (weight_fmt 4)", 6: "8-bit levels through fp8-limb operands (weight_fmt 6)"}.get(fmt, f"weight_fmt {fmt}")
 
     def _demote_fused(self, why: str, bad: Optional[int] = None) -> str:
         """The persistent step met a position its hand-off format is too narrow for — E4M3 limbs clip at +-448 x the edge's

@@ -97,6 +97,27 @@ def i8_to_stream(cb: np.ndarray, R: int) -> np.ndarray:
     return out.reshape(-1).view(np.uint8)
 
 
+def u8_to_stream(q: np.ndarray, R: int) -> np.ndarray:
+    """uint8 levels [R][N, K] of 8-bit ColBlock linears (R = 2: the c_fc1 / c_fc2 pair) -> the stream of mi355_fused_step's weight_fmt 6:
+    [tile][unit][r][piece e][lane = 16 g + row][16 B], byte b = column 128 u + 32 g + 16 e + 8 (b >> 3) + (0 4 1 5 2 6 3 7)[b & 7] — the
+    two pieces of a unit give `v & 0x0F0F0F0F` (low nibbles) and `(v >> 4) & 0x0F0F0F0F` (high nibbles) as the 32 A bytes of lane (g, row)
+    in the octet order of the limb planes (f8_planes below): y = sum_k (l_k + 16 h_k) x_k from two scaled MFMAs against ONE B operand."""
+    q = np.asarray(q, dtype=np.uint8).reshape(R, *q.shape[-2:])
+    _, N, K = q.shape
+    assert N % 16 == 0 and K % 128 == 0
+    perm = (0, 4, 1, 5, 2, 6, 3, 7)
+    out = np.zeros((N // 16, K // 128, R, 2, 64, 16), dtype=np.uint8)
+    lane = np.arange(64)
+    g, row = lane >> 4, lane & 15
+    for t in range(N // 16):
+        for u in range(K // 128):
+            for r in range(R):
+                for e in range(2):
+                    for b in range(16):
+                        out[t, u, r, e, :, b] = q[r, 16 * t + row, 128 * u + 32 * g + 16 * e + 8 * (b >> 3) + perm[b & 7]]
+    return out.reshape(-1)
+
+
 # ---- hand-off format of the persistent int4 step with fp8 operands (csrc/fused_step_ring.hip FMT 3, mi355_fused_step_args.weight_fmt = 3)
 def e4m3_decode(code: np.ndarray) -> np.ndarray:
     """OCP E4M3 (bias 7, subnormals m * 2^-9, no infinities; 0x7F / 0xFF = NaN) -> float64."""

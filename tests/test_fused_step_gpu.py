@@ -570,8 +570,12 @@ def test_bf16_fused_step_matches_launch_per_operator_engine_and_oracle(dev):
     assert err <= 0.05 * std, f"bf16 fused 7B-width logits off the oracle by {err:.4f} (std {std:.3f})"
 
 
-def test_gptq_int8_model_streams_as_bf16_on_the_persistent_step(dev):
-    """`--quantize gptq.int8` at the 7B width (round 5): the reference dequantises an 8-bit ColBlockQuantizedLinear into a matrix of the
+@pytest.mark.parametrize("u8", [1, 0])
+def test_gptq_int8_model_on_the_persistent_step(dev, monkeypatch, u8):
+    """`--quantize gptq.int8` at the 7B width.  Round 6 (u8 = 1, the default): the persistent step streams the 8-bit levels themselves
+    (weight_fmt 6: a byte is two int4 levels, low and high nibbles of a unit's two pieces as two scaled fp8 MFMAs against one operand;
+    y = scale (acc - zero S) in f32 — not the reference's bf16-rounded weights bit for bit, inside the same bars).  Round 5 (u8 = 0,
+    MI355_FUSED_U8=0; also what the launch-per-operator path and the prompt pass stream): the reference dequantises an 8-bit ColBlockQuantizedLinear into a matrix of the
     input's dtype on EVERY forward call and runs a dense linear on it (lit_llama/quantization.py:413-423); the engine builds that bf16
     matrix once (engine._dense_weight — the same values bit for bit: q - zero exact, one rounding of the product with the scale) and
     streams it through the BF16 instantiation of the persistent step.  Checked: the weights the engine streams == the module's own
@@ -589,8 +593,9 @@ def test_gptq_int8_model_streams_as_bf16_on_the_persistent_step(dev):
     w_ref = oracle.colblock_get_weight(sd["transformer.h.1.mlp.c_proj.quant_weight"], sd["transformer.h.1.mlp.c_proj.scales"],
                                        sd["transformer.h.1.mlp.c_proj.zeros"], 8, lin.tile_cols)
     assert torch.equal(lin.get_weight(torch.bfloat16).float().cpu(), w_ref.to(torch.bfloat16).float())
+    monkeypatch.setenv("MI355_FUSED_U8", str(u8))
     eng = need_fused(model)
-    assert eng.fused.weight_fmt == 1
+    assert eng.fused.weight_fmt == (6 if u8 else 1) and eng._full_rungs == [6 if u8 else 1, None]
     prompt = synth.make_prompt(20).to(dev)
     outs, logits = {}, {}
     for fused in (False, True):
@@ -598,8 +603,10 @@ def test_gptq_int8_model_streams_as_bf16_on_the_persistent_step(dev):
         model.reset_cache()
         outs[fused] = lit_llama_amd.generate(model, prompt, 16, top_k=1, max_seq_length=64).cpu()
         logits[fused] = teacher_forced(model, outs[False].to(dev), 20, 64, dev)
-        eng.check_status()
+        assert eng.check_status() is None and not eng.fused_demotions
     eng.fused_enabled = True
+    print(f"gptq.int8 persistent step (weight_fmt {int(eng.fused.weight_fmt)}) vs launch path: "
+          f"{(logits[True] - logits[False]).abs().max().item() / float(logits[False].std(-1).mean()):.4f} std")
     std = float(logits[False].std(-1).mean())
     err = (logits[True] - logits[False]).abs().max().item()
     assert err <= 0.03 * std, f"gptq.int8 fused vs unfused logits: {err:.4f} (std {std:.3f})"
@@ -613,7 +620,7 @@ def test_gptq_int8_model_streams_as_bf16_on_the_persistent_step(dev):
     eng.check_status()
     std = float(ref.std(-1).mean())
     err = (got - ref).abs().max().item()
-    print(f"gptq.int8 on BF16 streams, 2 blocks at the 7B width vs the f32 oracle: {err / std:.4f} std")
+    print(f"gptq.int8 (weight_fmt {int(eng.fused.weight_fmt)}), 2 blocks at the 7B width vs the f32 oracle: {err / std:.4f} std")
     assert err <= 0.05 * std, f"gptq.int8 7B-width logits off the oracle by {err:.4f} (std {std:.3f})"
 
 

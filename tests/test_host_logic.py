@@ -479,6 +479,45 @@ def test_fp8_operand_linear_arithmetic_statement():
         assert e8 < 2e-3
 
 
+def test_u8_stream_layout_and_arithmetic_statement():
+    """weight_fmt 6 (round 6, `gptq.int8` on the persistent step): (1) engine.u8_stream == the layout statement tests/layouts.py
+    u8_to_stream, single matrix and c_fc1 / c_fc2 pair; (2) the arithmetic of csrc/fused_step_ring.hip FS_RUN_U stated in numpy THROUGH
+    the stream and the limb planes: for lane (g, row) the low nibbles of a unit's two pieces (E4M3 codes x 2^9) and the high nibbles
+    (x 2^13) against the 32 plane bytes of the lane, summed over lanes, units and the three limb columns = sum_k q_k x_k up to the limb
+    rounding; y = scale (acc - zero S) against the exact (q - zero) scale x."""
+    import layouts
+    from lit_llama_amd.engine import u8_stream
+
+    rng = np.random.default_rng(11)
+    N, K = 32, 512
+    q = rng.integers(0, 256, size=(2, N, K)).astype(np.uint8)
+    assert np.array_equal(u8_stream([torch.from_numpy(q[0])]).numpy(), layouts.u8_to_stream(q[0], 1))
+    assert np.array_equal(u8_stream([torch.from_numpy(q[0]), torch.from_numpy(q[1])]).numpy(), layouts.u8_to_stream(q, 2))
+    x = rng.standard_normal(K)
+    x[rng.integers(0, K, size=3)] *= 25.0
+    zero = rng.integers(100, 156, size=N).astype(np.float64) + 0.5
+    scale = 0.002 * (1.0 + 0.1 * rng.random(N))
+    _, planes = layouts.f8_planes(x)                                   # uint8 [3, K] in the staged byte order
+    b_val = np.stack([layouts.e4m3_decode(planes[c]) * 2.0 ** (-4 * c) for c in range(3)])  # [3, K] values by plane position
+    st = layouts.u8_to_stream(q[0], 1).reshape(N // 16, K // 128, 2, 64, 16)
+    acc = np.zeros(N)
+    s_ones = 0.0
+    for u in range(K // 128):
+        for g in range(4):
+            pb = b_val[:, u * 128 + g * 32: u * 128 + g * 32 + 32].sum(0)   # the lane group's 32 operand bytes, limb columns added up
+            if True:
+                s_ones += pb.sum()
+            for t in range(N // 16):
+                for row in range(16):
+                    v = np.concatenate([st[t, u, 0, 16 * g + row], st[t, u, 1, 16 * g + row]])  # pieces e = 0, 1: 32 bytes
+                    lo = layouts.e4m3_decode(v & 0x0F) * 2.0 ** 9
+                    hi = layouts.e4m3_decode(v >> 4) * 2.0 ** 13
+                    acc[16 * t + row] += (lo * pb).sum() + (hi * pb).sum()
+    y = scale * (acc - zero * s_ones)
+    exact = scale * ((q[0].astype(np.float64) - zero[:, None]) @ x)
+    assert np.abs(y - exact).max() <= 2e-3 * np.abs(exact).mean(), np.abs(y - exact).max() / np.abs(exact).mean()
+
+
 def test_fp16_centred_operand_statement_and_massive_activations():
     """The fp16-operand rung of the persistent step (csrc/fused_step_ring.hip FMT 0, `nib2f16` + `nib_center`) stated in numpy, bit for bit:
     (w & 0x000F000F) | 0x64006400 is the fp16 pair (1024 + q_a, 1024 + q_b), (w & 0x00F000F0) | 0x64006400 the pair (1024 + 16 q, ...); one packed
