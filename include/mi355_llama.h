@@ -71,6 +71,12 @@ int mi355_q4_repack(const uint8_t* q0, const uint8_t* q1, int64_t stride_n, int6
 int mi355_bf16_repack(const void* w0, const void* w1, int dtype, int N, int K, int R, void* out,
                       mi355_stream_t stream);
 
+/* Repack the uint8 levels of an 8-bit ColBlockQuantizedLinear (quant_weight of lit_llama/quantization.py:340-423 with bits = 8: level (n, k)
+ * at q + n * stride_n + k * stride_k; the reference stores it with stride_n = 1, stride_k = N) into the stream mi355_fused_step reads with
+ * weight_fmt 6 (N x K bytes; N % 16 == 0, K % 128 == 0).  q1 != NULL: the c_fc1 / c_fc2 pair, R must be 2; else R = 1. */
+int mi355_u8_repack(const uint8_t* q0, const uint8_t* q1, int64_t stride_n, int64_t stride_k, int N, int K, int R, uint8_t* out,
+                    mi355_stream_t stream);
+
 /* Repack a row-major int8 [N, K] matrix (Linear8bitLt weight.CB, lit_llama/quantization.py:75-77). */
 int mi355_i8_repack(const int8_t* cb0, const int8_t* cb1, int N, int K, int R, int8_t* out,
                     mi355_stream_t stream);
@@ -553,7 +559,7 @@ typedef struct mi355_fused_step_args {
      * (lit_llama/quantization.py:340-423 with bits = 8, one (scale, zero) pair per row: `sz` / `sz_head` as for 0) at the 7B shape, streamed as they
      * are: `w` / `w_head` hold, per linear, [tile of 16 rows][unit of 128 columns][r][piece e = 0, 1][lane = 16 g + row][16 bytes] with byte b of
      * lane (g, row) of piece e = the level of column 128 u + 32 g + 16 e + 8 (b >> 3) + (0 4 1 5 2 6 3 7)[b & 7] (r = 0, 1: c_fc1, c_fc2 of the pair
-     * stream; a linear takes N x K bytes).  A byte is two int4 levels: the low nibbles of a unit's two pieces are one fp8 A operand (block scale
+     * stream; a linear takes N x K bytes; mi355_u8_repack builds it).  A byte is two int4 levels: the low nibbles of a unit's two pieces are one fp8 A operand (block scale
      * 2^9), the high nibbles another (2^13), both against the unit's three E4M3 limb planes; y = scale (acc - zero S) in f32.  Hand-offs,
      * tags, workspace rule and n_hidden limit of 3. */
     int32_t weight_fmt;

@@ -147,6 +147,7 @@ PROTOTYPES = {
     "mi355_q4_repack": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mi355_bf16_repack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mi355_i8_repack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mi355_u8_repack": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mi355_linear_fast": (c_int, [C.POINTER(LinearArgs), c_void_p]),
     "mi355_linear_gemm_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mi355_linear_gemm": (c_int, [C.POINTER(LinearArgs), c_void_p, c_size_t, c_void_p]),

@@ -879,6 +879,36 @@ __global__ void bf16_repack_kernel(const void* w0, const void* w1, int dtype, in
     }
 }
 
+// 8-bit ColBlock levels -> the stream of mi355_fused_step's weight_fmt 6: one thread per 16 B of lane (g, row) of piece e; byte b =
+// column 128 u + 32 g + 16 e + 8 (b >> 3) + (0 4 1 5 2 6 3 7)[b & 7] (the octet order of the fp8 step's limb planes)
+__global__ void u8_repack_kernel(const uint8_t* q0, const uint8_t* q1, int64_t stride_n, int64_t stride_k, int N, int K, int R, u32x4* out,
+                                 int64_t n_pieces) {
+    const int units = K / kUnitK;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pieces; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const int e = (int)((i >> 6) & 1);
+        int64_t rest = i >> 7;
+        const int r = (int)(rest % R);
+        rest /= R;
+        const int u = (int)(rest % units);
+        const int tile = (int)(rest / units);
+        const int g = lane >> 4, row = lane & 15;
+        const uint8_t* src = (q1 != nullptr && r == 1) ? q1 : q0;
+        const int n = q1 != nullptr ? tile * 16 + row : (tile * R + r) * 16 + row;
+        const int k0 = kUnitK * u + 32 * g + 16 * e;
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (n < N) {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const int j = b & 7;
+                const int k = k0 + 8 * (b >> 3) + (j >> 1) + 4 * (j & 1);  // (0 4 1 5 2 6 3 7)[j]
+                o[b >> 2] |= (uint32_t)src[(int64_t)n * stride_n + (int64_t)k * stride_k] << (8 * (b & 3));
+            }
+        }
+        out[i] = o;
+    }
+}
+
 // one thread per 16-B piece of 16 int8
 __global__ void i8_repack_kernel(const int8_t* c0, const int8_t* c1, int N, int K, int R, u32x4* out,
                                  int64_t n_pieces) {
@@ -1090,6 +1120,18 @@ extern "C" int mi355_i8_repack(const int8_t* cb0, const int8_t* cb1, int N, int 
     const int64_t n_pieces = padded_rows(N, R, cb1 != nullptr) * padded_cols(K) / 16;
     hipLaunchKernelGGL(i8_repack_kernel, dim3(repack_grid(n_pieces)), dim3(256), 0, (hipStream_t)stream, cb0, cb1, N,
                        K, R, (u32x4*)out, n_pieces);
+    MI355_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi355_u8_repack(const uint8_t* q0, const uint8_t* q1, int64_t stride_n, int64_t stride_k, int N, int K, int R, uint8_t* out,
+                               mi355_stream_t stream) {
+    MI355_CHECK_ARG(q0 && out, MI355_E_ARG, "u8_repack: null pointer");
+    MI355_CHECK_ARG(N > 0 && K > 0 && N % 16 == 0 && K % kUnitK == 0 && (R == 1 || (R == 2 && q1 != nullptr)) && (q1 == nullptr || R == 2),
+                    MI355_E_SHAPE, "u8_repack: N %d must be a multiple of 16, K %d of 128, R %d in {1, 2} (2: a pair q0 / q1)", N, K, R);
+    const int64_t n_pieces = (int64_t)N * (q1 != nullptr ? 2 : 1) * K / 16;
+    hipLaunchKernelGGL(u8_repack_kernel, dim3(repack_grid(n_pieces)), dim3(256), 0, (hipStream_t)stream, q0, q1, stride_n, stride_k, N, K, R,
+                       (u32x4*)out, n_pieces);
     MI355_LAUNCH_CHECK();
     return 0;
 }

@@ -499,11 +499,11 @@ class DecodeEngine:
             with torch.cuda.device(dev):
                 per_layer = []
                 for blk in model.transformer.h:
-                    per_layer.append(torch.cat([u8_stream([blk.attn.c_attn.quant_weight]), u8_stream([blk.attn.c_proj.quant_weight]),
-                                                u8_stream([blk.mlp.c_fc1.quant_weight, blk.mlp.c_fc2.quant_weight]),
-                                                u8_stream([blk.mlp.c_proj.quant_weight])]))
+                    per_layer.append(torch.cat([ops.repack_u8(blk.attn.c_attn.quant_weight), ops.repack_u8(blk.attn.c_proj.quant_weight),
+                                                ops.repack_u8(blk.mlp.c_fc1.quant_weight, blk.mlp.c_fc2.quant_weight),
+                                                ops.repack_u8(blk.mlp.c_proj.quant_weight)]))
                 u8_arena = torch.stack(per_layer).contiguous()
-                u8_head = u8_stream([model.lm_head.quant_weight])
+                u8_head = ops.repack_u8(model.lm_head.quant_weight)  # (`u8_stream` above states the same layout in torch: tests/test_host_logic.py)
                 sz = torch.empty((cfg.n_layer, 10 * C_ + 4 * H), dtype=torch.bfloat16, device=dev)
                 for i, blk in enumerate(model.transformer.h):
                     parts = []

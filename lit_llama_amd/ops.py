@@ -106,6 +106,23 @@ def repack_i8(c0: torch.Tensor, c1: Optional[torch.Tensor], R: int, out: Optiona
     return out
 
 
+def repack_u8(q0: torch.Tensor, q1: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 levels [N, K] of an 8-bit ColBlockQuantizedLinear (any strides: the reference keeps quant_weight column-major) -> the stream
+    of mi355_fused_step's weight_fmt 6 (include/mi355_llama.h mi355_u8_repack); q1: the c_fc2 half of the c_fc1 / c_fc2 pair."""
+    N, K = q0.shape
+    if q0.dtype != torch.uint8 or q0.device.type != "cuda" or (q1 is not None and (q1.shape != q0.shape or q1.dtype != torch.uint8
+                                                                                     or q1.stride() != q0.stride() or q1.device != q0.device)):
+        raise nat.NativeError("repack_u8: uint8 CUDA matrices of one shape and one stride pattern")
+    nbytes = N * K * (2 if q1 is not None else 1)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=q0.device)
+    elif out.dtype != torch.uint8 or out.numel() != nbytes or not out.is_contiguous() or out.device != q0.device:
+        raise nat.NativeError(f"repack_u8: `out` must be a contiguous uint8 tensor of {nbytes} bytes on {q0.device}")
+    check(lib().mi355_u8_repack(ptr(q0), ptr(q1), q0.stride(0), q0.stride(1), N, K, 2 if q1 is not None else 1, ptr(out), stream_ptr()),
+          "mi355_u8_repack")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ linears
 def linear_fast(
     x2d: torch.Tensor,

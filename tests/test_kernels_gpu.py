@@ -63,6 +63,28 @@ def test_bf16_and_i8_repack_layouts(dev):
         assert np.array_equal(s, layouts.i8_to_stream(cb.numpy(), R))
 
 
+def test_u8_repack_layout_of_the_8_bit_colblock_stream(dev):
+    """mi355_u8_repack (weight_fmt 6 of mi355_fused_step) == tests/layouts.py u8_to_stream == lit_llama_amd.engine.u8_stream, from the
+    reference's column-major quant_weight (lit_llama/quantization.py:350-359: `.t().contiguous().t()`) and from a row-major matrix, single and
+    as the c_fc1 / c_fc2 pair; shapes the stream cannot hold are refused."""
+    from lit_llama_amd import _native as nat
+    from lit_llama_amd.engine import u8_stream
+
+    gen = torch.Generator().manual_seed(9)
+    q = torch.randint(0, 256, (2, 48, 384), generator=gen, dtype=torch.uint8)
+    want1, want2 = layouts.u8_to_stream(q[0].numpy(), 1), layouts.u8_to_stream(q.numpy(), 2)
+    for colmajor in (True, False):
+        a, b = (t.to(dev).t().contiguous().t() if colmajor else t.to(dev).contiguous() for t in (q[0], q[1]))
+        assert a.stride() == ((1, 48) if colmajor else (384, 1))
+        assert np.array_equal(ops.repack_u8(a).cpu().numpy(), want1)
+        assert np.array_equal(ops.repack_u8(a, b).cpu().numpy(), want2)
+    assert np.array_equal(u8_stream([q[0].to(dev), q[1].to(dev)]).cpu().numpy(), want2)
+    with pytest.raises(nat.NativeError):
+        ops.repack_u8(torch.zeros((40, 384), dtype=torch.uint8, device=dev))
+    with pytest.raises(nat.NativeError):
+        ops.repack_u8(torch.zeros((48, 200), dtype=torch.uint8, device=dev))
+
+
 # ---------------------------------------------------------------------------------------------- int4 fast linear
 def _q4_problem(N, K, M, seed, dev, x_scale=1.0):
     gen = torch.Generator().manual_seed(seed)
