@@ -36,6 +36,9 @@ constexpr int kBM = 128;     // tokens per block
 #define MI355_GEMM_TPW 2
 #endif
 constexpr int kTPW = MI355_GEMM_TPW;
+#ifndef MI355_GEMM_XDMA
+#define MI355_GEMM_XDMA 1
+#endif
 #ifndef MI355_GEMM_PIN_LOADS
 #define MI355_GEMM_PIN_LOADS 1
 #endif
@@ -383,8 +386,26 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
             dst[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rw : rw0, lane_off, ok ? off + d * 1024u : 0u, 0));
     };
     // activation block of unit u: 2048 chunks of 16 B, kXChunks per thread; chunk = (token, 16-B column)
-    u32x4 stage[kXChunks];
+    // Round 6: the activation block of the NEXT unit goes global -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane: one instruction
+    // fills 1 KiB = four token rows of the buffer; the XOR swizzle is applied on the SOURCE side — LDS slot c of token t takes column
+    // c ^ swz(t)), requested at the unit's start.  The staged version held the block in 32 registers per thread, which hipcc could only
+    // afford by sinking the requests to the unit's END, right in front of the LDS stores that wait for them: every unit paid the memory
+    // latency in front of its barrier (rocprofv3 --pmc: SQ_WAIT_ANY 0.53 of the wave cycles, 0.28 issue stalls, 0.19 active;
+    // profiles/r06_prefill_gemm_ab.txt).
+    constexpr bool kXDma = MI355_GEMM_XDMA != 0 && GRP == 0;
+    [[maybe_unused]] auto xdma = [&](int u, int buf) {
+#pragma unroll
+        for (int i = 0; i < kXChunks; ++i) {
+            const int ch = i * kThreads + threadIdx.x;   // = LDS chunk: consecutive lanes, consecutive 16 B
+            const int tok = ch >> 4, slot = ch & 15;
+            const unsigned off = (unsigned)(((int64_t)(m0 + tok) * p.ldxb) * 2) + (unsigned)u * 256u + (unsigned)((slot ^ swz(tok)) * 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(smem + buf * (BM * 256) + (i * kThreads + wave * 64) * 16),
+                                                     16, (m0 + tok) < p.M ? off : 0xFFFFFFF0u, 0, 0, 0);
+        }
+    };
+    u32x4 stage[kXDma ? 1 : kXChunks];
     auto xload = [&](int u) {
+        if constexpr (kXDma) return;
 #pragma unroll
         for (int i = 0; i < kXChunks; ++i) {
             const int ch = i * kThreads + threadIdx.x;
@@ -395,6 +416,7 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
         }
     };
     auto xstore = [&](int buf) {
+        if constexpr (kXDma) return;
 #pragma unroll
         for (int i = 0; i < kXChunks; ++i) {
             const int ch = i * kThreads + threadIdx.x;
@@ -412,6 +434,7 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
     u32x4 wcur[kTPW][kWP], wnext[kTPW][kWP];
 #pragma unroll
     for (int t = 0; t < kTPW; ++t) wload(t, u_lo, wcur[t]);
+    if constexpr (kXDma) xdma(u_lo, u_lo & 1);
     xload(u_lo);
     if constexpr (FUSE) {
         if (p.f_in) {
@@ -489,6 +512,14 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
             return;
         }
 #endif
+        if constexpr (kXDma) {
+            // (weights first: HBM latency; both pinned at the unit's start — they cost 8 registers now, not 40)
+#pragma unroll
+            for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
+            xdma(u + 1, (u & 1) ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         xload(u + 1);
 #pragma unroll
         for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
