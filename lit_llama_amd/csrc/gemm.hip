@@ -39,6 +39,11 @@ constexpr int kTPW = MI355_GEMM_TPW;
 #ifndef MI355_GEMM_XDMA
 #define MI355_GEMM_XDMA 1
 #endif
+#ifndef MI355_GEMM_BPIPE
+#define MI355_GEMM_BPIPE 4   // 128-token blocks: B fragments requested this many LDS reads ahead of the MFMAs that take them (0: hipcc's
+                             // order, which waits for every pair of reads right behind their issue); 2 / 3 / 4: -1.4 / -1.9 / -2.0 % per 2048-token
+                             // prompt (profiles/r06_prefill_gemm_ab.txt); 124-127 VGPRs at 4, still two workgroups per CU
+#endif
 #ifndef MI355_GEMM_PIN_LOADS
 #define MI355_GEMM_PIN_LOADS 1
 #endif
@@ -537,9 +542,17 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
     asm volatile("" : "+s"(cmask));
     asm volatile("" : "+v"(cmagic));
 #endif
+    constexpr int kBPipe = (GRP == 0 && FMT == MI355_W_Q4 && BM == 128) ? MI355_GEMM_BPIPE : 0;
+    auto bread = [&](const char* xs, int d, int tt, bool mine) {
+        const int tok = tt * 16 + c;
+        u32x4 braw = *(const u32x4*)(xs + tok * 256 + (((4 * g + d) ^ swz(tok)) << 4));
+        if constexpr (GRP == 2) braw = mine ? braw : u32x4{0u, 0u, 0u, 0u};
+        return braw;
+    };
     auto mfmas = [&](int buf, int sub, int sub_shift) {
         const char* xs = smem + buf * (BM * 256);
         const bool mine = GRP != 2 || (g >> sub_shift) == sub;
+        [[maybe_unused]] u32x4 bq[kBPipe > 0 ? kBPipe : 1];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             // int4 -> bf16 MFMA A fragments of k-quarter d: (w >> 4i) & 0x000F000F | 0x43004300 = (128 + q_2i, 128 + q_2i+1)
@@ -568,14 +581,31 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
                     a[t] = __builtin_bit_cast(bf16x8, f);
                 }
             }
+            if constexpr (kBPipe > 0) {
+                // fragment s = d * kTT + tt of the unit; bq holds the next kBPipe of them.  The group barriers pin "one LDS read (of
+                // fragment s + kBPipe), then the MFMAs of fragment s": without them hipcc sinks every read to its use again
 #pragma unroll
-            for (int tt = 0; tt < kTT; ++tt) {
-                const int tok = tt * 16 + c;
-                u32x4 braw = *(const u32x4*)(xs + tok * 256 + (((4 * g + d) ^ swz(tok)) << 4));
-                if constexpr (GRP == 2) braw = mine ? braw : u32x4{0u, 0u, 0u, 0u};
-                const bf16x8 b = __builtin_bit_cast(bf16x8, braw);
+                for (int tt = 0; tt < kTT; ++tt) {
+                    const int s = d * kTT + tt;
+                    if (s == 0) {
 #pragma unroll
-                for (int t = 0; t < kTPW; ++t) acc[t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[t][tt], 0, 0, 0);
+                        for (int q = 0; q < kBPipe; ++q) bq[q] = bread(xs, q / kTT, q % kTT, mine);
+                        __builtin_amdgcn_sched_group_barrier(0x100, kBPipe, 0);  // the unit's first kBPipe reads up front
+                    }
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, bq[s % kBPipe]);
+                    if (s + kBPipe < 4 * kTT) bq[s % kBPipe] = bread(xs, (s + kBPipe) / kTT, (s + kBPipe) % kTT, mine);
+#pragma unroll
+                    for (int t = 0; t < kTPW; ++t) acc[t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[t][tt], 0, 0, 0);
+                    if (s + kBPipe < 4 * kTT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, kTPW, 0);
+                }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < kTT; ++tt) {
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, bread(xs, d, tt, mine));
+#pragma unroll
+                    for (int t = 0; t < kTPW; ++t) acc[t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[t][tt], 0, 0, 0);
+                }
             }
         }
     };
