@@ -19,6 +19,37 @@ from . import ops
 from ._native import BF16, F32, W_BF16, W_I8, W_Q4, Layer, Model, Weight, check, dtype_code, lib, ptr
 
 
+
+class _UncachedBytes:
+    """Device bytes from `mi355_tp_buffer_alloc` (hipDeviceMallocUncached), seen by torch through the CUDA array interface."""
+
+    def __init__(self, nbytes: int):
+        buf = C.c_void_p()
+        check(lib().mi355_tp_buffer_alloc(nbytes, C.byref(buf)), "mi355_tp_buffer_alloc")
+        self.ptr, self.nbytes = buf.value, nbytes
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
+
+    def __del__(self):
+        try:
+            lib().mi355_tp_buffer_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def _handoff_workspace(nbytes: int, dev) -> torch.Tensor:
+    """The persistent step's hand-off workspace, zeroed, in UNCACHED device memory: the all-gathers of the step run over it 3-7 %
+    faster than over a plain allocation in the microbenchmark (profiles/r06_allgather_scalar_publish_microbench.txt) and the 7B
+    int4 step 870-874 -> 860-863 us (profiles/r06_ab4_uncached_workspace.txt).  MI355_FUSED_WS_UNCACHED=0: a torch allocation."""
+    if os.environ.get("MI355_FUSED_WS_UNCACHED", "1") != "0":
+        owner = _UncachedBytes(nbytes)
+        t = torch.as_tensor(owner, device=dev)
+        if t.data_ptr() != owner.ptr:
+            raise RuntimeError("the uncached hand-off workspace was copied instead of wrapped")
+        t._mi355_owner = owner  # keeps the allocation alive as long as the tensor
+        return t
+    return torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+
+
 class EngineUnavailable(RuntimeError):
     pass
 
@@ -487,7 +518,7 @@ class DecodeEngine:
                 norms[2 * i].copy_(blk.rms_1.scale.detach())
                 norms[2 * i + 1].copy_(blk.rms_2.scale.detach())
             norms[2 * cfg.n_layer].copy_(model.transformer.ln_f.scale.detach())
-            ws = torch.zeros(int(lib().mi355_fused_step_workspace_bytes(H)), dtype=torch.uint8, device=dev)
+            ws = _handoff_workspace(int(lib().mi355_fused_step_workspace_bytes(H)), dev)
         a = nat.FusedStepArgs()
         a.w, a.layer_stride = ptr(self.w_arena), plan["layer_bytes"]
         a.off_attn, a.off_proj, a.off_fc, a.off_mproj = plan["offs"]
