@@ -226,9 +226,11 @@ int main(int argc, char** argv) {
     CK(hipMemset(w, 1, w_bytes));
     u64* gran;
     const int uc = argc > 1 ? atoi(argv[1]) : 1;
-    if (uc) CK(hipExtMallocWithFlags((void**)&gran, 8 * 2 * kNGran * 8, hipDeviceMallocUncached));
+    if (uc == 2) CK(hipExtMallocWithFlags((void**)&gran, 8 * 2 * kNGran * 8, hipDeviceMallocFinegrained));
+    else if (uc == 3) CK(hipExtMallocWithFlags((void**)&gran, 8 * 2 * kNGran * 8, hipMallocSignalMemory));
+    else if (uc) CK(hipExtMallocWithFlags((void**)&gran, 8 * 2 * kNGran * 8, hipDeviceMallocUncached));
     else CK(hipMalloc(&gran, 8 * 2 * kNGran * 8));
-    printf("granules in %s memory\n", uc ? "UNCACHED (hipDeviceMallocUncached)" : "plain hipMalloc");
+    printf("granules in %s memory\n", uc == 2 ? "FINE-GRAINED" : uc == 3 ? "SIGNAL" : uc ? "UNCACHED (hipDeviceMallocUncached)" : "plain hipMalloc");
     CK(hipMemset(gran, 0, 8 * 2 * kNGran * 8));
     unsigned* flags;
     CK(hipMalloc(&flags, 16));
