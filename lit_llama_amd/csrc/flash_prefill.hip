@@ -126,20 +126,28 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, n_keys * 256, 0x00020000);
     // tile staging.  K: 1024 chunks of 16 B, four per thread: chunk = (key, 16-B column).  V: one (run of 4 consecutive
     // keys, 16-B column) per thread: 4 loads, transposed in registers.
-    u32x4 ks_[4], vs[4];
+    u32x4 vs[4];
     // a wave covers all 16 runs of the 64-key tile for 4 of the 16 columns: one store instruction of the transposition
     // below then writes 16 different 8-byte slots of the SAME 4 d-rows (2-way bank conflicts at most) with compile-time
     // register indices (the round-2 mapping, 16 columns per instruction, needed a per-lane rotation of the rows: dynamic
     // register selects, ~100 VALU instructions per step)
     const int vrun = threadIdx.x & 15, vcol = (threadIdx.x >> 6) * 4 + ((threadIdx.x >> 4) & 3);
-    auto tload = [&](int kb) {
+    // Round 6: K runs ONE key step ahead of V.  The scores of step kb + 1 are issued in front of the softmax of step kb, so that a
+    // wave's own MFMAs run under its VALU work (round 3-5: scores -> softmax -> weighted values strictly in turn, the matrix pipe 20 %
+    // busy): K tile j lives in K buffer j & 1, V tile j in V buffer j & 1, and step kb stages K(kb + 2) and V(kb + 1).
+    // K tiles go global -> LDS by LDS-DMA (16 B per lane, one instruction fills 1 KiB = four key rows; the XOR swizzle is applied on the
+    // SOURCE side: LDS slot s of key k takes column s ^ (k & 15)): no staging registers (the second set of scores needs them)
+    auto dmaK = [&](int kb) {
+        char* kt = smem + (kb & 1) * kKTile;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int ch = i * kThreadsF + threadIdx.x;
-            const int key = kb * kBK + (ch >> 4);
-            const unsigned off = key < n_keys ? (unsigned)key * 256u + (unsigned)(ch & 15) * 16u : 0xFFFFFFF0u;
-            ks_[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0));
+            const int ch = i * kThreadsF + threadIdx.x;  // = LDS chunk: consecutive lanes, consecutive 16 B
+            const int kl = ch >> 4, key = kb * kBK + kl;
+            const unsigned off = key < n_keys ? (unsigned)key * 256u + (unsigned)(((ch & 15) ^ (kl & 15)) * 16) : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kt + (i * kThreadsF + wave * 64) * 16), 16, off, 0, 0, 0);
         }
+    };
+    auto tloadV = [&](int kb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = kb * kBK + vrun * 4 + r;
@@ -147,54 +155,28 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
             vs[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
         }
     };
-    auto tstore = [&](int buf) {
-        char* kt = smem + buf * (kKTile + kVTile);
-        char* vt = kt + kKTile;
+    auto tstoreV = [&](int buf) {
+        char* vt = smem + 2 * kKTile + buf * kVTile;
+        // run r of 16-key group G sits at k-slots 4 perm[r] .. + 3 of the group (perm = 0, 2, 1, 3): 8 bytes
+        const int G = vrun >> 2, r = vrun & 3;
+        const int pbyte = (G * 16 + 4 * ((r & 1) * 2 + (r >> 1))) * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = i * kThreadsF + threadIdx.x;
-            const int key = ch >> 4, col = ch & 15;
-            *(u32x4*)(kt + key * 256 + ((col ^ (key & 15)) << 4)) = ks_[i];
-        }
-        {
-            // run r of 16-key group G sits at k-slots 4 perm[r] .. + 3 of the group (perm = 0, 2, 1, 3): 8 bytes
-            const int G = vrun >> 2, r = vrun & 3;
-            const int pbyte = (G * 16 + 4 * ((r & 1) * 2 + (r >> 1))) * 2;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int dw = e >> 1;
-                u32x2 o;
-                if (e & 1) {
-                    o[0] = __builtin_amdgcn_perm(vs[1][dw], vs[0][dw], 0x07060302u);
-                    o[1] = __builtin_amdgcn_perm(vs[3][dw], vs[2][dw], 0x07060302u);
-                } else {
-                    o[0] = __builtin_amdgcn_perm(vs[1][dw], vs[0][dw], 0x05040100u);
-                    o[1] = __builtin_amdgcn_perm(vs[3][dw], vs[2][dw], 0x05040100u);
-                }
-                *(u32x2*)(vt + (vcol * 8 + e) * kVtRow + pbyte) = o;
+        for (int e = 0; e < 8; ++e) {
+            const int dw = e >> 1;
+            u32x2 o;
+            if (e & 1) {
+                o[0] = __builtin_amdgcn_perm(vs[1][dw], vs[0][dw], 0x07060302u);
+                o[1] = __builtin_amdgcn_perm(vs[3][dw], vs[2][dw], 0x07060302u);
+            } else {
+                o[0] = __builtin_amdgcn_perm(vs[1][dw], vs[0][dw], 0x05040100u);
+                o[1] = __builtin_amdgcn_perm(vs[3][dw], vs[2][dw], 0x05040100u);
             }
+            *(u32x2*)(vt + (vcol * 8 + e) * kVtRow + pbyte) = o;
         }
     };
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[dt][i] = 0.f;
-    float m_run = -1.0e30f, l_run = 0.f;
-
-    tload(0);
-    tstore(0);
-    __syncthreads();
-    for (int kb = 0; kb < n_kb; ++kb) {
-        const int buf = kb & 1;
-#ifndef FLASH_NO_STAGE
-        tload(kb + 1);  // unconditional (past the last block: offsets beyond n_keys read zeros): no vmcnt drain at a join
-#endif
-        const char* kt = smem + buf * (kKTile + kVTile);
-        const char* vt = kt + kKTile;
-        // ---- S^T[key][q] of the two 32-key tiles: 2 x 8 MFMAs over the 128 dimensions, two independent accumulators
-        f32x16 st[2];
+    // S^T[key][q] of the two 32-key tiles of K buffer `buf`: 2 x 8 MFMAs over the 128 dimensions, two independent accumulators
+    auto scores = [&](int buf, f32x16 (&st)[2]) {
+        const char* kt = smem + buf * kKTile;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -208,6 +190,30 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
                 st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, bq[ks], st[t2], 0, 0, 0);
             }
         }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[dt][i] = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;
+
+    f32x16 st[2], sn[2];  // the scores of this step and of the next one
+    dmaK(0);
+    dmaK(1);
+    tloadV(0);
+    __syncthreads();  // (waits vmcnt(0): both K tiles have landed)
+    scores(0, sn);
+    tstoreV(0);
+    __syncthreads();
+    for (int kb = 0; kb < n_kb; ++kb) {
+        // unconditional (past the last block: offsets beyond n_keys read zeros): no vmcnt drain at a join
+        dmaK(kb + 2);  // into the buffer K(kb) left during step kb - 1; landed at this step's barrier
+        tloadV(kb + 1);
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) st[t2] = sn[t2];
+        const char* vt = smem + 2 * kKTile + (kb & 1) * kVTile;
         // ---- causal mask (only where the step reaches the wave's diagonal: wave-uniform), online softmax over this
         // lane's query in the exp2 domain (32 keys here, the other 32 in lane ^ 32)
         if (kb * kBK + kBK - 1 > q_min) {
@@ -240,6 +246,9 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[dt][i] *= corr;
         }
+        // the NEXT step's scores, in the same basic block as this step's exponentials: hipcc interleaves the two (in front of the mask /
+        // rescale branches the 16 MFMAs stayed a block of their own).  Past the last step: a tile of zeros, never used.
+        scores((kb + 1) & 1, sn);
         float psum = 0.f;
         u32x4 pb[2][2];
 #pragma unroll
@@ -263,9 +272,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
                 acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pfrag, acc[dt], 0, 0, 0);
             }
         }
-#ifndef FLASH_NO_STAGE
-        tstore(buf ^ 1);
-#endif
+        tstoreV((kb + 1) & 1);  // V(kb + 1): V(kb - 1) was read during step kb - 1
         __syncthreads();
     }
     float l = l_run + lane_xor32(l_run);
