@@ -184,6 +184,27 @@ def test_fused_step_is_reproducible_and_modes_agree(dev):
     eng.check_status()
 
 
+def test_hand_off_workspace_is_uncached_memory_and_a_plain_one_gives_the_same_bits(dev, monkeypatch):
+    """Round 6: the granules live in hipDeviceMallocUncached memory wrapped as a torch tensor (engine._handoff_workspace): wrapped, not
+    copied; the host-side status reads / clears work on it; a plain torch allocation (MI355_FUSED_WS_UNCACHED=0) is the same protocol
+    over slower memory — bit-identical logits."""
+    model, _, cfg = build(2, dev, seed=1)
+    eng = need_fused(model)
+    ws = eng._fused_ws
+    assert hasattr(ws, "_mi355_owner") and ws.data_ptr() == ws._mi355_owner.ptr and ws.numel() == ws._mi355_owner.nbytes
+    prompt = synth.make_prompt(9, seed=5).to(dev)
+    a = lit_llama_amd.generate(model, prompt, 20, top_k=1, max_seq_length=40)
+    l1 = teacher_forced(model, a, 9, 40, dev)
+    assert eng.check_status() is None  # (status words read through the wrapped tensor: nothing clipped, nothing timed out)
+    monkeypatch.setenv("MI355_FUSED_WS_UNCACHED", "0")
+    model2, _, _ = build(2, dev, seed=1)
+    eng2 = need_fused(model2)
+    assert not hasattr(eng2._fused_ws, "_mi355_owner")
+    b = lit_llama_amd.generate(model2, prompt, 20, top_k=1, max_seq_length=40)
+    l2 = teacher_forced(model2, a, 9, 40, dev)
+    assert torch.equal(a, b) and torch.equal(l1, l2)
+
+
 def test_fused_step_refuses_positions_outside_the_cache(dev):
     model, _, cfg = build(1, dev)
     eng = need_fused(model)
