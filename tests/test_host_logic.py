@@ -591,3 +591,34 @@ def test_bench_model_weights_are_zero_mean_with_unit_gain():
         w = lin.get_weight(torch.float32)
         if bits == 4:  # rounds 1-4: mean -0.5 scale, std 4.6 scale with scale = 0.48 / sqrt(K)
             assert -0.30 < float(w.mean()) * 512 ** 0.5 < -0.18 and 2.0 < float(w.std()) * 512 ** 0.5 < 2.4
+
+
+def test_int8_row_absmax_from_the_largest_staged_magnitude_statement():
+    """The LLM.int8 persistent step's one-pass path (csrc/fused_step_ring.hip q8_rowmax / q8_fast, round 6): the gatherers keep the
+    largest f16 MAGNITUDE h_max they stage; the streamers take a = |f16(f32(h_max) * rn)| and, when a < 6 (no column past the
+    threshold of bnb's Linear8bitLt, /root/reference lit_llama/quantization.py:38-77 with threshold 6.0), quantise with 127 / a
+    without the absmax pass and its barrier.  Stated here in numpy: (1) f16(f32(h) * rn) is monotonic in |h| for every f16 h and
+    positive f32 rn, so a IS max_i |f16(f32(h_i) * rn)|; (2) the one-pass row equals the two-pass row bit for bit."""
+    rng = np.random.default_rng(7)
+    mags = np.arange(0, 0x7C00, dtype=np.uint16).view(np.float16)  # every finite non-negative f16, ascending
+    for rn in [np.float32(1.0)] + list(rng.uniform(1e-3, 40.0, 12).astype(np.float32)) + [np.float32(2.0 ** -14), np.float32(3.0e4)]:
+        with np.errstate(over="ignore"):
+            r = (mags.astype(np.float32) * rn).astype(np.float16)
+        rf = r.astype(np.float32)
+        assert np.all(rf[1:] >= rf[:-1]), rn  # (inf included: it orders above everything and fails `< 6`)
+    for _ in range(20):
+        h = (rng.standard_normal(4096) * rng.uniform(0.05, 1.5)).astype(np.float16)
+        rn = np.float32(rng.uniform(0.2, 3.0))
+        xh = (h.astype(np.float32) * rn).astype(np.float16)  # pass 1
+        outl = np.abs(xh.astype(np.float32)) >= 6.0
+        amax2 = np.abs(xh[~outl].astype(np.float32)).max() if (~outl).any() else np.float32(0)
+        hmax = np.abs(h.astype(np.float32)).max().astype(np.float16)
+        a = np.abs((hmax.astype(np.float32) * rn).astype(np.float16).astype(np.float32))
+        if outl.any():
+            assert a >= 6.0  # the two-pass path is taken
+            continue
+        assert a < 6.0 and a == amax2
+        inv = np.float32(127.0) / a
+        q1 = np.rint(xh.astype(np.float32) * inv).astype(np.int8)
+        q2 = np.where(outl, 0, np.rint(xh.astype(np.float32) * (np.float32(127.0) / amax2))).astype(np.int8)
+        assert np.array_equal(q1, q2)
