@@ -36,6 +36,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 constexpr int kHs = 128;
 constexpr int kBQ = 128;    // queries per workgroup (4 waves x 32)
 constexpr int kThreadsF = 256;
@@ -111,11 +117,11 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
             const f32x4 r0 = *(const f32x4*)(rrow + d0), r1 = *(const f32x4*)(rrow + d0 + 4);  // (c, s, c, s)
             // the softmax scale and log2(e) ride on q (f32, before the one rounding to bf16): the scores leave the MFMA in
             // the exp2 domain and the 16 scores per lane and tile need no multiply
-            u32x4 o;
-            o[0] = (uint32_t)f32_to_bf16(qs * (a[0] * r0[0] - a[1] * r0[1])) | ((uint32_t)f32_to_bf16(qs * (a[1] * r0[0] + a[0] * r0[1])) << 16);
-            o[1] = (uint32_t)f32_to_bf16(qs * (a[2] * r0[2] - a[3] * r0[3])) | ((uint32_t)f32_to_bf16(qs * (a[3] * r0[2] + a[2] * r0[3])) << 16);
-            o[2] = (uint32_t)f32_to_bf16(qs * (b[0] * r1[0] - b[1] * r1[1])) | ((uint32_t)f32_to_bf16(qs * (b[1] * r1[0] + b[0] * r1[1])) << 16);
-            o[3] = (uint32_t)f32_to_bf16(qs * (b[2] * r1[2] - b[3] * r1[3])) | ((uint32_t)f32_to_bf16(qs * (b[3] * r1[2] + b[2] * r1[3])) << 16);
+            u32x4 o;  // (v_cvt_pk_bf16_f32: the same round-to-nearest-even as f32_to_bf16, one instruction per pair)
+            o[0] = pack_bf16x2(qs * (a[0] * r0[0] - a[1] * r0[1]), qs * (a[1] * r0[0] + a[0] * r0[1]));
+            o[1] = pack_bf16x2(qs * (a[2] * r0[2] - a[3] * r0[3]), qs * (a[3] * r0[2] + a[2] * r0[3]));
+            o[2] = pack_bf16x2(qs * (b[0] * r1[0] - b[1] * r1[1]), qs * (b[1] * r1[0] + b[0] * r1[1]));
+            o[3] = pack_bf16x2(qs * (b[2] * r1[2] - b[3] * r1[3]), qs * (b[3] * r1[2] + b[2] * r1[3]));
             bq[ks] = __builtin_bit_cast(bf16x8, o);
         }
     }
@@ -199,24 +205,23 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
         for (int i = 0; i < 16; ++i) acc[dt][i] = 0.f;
     float m_run = -1.0e30f, l_run = 0.f;
 
-    f32x16 st[2], sn[2];  // the scores of this step and of the next one
+    f32x16 sa[2], sb[2];  // the scores of this step and of the next one, swapping roles (the loop is unrolled by two: no copies)
     dmaK(0);
     dmaK(1);
     tloadV(0);
     __syncthreads();  // (waits vmcnt(0): both K tiles have landed)
-    scores(0, sn);
+    scores(0, sa);
     tstoreV(0);
     __syncthreads();
-    for (int kb = 0; kb < n_kb; ++kb) {
+    auto step = [&](const int kb, f32x16 (&st)[2], f32x16 (&sn)[2]) {
         // unconditional (past the last block: offsets beyond n_keys read zeros): no vmcnt drain at a join
         dmaK(kb + 2);  // into the buffer K(kb) left during step kb - 1; landed at this step's barrier
         tloadV(kb + 1);
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) st[t2] = sn[t2];
         const char* vt = smem + 2 * kKTile + (kb & 1) * kVTile;
         // ---- causal mask (only where the step reaches the wave's diagonal: wave-uniform), online softmax over this
         // lane's query in the exp2 domain (32 keys here, the other 32 in lane ^ 32)
         if (kb * kBK + kBK - 1 > q_min) {
+            asm volatile("" ::: "memory");  // (keeps the mask a branch: if-converted it costs ~110 VALU instructions in EVERY step)
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -225,16 +230,18 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
                     st[t2][i] = key_abs <= q_abs ? st[t2][i] : -1.0e30f;
                 }
         }
-        float m_blk = -1.0e30f;
+        // (v_max3_f32: 16 instructions for the 32 scores; fmaxf() would canonicalise every MFMA result first)
+        float m_blk = max3f(st[0][0], st[0][1], st[0][2]);
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+        for (int i = 3; i < 15; i += 2) m_blk = max3f(m_blk, st[0][i], st[0][i + 1]);
+        m_blk = max3f(m_blk, st[0][15], st[1][0]);
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) m_blk = fmaxf(m_blk, fmaxf(st[t2][i], st[t2][i + 1]));
-        m_blk = fmaxf(m_blk, lane_xor32(m_blk));
+        for (int i = 1; i < 15; i += 2) m_blk = max3f(m_blk, st[1][i], st[1][i + 1]);
+        m_blk = max3f(m_blk, st[1][15], lane_xor32(max3f(m_blk, st[1][15], st[1][15])));
         // Lazy rescale: the running reference maximum m_run of a query moves only when the step's maximum exceeds it by
         // more than 2^8 (exp2 domain) — probabilities then stay below 256, which bf16 and the f32 sums hold easily — and
-        // the 64 accumulator registers (which live in AGPRs: every VALU touch is a v_accvgpr round trip) are rescaled
-        // only in the steps where some query of the wave moves: the first one and a handful after it.
+        // the 64 accumulator registers are rescaled only in the steps where some query of the wave moves: the first one
+        // and a handful after it.
         const bool move = m_blk > m_run + 8.0f;
         if (__any(move)) {
             const float m_new = move ? m_blk : m_run;
@@ -246,34 +253,78 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[dt][i] *= corr;
         }
-        // the NEXT step's scores, in the same basic block as this step's exponentials: hipcc interleaves the two (in front of the mask /
-        // rescale branches the 16 MFMAs stayed a block of their own).  Past the last step: a tile of zeros, never used.
-        scores((kb + 1) & 1, sn);
-        float psum = 0.f;
-        u32x4 pb[2][2];
+        // ---- the block's software pipeline, written out and pinned with sched_barrier (hipcc's own order is fragile: with the loop
+        // unrolled by two it issued the 16 score MFMAs, then all 32 exponentials, then the 16 value MFMAs, every MFMA behind the wait for
+        // its own fragment read).  32 MFMAs in turn: the NEXT step's scores (16: K buffer (kb + 1) & 1), then O^T += V^T P^T (16).  Every
+        // MFMA's LDS fragment is requested kAhead MFMAs earlier (ring of kAhead + 1 registers); under MFMA i runs one piece of VALU work:
+        // a pair of probabilities (subtract, v_exp, packed bf16, sum) under score MFMAs 0..11 and value MFMAs 0..3 — value group sg needs
+        // pairs 4 sg .. 4 sg + 3 only — and the transposition of V(kb + 1) under value MFMAs 4..11.
+        constexpr int kAhead = 2;
+        const char* kt = smem + ((kb + 1) & 1) * kKTile;
+        auto frag = [&](int i) {  // operand A of MFMA i
+            if (i < 16) {
+                const int ks = i >> 1, key = (i & 1) * 32 + c;
+                return *(const bf16x8*)(kt + key * 256 + (((2 * ks + hh) ^ (key & 15)) << 4));
+            }
+            const int sg = (i - 16) >> 2, dt = (i - 16) & 3;
+            return *(const bf16x8*)(vt + (dt * 32 + c) * kVtRow + sg * 32 + hh * 16);
+        };
+        bf16x8 fr[kAhead + 1];
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) fr[i] = frag(i);
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                // masked scores are -1e30: exp2 underflows to exactly 0.  The denominator sums the f32 probabilities, the
-                // numerator their bf16 roundings (v_cvt_pk_bf16_f32): zero-mean relative differences of 2^-9 per key
-                const float p0 = exp2_fast(st[t2][2 * i] - m_run), p1 = exp2_fast(st[t2][2 * i + 1] - m_run);
-                psum += p0 + p1;
-                pb[t2][i >> 2][i & 3] = pack_bf16x2(p0, p1);
+            for (int i = 0; i < 16; ++i) sn[t2][i] = 0.f;
+        float psum = 0.f;
+        u32x4 pb[2][2];
+        auto pair = [&](int pr) {
+            // masked scores are -1e30: exp2 underflows to exactly 0.  The denominator sums the f32 probabilities, the
+            // numerator their bf16 roundings (v_cvt_pk_bf16_f32): zero-mean relative differences of 2^-9 per key
+            const int t2 = pr >> 3, i = pr & 7;
+            const float p0 = exp2_fast(st[t2][2 * i] - m_run), p1 = exp2_fast(st[t2][2 * i + 1] - m_run);
+            psum += p0 + p1;
+            uint32_t w = pack_bf16x2(p0, p1);
+            asm volatile("" : "+v"(psum), "+v"(w));  // (inside its piece: hipcc otherwise keeps all 32 probabilities live to sum them at the end)
+            pb[t2][i >> 2][i & 3] = w;
+        };
+        char* vtn = smem + 2 * kKTile + ((kb + 1) & 1) * kVTile;  // V(kb + 1): V(kb - 1) was read during step kb - 1
+        const int vG = vrun >> 2, vr = vrun & 3;
+        const int pbyte = (vG * 16 + 4 * ((vr & 1) * 2 + (vr >> 1))) * 2;
+        auto vpiece = [&](int e) {  // one 8-byte group of the transposition (tstoreV)
+            const int dw = e >> 1;
+            u32x2 o;
+            if (e & 1) {
+                o[0] = __builtin_amdgcn_perm(vs[1][dw], vs[0][dw], 0x07060302u);
+                o[1] = __builtin_amdgcn_perm(vs[3][dw], vs[2][dw], 0x07060302u);
+            } else {
+                o[0] = __builtin_amdgcn_perm(vs[1][dw], vs[0][dw], 0x05040100u);
+                o[1] = __builtin_amdgcn_perm(vs[3][dw], vs[2][dw], 0x05040100u);
             }
-        l_run += psum;
-        // ---- O^T[d][q] += V^T P^T: four 16-key groups x four 32-dimension tiles
+            *(u32x2*)(vtn + (vcol * 8 + e) * kVtRow + pbyte) = o;
+        };
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-            const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb[sg >> 1][sg & 1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 va = *(const bf16x8*)(vt + (dt * 32 + c) * kVtRow + sg * 32 + hh * 16);
-                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pfrag, acc[dt], 0, 0, 0);
+        for (int i = 0; i < 32; ++i) {
+            if (i + kAhead < 32) fr[(i + kAhead) % (kAhead + 1)] = frag(i + kAhead);
+            if (i < 16) {
+                sn[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % (kAhead + 1)], bq[i >> 1], sn[i & 1], 0, 0, 0);
+                if (i < 12) pair(i);
+            } else {
+                const int sg = (i - 16) >> 2, dt = (i - 16) & 3;
+                const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb[sg >> 1][sg & 1]);
+                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % (kAhead + 1)], pfrag, acc[dt], 0, 0, 0);
+                if (i < 20) pair(i - 4);
+                else if (i < 28) vpiece(i - 20);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        tstoreV((kb + 1) & 1);  // V(kb + 1): V(kb - 1) was read during step kb - 1
+        l_run += psum;
         __syncthreads();
+    };
+    for (int kb = 0; kb < n_kb; kb += 2) {
+        step(kb, sa, sb);
+        if (kb + 1 < n_kb) step(kb + 1, sb, sa);
     }
     float l = l_run + lane_xor32(l_run);
     float osum = 0.f;  // this lane's 64 of the query's 128 outputs, as the bf16 values the consumer multiplies
@@ -284,14 +335,12 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                bf16_t ob[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(acc[dt][4 * gq + r] * inv);
                 u32x2 o;
-                o[0] = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
-                o[1] = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
+                o[0] = pack_bf16x2(acc[dt][4 * gq] * inv, acc[dt][4 * gq + 1] * inv);
+                o[1] = pack_bf16x2(acc[dt][4 * gq + 2] * inv, acc[dt][4 * gq + 3] * inv);
                 *(u32x2*)(yrow + dt * 32 + 8 * gq + 4 * hh) = o;
-                osum += (bf16_to_f32(ob[0]) + bf16_to_f32(ob[1])) + (bf16_to_f32(ob[2]) + bf16_to_f32(ob[3]));
+                osum += (__uint_as_float(o[0] << 16) + __uint_as_float(o[0] & 0xffff0000u)) +
+                        (__uint_as_float(o[1] << 16) + __uint_as_float(o[1] & 0xffff0000u));
             }
     }
     if (p.sx_part != nullptr) {  // (wave-uniform; the other half of the dimensions sits in lane ^ 32)
