@@ -365,9 +365,12 @@ static int fused_segment(const mi355_model* m, int T, int layer, int seg, hipStr
             f.S = m->S;
             f.n_head = m->n_head;
             f.hs = m->hs;
+            // q leaves the epilogue as the attention kernel's operand (rotated, scaled by softmax scale x log2 e, bf16): the kernel's
+            // prologue then reads 8 MB instead of 32 MB of f32 rows + the RoPE table at T = 2048
+            f.q_scale = (1.0f / sqrtf((float)m->hs)) * 1.44269504088896340736f;
             if (int rc = mi355_linear_gemm_fused(&a, &f, m->gemm_ws, (size_t)m->gemm_ws_bytes, s)) return rc;
             fz->have_x = false;
-            return mi355_flash_prefill(m->qkv, MI355_F32, 3 * C, m->rope, 0, m->pos, L.kcache, L.vcache, T, m->n_head, m->S, m->att,
+            return mi355_flash_prefill(m->qkv, MI355_Q_READY, 6 * C, m->rope, 0, m->pos, L.kcache, L.vcache, T, m->n_head, m->S, m->att,
                                        C, 1.0f / sqrtf((float)m->hs), fz->att.sx, s);
         }
         case 1:  // attn.c_proj over the attention output as it is; the residual epilogue emits the operand of c_fc1 / c_fc2

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
     const int jq = idx % p.q_blocks;
     const bool up = (32 % p.q_blocks == 0) && ((idx >> 5) & 1);
     const int qb = up ? jq : p.q_blocks - 1 - jq;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hh = lane >> 5, c = lane & 31;      // lane half (k-slots 8 hh .. + 7 of an operand), column / row 0 .. 31
     const int q_idx = qb * kBQ + wave * 32 + c;  // this lane's query (column of every MFMA result below)
     const bool q_ok = q_idx < p.T;
@@ -103,6 +103,10 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const int d0 = 16 * ks + 8 * hh;
+            if (p.qkv_dtype == MI355_Q_READY) {  // the c_attn epilogue did the rotation, the scale and the rounding (gemm_fuse.h: q_scale)
+                bq[ks] = *(const bf16x8*)((const bf16_t*)p.qkv + qoff + d0);
+                continue;
+            }
             f32x4 a, b;
             if (p.qkv_dtype == MI355_F32) {
                 a = *(const f32x4*)((const float*)p.qkv + qoff + d0);
@@ -143,23 +147,21 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
     // busy): K tile j lives in K buffer j & 1, V tile j in V buffer j & 1, and step kb stages K(kb + 2) and V(kb + 1).
     // K tiles go global -> LDS by LDS-DMA (16 B per lane, one instruction fills 1 KiB = four key rows; the XOR swizzle is applied on the
     // SOURCE side: LDS slot s of key k takes column s ^ (k & 15)): no staging registers (the second set of scores needs them)
+    // (keys past n_keys: the VECTOR offset leaves the descriptor's n_keys x 256 bytes — the loads return zeros, the DMA writes zeros — so a
+    // step's eight requests cost one v_add each: chunk i of the K tile is 16 keys = 4096 B behind chunk 0 with the same swizzle term)
+    const unsigned koff0 = (unsigned)(threadIdx.x >> 4) * 256u + (unsigned)(((threadIdx.x & 15) ^ ((threadIdx.x >> 4) & 15)) * 16);
+    const unsigned voff0 = (unsigned)(vrun * 4) * 256u + (unsigned)vcol * 16u;
     auto dmaK = [&](int kb) {
         char* kt = smem + (kb & 1) * kKTile;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = i * kThreadsF + threadIdx.x;  // = LDS chunk: consecutive lanes, consecutive 16 B
-            const int kl = ch >> 4, key = kb * kBK + kl;
-            const unsigned off = key < n_keys ? (unsigned)key * 256u + (unsigned)(((ch & 15) ^ (kl & 15)) * 16) : 0xFFFFFFF0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kt + (i * kThreadsF + wave * 64) * 16), 16, off, 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)  // LDS chunk i * 256 + thread: consecutive lanes, consecutive 16 B
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kt + (i * kThreadsF + wave * 64) * 16), 16,
+                                                     koff0 + (unsigned)(kb * kBK * 256 + i * 4096), 0, 0, 0);
     };
     auto tloadV = [&](int kb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = kb * kBK + vrun * 4 + r;
-            const unsigned off = key < n_keys ? (unsigned)key * 256u + (unsigned)vcol * 16u : 0xFFFFFFF0u;
-            vs[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0));
-        }
+        for (int r = 0; r < 4; ++r)
+            vs[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, voff0 + (unsigned)(kb * kBK * 256 + r * 256), 0, 0));
     };
     auto tstoreV = [&](int buf) {
         char* vt = smem + 2 * kKTile + buf * kVTile;
@@ -205,6 +207,18 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
         for (int i = 0; i < 16; ++i) acc[dt][i] = 0.f;
     float m_run = -1.0e30f, l_run = 0.f;
 
+    // (v_max3_f32: 16 instructions for the 32 scores of a lane; fmaxf() would canonicalise every MFMA result first)
+    auto smax = [&](const f32x16 (&st)[2]) {
+        float m = max3f(st[0][0], st[0][1], st[0][2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) m = max3f(m, st[0][i], st[0][i + 1]);
+        m = max3f(m, st[0][15], st[1][0]);
+#pragma unroll
+        for (int i = 1; i < 15; i += 2) m = max3f(m, st[1][i], st[1][i + 1]);
+        const float mh = max3f(m, st[1][15], st[1][15]);
+        return max3f(mh, mh, lane_xor32(mh));
+    };
+    float m_blk;  // the maximum of the step's scores: taken under the value MFMAs of the step before (unmasked; a diagonal step takes it again)
     f32x16 sa[2], sb[2];  // the scores of this step and of the next one, swapping roles (the loop is unrolled by two: no copies)
     dmaK(0);
     dmaK(1);
@@ -212,11 +226,13 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
     __syncthreads();  // (waits vmcnt(0): both K tiles have landed)
     scores(0, sa);
     tstoreV(0);
+    m_blk = smax(sa);
     __syncthreads();
     auto step = [&](const int kb, f32x16 (&st)[2], f32x16 (&sn)[2]) {
         // unconditional (past the last block: offsets beyond n_keys read zeros): no vmcnt drain at a join
-        dmaK(kb + 2);  // into the buffer K(kb) left during step kb - 1; landed at this step's barrier
+        // (V first: the transposition then waits for its four loads with the four K requests still in flight — vmcnt retires in order)
         tloadV(kb + 1);
+        dmaK(kb + 2);  // into the buffer K(kb) left during step kb - 1; landed at this step's barrier
         const char* vt = smem + 2 * kKTile + (kb & 1) * kVTile;
         // ---- causal mask (only where the step reaches the wave's diagonal: wave-uniform), online softmax over this
         // lane's query in the exp2 domain (32 keys here, the other 32 in lane ^ 32)
@@ -229,15 +245,8 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
                     const int key_abs = kb * kBK + t2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
                     st[t2][i] = key_abs <= q_abs ? st[t2][i] : -1.0e30f;
                 }
+            m_blk = smax(st);
         }
-        // (v_max3_f32: 16 instructions for the 32 scores; fmaxf() would canonicalise every MFMA result first)
-        float m_blk = max3f(st[0][0], st[0][1], st[0][2]);
-#pragma unroll
-        for (int i = 3; i < 15; i += 2) m_blk = max3f(m_blk, st[0][i], st[0][i + 1]);
-        m_blk = max3f(m_blk, st[0][15], st[1][0]);
-#pragma unroll
-        for (int i = 1; i < 15; i += 2) m_blk = max3f(m_blk, st[1][i], st[1][i + 1]);
-        m_blk = max3f(m_blk, st[1][15], lane_xor32(max3f(m_blk, st[1][15], st[1][15])));
         // Lazy rescale: the running reference maximum m_run of a query moves only when the step's maximum exceeds it by
         // more than 2^8 (exp2 domain) — probabilities then stay below 256, which bf16 and the f32 sums hold easily — and
         // the 64 accumulator registers are rescaled only in the steps where some query of the wave moves: the first one
@@ -258,8 +267,9 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
         // its own fragment read).  32 MFMAs in turn: the NEXT step's scores (16: K buffer (kb + 1) & 1), then O^T += V^T P^T (16).  Every
         // MFMA's LDS fragment is requested kAhead MFMAs earlier (ring of kAhead + 1 registers); under MFMA i runs one piece of VALU work:
         // a pair of probabilities (subtract, v_exp, packed bf16, sum) under score MFMAs 0..11 and value MFMAs 0..3 — value group sg needs
-        // pairs 4 sg .. 4 sg + 3 only — and the transposition of V(kb + 1) under value MFMAs 4..11.
-        constexpr int kAhead = 2;
+        // pairs 4 sg .. 4 sg + 3 only — the next step's row maximum under value MFMA 4, and the transposition of V(kb + 1) under value MFMAs 8..15 (its loads were
+        // requested at the step's start).
+        constexpr int kAhead = 3;
         const char* kt = smem + ((kb + 1) & 1) * kKTile;
         auto frag = [&](int i) {  // operand A of MFMA i
             if (i < 16) {
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
             for (int i = 0; i < 16; ++i) sn[t2][i] = 0.f;
-        float psum = 0.f;
+        float psum = 0.f, m_next = 0.f;
         u32x4 pb[2][2];
         auto pair = [&](int pr) {
             // masked scores are -1e30: exp2 underflows to exactly 0.  The denominator sums the f32 probabilities, the
@@ -315,11 +325,13 @@ __global__ __launch_bounds__(kThreadsF, 2) void flash_prefill_kernel(const Flash
                 const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb[sg >> 1][sg & 1]);
                 acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % (kAhead + 1)], pfrag, acc[dt], 0, 0, 0);
                 if (i < 20) pair(i - 4);
-                else if (i < 28) vpiece(i - 20);
+                else if (i == 20) m_next = smax(sn);
+                else if (i >= 24) vpiece(i - 24);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         l_run += psum;
+        m_blk = m_next;
         __syncthreads();
     };
     for (int kb = 0; kb < n_kb; kb += 2) {

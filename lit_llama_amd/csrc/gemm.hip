@@ -101,7 +101,22 @@ struct GemmParams {
     bf16_t* kcache;
     bf16_t* vcache;
     int S, C, rope_gathered;
+    float q_scale;        // != 0: q leaves rotated, scaled by q_scale and rounded to bf16 (gemm_fuse.h: q_scale), rows of 2 * ldy bf16
 };
+
+// c_attn's q rows as the prompt attention multiplies them (flash_prefill.hip's own prologue, moved to the producer: the same f32
+// arithmetic and the one rounding, so the same bits): four outputs = two interleaved pairs at row m, column n < C
+__device__ __forceinline__ void store_q_ready(const GemmParams& p, int m, int n, int posm, float o0, float o1, float o2, float o3) {
+    const f32x4 cs = *(const f32x4*)(p.rope + (int64_t)(p.rope_gathered ? m : posm) * 128 + (n & 127));
+    const float qs = p.q_scale;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    const bf2 a = {(__bf16)(qs * (o0 * cs[0] - o1 * cs[1])), (__bf16)(qs * (o1 * cs[0] + o0 * cs[1]))};
+    const bf2 b = {(__bf16)(qs * (o2 * cs[2] - o3 * cs[3])), (__bf16)(qs * (o3 * cs[2] + o2 * cs[3]))};
+    u32x2 pk;
+    pk[0] = __builtin_bit_cast(uint32_t, a);
+    pk[1] = __builtin_bit_cast(uint32_t, b);
+    *(u32x2*)((bf16_t*)p.y + (int64_t)m * (2 * p.ldy) + n) = pk;
+}
 
 constexpr size_t kSplitBudget = (size_t)32 << 20;  // bytes of split-K partials a workspace holds
 constexpr int kMaxSplit = 8;
@@ -296,6 +311,10 @@ __global__ __launch_bounds__(256) void splitk_fused_reduce_kernel(const GemmPara
                     pk[0] = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
                     pk[1] = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
                     *(u32x2*)((sec == 1 ? p.kcache : p.vcache) + ((int64_t)h * p.S + slot) * 128 + d) = pk;
+                    continue;
+                }
+                if (p.rope != nullptr && p.q_scale != 0.f) {
+                    store_q_ready(p, m, n, p.pos[m], o[0], o[1], o[2], o[3]);
                     continue;
                 }
             }
@@ -814,6 +833,10 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
                         *(u32x2*)dst = pk;
                         continue;
                     }
+                    if (p.rope != nullptr && p.q_scale != 0.f) {
+                        store_q_ready(p, m, n, posm, v[t][0], v[t][1], v[t][2], v[t][3]);
+                        continue;
+                    }
                 }
                 if (p.y_dtype == MI355_F32) {
                     float* dst = (float*)p.y + (int64_t)m * p.ldy + n;
@@ -1212,6 +1235,7 @@ int mi355_linear_gemm_fused(const mi355_linear_args* a, const mi355_gemm_fuse* f
         p.S = f->S;
         p.C = f->n_head * f->hs;
         p.rope_gathered = f->rope_gathered;
+        p.q_scale = f->rope != nullptr ? f->q_scale : 0.f;
         if (q4) return launch_gemm_epi<MI355_W_Q4, true>(p, a->epi, s);
         return launch_gemm_epi<MI355_W_BF16, true>(p, a->epi, s);
     }

@@ -36,7 +36,12 @@ struct mi355_gemm_fuse {
     bf16_t* kcache;       // [n_head, S, hs]
     bf16_t* vcache;
     int S, n_head, hs, rope_gathered;
+    // != 0 (with rope, f32 y): q leaves as the prompt attention's MFMA operand — rotated, multiplied by q_scale (softmax scale x log2 e),
+    // rounded once to bf16 — in the first 2 C bytes of its y row (row pitch unchanged: 2 * ldy bf16); mi355_flash_prefill takes it
+    // with qkv_dtype MI355_Q_READY.  0: plain f32 q rows.
+    float q_scale;
 };
+#define MI355_Q_READY 100  // qkv_dtype of mi355_flash_prefill: bf16 q rows, rotated and scaled by the producer (q_scale above)
 
 // how a launch of the wide GEMM is cut: K-slices (1 = none), the partial sums ("shares") a producer writes per row and how
 // many of them make a 128-column unit.  A launch split over K produces through the reduction of its slices
