@@ -29,6 +29,16 @@
 #include "common.h"
 #include "gemm_fuse.h"
 
+// The epilogues' conversions on the hardware paths (round 6: with IEEE division + expf in SiLU and the six-instruction software rounding
+// the c_fc1 / c_fc2 epilogue was VALU-bound — 33 us of a 269-us launch at T = 2048 against 9 us for its 45 MB of stores,
+// profiles/r06_prefill_epilogue_cost.txt): v_cvt_pk_bf16_f32 rounds to nearest even exactly as f32_to_bf16 does (finite inputs),
+// v_exp_f32 / v_rcp_f32 are within 1 ulp of f32 — 2^-15 of the bf16 step the result is rounded to.
+__device__ __forceinline__ bf16_t bf16_hw(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float swiglu_fast(float a, float b) {
+    // silu(a) * b = a / (1 + 2^(-a log2 e)) * b; a -> -inf: 2^(+inf) = inf, rcp = 0; a -> +inf: rcp(1) = 1
+    return (a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * -1.44269504088896340736f))) * b;
+}
+
 namespace {
 
 constexpr int kBM = 128;     // tokens per block
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256) void stage_rows_kernel(const void* x, int x_dt
                     ss += v * v;
                     v *= ld_as_f32(norm_scale, k, norm_dtype);
                 }
-                o = f32_to_bf16(v);
+                o = bf16_hw(v);
                 sum += bf16_to_f32(o);
             }
             xb[(int64_t)m * ldxb + k] = o;
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(256) void stage_rows_grouped_kernel(const void* x, 
                     ss += v * v;
                     v *= ld_as_f32(norm_scale, k, norm_dtype);
                 }
-                o = f32_to_bf16(v);
+                o = bf16_hw(v);
                 sum += bf16_to_f32(o);
             }
             xb[(int64_t)m * ldxb + k] = o;
@@ -237,8 +247,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
             }
             bf16_t* dst = (bf16_t*)y + (int64_t)m * ldy + n;
             u32x2 pk;
-            pk[0] = (uint32_t)f32_to_bf16(swiglu_f32(o[0], b[0])) | ((uint32_t)f32_to_bf16(swiglu_f32(o[1], b[1])) << 16);
-            pk[1] = (uint32_t)f32_to_bf16(swiglu_f32(o[2], b[2])) | ((uint32_t)f32_to_bf16(swiglu_f32(o[3], b[3])) << 16);
+            pk[0] = (uint32_t)bf16_hw(swiglu_fast(o[0], b[0])) | ((uint32_t)bf16_hw(swiglu_fast(o[1], b[1])) << 16);
+            pk[1] = (uint32_t)bf16_hw(swiglu_fast(o[2], b[2])) | ((uint32_t)bf16_hw(swiglu_fast(o[3], b[3])) << 16);
             *(u32x2*)dst = pk;
         } else if (y_dtype == MI355_F32) {
             float* dst = (float*)y + (int64_t)m * ldy + n;
@@ -253,8 +263,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
             }
             for (int s = 0; s < ksplit; ++s) o += *(const f32x4*)(part + ((int64_t)s * M + m) * N + n);
             u32x2 pk;
-            pk[0] = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-            pk[1] = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+            pk[0] = (uint32_t)bf16_hw(o[0]) | ((uint32_t)bf16_hw(o[1]) << 16);
+            pk[1] = (uint32_t)bf16_hw(o[2]) | ((uint32_t)bf16_hw(o[3]) << 16);
             *(u32x2*)dst = pk;
         }
     }
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(256) void splitk_fused_reduce_kernel(const GemmPara
             }
             bf16_t ob[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(swiglu_f32(a[r], b[r]));
+            for (int r = 0; r < 4; ++r) ob[r] = bf16_hw(swiglu_fast(a[r], b[r]));
             u32x2 pk;
             pk[0] = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
             pk[1] = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
@@ -308,8 +318,8 @@ __global__ __launch_bounds__(256) void splitk_fused_reduce_kernel(const GemmPara
                     }
                     const int slot = posm < p.S - 1 ? posm : p.S - 1;
                     u32x2 pk;
-                    pk[0] = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                    pk[1] = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    pk[0] = (uint32_t)bf16_hw(o[0]) | ((uint32_t)bf16_hw(o[1]) << 16);
+                    pk[1] = (uint32_t)bf16_hw(o[2]) | ((uint32_t)bf16_hw(o[3]) << 16);
                     *(u32x2*)((sec == 1 ? p.kcache : p.vcache) + ((int64_t)h * p.S + slot) * 128 + d) = pk;
                     continue;
                 }
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(256) void splitk_fused_reduce_kernel(const GemmPara
                 if (p.out_xb != nullptr) {
                     bf16_t ob[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(o[r] * ldsz(p.next_norm, n + r, p.next_norm_dtype));
+                    for (int r = 0; r < 4; ++r) ob[r] = bf16_hw(o[r] * ldsz(p.next_norm, n + r, p.next_norm_dtype));
                     u32x2 pk;
                     pk[0] = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
                     pk[1] = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
@@ -795,7 +805,7 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
                     bf16_t* dst = (bf16_t*)p.y + (int64_t)m * p.ldy + n;
                     bf16_t ob[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(swiglu_f32(v[t][r], v[t + 1][r]));
+                    for (int r = 0; r < 4; ++r) ob[r] = bf16_hw(swiglu_fast(v[t][r], v[t + 1][r]));
                     u32x2 o;
                     o[0] = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
                     o[1] = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
@@ -828,8 +838,8 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
                         const int slot = posm < p.S - 1 ? posm : p.S - 1;
                         bf16_t* dst = (sec == 1 ? p.kcache : p.vcache) + ((int64_t)h * p.S + slot) * 128 + d;
                         u32x2 pk;
-                        pk[0] = (uint32_t)f32_to_bf16(o0) | ((uint32_t)f32_to_bf16(o1) << 16);
-                        pk[1] = (uint32_t)f32_to_bf16(o2) | ((uint32_t)f32_to_bf16(o3) << 16);
+                        pk[0] = (uint32_t)bf16_hw(o0) | ((uint32_t)bf16_hw(o1) << 16);
+                        pk[1] = (uint32_t)bf16_hw(o2) | ((uint32_t)bf16_hw(o3) << 16);
                         *(u32x2*)dst = pk;
                         continue;
                     }
@@ -847,7 +857,7 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
                         if (emit) {  // the next linear's operand: bf16(norm scale * x), as stage_rows_kernel rounds it
                             bf16_t ob[4];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(o[r] * ns[t][r]);
+                            for (int r = 0; r < 4; ++r) ob[r] = bf16_hw(o[r] * ns[t][r]);
                             u32x2 pk;
                             pk[0] = (uint32_t)ob[0] | ((uint32_t)ob[1] << 16);
                             pk[1] = (uint32_t)ob[2] | ((uint32_t)ob[3] << 16);
@@ -864,8 +874,8 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
                         for (int r = 0; r < 4; ++r) o[r] += bf16_to_f32(dst[r]);
                     }
                     u32x2 pk;
-                    pk[0] = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                    pk[1] = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    pk[0] = (uint32_t)bf16_hw(o[0]) | ((uint32_t)bf16_hw(o[1]) << 16);
+                    pk[1] = (uint32_t)bf16_hw(o[2]) | ((uint32_t)bf16_hw(o[3]) << 16);
                     *(u32x2*)dst = pk;
                 }
             }
