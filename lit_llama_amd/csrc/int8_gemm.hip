@@ -32,6 +32,13 @@ constexpr int kLdsEpi = (kBM + kSlots * 16) * kOutChunk * 2;  // f16 [128 tokens
 constexpr int kLds = kLdsMain > kLdsEpi ? kLdsMain : kLdsEpi;
 
 __device__ __forceinline__ float f16r(float v) { return f16_to_f32(f32_to_f16(v)); }
+// the same for a value that must be an f32 PRODUCT rounded to f32 first (MatMul8bitLt's dequantisation multiplies in f32 and converts): hipcc
+// otherwise may contract the last multiply and the conversion into v_fma_mixlo_f16 — one rounding instead of two, a bf16 ulp in ~1e-5 of the
+// outputs against the oracle (seen when the outlier side product moved to MFMA and the register allocation around it changed)
+__device__ __forceinline__ float f16r_of_f32(float v) {
+    asm volatile("" : "+v"(v));
+    return f16r(v);
+}
 // 16-B chunk swizzle of a 128-B activation row in LDS: rows alternate bank halves (128-B pitch), pairs of rows rotate the
 // 8 chunks — the 16 lanes a ds_read_b128 serves together (tokens {0-3, 12-15} with one k-group, {4-11} with the next)
 // land in 16 different bank groups
@@ -279,30 +286,35 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
 #pragma unroll
         for (int t = 0; t < kTPW; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d[t][tt][r] = f16r((((float)acc[t][tt][r] * 6.200012e-05f) * sa) * scb[t][r]);
+            for (int r = 0; r < 4; ++r) d[t][tt][r] = f16r_of_f32((((float)acc[t][tt][r] * 6.200012e-05f) * sa) * scb[t][r]);
     }
     const int n_out = p.olist[0];
     if (n_out > 0) {
         // mixed-precision decomposition: the outlier columns in f16, ascending k, kOutChunk columns per pass through LDS
         f16_t* xo = (f16_t*)smem;                     // [128 tokens][kOutChunk]
         f16_t* so = xo + kBM * kOutChunk;             // [kSlots x 16 rows][kOutChunk]: f16(CB[n, k] * SCB[n] / 127)
-        float o[kTPW][8][4];
+        // (round 6: the side product runs on v_mfma_f32_16x16x32_f16 — A = 16 rows x 32 outlier columns of `so`, B = 16 tokens x the same
+        // columns of `xo`, result in the accumulators' own layout: lane (g, c) holds rows 4 g .. 4 g + 3 for token c.  The products of two f16
+        // values are exact in f32 and the sum is f32 as before; its ORDER inside a block of 32 columns is the hardware's instead of
+        // ascending k — bitsandbytes' own f16 GEMM promises no order either, and the tests allow the one f16 ulp this can move.  The scalar
+        // loop it replaces (64 FMAs per lane and outlier column) took 1.4 ms per attn.c_proj / mlp.c_proj launch at T = 2048, where ~10 % of
+        // the columns of a 2048-token call hold an outlier: profiles/r06_prefill_int8_outliers.txt.)
+        typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+        f32x4 o[kTPW][8];
 #pragma unroll
         for (int t = 0; t < kTPW; ++t)
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[t][tt][r] = 0.f;
+            for (int tt = 0; tt < 8; ++tt) o[t][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int base = 0; base < n_out; base += kOutChunk) {
             const int nc = n_out - base < kOutChunk ? n_out - base : kOutChunk;
             __syncthreads();  // (the main loop / the previous pass is done with the LDS)
-            for (int idx = threadIdx.x; idx < kBM * nc; idx += kThreads) {
-                const int tok = idx / nc, i = idx - tok * nc;
+            for (int idx = threadIdx.x; idx < kBM * kOutChunk; idx += kThreads) {
+                const int tok = idx / kOutChunk, i = idx - tok * kOutChunk;
                 const int m = m0 + tok;
-                xo[tok * kOutChunk + i] = m < p.M ? p.xh[(int64_t)m * p.Kp + p.olist[1 + base + i]] : (f16_t)0;
+                xo[idx] = (m < p.M && i < nc) ? p.xh[(int64_t)m * p.Kp + p.olist[1 + base + i]] : (f16_t)0;
             }
-            for (int idx = threadIdx.x; idx < kSlots * 16 * nc; idx += kThreads) {
-                const int sr = idx / nc, i = idx - sr * nc;  // sr = slot * 16 + row
+            for (int idx = threadIdx.x; idx < kSlots * 16 * kOutChunk; idx += kThreads) {
+                const int sr = idx / kOutChunk, i = idx - sr * kOutChunk;  // sr = slot * 16 + row
                 const int slot = sr >> 4, row = sr & 15;
                 const int wv = slot / kTPW, t = slot - wv * kTPW;
                 int tl, r1;
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
                 }
                 const int n = tl * 16 + row;
                 f16_t sub = 0;
-                if (tl < p.n_tiles && n < p.N) {
+                if (i < nc && tl < p.n_tiles && n < p.N) {
                     const int k = p.olist[1 + base + i];
                     const int u = k >> 7, e = (k >> 6) & 1, gg = (k >> 4) & 3, jj = k & 15;
                     const int64_t off = ((((int64_t)tl * p.units + u) * R + r1) * 2 + e) * 1024 + (gg * 16 + row) * 16 + jj;
@@ -323,22 +335,20 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
                     const float s = ((PAIR && r1 == 1) ? p.scb2 : p.scb)[n];
                     sub = f32_to_f16(__fdiv_rn(cb * s, 127.0f));
                 }
-                so[sr * kOutChunk + i] = sub;
+                so[idx] = sub;
             }
             __syncthreads();
-            for (int i = 0; i < nc; ++i) {
-                float sv[kTPW][4];
 #pragma unroll
-                for (int t = 0; t < kTPW; ++t)
+            for (int kb = 0; kb < kOutChunk / 32; ++kb) {
+                if (kb * 32 >= nc) break;
+                f16x8_t a[kTPW];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sv[t][r] = f16_to_f32(so[((wave * kTPW + t) * 16 + 4 * g + r) * kOutChunk + i]);
+                for (int t = 0; t < kTPW; ++t) a[t] = *(const f16x8_t*)(so + ((wave * kTPW + t) * 16 + c) * kOutChunk + kb * 32 + 8 * g);
 #pragma unroll
                 for (int tt = 0; tt < 8; ++tt) {
-                    const float xv = f16_to_f32(xo[(tt * 16 + c) * kOutChunk + i]);
+                    const f16x8_t b = *(const f16x8_t*)(xo + (tt * 16 + c) * kOutChunk + kb * 32 + 8 * g);
 #pragma unroll
-                    for (int t = 0; t < kTPW; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[t][tt][r] += xv * sv[t][r];
+                    for (int t = 0; t < kTPW; ++t) o[t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b, o[t][tt], 0, 0, 0);
                 }
             }
         }

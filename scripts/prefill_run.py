@@ -18,6 +18,19 @@ if mode == "none":
         model = LLaMA(cfg)
     for prm in model.parameters():
         prm.data.normal_(0.0, 0.02)
+elif mode == "llm.int8":  # BASELINE configs[3], weights as bench.py draws them
+    with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="llm.int8"):
+        model = LLaMA(cfg)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if name.endswith("scale"):
+                prm.copy_((1 + 0.1 * torch.randn(prm.shape, generator=gen, device=dev)).to(prm.dtype))
+            elif name.endswith("wte.weight"):
+                prm.copy_(torch.randn(prm.shape, generator=gen, device=dev).to(prm.dtype))
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Linear):
+                mod._quantize_weight(torch.randn(mod.weight.shape, generator=gen, device=dev) * mod.in_features**-0.5)
 else:
     with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
         model = LLaMA(cfg)
