@@ -64,7 +64,11 @@ constexpr int kTPW = MI355_GEMM_TPW;
 #define MI355_GEMM_PIN_W 0
 #endif
 #ifndef MI355_GEMM_BF16_OCC
-#define MI355_GEMM_BF16_OCC 1
+// 1 held the BF16-stream kernels at 128 VGPRs (two workgroups per CU) since round 3 — with 100-112 bytes of scratch per lane in the 128-token
+// blocks, inside the unit loop.  Round 6 measured it: a 2048-token prompt of the bf16 7B model 69.3 ms with it, 37.5 ms without (130-136 VGPRs,
+// one workgroup per CU, no scratch); 64-token blocks (118 VGPRs either way) and prompts up to 512 tokens are unchanged
+// (profiles/r06_prefill_bf16_occupancy.txt).
+#define MI355_GEMM_BF16_OCC 0
 #endif  // 16-row tile slots per wave: one B fragment read from LDS feeds kTPW MFMAs
 // Waves per workgroup: 8 (a block = 16 row tiles x 128 tokens) for prompts that fill the chip; 2 (4 row tiles) when the
 // launch would otherwise be a few dozen workgroups — a 128-token prompt of a 7B model is ONE token block, i.e. 16 workgroups
