@@ -63,6 +63,9 @@ constexpr int kTPW = MI355_GEMM_TPW;
 #ifndef MI355_GEMM_PIN_W
 #define MI355_GEMM_PIN_W 0
 #endif
+#ifndef MI355_GEMM_BF16_REFILL
+#define MI355_GEMM_BF16_REFILL 1
+#endif
 #ifndef MI355_GEMM_BF16_OCC
 // 1 held the BF16-stream kernels at 128 VGPRs (two workgroups per CU) since round 3 — with 100-112 bytes of scratch per lane in the 128-token
 // blocks, inside the unit loop.  Round 6 measured it: a 2048-token prompt of the bf16 7B model 69.3 ms with it, 37.5 ms without (130-136 VGPRs,
@@ -423,6 +426,14 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
         for (int d = 0; d < kWP; ++d)
             dst[d] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rw : rw0, lane_off, ok ? off + d * 1024u : 0u, 0));
     };
+    // BF16 streams (round 6): piece d of the NEXT unit is requested into the registers piece d of this unit just left (behind its MFMAs):
+    // no second register set — 32 registers less, two workgroups per CU without the scratch the occupancy hint had bought them with
+    constexpr bool kRefill = FMT == MI355_W_BF16 && GRP == 0 && MI355_GEMM_BF16_REFILL;
+    [[maybe_unused]] auto wload1 = [&](int t, int u, int d, u32x4& dst) {
+        const bool ok = tile[t] < p.n_tiles && u < u_hi;
+        const unsigned off = (unsigned)((tile[t] * p.units + u) * (PAIR ? 2 : 1) + rr[t]) * (1024u * kWP);
+        dst = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? rw : rw0, lane_off, ok ? off + d * 1024u : 0u, 0));
+    };
     // activation block of unit u: 2048 chunks of 16 B, kXChunks per thread; chunk = (token, 16-B column)
     // Round 6: the activation block of the NEXT unit goes global -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane: one instruction
     // fills 1 KiB = four token rows of the buffer; the XOR swizzle is applied on the SOURCE side — LDS slot c of token t takes column
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
 #pragma unroll
         for (int tt = 0; tt < kTT; ++tt) acc[t][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 wcur[kTPW][kWP], wnext[kTPW][kWP];
+    u32x4 wcur[kTPW][kWP], wnext[kRefill ? 1 : kTPW][kRefill ? 1 : kWP];
 #pragma unroll
     for (int t = 0; t < kTPW; ++t) wload(t, u_lo, wcur[t]);
     if constexpr (kXDma) xdma(u_lo, u_lo & 1);
@@ -552,15 +563,19 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
 #endif
         if constexpr (kXDma) {
             // (weights first: HBM latency; both pinned at the unit's start — they cost 8 registers now, not 40)
+            if constexpr (!kRefill) {
 #pragma unroll
-            for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
+                for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
+            }
             xdma(u + 1, (u & 1) ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             return;
         }
         xload(u + 1);
+        if constexpr (!kRefill) {
 #pragma unroll
-        for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
+            for (int t = 0; t < kTPW; ++t) wload(t, u + 1, wnext[t]);
+        }
         // hipcc sinks these requests to the END of the unit, right in front of the LDS stores that wait for them (the
         // 24 registers they land in would otherwise be live across the MFMAs): a unit pays the memory latency in front
         // of its barrier, covered by the other waves of the SIMD.  Pinned here they fly under the unit's MFMAs — at
@@ -582,6 +597,7 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
         if constexpr (GRP == 2) braw = mine ? braw : u32x4{0u, 0u, 0u, 0u};
         return braw;
     };
+    [[maybe_unused]] int u_refill = 0;  // kRefill: the unit whose pieces mfmas() requests
     auto mfmas = [&](int buf, int sub, int sub_shift) {
         const char* xs = smem + buf * (BM * 256);
         const bool mine = GRP != 2 || (g >> sub_shift) == sub;
@@ -640,14 +656,20 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
                     for (int t = 0; t < kTPW; ++t) acc[t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[t][tt], 0, 0, 0);
                 }
             }
+            if constexpr (kRefill) {
+#pragma unroll
+                for (int t = 0; t < kTPW; ++t) wload1(t, u_refill, d, wcur[t][d]);
+            }
         }
     };
     auto rotate = [&](int buf) {
         xstore(buf ^ 1);
+        if constexpr (!kRefill) {
 #pragma unroll
-        for (int t = 0; t < kTPW; ++t)
+            for (int t = 0; t < kTPW; ++t)
 #pragma unroll
-            for (int d = 0; d < kWP; ++d) wcur[t][d] = wnext[t][d];
+                for (int d = 0; d < kWP; ++d) wcur[t][d] = wnext[t][d];
+        }
         __syncthreads();
     };
 
@@ -655,6 +677,7 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
     if constexpr (GRP == 0) {
         for (int u = u_lo; u < u_hi; ++u) {
             prefetch(u);
+            u_refill = u + 1;
             mfmas(u & 1, 0, 0);
             rotate(u & 1);
         }
