@@ -415,8 +415,11 @@ constexpr int kMaxThreads = (FMT == MI355_W_Q4 && P <= 4 && !GRP) ? 1024 : 512;
 // in LDS at the tile switch; inside the k loop every wave applies  accf += s (acc - (128 + z) sum_x)  at each group
 // boundary of its unit range (sum_x from the all-ones MFMA of the same columns) and restarts acc / sum_x.  The partial
 // tiles that reach the epilogue are then plain sums.
-constexpr int kGrpLoadsMax = 4;  // GRP = (scale, zero) pairs per thread, matrix and tile: 16 n_groups <= GRP x threads (1 or 4;
-                                 // every pair is an issued buffer load whether it fetches or not: 32 groups over 512 threads need one)
+constexpr int kGrpLoadsMax = 12; // GRP = (scale, zero) pairs per thread, matrix and tile: 16 n_groups <= GRP x threads (1, 4 or 12;
+                                 // every pair is an issued buffer load whether it fetches or not: 32 groups over 512 threads need one).
+                                 // 12 (round 6) admits 384 groups per row: groupsize 32 against K = 11008 (344), which the cap of 4 x 512 / 16
+                                 // = 128 groups had kept — with groupsize 64 (172) — off the engine altogether
+constexpr int kGrpLoadsMid = 4;
 
 template <int FMT, int R, int P, int EPI, int VMODE, bool MULTI, int GRP = 0>
 __global__ __launch_bounds__((kMaxThreads<FMT, P, GRP>)) void gemv_kernel(const GemvParams p) {
@@ -1036,8 +1039,9 @@ int dispatch_p(const GemvParams& p, int /*prefetch*/, int grid, int waves, size_
     constexpr int PA = FMT == MI355_W_Q4 ? 4 : 2;
     if constexpr (FMT == MI355_W_Q4) {
         if (p.n_groups > 0)
-            return 16 * p.n_groups <= waves * 64 ? launch_gemv<FMT, R, PA, 1>(p, grid, waves, lds, s)
-                                                 : launch_gemv<FMT, R, PA, kGrpLoadsMax>(p, grid, waves, lds, s);
+            return 16 * p.n_groups <= waves * 64                  ? launch_gemv<FMT, R, PA, 1>(p, grid, waves, lds, s)
+                   : 16 * p.n_groups <= kGrpLoadsMid * waves * 64 ? launch_gemv<FMT, R, PA, kGrpLoadsMid>(p, grid, waves, lds, s)
+                                                                   : launch_gemv<FMT, R, PA, kGrpLoadsMax>(p, grid, waves, lds, s);
     }
     return launch_gemv<FMT, R, PA, false>(p, grid, waves, lds, s);
 }

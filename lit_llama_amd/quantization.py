@@ -150,7 +150,7 @@ class ColBlockQuantizedLinear(torch.nn.Module):
     # ---- hot path -----------------------------------------------------------------------------------
     def fast_eligible(self, dtype: torch.dtype) -> bool:
         """MFMA weight-streaming kernel: 4 bits, bf16 I/O, one scale/zero per row (gptq.int4's tile_cols = -1) or per
-        row and group of 32 * 2^n columns (bf16 tables, at most 128 groups: `grouped_fast`)."""
+        row and group of 32 * 2^n columns (bf16 tables, at most 384 groups — groupsize 32 against K = 11008: `grouped_fast`)."""
         return (
             self.bits == 4
             and (self.scales.shape[1] == 1 or self.grouped_fast())
@@ -161,7 +161,7 @@ class ColBlockQuantizedLinear(torch.nn.Module):
 
     def grouped_fast(self) -> bool:
         g, ng = self.tile_cols, self.scales.shape[1]
-        return (ng > 1 and g >= 32 and (g & (g - 1)) == 0 and ng <= 128 and self.scales.dtype == torch.bfloat16
+        return (ng > 1 and g >= 32 and (g & (g - 1)) == 0 and ng <= 384 and self.scales.dtype == torch.bfloat16
                 and ng == -(-self.in_features // g))
 
     def weight_stream(self, R: int = 1) -> torch.Tensor:

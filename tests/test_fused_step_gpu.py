@@ -167,6 +167,26 @@ def test_fused_step_with_grouped_scales(dev, g):
         assert (logits[fmt] - ref).abs().max().item() <= 0.05 * float(ref.std(-1).mean())
 
 
+@pytest.mark.parametrize("g", [64, 32])
+def test_small_groups_at_the_7b_width_run_on_the_engine(dev, g):
+    """GPTQ groupsize 64 / 32 checkpoints at the 7B width: mlp.c_proj (K = 11008) has 172 / 344 groups per row.  Until round 6 the skinny
+    kernel's table prefetch admitted 128, `fast_eligible` said no and the WHOLE model fell off the native engine; now (12 table pairs per
+    thread and tile) they run the launch-per-operator step: prompt pass (grouped GEMM) and decode steps against the CPU oracle."""
+    model, sd, cfg = build_grouped(2, dev, g)
+    eng = model.engine()
+    assert eng is not None, model._engine_failed
+    prompt = synth.make_prompt(40, seed=3).to(dev)  # (40 tokens: the wide grouped GEMM takes the prompt)
+    out = lit_llama_amd.generate(model, prompt, 8, top_k=1, max_seq_length=64).cpu()
+    logits = teacher_forced(model, out.to(dev), 40, 64, dev)
+    om = oracle.Model(oracle.Config(n_layer=2, **W7B), {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()},
+                      mode="gptq.int4")
+    ref = oracle.teacher_forced_logits(om, out, 40)
+    std = float(ref.std(-1).mean())
+    err = (logits - ref).abs().max().item()
+    print(f"grouped g{g} at the 7B width on the engine: {err / std:.4f} std")
+    assert err <= 0.05 * std, f"g{g}: {err:.4f} (std {std:.3f})"
+
+
 def test_fused_step_is_reproducible_and_modes_agree(dev):
     model, _, cfg = build(2, dev, seed=1)
     eng = need_fused(model)
