@@ -31,9 +31,16 @@ elif mode == "llm.int8":  # BASELINE configs[3], weights as bench.py draws them
         for mod in model.modules():
             if isinstance(mod, torch.nn.Linear):
                 mod._quantize_weight(torch.randn(mod.weight.shape, generator=gen, device=dev) * mod.in_features**-0.5)
-else:
+else:  # "gptq.int4", or "g128" / "g64" ...: GPTQ groupsize checkpoints (scales / zeros per row and group of columns)
     with EmptyInitOnDevice(device=dev, dtype=torch.bfloat16, quantization_mode="gptq.int4"):
         model = LLaMA(cfg)
+    if mode.startswith("g") and mode[1:].isdigit():
+        from lit_llama_amd.quantization import ColBlockQuantizedLinear
+        for _, mod in list(model.named_modules()):
+            for cname, child in list(mod.named_children()):
+                if isinstance(child, ColBlockQuantizedLinear):
+                    q = ColBlockQuantizedLinear(child.in_features, child.out_features, bias=False, bits=4, tile_cols=int(mode[1:]))
+                    setattr(mod, cname, q.to(device=dev, dtype=torch.bfloat16))
     synth.fill_model_random_int4(model, seed=0)
 model.eval()
 eng = model.engine()
