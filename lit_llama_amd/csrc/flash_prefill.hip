@@ -19,8 +19,13 @@
 //     TRANSPOSED on the way in (d-major, keys in the permuted order, rows padded to 144 B: conflict-free 16-B fragment
 //     reads), both double buffered.  The transposition happens in registers: a thread loads the same 8 dimensions of 4
 //     consecutive keys and writes 8-byte groups of 4 keys (v_perm_b32), the row it writes rotated by its column.
-//   * q is RoPE'd in registers while it is loaded (f32 qkv rows, rope row = the token's position); the new K / V rows
-//     were written to the cache by rope_kv_write_kernel before this launch.
+//   * q is RoPE'd in registers while it is loaded (f32 qkv rows, rope row = the token's position) — or, inside the fused prompt chain,
+//     arrives as the finished operand from the c_attn epilogue (MI355_Q_READY, gemm_fuse.h: rotated, scaled, bf16); the new K / V rows
+//     were written to the cache by rope_kv_write_kernel / that epilogue before this launch.
+//   * Round 6: the key step is a written-out software pipeline (see `step`): 32 MFMAs in turn — the NEXT step's 16 score MFMAs, then
+//     this step's 16 value MFMAs — each followed by one piece of VALU work and a sched_barrier, LDS fragments requested three MFMAs
+//     ahead.  Timing-only builds had shown the kernel slow per step (1.47 us solo / 2.35 us paired against 0.43 us of MFMA work), not
+//     for lack of company on its CU; 68 -> 52-60 us per launch at T = 2048 (profiles/r06_prefill_flash_pipeline_ab.txt).
 #include "common.h"
 #include "gemm_fuse.h"
 
