@@ -66,6 +66,15 @@ constexpr int kTPW = MI355_GEMM_TPW;
 #ifndef MI355_GEMM_BF16_REFILL
 #define MI355_GEMM_BF16_REFILL 1
 #endif
+#ifndef MI355_GEMM_BF16_ROWMAJOR
+// workgroup order of the BF16 streams: row block major (an XCD runs every token block of a few row blocks side by side).  Token block major
+// (the int4 order) carried every weight piece across the fabric once per token block: 16 x 13.5 GB = 216 GB per 2048-token pass of the 7B
+// model, 6.3 TB/s of its 34 ms.  2048 tokens 34.0 -> 28.5 ms, 512 tokens 16.5 -> 10.6 ms (profiles/r06_ab_bf16_block_order.txt)
+#define MI355_GEMM_BF16_ROWMAJOR 1
+#endif
+#ifndef MI355_GEMM_Q4_ROWMAJOR
+#define MI355_GEMM_Q4_ROWMAJOR 0
+#endif
 #ifndef MI355_GEMM_BF16_OCC
 // 1 held the BF16-stream kernels at 128 VGPRs (two workgroups per CU) since round 3 — with 100-112 bytes of scratch per lane in the 128-token
 // blocks, inside the unit loop.  Round 6 measured it: a 2048-token prompt of the bf16 7B model 69.3 ms with it, 37.5 ms without (130-136 VGPRs,
@@ -392,7 +401,17 @@ __global__ __launch_bounds__(64 * kWaves, (FMT == MI355_W_BF16 && kWaves == 8 &&
     const int L2 = xcd * p.per_xcd + j;
     if (j >= p.per_xcd || L2 >= p.total_blocks * p.ksplit) return;
     const int L = L2 / p.ksplit, ks = L2 - L * p.ksplit;  // (ksplit = 1: ks = 0, all units)
-    const int mb = L / n_blocks, nb = L - mb * n_blocks;
+    int mb, nb;
+    if constexpr (FMT == MI355_W_BF16 ? MI355_GEMM_BF16_ROWMAJOR != 0 : MI355_GEMM_Q4_ROWMAJOR != 0) {
+        // row block major — an XCD runs every token block of a few row blocks side by side, so a weight piece (BF16: 4 x the
+        // bytes of an int4 one) crosses the fabric once per XCD instead of once per token block
+        const int m_blocks = p.total_blocks / n_blocks;
+        nb = L / m_blocks;
+        mb = L - nb * m_blocks;
+    } else {
+        mb = L / n_blocks;
+        nb = L - mb * n_blocks;
+    }
     const int m0 = mb * BM;
     [[maybe_unused]] float* fr = (float*)(smem + 2 * BM * 256);  // FUSE: [BM] 1/rms, [BM] operand sums of the block's rows
     // K-slice: units [u_lo, u_hi); GRP 1 cuts at group boundaries (groups [g_lo, g_hi) of upg units each)
@@ -1053,17 +1072,19 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     if (sh.waves == 2) return launch_gemm_w<EPI, PAIR, FMT, 2, kBM, 0, FUSE>(p, s);
     return launch_gemm_w<EPI, PAIR, FMT, 1, kBM, 0, FUSE>(p, s);
 }
-// grouped scales: blocks of kGrpBM tokens x 4 waves (the second accumulator set costs the registers of more tokens or
-// waves)
-#ifndef MI355_GEMM_GRP_BM
-#define MI355_GEMM_GRP_BM 64
-#endif
-constexpr int kGrpBM = MI355_GEMM_GRP_BM;
+// grouped scales: blocks of 64 tokens x 4 waves (the second accumulator set costs the registers of more tokens or waves);
+// from kGrpWideM tokens on, 128 tokens x 8 waves (2048-token g128 prompt 41.9 -> 39.4 ms; at 512 tokens it is the slower
+// one, 16.3 -> 17.6 ms, at 1024 22.5 -> 27.3 ms, and 64 x 8 / 128 x 4 lose everywhere: profiles/r06_ab_grouped_prompt.txt)
+constexpr int kGrpBM = 64;
+constexpr int kGrpWideM = 2048;
 template <int EPI, bool PAIR, int GRP>
 int launch_gemm_grouped(const GemmParams& p, hipStream_t s) {
     const int per_block8 = PAIR ? 8 * kTPW / 2 : 8 * kTPW;
     const int blocks8 = ((p.n_tiles + per_block8 - 1) / per_block8) * ((p.M + kGrpBM - 1) / kGrpBM);
     if (p.ksplit > 1) return launch_gemm_w<EPI, PAIR, MI355_W_Q4, 4, 64, GRP>(p, s);
+    if constexpr (GRP == 1) {  // groups below a unit (GRP 2) carry masked passes: 128 x 8 does not fit their registers
+        if (blocks8 >= 128 && p.M >= kGrpWideM) return launch_gemm_w<EPI, PAIR, MI355_W_Q4, 8, 128, GRP>(p, s);
+    }
     if (blocks8 >= 128) return launch_gemm_w<EPI, PAIR, MI355_W_Q4, 4, kGrpBM, GRP>(p, s);
     if (blocks8 * 4 >= 128) return launch_gemm_w<EPI, PAIR, MI355_W_Q4, 2, 64, GRP>(p, s);
     return launch_gemm_w<EPI, PAIR, MI355_W_Q4, 1, 64, GRP>(p, s);

@@ -643,6 +643,9 @@ GROUPED_GEMM_SHAPES = [
     (130, 1000, 512, 128, "store"),      # N not a multiple of 16
     (128, 11008, 4096, 128, "swiglu"),   # short prompt: K-slices of whole groups (deterministic split-K) on the pair stream
     (64, 12288, 4096, 64, "store"),      # split-K over units with sub-unit groups
+    (2048, 4096, 4096, 128, "accum"),    # long prompt: blocks of 128 tokens x 8 waves (kGrpWideM of csrc/gemm.hip)
+    (2049, 4096, 11008, 256, "accum"),   # the same tiling, last block of one token, a group over two units
+    (2050, 2064, 4096, 128, "swiglu"),   # the same tiling on the pair stream, last tile column partial
 ]
 
 
