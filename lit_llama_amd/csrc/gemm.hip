@@ -1019,20 +1019,20 @@ struct GemmShape {
 };
 // tuning override for sweeps (scripts/sweep_gemm_shapes.sh): MI355_GEMM_FORCE="waves:bm:ksplit", 0 = the rule's choice
 struct GemmForce {
-    int waves, bm, ksplit;
+    int waves, bm, ksplit, bf16_blocks;  // bf16_blocks: the BF16 streams' 64-token-block threshold (sweeps)
 };
 GemmForce gemm_force() {
     // parsed ONCE per process (advisor r4: a getenv + sscanf per launch sat on the production path, and a change of the variable
     // between mi355_linear_gemm_plan and the launch would have desynchronised the share layout of the fused chain; the sweep starts
     // one process per setting)
     static const GemmForce f = [] {
-        GemmForce g = {0, 0, 0};
-        if (const char* e = getenv("MI355_GEMM_FORCE")) sscanf(e, "%d:%d:%d", &g.waves, &g.bm, &g.ksplit);
+        GemmForce g = {0, 0, 0, 0};
+        if (const char* e = getenv("MI355_GEMM_FORCE")) sscanf(e, "%d:%d:%d:%d", &g.waves, &g.bm, &g.ksplit, &g.bf16_blocks);
         return g;
     }();
     return f;
 }
-GemmShape gemm_shape(int n_tiles, int M, bool pair, int ksplit) {
+GemmShape gemm_shape(int n_tiles, int M, bool pair, int ksplit, bool bf16 = false) {
     const GemmForce fo = gemm_force();
     if ((fo.waves == 8 && (fo.bm == 64 || fo.bm == kBM)) || ((fo.waves == 2 || fo.waves == 1) && (fo.bm == 0 || fo.bm == kBM)))
         return {fo.waves, fo.bm ? fo.bm : kBM};
@@ -1042,8 +1042,12 @@ GemmShape gemm_shape(int n_tiles, int M, bool pair, int ksplit) {
         if (blocks8 * 4 >= 128) return {2, kBM};
         return {1, kBM};
     }
+    // (only the WAVES of the answer enter mi355_linear_gemm_plan's share layout: the format may pick its own token block)
+    // BF16 streams fill a CU's L1 at the rate its MFMAs consume a 128-token block's pieces and a 64-token block needs twice that: they
+    // keep 128 tokens as long as those blocks cover 5/8 of the CUs, K-slices or not (7B: 2048 tokens 28.5 -> 25.6 ms, 1536 23.2 -> 22.0,
+    // 512 10.6 -> 9.8; at 128 blocks — N = 4096 at 1024 tokens — 64 tokens win, 15.2 vs 16.7 ms; profiles/r06_bf16_gemm_tilings.txt)
 #ifndef MI355_GEMM_NO_BM64
-    if (blocks8 * ksplit < 384) return {8, 64};
+    if (bf16 ? blocks8 < (fo.bf16_blocks ? fo.bf16_blocks : 160) : blocks8 * ksplit < 384) return {8, 64};
 #endif
     return {8, kBM};
 }
@@ -1064,7 +1068,7 @@ int gemm_ksplit(int M, int N, int K, bool swiglu) {
 }
 template <int EPI, bool PAIR, int FMT, bool FUSE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
-    const GemmShape sh = gemm_shape(p.n_tiles, p.M, PAIR, p.ksplit);
+    const GemmShape sh = gemm_shape(p.n_tiles, p.M, PAIR, p.ksplit, FMT == MI355_W_BF16);
     if (sh.waves == 8) {
         if (sh.bm == 64) return launch_gemm_w<EPI, PAIR, FMT, 8, 64, 0, FUSE>(p, s);
         return launch_gemm_w<EPI, PAIR, FMT, 8, kBM, 0, FUSE>(p, s);

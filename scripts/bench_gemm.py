@@ -15,14 +15,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--M", type=int, default=2048)
     ap.add_argument("--group", type=int, default=0, help="grouped scales: input columns per (scale, zero) pair")
+    ap.add_argument("--fmt", default="q4", choices=["q4", "bf16"], help="bf16: the unquantised stream (BASELINE configs[1])")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M = a.M
     total = 0.0
     for name, N, K, R, epi in [("c_attn", 12288, 4096, 1, nat.EPI_STORE), ("c_proj", 4096, 4096, 1, nat.EPI_ACCUM),
                                ("fc pair", 11008, 4096, 2, nat.EPI_SWIGLU), ("mlp.c_proj", 4096, 11008, 1, nat.EPI_ACCUM)]:
-        nbytes = ops.packed_bytes(nat.W_Q4, N, K, R, R == 2)
-        stream = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device=dev)
+        fmt = nat.W_BF16 if a.fmt == "bf16" else nat.W_Q4
+        nbytes = ops.packed_bytes(fmt, N, K, R, R == 2)
+        if a.fmt == "bf16":  # finite values (random bytes would hold NaNs); the layout does not matter to the clock
+            stream = (torch.randn(nbytes // 2, device=dev) * 0.02).to(torch.bfloat16).view(torch.uint8)
+        else:
+            stream = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device=dev)
         ng = -(-K // a.group) if a.group else 1
         sc = (torch.rand(N * ng, device=dev) * 0.01 + 0.005).to(torch.bfloat16)
         z = torch.full((N * ng,), 8.0, device=dev, dtype=torch.bfloat16)
@@ -30,7 +35,7 @@ def main():
         x = torch.randn((M, K), device=dev, dtype=torch.float32 if norm else torch.bfloat16)
         g = torch.ones(K, device=dev, dtype=torch.bfloat16) if norm else None
         out = torch.zeros((M, N), device=dev, dtype=torch.bfloat16 if R == 2 else torch.float32)
-        kw = dict(scales=sc, zeros=z, norm_scale=g, epi=epi, out=out, group_cols=a.group)
+        kw = dict(scales=sc, zeros=z, norm_scale=g, epi=epi, out=out, group_cols=a.group, fmt=fmt)
         if R == 2:
             kw.update(scales2=sc, zeros2=z)
         for _ in range(3):
