@@ -72,6 +72,9 @@ constexpr int kTPW = MI355_GEMM_TPW;
 // model, 6.3 TB/s of its 34 ms.  2048 tokens 34.0 -> 28.5 ms, 512 tokens 16.5 -> 10.6 ms (profiles/r06_ab_bf16_block_order.txt)
 #define MI355_GEMM_BF16_ROWMAJOR 1
 #endif
+#ifndef MI355_GEMM_ONE_PER_CU
+#define MI355_GEMM_ONE_PER_CU 1
+#endif
 #ifndef MI355_GEMM_Q4_ROWMAJOR
 #define MI355_GEMM_Q4_ROWMAJOR 0
 #endif
@@ -1019,15 +1022,15 @@ struct GemmShape {
 };
 // tuning override for sweeps (scripts/sweep_gemm_shapes.sh): MI355_GEMM_FORCE="waves:bm:ksplit", 0 = the rule's choice
 struct GemmForce {
-    int waves, bm, ksplit, bf16_blocks;  // bf16_blocks: the BF16 streams' 64-token-block threshold (sweeps)
+    int waves, bm, ksplit, bf16_blocks, q4_blocks;  // *_blocks: the 64-token-block thresholds of the two formats (sweeps)
 };
 GemmForce gemm_force() {
     // parsed ONCE per process (advisor r4: a getenv + sscanf per launch sat on the production path, and a change of the variable
     // between mi355_linear_gemm_plan and the launch would have desynchronised the share layout of the fused chain; the sweep starts
     // one process per setting)
     static const GemmForce f = [] {
-        GemmForce g = {0, 0, 0, 0};
-        if (const char* e = getenv("MI355_GEMM_FORCE")) sscanf(e, "%d:%d:%d:%d", &g.waves, &g.bm, &g.ksplit, &g.bf16_blocks);
+        GemmForce g = {0, 0, 0, 0, 0};
+        if (const char* e = getenv("MI355_GEMM_FORCE")) sscanf(e, "%d:%d:%d:%d:%d", &g.waves, &g.bm, &g.ksplit, &g.bf16_blocks, &g.q4_blocks);
         return g;
     }();
     return f;
@@ -1047,7 +1050,10 @@ GemmShape gemm_shape(int n_tiles, int M, bool pair, int ksplit, bool bf16 = fals
     // keep 128 tokens as long as those blocks cover 5/8 of the CUs, K-slices or not (7B: 2048 tokens 28.5 -> 25.6 ms, 1536 23.2 -> 22.0,
     // 512 10.6 -> 9.8; at 128 blocks — N = 4096 at 1024 tokens — 64 tokens win, 15.2 vs 16.7 ms; profiles/r06_bf16_gemm_tilings.txt)
 #ifndef MI355_GEMM_NO_BM64
-    if (bf16 ? blocks8 < (fo.bf16_blocks ? fo.bf16_blocks : 160) : blocks8 * ksplit < 384) return {8, 64};
+    // int4 streams: 64-token blocks below 384 blocks — unless the 128-token blocks are exactly one per CU (N = 4096 at 2048 tokens:
+    // no tail; 2048-token prompt 21.85 -> 21.5 ms, where a plain threshold of 256 cost 2 % at 384 / 512 tokens: profiles/r06_q4_gemm_tilings.txt)
+    const bool one_per_cu = blocks8 * ksplit == 256 && MI355_GEMM_ONE_PER_CU;
+    if (bf16 ? blocks8 < (fo.bf16_blocks ? fo.bf16_blocks : 160) : (blocks8 * ksplit < (fo.q4_blocks ? fo.q4_blocks : 384) && !one_per_cu)) return {8, 64};
 #endif
     return {8, kBM};
 }
