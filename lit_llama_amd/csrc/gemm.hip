@@ -1046,8 +1046,8 @@ GemmShape gemm_shape(int n_tiles, int M, bool pair, int ksplit, bool bf16 = fals
         return {1, kBM};
     }
     // (only the WAVES of the answer enter mi355_linear_gemm_plan's share layout: the format may pick its own token block)
-    // BF16 streams fill a CU's L1 at the rate its MFMAs consume a 128-token block's pieces and a 64-token block needs twice that: they
-    // keep 128 tokens as long as those blocks cover 5/8 of the CUs, K-slices or not (7B: 2048 tokens 28.5 -> 25.6 ms, 1536 23.2 -> 22.0,
+    // BF16 streams are bound by the weight bytes a CU requests per MFMA (pieces four times an int4 one's, a 64-token block requests twice
+    // a 128-token block's): they keep 128 tokens as long as those blocks cover 5/8 of the CUs, K-slices or not (7B: 2048 tokens 28.5 -> 25.6 ms, 1536 23.2 -> 22.0,
     // 512 10.6 -> 9.8; at 128 blocks — N = 4096 at 1024 tokens — 64 tokens win, 15.2 vs 16.7 ms; profiles/r06_bf16_gemm_tilings.txt)
 #ifndef MI355_GEMM_NO_BM64
     // int4 streams: 64-token blocks below 384 blocks — unless the 128-token blocks are exactly one per CU (N = 4096 at 2048 tokens:
