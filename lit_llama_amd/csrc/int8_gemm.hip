@@ -311,6 +311,7 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
             for (int idx = threadIdx.x; idx < kBM * kOutChunk; idx += kThreads) {
                 const int tok = idx / kOutChunk, i = idx - tok * kOutChunk;
                 const int m = m0 + tok;
+                if (MODE == 2 && ((tok >> 4) < tt_lo || (tok >> 4) >= tt_hi)) continue;  // (another workgroup finishes that token tile)
                 xo[idx] = (m < p.M && i < nc) ? p.xh[(int64_t)m * p.Kp + p.olist[1 + base + i]] : (f16_t)0;
             }
             for (int idx = threadIdx.x; idx < kSlots * 16 * kOutChunk; idx += kThreads) {
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
                 for (int t = 0; t < kTPW; ++t) a[t] = *(const f16x8_t*)(so + ((wave * kTPW + t) * 16 + c) * kOutChunk + kb * 32 + 8 * g);
 #pragma unroll
                 for (int tt = 0; tt < 8; ++tt) {
+                    if (MODE == 2 && (tt < tt_lo || tt >= tt_hi)) continue;
                     const f16x8_t b = *(const f16x8_t*)(xo + (tt * 16 + c) * kOutChunk + kb * 32 + 8 * g);
 #pragma unroll
                     for (int t = 0; t < kTPW; ++t) o[t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b, o[t][tt], 0, 0, 0);
