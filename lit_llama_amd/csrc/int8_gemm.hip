@@ -149,7 +149,11 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
     const int nsplit = MODE == 1 ? p.ksplit : MODE == 2 ? 8 : 1;
     if (j0 >= p.per_xcd || L2 >= p.total_blocks * nsplit) return;
     const int L = L2 / nsplit, ks = L2 - L * nsplit;
-    const int tt_lo = MODE == 2 ? ks : 0, tt_hi = MODE == 2 ? ks + 1 : 8;  // token tiles this workgroup finishes
+    // MODE 2: workgroup ks of a block finishes the rows of slot group ks (the rows wave ks owns in the product launch) for all 128
+    // tokens, wave w its token tile w — so the outlier columns' weights (the expensive side of the staging: byte gathers and an IEEE
+    // division each) are staged once per block, not once per token tile
+    const int tt_lo = MODE == 2 ? wave : 0, tt_hi = MODE == 2 ? wave + 1 : 8;  // token tiles this wave finishes
+    const int wslot = MODE == 2 ? ks : wave;                                   // slot group of this wave's row tiles
     const int mb = L / p.n_blocks, nb = L - mb * p.n_blocks;
     const int m0 = mb * kBM;
     const int u_lo = MODE == 1 ? (int)((int64_t)ks * p.units / p.ksplit) : 0;
@@ -160,10 +164,10 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
 #pragma unroll
     for (int t = 0; t < kTPW; ++t) {
         if (PAIR) {
-            tile[t] = nb * (kSlots / 2) + (kTPW / 2) * wave + (t >> 1);  // pair tile: 16 rows of c_fc1 (r = 0) and c_fc2 (r = 1)
+            tile[t] = nb * (kSlots / 2) + (kTPW / 2) * wslot + (t >> 1);  // pair tile: 16 rows of c_fc1 (r = 0) and c_fc2 (r = 1)
             rr[t] = t & 1;
         } else {
-            tile[t] = nb * kSlots + kTPW * wave + t;
+            tile[t] = nb * kSlots + kTPW * wslot + t;
             rr[t] = 0;
         }
     }
@@ -311,10 +315,11 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
             for (int idx = threadIdx.x; idx < kBM * kOutChunk; idx += kThreads) {
                 const int tok = idx / kOutChunk, i = idx - tok * kOutChunk;
                 const int m = m0 + tok;
-                if (MODE == 2 && ((tok >> 4) < tt_lo || (tok >> 4) >= tt_hi)) continue;  // (another workgroup finishes that token tile)
                 xo[idx] = (m < p.M && i < nc) ? p.xh[(int64_t)m * p.Kp + p.olist[1 + base + i]] : (f16_t)0;
             }
-            for (int idx = threadIdx.x; idx < kSlots * 16 * kOutChunk; idx += kThreads) {
+            const int so_lo = MODE == 2 ? ks * kTPW * 16 * kOutChunk : 0;  // MODE 2: the rows of slot group ks only
+            const int so_hi = MODE == 2 ? so_lo + kTPW * 16 * kOutChunk : kSlots * 16 * kOutChunk;
+            for (int idx = so_lo + threadIdx.x; idx < so_hi; idx += kThreads) {
                 const int sr = idx / kOutChunk, i = idx - sr * kOutChunk;  // sr = slot * 16 + row
                 const int slot = sr >> 4, row = sr & 15;
                 const int wv = slot / kTPW, t = slot - wv * kTPW;
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
                 if (kb * 32 >= nc) break;
                 f16x8_t a[kTPW];
 #pragma unroll
-                for (int t = 0; t < kTPW; ++t) a[t] = *(const f16x8_t*)(so + ((wave * kTPW + t) * 16 + c) * kOutChunk + kb * 32 + 8 * g);
+                for (int t = 0; t < kTPW; ++t) a[t] = *(const f16x8_t*)(so + ((wslot * kTPW + t) * 16 + c) * kOutChunk + kb * 32 + 8 * g);
 #pragma unroll
                 for (int tt = 0; tt < 8; ++tt) {
                     if (MODE == 2 && (tt < tt_lo || tt >= tt_hi)) continue;
