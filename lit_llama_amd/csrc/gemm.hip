@@ -1020,7 +1020,8 @@ int launch_gemm_w(const GemmParams& p, hipStream_t s) {  // p.n_tiles: 16-row ti
 struct GemmShape {
     int waves, bm;
 };
-// tuning override for sweeps (scripts/sweep_gemm_shapes.sh): MI355_GEMM_FORCE="waves:bm:ksplit", 0 = the rule's choice
+// tuning override for sweeps (scripts/sweep_gemm_shapes.sh): MI355_GEMM_FORCE="waves:bm:ksplit[:bf16_blocks[:q4_blocks]]", 0 = the rule's choice
+// (fields 4 / 5: the block counts below which the BF16 / int4 streams take 64-token blocks)
 struct GemmForce {
     int waves, bm, ksplit, bf16_blocks, q4_blocks;  // *_blocks: the 64-token-block thresholds of the two formats (sweeps)
 };
