@@ -312,15 +312,25 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
         for (int base = 0; base < n_out; base += kOutChunk) {
             const int nc = n_out - base < kOutChunk ? n_out - base : kOutChunk;
             __syncthreads();  // (the main loop / the previous pass is done with the LDS)
+            // a thread's outlier column is the same in every iteration (kThreads and so_lo are multiples of kOutChunk): its list entry and
+            // the column's place inside a unit are read once per pass, which leaves ONE gather per element in loops that can be unrolled
+            // (with the list read inside, each of the 32 iterations waited for two dependent loads: ~40 us per pass of 64 columns)
+            static_assert(kThreads % kOutChunk == 0 && (kOutChunk & (kOutChunk - 1)) == 0, "column index per thread is loop-invariant");
+            const int oi = threadIdx.x & (kOutChunk - 1);
+            const bool col_ok = oi < nc;
+            const int k = col_ok ? p.olist[1 + base + oi] : 0;
+#pragma unroll 8
             for (int idx = threadIdx.x; idx < kBM * kOutChunk; idx += kThreads) {
-                const int tok = idx / kOutChunk, i = idx - tok * kOutChunk;
+                const int tok = idx / kOutChunk;
                 const int m = m0 + tok;
-                xo[idx] = (m < p.M && i < nc) ? p.xh[(int64_t)m * p.Kp + p.olist[1 + base + i]] : (f16_t)0;
+                xo[idx] = (m < p.M && col_ok) ? p.xh[(int64_t)m * p.Kp + k] : (f16_t)0;
             }
             const int so_lo = MODE == 2 ? ks * kTPW * 16 * kOutChunk : 0;  // MODE 2: the rows of slot group ks only
             const int so_hi = MODE == 2 ? so_lo + kTPW * 16 * kOutChunk : kSlots * 16 * kOutChunk;
+            const int ku = k >> 7, ke = (k >> 6) & 1, kgg = (k >> 4) & 3, kjj = k & 15;
+#pragma unroll 8
             for (int idx = so_lo + threadIdx.x; idx < so_hi; idx += kThreads) {
-                const int sr = idx / kOutChunk, i = idx - sr * kOutChunk;  // sr = slot * 16 + row
+                const int sr = idx / kOutChunk;  // sr = slot * 16 + row
                 const int slot = sr >> 4, row = sr & 15;
                 const int wv = slot / kTPW, t = slot - wv * kTPW;
                 int tl, r1;
@@ -333,10 +343,8 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
                 }
                 const int n = tl * 16 + row;
                 f16_t sub = 0;
-                if (i < nc && tl < p.n_tiles && n < p.N) {
-                    const int k = p.olist[1 + base + i];
-                    const int u = k >> 7, e = (k >> 6) & 1, gg = (k >> 4) & 3, jj = k & 15;
-                    const int64_t off = ((((int64_t)tl * p.units + u) * R + r1) * 2 + e) * 1024 + (gg * 16 + row) * 16 + jj;
+                if (col_ok && tl < p.n_tiles && n < p.N) {
+                    const int64_t off = ((((int64_t)tl * p.units + ku) * R + r1) * 2 + ke) * 1024 + (kgg * 16 + row) * 16 + kjj;
                     const float cb = (float)(int8_t)p.w[off];
                     const float s = ((PAIR && r1 == 1) ? p.scb2 : p.scb)[n];
                     sub = f32_to_f16(__fdiv_rn(cb * s, 127.0f));
