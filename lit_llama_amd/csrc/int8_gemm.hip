@@ -28,7 +28,8 @@ constexpr int kThreads = 64 * kWaves;
 constexpr int kXTile = kBM * 128;        // bytes of one activation tile (int8)
 constexpr int kOutChunk = 64;            // outlier columns staged per pass of the epilogue
 constexpr int kLdsMain = 2 * kXTile;
-constexpr int kLdsEpi = (kBM + kSlots * 16) * kOutChunk * 2;  // f16 [128 tokens + 256 rows][kOutChunk]
+constexpr int kSoLd = kOutChunk + 8;     // row pitch of the staged outlier weights (halves): 144 B, so that 16 rows written side by side fall into 16 banks
+constexpr int kLdsEpi = (kBM * kOutChunk + kSlots * 16 * kSoLd) * 2;  // f16 [128 tokens][kOutChunk] + [256 rows][kSoLd]
 constexpr int kLds = kLdsMain > kLdsEpi ? kLdsMain : kLdsEpi;
 
 __device__ __forceinline__ float f16r(float v) { return f16_to_f32(f32_to_f16(v)); }
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
         for (int base = 0; base < n_out; base += kOutChunk) {
             const int nc = n_out - base < kOutChunk ? n_out - base : kOutChunk;
             __syncthreads();  // (the main loop / the previous pass is done with the LDS)
-            // a thread's outlier column is the same in every iteration (kThreads and so_lo are multiples of kOutChunk): its list entry and
+            // a thread's outlier column is the same in every iteration (kThreads is a multiple of kOutChunk): its list entry and
             // the column's place inside a unit are read once per pass, which leaves ONE gather per element in loops that can be unrolled
             // (with the list read inside, each of the 32 iterations waited for two dependent loads: ~40 us per pass of 64 columns)
             static_assert(kThreads % kOutChunk == 0 && (kOutChunk & (kOutChunk - 1)) == 0, "column index per thread is loop-invariant");
@@ -325,13 +326,16 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
                 const int m = m0 + tok;
                 xo[idx] = (m < p.M && col_ok) ? p.xh[(int64_t)m * p.Kp + k] : (f16_t)0;
             }
-            const int so_lo = MODE == 2 ? ks * kTPW * 16 * kOutChunk : 0;  // MODE 2: the rows of slot group ks only
-            const int so_hi = MODE == 2 ? so_lo + kTPW * 16 * kOutChunk : kSlots * 16 * kOutChunk;
-            const int ku = k >> 7, ke = (k >> 6) & 1, kgg = (k >> 4) & 3, kjj = k & 15;
+            // weights: ROW fastest — 16 lanes = the 16 rows of a tile at one outlier column (16 B apart in the stream: two cache lines),
+            // four columns per wave (the column-fastest order touched 64 lines per wave load); a thread sees two columns, oc and oc + 32
+            static_assert(kThreads == 512 && kOutChunk == 64, "element e = j * 512 + thread: row e & 15, column (e >> 4) & 63, slot e >> 10 = j >> 1");
+            const int oc = threadIdx.x >> 4, row = threadIdx.x & 15;
+            const bool c_ok[2] = {oc < nc, oc + 32 < nc};
+            const int k2[2] = {c_ok[0] ? p.olist[1 + base + oc] : 0, c_ok[1] ? p.olist[1 + base + oc + 32] : 0};
+            const int j_lo = MODE == 2 ? 2 * ks * kTPW : 0, j_hi = MODE == 2 ? j_lo + 2 * kTPW : 2 * kSlots;  // MODE 2: the rows of slot group ks only
 #pragma unroll 8
-            for (int idx = so_lo + threadIdx.x; idx < so_hi; idx += kThreads) {
-                const int sr = idx / kOutChunk;  // sr = slot * 16 + row
-                const int slot = sr >> 4, row = sr & 15;
+            for (int j = j_lo; j < j_hi; ++j) {
+                const int slot = j >> 1, h = j & 1;
                 const int wv = slot / kTPW, t = slot - wv * kTPW;
                 int tl, r1;
                 if (PAIR) {
@@ -342,14 +346,16 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
                     r1 = 0;
                 }
                 const int n = tl * 16 + row;
+                const int kk = h ? k2[1] : k2[0];
                 f16_t sub = 0;
-                if (col_ok && tl < p.n_tiles && n < p.N) {
+                if ((h ? c_ok[1] : c_ok[0]) && tl < p.n_tiles && n < p.N) {
+                    const int ku = kk >> 7, ke = (kk >> 6) & 1, kgg = (kk >> 4) & 3, kjj = kk & 15;
                     const int64_t off = ((((int64_t)tl * p.units + ku) * R + r1) * 2 + ke) * 1024 + (kgg * 16 + row) * 16 + kjj;
                     const float cb = (float)(int8_t)p.w[off];
                     const float s = ((PAIR && r1 == 1) ? p.scb2 : p.scb)[n];
                     sub = f32_to_f16(__fdiv_rn(cb * s, 127.0f));
                 }
-                so[idx] = sub;
+                so[(slot * 16 + row) * kSoLd + oc + 32 * h] = sub;
             }
             __syncthreads();
 #pragma unroll
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(kThreads) void i8_gemm_kernel(const I8GemmParams p)
                 if (kb * 32 >= nc) break;
                 f16x8_t a[kTPW];
 #pragma unroll
-                for (int t = 0; t < kTPW; ++t) a[t] = *(const f16x8_t*)(so + ((wslot * kTPW + t) * 16 + c) * kOutChunk + kb * 32 + 8 * g);
+                for (int t = 0; t < kTPW; ++t) a[t] = *(const f16x8_t*)(so + ((wslot * kTPW + t) * 16 + c) * kSoLd + kb * 32 + 8 * g);
 #pragma unroll
                 for (int tt = 0; tt < 8; ++tt) {
                     if (MODE == 2 && (tt < tt_lo || tt >= tt_hi)) continue;
